@@ -1,0 +1,135 @@
+/*
+ * mapf_env.h -- C ABI of the MI355X-native vectorised MAPF environment (libmapf_env.so).
+ *
+ * This is the drop-in boundary for the reference's environment hot path (ZiyuanMa/MAPF_RL):
+ * the reference has no FFI, the path sits behind the Python class `Environment`
+ * (reference environment.py:74-467).  Each entry point names the reference code it replaces.
+ * A handle owns E independent lock-step environments of identical shape (L x L map, N agents,
+ * FOV radius r) resident in HBM; all heavy entry points are asynchronous launches on the
+ * caller's HIP stream.
+ *
+ * Conventions: plain C types only, no exceptions cross the ABI, every function returns an int
+ * status (0 = MAPF_OK, negative = error).  Pointers named *_dev are device pointers owned by the
+ * caller; `stream` is a hipStream_t passed as void* (NULL = the default stream).  A handle is not
+ * thread-safe; distinct handles are independent.
+ *
+ * Layouts (row-major, C order):
+ *   maps     int8  [E][L][L]      0 free, 1 obstacle                (reference environment.py:82-84)
+ *   agents   int16 [E][N][2]      (row, col)                        (reference environment.py:112)
+ *   goals    int16 [E][N][2]
+ *   actions  int8  [E][N]         0 stay 1 up 2 down 3 left 4 right (reference environment.py:12)
+ *   obs      uint8 [E][N][6][2r+1][2r+1]  0/1 per flag              (reference environment.py:444-465)
+ *   reward_class int8 [E][N]      index into the reward table below
+ *   reward   float [E][N]
+ *   done     uint8 [E]
+ */
+#ifndef MAPF_ENV_H
+#define MAPF_ENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAPF_ABI_VERSION 1
+
+/* status codes; the reference's exception each one stands for is in the comment */
+#define MAPF_OK 0
+#define MAPF_ERR_INVALID_ARG (-1)   /* bad pointer / shape / position outside the map */
+#define MAPF_ERR_ACTION (-2)        /* AssertionError 'action index out of range', environment.py:289-290 */
+#define MAPF_ERR_OVERLAP (-3)       /* RuntimeError('unique'): two agents on one cell, environment.py:424-428 */
+#define MAPF_ERR_HIP (-4)           /* a HIP runtime call failed (no GPU, OOM, launch failure) */
+#define MAPF_ERR_UNSUPPORTED (-5)   /* shape outside what the kernels are built for (L > 64, N > 256, r != 4) */
+#define MAPF_ERR_NO_SPACE (-6)      /* ValueError from placement exhaustion, environment.py:120 */
+#define MAPF_ERR_NOT_READY (-7)     /* step/observe before load + build_navi */
+
+/* reward classes = keys of the reference's config.reward_fn (config.py:8-12), in this order */
+#define MAPF_RC_MOVE 0          /* -0.075 */
+#define MAPF_RC_STAY_ON_GOAL 1  /*  0     */
+#define MAPF_RC_STAY_OFF_GOAL 2 /* -0.075 */
+#define MAPF_RC_COLLISION 3     /* -0.5   */
+#define MAPF_RC_FINISH 4        /*  3     */
+
+typedef struct mapf_env mapf_env_t;
+
+int mapf_abi_version(void);
+const char *mapf_strerror(int status);
+
+/* Number of HIP devices visible (0 without a GPU); never fails. */
+int mapf_device_count(void);
+
+/*
+ * Replaces Environment.__init__'s shape arguments (environment.py:75-76): allocates device state for
+ * E environments of map side L (2..64), N agents (1..256), FOV radius r (must be 4: the model's
+ * obs_shape (6,9,9) is hard-wired, config.py:14, model.py:148,164,235).
+ */
+int mapf_create(int num_envs, int map_len, int num_agents, int obs_radius, int device, mapf_env_t **out);
+int mapf_destroy(mapf_env_t *env);
+
+/* config.reward_fn (config.py:8-12) in MAPF_RC_* order; default {-0.075, 0, -0.075, -0.5, 3}. */
+int mapf_set_reward_table(mapf_env_t *env, const float table[5]);
+
+/*
+ * Replaces Environment.load (environment.py:198-215), batched: ingest E scenarios, zero the step
+ * counters.  Source buffers are host memory (src_on_device = 0; positions are range-checked) or
+ * device memory (src_on_device = 1; an out-of-range position raises the sticky device status).
+ * Does NOT build the navi field: call mapf_build_navi next (load = this + build_navi).
+ */
+int mapf_load(mapf_env_t *env, const int8_t *maps, const int16_t *agents, const int16_t *goals,
+              int src_on_device, void *stream);
+
+/* Overwrite agent positions only (e.g. rewind to the start of an action tape); steps := 0. */
+int mapf_set_agents(mapf_env_t *env, const int16_t *agents_dev, void *stream);
+
+/*
+ * Replaces Environment.get_navi_map (environment.py:217-276) == search.compute_heuristics
+ * (search.py:24-55) for all E x N goals: bit-parallel BFS, one wavefront per distance field.
+ */
+int mapf_build_navi(mapf_env_t *env, void *stream);
+
+/*
+ * Replaces Environment.step (environment.py:278-430) incl. the observe() it returns (:430 -> :433-467),
+ * for all E environments in one launch.  Any output pointer may be NULL (obs_dev == NULL skips the
+ * observation build).  Errors detected on the device (action outside [0,5), overlap) are sticky and
+ * reported by mapf_check_status.
+ */
+int mapf_step(mapf_env_t *env, const int8_t *actions_dev, uint8_t *obs_dev, int16_t *pos_dev,
+              int8_t *reward_class_dev, float *reward_dev, uint8_t *done_dev, void *stream);
+
+/* Replaces Environment.observe (environment.py:433-467) for all E environments. */
+int mapf_observe(mapf_env_t *env, uint8_t *obs_dev, int16_t *pos_dev, void *stream);
+
+/* State read-back (device -> caller's device buffers). navi: uint8 [E][N][4][L][L], unpadded. */
+int mapf_get_navi(mapf_env_t *env, uint8_t *navi_dev, void *stream);
+int mapf_get_agents(mapf_env_t *env, int16_t *agents_dev, void *stream);
+int mapf_get_goals(mapf_env_t *env, int16_t *goals_dev, void *stream);
+int mapf_get_maps(mapf_env_t *env, int8_t *maps_dev, void *stream);
+int mapf_get_steps(mapf_env_t *env, int32_t *steps_dev, void *stream);
+
+/* Synchronises `stream`, returns and clears the sticky device status (MAPF_OK, MAPF_ERR_ACTION, ...). */
+int mapf_check_status(mapf_env_t *env, void *stream);
+
+/* Shape queries. */
+int mapf_num_envs(const mapf_env_t *env);
+int mapf_map_len(const mapf_env_t *env);
+int mapf_num_agents(const mapf_env_t *env);
+int mapf_obs_radius(const mapf_env_t *env);
+
+/*
+ * Host-side scenario generator following the reference's rule (environment.py:100-138,
+ * map_partition :21-70): Bernoulli(density) map, keep connected components of >= 2 free cells,
+ * per agent pick a component with probability proportional to its size, then start and goal
+ * uniformly without replacement from it.  density < 0 draws rho ~ triangular(0, 0.33, 0.5) per
+ * environment like the reference.  Own counter-based RNG (statistical, not bitwise, parity with
+ * the reference's global Python/numpy RNG).  An environment whose map cannot host N agents is
+ * re-drawn (the reference raises ValueError there); `redraws` (may be NULL) receives the total.
+ * Outputs are HOST buffers.
+ */
+int mapf_generate(int num_envs, int map_len, int num_agents, float density, uint64_t seed,
+                  int8_t *maps, int16_t *agents, int16_t *goals, int32_t *redraws);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAPF_ENV_H */

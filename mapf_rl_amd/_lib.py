@@ -1,0 +1,70 @@
+"""ctypes binding of libmapf_env.so (include/mapf_env.h).  There is NO fallback: if the HIP library is
+missing or fails to load, importing this module raises -- the product path never silently degrades to a
+CPU implementation."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmapf_env.so")
+
+OK = 0
+ERR_INVALID_ARG, ERR_ACTION, ERR_OVERLAP, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_SPACE, ERR_NOT_READY = (
+    -1, -2, -3, -4, -5, -6, -7)
+
+# every symbol include/mapf_env.h declares: (name, restype, argtypes)
+_vp, _i, _u64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_float
+SYMBOLS = [
+    ("mapf_abi_version", _i, []),
+    ("mapf_strerror", ctypes.c_char_p, [_i]),
+    ("mapf_device_count", _i, []),
+    ("mapf_create", _i, [_i, _i, _i, _i, _i, ctypes.POINTER(_vp)]),
+    ("mapf_destroy", _i, [_vp]),
+    ("mapf_set_reward_table", _i, [_vp, ctypes.POINTER(_f)]),
+    ("mapf_load", _i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    ("mapf_set_agents", _i, [_vp, _vp, _vp]),
+    ("mapf_build_navi", _i, [_vp, _vp]),
+    ("mapf_step", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("mapf_observe", _i, [_vp, _vp, _vp, _vp]),
+    ("mapf_get_navi", _i, [_vp, _vp, _vp]),
+    ("mapf_get_agents", _i, [_vp, _vp, _vp]),
+    ("mapf_get_goals", _i, [_vp, _vp, _vp]),
+    ("mapf_get_maps", _i, [_vp, _vp, _vp]),
+    ("mapf_get_steps", _i, [_vp, _vp, _vp]),
+    ("mapf_check_status", _i, [_vp, _vp]),
+    ("mapf_num_envs", _i, [_vp]),
+    ("mapf_map_len", _i, [_vp]),
+    ("mapf_num_agents", _i, [_vp]),
+    ("mapf_obs_radius", _i, [_vp]),
+    ("mapf_generate", _i, [_i, _i, _i, _f, _u64, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_int32)]),
+]
+
+
+class MapfError(RuntimeError):
+    def __init__(self, status, where=""):
+        self.status = status
+        msg = lib.mapf_strerror(status).decode() if lib is not None else str(status)
+        super().__init__("%s%s (status %d)" % (where + ": " if where else "", msg, status))
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "mapf_rl_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if L.mapf_abi_version() != 1:
+        raise ImportError("mapf_rl_amd: ABI version mismatch")
+    return L
+
+
+lib = None
+lib = _load()
+
+
+def check(status, where=""):
+    if status != OK:
+        raise MapfError(status, where)

@@ -1,0 +1,914 @@
+// mapf_env.hip -- MI355X (gfx950) kernels + C ABI of the vectorised MAPF environment.
+//
+// Hot path of the reference being replaced (ZiyuanMa/MAPF_RL): Environment.load / get_navi_map /
+// step / observe, reference environment.py:198-467.  See include/mapf_env.h for the boundary and
+// DESIGN.md for the data layout and the per-kernel roofline.
+//
+// Data layout in HBM (per handle; W = uint32_t when L <= 32, uint64_t when L <= 64):
+//   map_rows W[E][L]          bit y of row x = obstacle at (x, y)
+//   agents   int16[E][N][2]   current (row, col)
+//   goals    int16[E][N][2]
+//   navi     W[E][N][L][4]    per (agent, row) one 16/32-byte record {up, down, left, right}: bit y of
+//                             word k = "neighbour k of (row, y) is strictly closer to the agent's goal"
+//   steps    int32[E]
+// All integer/bit work: the kernels are HBM-bound (obs write 486 B/agent dominates), not MFMA work.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "mapf_env.h"
+
+namespace {
+
+constexpr int kStatusAction = 1;   // action outside [0,5)
+constexpr int kStatusOverlap = 2;  // two agents on one cell after a step
+constexpr int kStatusRange = 4;    // position outside the map in a device-side load
+
+// LDS atomic OR on a bit row (uint64_t is `unsigned long` here; HIP's overload wants unsigned long long)
+__device__ __forceinline__ uint32_t lds_or(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
+__device__ __forceinline__ uint64_t lds_or(uint64_t *p, uint64_t v) {
+    return (uint64_t)atomicOr(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v);
+}
+
+template <typename W>
+struct alignas(16) NaviRec {
+    W w[4];
+};
+
+struct StepParams {
+    int E, L, N;
+    const void *map_rows;
+    int16_t *agents;
+    const int16_t *goals;
+    const void *navi;
+    int32_t *steps;
+    int32_t *status;
+    const int8_t *actions;
+    uint8_t *obs;
+    int16_t *pos_out;
+    int8_t *rclass;
+    float *reward;
+    uint8_t *done;
+    float rtab[5];
+};
+
+// columns y-R .. y+R of a bit row -> bits 0 .. 2R (out-of-range columns read 0)
+template <typename W, int R>
+__device__ __forceinline__ unsigned window_bits(W row, int y) {
+    constexpr unsigned M = (1u << (2 * R + 1)) - 1u;
+    return (y >= R) ? ((unsigned)(row >> (y - R)) & M) : (((unsigned)row << (R - y)) & M);
+}
+
+// 4 bits -> 4 bytes of 0/1 (bit k -> byte k)
+__device__ __forceinline__ unsigned expand4(unsigned nib) { return (nib * 0x00204081u) & 0x01010101u; }
+
+// ---------------------------------------------------------------------------------------------
+// env_step_kernel: one workgroup per environment.
+//   phase 0  stage obstacle bit rows in LDS (padded by R zero rows), load agent state
+//   phase 1  (DO_STEP) Environment.step, reference environment.py:278-430, as a parallel fixed point:
+//            S0 move / stay, S1 wall + obstacle, S2 swap (one pass: depends only on post-S1 targets),
+//            S3 vertex: (b) a mover that is not the lowest-id mover into its target reverts,
+//                       (a) a mover whose target cell is held by a settled agent reverts; iterate (a)
+//            until stable (cascade), S4 commit, done, rewards.
+//   phase 2  Environment.observe, reference environment.py:433-467: per (agent, window row) extract
+//            the 6 channel bit-fields of width 2R+1 into LDS; the observation block of the env is then
+//            exactly the byte expansion of the concatenated fields, streamed out with VEC-byte stores.
+// ---------------------------------------------------------------------------------------------
+template <typename W, int R, bool DO_STEP, int VEC>
+__global__ void __launch_bounds__(256) env_step_kernel(StepParams p) {
+    constexpr int WW = 2 * R + 1;
+    const int e = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+    const int L = p.L, N = p.N;
+    const int LP = L + 2 * R;
+    const int NP = (N + 3) & ~3;
+    const int NF = N * 6 * WW;
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    W *s_obst = reinterpret_cast<W *>(smem);  // [LP] padded obstacle rows
+    W *s_agent = s_obst + LP;                 // [LP] padded agent-occupancy rows (after the step)
+    unsigned short *s_cur = reinterpret_cast<unsigned short *>(s_agent + LP);  // [NP] (x<<8)|y
+    unsigned short *s_next = s_cur + NP;                                      // [NP]
+    unsigned short *s_mov = s_next + NP;                                      // [NP] 1 = still a mover
+    unsigned short *s_F = s_mov + NP;                                         // [NF + 8] channel fields
+
+    const W *map_rows = reinterpret_cast<const W *>(p.map_rows) + (size_t)e * L;
+    for (int r = t; r < LP; r += nt) {
+        int rr = r - R;
+        s_obst[r] = (rr >= 0 && rr < L) ? map_rows[rr] : (W)0;
+        s_agent[r] = (W)0;
+    }
+    if (t < 8) s_F[NF + t] = 0;
+
+    const bool agent = t < N;
+    int cx = 0, cy = 0;
+    if (agent) {
+        const int16_t *a = p.agents + ((size_t)e * N + t) * 2;
+        cx = a[0];
+        cy = a[1];
+    }
+    int nx = cx, ny = cy;
+    __syncthreads();
+
+    if constexpr (DO_STEP) {
+        int gx = 0, gy = 0, act = 0, rc = MAPF_RC_STAY_ON_GOAL;
+        bool mover = false;
+        if (agent) {
+            const int16_t *g = p.goals + ((size_t)e * N + t) * 2;
+            gx = g[0];
+            gy = g[1];
+            act = p.actions[(size_t)e * N + t];
+            if (act < 0 || act > 4) {  // reference: AssertionError (environment.py:290)
+                atomicOr(p.status, kStatusAction);
+                act = 0;
+            }
+            // S0 (environment.py:298-311)
+            mover = act != 0;
+            nx = cx + (act == 2) - (act == 1);  // action_list, environment.py:12
+            ny = cy + (act == 4) - (act == 3);
+            rc = mover ? MAPF_RC_MOVE : ((cx == gx && cy == gy) ? MAPF_RC_STAY_ON_GOAL : MAPF_RC_STAY_OFF_GOAL);
+            // S1 (environment.py:320-332)
+            if (mover) {
+                bool blocked = nx < 0 || ny < 0 || nx >= L || ny >= L;
+                if (!blocked) blocked = (s_obst[nx + R] >> ny) & 1;
+                if (blocked) {
+                    mover = false;
+                    rc = MAPF_RC_COLLISION;
+                    nx = cx;
+                    ny = cy;
+                }
+            }
+            s_cur[t] = (unsigned short)((cx << 8) | cy);
+            s_next[t] = (unsigned short)((nx << 8) | ny);
+            s_mov[t] = mover;
+        }
+        __syncthreads();
+
+        // S2 swap (environment.py:335-365): occupant j of my target, whose own target is my cell
+        const unsigned my_cur = (unsigned)((cx << 8) | cy);
+        const unsigned my_next = (unsigned)((nx << 8) | ny);
+        int occ = -1;
+        bool swap = false;
+        if (mover) {
+            for (int j = 0; j < N; ++j)
+                if (s_cur[j] == my_next) occ = j;  // unique; j != t because my_next != my_cur
+            if (occ >= 0) swap = s_mov[occ] && s_next[occ] == my_cur;
+        }
+        __syncthreads();
+        if (swap) {
+            mover = false;
+            rc = MAPF_RC_COLLISION;
+            nx = cx;
+            ny = cy;
+            s_next[t] = (unsigned short)my_cur;
+            s_mov[t] = 0;
+        }
+        __syncthreads();
+
+        // S3 vertex (environment.py:368-406), rule (b): a lower-id mover claims the same cell
+        bool lose = false;
+        if (mover) {
+            for (int j = 0; j < t; ++j) lose |= (s_mov[j] && s_next[j] == my_next);
+        }
+        // rule (a) + cascade: target cell held by an agent that is (now) settled
+        for (int round = 0; round <= N; ++round) {
+            bool revert = mover && (lose || (occ >= 0 && !s_mov[occ]));
+            int any = __syncthreads_or(revert);
+            if (revert) {
+                mover = false;
+                rc = MAPF_RC_COLLISION;
+                nx = cx;
+                ny = cy;
+                s_mov[t] = 0;
+            }
+            if (!any) break;
+            __syncthreads();
+        }
+
+        // S4 (environment.py:410-430)
+        bool on_goal = !agent || (nx == gx && ny == gy);
+        int all_done = __syncthreads_and(on_goal);
+        if (agent) {
+            if (all_done) rc = MAPF_RC_FINISH;
+            size_t o = (size_t)e * N + t;
+            int16_t *a = p.agents + o * 2;
+            a[0] = (int16_t)nx;
+            a[1] = (int16_t)ny;
+            if (p.pos_out) {
+                p.pos_out[o * 2] = (int16_t)nx;
+                p.pos_out[o * 2 + 1] = (int16_t)ny;
+            }
+            if (p.rclass) p.rclass[o] = (int8_t)rc;
+            if (p.reward) p.reward[o] = p.rtab[rc];
+        }
+        if (t == 0) {
+            if (p.done) p.done[e] = (uint8_t)(all_done != 0);
+            p.steps[e] += 1;
+        }
+    } else {
+        if (agent && p.pos_out) {
+            size_t o = (size_t)e * N + t;
+            p.pos_out[o * 2] = (int16_t)cx;
+            p.pos_out[o * 2 + 1] = (int16_t)cy;
+        }
+    }
+
+    if (p.obs == nullptr) {
+        if constexpr (DO_STEP) {
+            // still run the overlap invariant (environment.py:424-428) on the new positions
+            if (agent) {
+                W bit = (W)1 << ny;
+                W old = lds_or(&s_agent[nx + R], bit);
+                if (old & bit) atomicOr(p.status, kStatusOverlap);
+            }
+        }
+        return;
+    }
+
+    // ---- observe: agent occupancy rows after the step ----
+    if (agent) {
+        W bit = (W)1 << ny;
+        W old = lds_or(&s_agent[nx + R], bit);
+        if (DO_STEP && (old & bit)) atomicOr(p.status, kStatusOverlap);
+        s_cur[t] = (unsigned short)((nx << 8) | ny);
+    }
+    __syncthreads();
+
+    // ---- per (agent, window row): 6 fields of WW bits ----
+    const NaviRec<W> *navi = reinterpret_cast<const NaviRec<W> *>(p.navi) + (size_t)e * N * L;
+    for (int task = t; task < N * WW; task += nt) {
+        int i = task / WW, dy = task - i * WW;
+        unsigned key = s_cur[i];
+        int x = key >> 8, y = key & 255;
+        unsigned f_ag = window_bits<W, R>(s_agent[x + dy], y);
+        if (dy == R) f_ag &= ~(1u << R);  // centre of channel 0 forced to 0 (environment.py:461)
+        unsigned f_ob = window_bits<W, R>(s_obst[x + dy], y);
+        int rr = x + dy - R;
+        unsigned f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+        if (rr >= 0 && rr < L) {
+            NaviRec<W> rec = navi[(size_t)i * L + rr];
+            f0 = window_bits<W, R>(rec.w[0], y);
+            f1 = window_bits<W, R>(rec.w[1], y);
+            f2 = window_bits<W, R>(rec.w[2], y);
+            f3 = window_bits<W, R>(rec.w[3], y);
+        }
+        unsigned short *F = s_F + i * 6 * WW + dy;
+        F[0] = (unsigned short)f_ag;
+        F[WW] = (unsigned short)f_ob;
+        F[2 * WW] = (unsigned short)f0;
+        F[3 * WW] = (unsigned short)f1;
+        F[4 * WW] = (unsigned short)f2;
+        F[5 * WW] = (unsigned short)f3;
+    }
+    __syncthreads();
+
+    // ---- byte expansion of the field string, VEC bytes per lane per store ----
+    const int total = NF * WW;  // bytes of this env's observation block = N*6*WW*WW
+    uint8_t *out = p.obs + (size_t)e * total;
+    constexpr int NFLD = (WW - 1 + VEC + WW - 1) / WW;
+    const int ntask = total / VEC;
+    for (int task = t; task < ntask; task += nt) {
+        int b = task * VEC;
+        int f = b / WW, s = b - f * WW;
+        unsigned long long acc = 0;
+#pragma unroll
+        for (int k = 0; k < NFLD; ++k) acc |= (unsigned long long)s_F[f + k] << (k * WW);
+        unsigned bits = (unsigned)(acc >> s);
+        if constexpr (VEC == 16) {
+            uint4 v;
+            v.x = expand4(bits & 15u);
+            v.y = expand4((bits >> 4) & 15u);
+            v.z = expand4((bits >> 8) & 15u);
+            v.w = expand4((bits >> 12) & 15u);
+            *reinterpret_cast<uint4 *>(out + b) = v;
+        } else if constexpr (VEC == 4) {
+            *reinterpret_cast<unsigned *>(out + b) = expand4(bits & 15u);
+        } else {
+            out[b] = (uint8_t)(bits & 1u);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// navi_bfs_kernel: Environment.get_navi_map (environment.py:217-276) as a bit-parallel BFS.
+// lane = map row, the frontier / visited sets are one W-bit word per row; one BFS level is
+// (up | down | left | right neighbours of the frontier) & free & ~visited, and a cell first reached at
+// level d from a frontier cell in direction k has exactly the reference's "neighbour k is strictly
+// closer" flag.  L <= 32: two fields per wavefront; L <= 64: one.
+// ---------------------------------------------------------------------------------------------
+template <typename W>
+__device__ __forceinline__ W shfl_up_w(W v, int width) {
+    if constexpr (sizeof(W) == 4) {
+        return (W)__shfl_up((unsigned)v, 1, width);
+    } else {
+        unsigned lo = __shfl_up((unsigned)v, 1, width);
+        unsigned hi = __shfl_up((unsigned)(v >> 32), 1, width);
+        return ((W)hi << 32) | lo;
+    }
+}
+template <typename W>
+__device__ __forceinline__ W shfl_down_w(W v, int width) {
+    if constexpr (sizeof(W) == 4) {
+        return (W)__shfl_down((unsigned)v, 1, width);
+    } else {
+        unsigned lo = __shfl_down((unsigned)v, 1, width);
+        unsigned hi = __shfl_down((unsigned)(v >> 32), 1, width);
+        return ((W)hi << 32) | lo;
+    }
+}
+
+template <typename W>
+__global__ void __launch_bounds__(256) navi_bfs_kernel(int E, int L, int N, const W *map_rows,
+                                                      const int16_t *goals, NaviRec<W> *navi, int32_t *status) {
+    constexpr int LPF = sizeof(W) == 4 ? 32 : 64;  // lanes per field
+    constexpr int FPW = 64 / LPF;                  // fields per wavefront
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long field = wave * FPW + lane / LPF;
+    const int row = lane % LPF;
+    const bool valid = field < (long long)E * N;
+    const int e = valid ? (int)(field / N) : 0;
+    const bool in_map = valid && row < L;
+    const W lmask = (L == (int)(8 * sizeof(W))) ? ~(W)0 : (((W)1 << L) - 1);
+    W freec = 0;
+    if (in_map) freec = ~map_rows[(size_t)e * L + row] & lmask;
+    int gx = -1, gy = 0;
+    if (valid) {
+        gx = goals[field * 2];
+        gy = goals[field * 2 + 1];
+        if (gx < 0 || gx >= L || gy < 0 || gy >= L) {
+            if (row == 0) atomicOr(status, kStatusRange);
+            gx = -1;
+            gy = 0;
+        }
+    }
+    W vis = (in_map && row == gx) ? ((W)1 << gy) : (W)0;  // dist[goal] = 0 unconditionally (:223)
+    W fr = vis;
+    W up = 0, down = 0, left = 0, right = 0;
+    const int max_iter = L * L;
+    for (int it = 0; it < max_iter; ++it) {
+        W fu = shfl_up_w<W>(fr, LPF);
+        if (row == 0) fu = 0;
+        W fd = shfl_down_w<W>(fr, LPF);
+        if (row == LPF - 1) fd = 0;
+        W fl = fr << 1, frr = fr >> 1;
+        W nw = (fu | fd | fl | frr) & freec & ~vis;
+        up |= nw & fu;      // neighbour (x-1, y) strictly closer  (:260-262)
+        down |= nw & fd;    // (x+1, y)                           (:264-266)
+        left |= nw & fl;    // (x, y-1)                           (:268-270)
+        right |= nw & frr;  // (x, y+1)                           (:272-274)
+        vis |= nw;
+        fr = nw;
+        if (__ballot(nw != 0) == 0ull) break;
+    }
+    if (in_map) {
+        NaviRec<W> rec;
+        rec.w[0] = up;
+        rec.w[1] = down;
+        rec.w[2] = left;
+        rec.w[3] = right;
+        navi[field * L + row] = rec;
+    }
+}
+
+// int8 map [E][L][L] -> bit rows; also range-checks agent/goal positions of a device-side load
+template <typename W>
+__global__ void pack_map_kernel(int E, int L, const int8_t *maps, W *rows) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)E * L) return;
+    const int8_t *m = maps + idx * L;
+    W w = 0;
+    for (int y = 0; y < L; ++y) w |= (W)(m[y] != 0) << y;
+    rows[idx] = w;
+}
+
+template <typename W>
+__global__ void unpack_map_kernel(int E, int L, const W *rows, int8_t *maps) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)E * L * L) return;
+    long long r = idx / L;
+    int y = (int)(idx - r * L);
+    maps[idx] = (int8_t)((rows[r] >> y) & 1);
+}
+
+__global__ void check_positions_kernel(long long n, int L, const int16_t *a, const int16_t *g, int32_t *status) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    int v = a[idx], u = g[idx];
+    if (v < 0 || v >= L || u < 0 || u >= L) atomicOr(status, kStatusRange);
+}
+
+// navi records -> uint8 [E][N][4][L][L]
+template <typename W>
+__global__ void unpack_navi_kernel(long long fields, int L, const NaviRec<W> *navi, uint8_t *out) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over fields*4*L*L
+    long long total = fields * 4 * L * L;
+    if (idx >= total) return;
+    int y = (int)(idx % L);
+    long long q = idx / L;
+    int x = (int)(q % L);
+    q /= L;
+    int k = (int)(q % 4);
+    long long f = q / 4;
+    out[idx] = (uint8_t)((navi[f * L + x].w[k] >> y) & 1);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct mapf_env {
+    int E, L, N, R, device;
+    bool wide;  // 64-bit rows
+    void *map_rows;
+    int16_t *agents;
+    int16_t *goals;
+    void *navi;
+    int32_t *steps;
+    int32_t *status;
+    bool loaded, navi_ready;
+    float rtab[5];
+};
+
+namespace {
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            std::fprintf(stderr, "mapf_env: %s failed: %s\n", #expr, hipGetErrorString(_e));            \
+            return MAPF_ERR_HIP;                                                                        \
+        }                                                                                               \
+    } while (0)
+
+size_t word_bytes(const mapf_env *h) { return h->wide ? 8 : 4; }
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
+    }
+    ~DeviceGuard() {
+        if (ok && prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+size_t step_smem_bytes(const mapf_env *h) {
+    const int WW = 2 * h->R + 1;
+    size_t LP = h->L + 2 * h->R;
+    size_t NP = (h->N + 3) & ~3;
+    return 2 * LP * word_bytes(h) + 3 * NP * 2 + ((size_t)h->N * 6 * WW + 8) * 2;
+}
+
+int step_block_threads(const mapf_env *h) {
+    int t = 128;
+    while (t < h->N) t += 64;
+    return t;
+}
+
+template <typename W, bool DO_STEP>
+int launch_step_vec(const mapf_env *h, const StepParams &p, hipStream_t s) {
+    const int total = h->N * 6 * 81;
+    const size_t smem = step_smem_bytes(h);
+    const int threads = step_block_threads(h);
+    const bool a16 = (total % 16 == 0) && ((reinterpret_cast<uintptr_t>(p.obs) & 15) == 0);
+    const bool a4 = (total % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.obs) & 3) == 0);
+    if (p.obs == nullptr || a16)
+        hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, 16>), dim3(h->E), dim3(threads), smem, s, p);
+    else if (a4)
+        hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, 4>), dim3(h->E), dim3(threads), smem, s, p);
+    else
+        hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, 1>), dim3(h->E), dim3(threads), smem, s, p);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+template <bool DO_STEP>
+int launch_step(const mapf_env *h, const StepParams &p, hipStream_t s) {
+    return h->wide ? launch_step_vec<uint64_t, DO_STEP>(h, p, s) : launch_step_vec<uint32_t, DO_STEP>(h, p, s);
+}
+
+StepParams make_params(mapf_env *h) {
+    StepParams p{};
+    p.E = h->E;
+    p.L = h->L;
+    p.N = h->N;
+    p.map_rows = h->map_rows;
+    p.agents = h->agents;
+    p.goals = h->goals;
+    p.navi = h->navi;
+    p.steps = h->steps;
+    p.status = h->status;
+    std::memcpy(p.rtab, h->rtab, sizeof(p.rtab));
+    return p;
+}
+
+inline unsigned blocks_for(long long n, int threads) { return (unsigned)((n + threads - 1) / threads); }
+
+// ---- host RNG for the scenario generator (splitmix64 -> xoshiro256**) ----
+struct Rng {
+    uint64_t s[4];
+    static uint64_t splitmix(uint64_t &x) {
+        uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    explicit Rng(uint64_t seed) {
+        for (auto &v : s) v = splitmix(seed);
+    }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next() {
+        uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0];
+        s[3] ^= s[1];
+        s[1] ^= s[2];
+        s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = rotl(s[3], 45);
+        return r;
+    }
+    double uniform() { return (next() >> 11) * (1.0 / 9007199254740992.0); }
+    uint32_t below(uint32_t n) {  // unbiased
+        uint64_t m = (uint64_t)(uint32_t)next() * n;
+        uint32_t l = (uint32_t)m;
+        if (l < n) {
+            uint32_t t = (0u - n) % n;
+            while (l < t) {
+                m = (uint64_t)(uint32_t)next() * n;
+                l = (uint32_t)m;
+            }
+        }
+        return (uint32_t)(m >> 32);
+    }
+};
+
+// one scenario by the reference's rule (environment.py:100-138); false = cells ran out (:120)
+bool generate_one(int L, int N, double density, Rng &rng, int8_t *map, int16_t *agents, int16_t *goals) {
+    for (int c = 0; c < L * L; ++c) map[c] = rng.uniform() < density ? 1 : 0;
+    // connected components of free cells (map_partition, :21-70)
+    std::vector<int> label(L * L, -1);
+    std::vector<std::vector<int>> parts;
+    std::vector<int> queue;
+    for (int c0 = 0; c0 < L * L; ++c0) {
+        if (map[c0] != 0 || label[c0] >= 0) continue;
+        int id = (int)parts.size();
+        parts.emplace_back();
+        queue.clear();
+        queue.push_back(c0);
+        label[c0] = id;
+        for (size_t h = 0; h < queue.size(); ++h) {
+            int c = queue[h], x = c / L, y = c % L;
+            parts[id].push_back(c);
+            const int nb[4][2] = {{x - 1, y}, {x + 1, y}, {x, y - 1}, {x, y + 1}};
+            for (auto &n : nb) {
+                if (n[0] < 0 || n[0] >= L || n[1] < 0 || n[1] >= L) continue;
+                int d = n[0] * L + n[1];
+                if (map[d] == 0 && label[d] < 0) {
+                    label[d] = id;
+                    queue.push_back(d);
+                }
+            }
+        }
+    }
+    auto prune = [&parts]() {
+        size_t k = 0;
+        for (size_t i = 0; i < parts.size(); ++i)
+            if (parts[i].size() >= 2) {
+                if (k != i) parts[k] = std::move(parts[i]);
+                ++k;
+            }
+        parts.resize(k);
+    };
+    prune();  // :105
+    if (parts.empty()) return false;
+    for (int i = 0; i < N; ++i) {
+        size_t pos_num = 0;
+        for (auto &p : parts) pos_num += p.size();
+        if (pos_num == 0) return false;  // reference: random.randint(0, -1) raises ValueError (:120)
+        uint32_t idx = rng.below((uint32_t)pos_num);
+        size_t pi = 0;
+        while (idx >= parts[pi].size()) {
+            idx -= (uint32_t)parts[pi].size();
+            ++pi;
+        }
+        auto &part = parts[pi];
+        uint32_t k = rng.below((uint32_t)part.size());
+        int c = part[k];
+        part.erase(part.begin() + k);
+        agents[2 * i] = (int16_t)(c / L);
+        agents[2 * i + 1] = (int16_t)(c % L);
+        k = rng.below((uint32_t)part.size());
+        c = part[k];
+        part.erase(part.begin() + k);
+        goals[2 * i] = (int16_t)(c / L);
+        goals[2 * i + 1] = (int16_t)(c % L);
+        prune();  // :137
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mapf_abi_version(void) { return MAPF_ABI_VERSION; }
+
+const char *mapf_strerror(int status) {
+    switch (status) {
+        case MAPF_OK: return "ok";
+        case MAPF_ERR_INVALID_ARG: return "invalid argument";
+        case MAPF_ERR_ACTION: return "action index out of range";
+        case MAPF_ERR_OVERLAP: return "unique: two agents on one cell";
+        case MAPF_ERR_HIP: return "HIP runtime error";
+        case MAPF_ERR_UNSUPPORTED: return "unsupported shape";
+        case MAPF_ERR_NO_SPACE: return "no empty position";
+        case MAPF_ERR_NOT_READY: return "environment not loaded / navi not built";
+        default: return "unknown status";
+    }
+}
+
+int mapf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mapf_create(int num_envs, int map_len, int num_agents, int obs_radius, int device, mapf_env_t **out) {
+    if (!out) return MAPF_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (num_envs < 1 || map_len < 2 || num_agents < 1 || device < 0) return MAPF_ERR_INVALID_ARG;
+    if (map_len > 64 || num_agents > 256 || obs_radius != 4) return MAPF_ERR_UNSUPPORTED;
+    if (device >= mapf_device_count()) return MAPF_ERR_HIP;
+    mapf_env *h = new (std::nothrow) mapf_env();
+    if (!h) return MAPF_ERR_HIP;
+    h->E = num_envs;
+    h->L = map_len;
+    h->N = num_agents;
+    h->R = obs_radius;
+    h->device = device;
+    h->wide = map_len > 32;
+    h->loaded = h->navi_ready = false;
+    const float def[5] = {-0.075f, 0.0f, -0.075f, -0.5f, 3.0f};
+    std::memcpy(h->rtab, def, sizeof(def));
+    DeviceGuard guard(device);
+    if (!guard.ok) {
+        delete h;
+        return MAPF_ERR_HIP;
+    }
+    const size_t E = h->E, L = h->L, N = h->N, wb = word_bytes(h);
+    hipError_t err = hipSuccess;
+    auto alloc = [&err](void **p, size_t bytes) {
+        if (err == hipSuccess) err = hipMalloc(p, bytes);
+    };
+    alloc(&h->map_rows, E * L * wb);
+    alloc(reinterpret_cast<void **>(&h->agents), E * N * 2 * sizeof(int16_t));
+    alloc(reinterpret_cast<void **>(&h->goals), E * N * 2 * sizeof(int16_t));
+    alloc(&h->navi, E * N * L * 4 * wb);
+    alloc(reinterpret_cast<void **>(&h->steps), E * sizeof(int32_t));
+    alloc(reinterpret_cast<void **>(&h->status), sizeof(int32_t));
+    if (err == hipSuccess) err = hipMemset(h->steps, 0, E * sizeof(int32_t));
+    if (err == hipSuccess) err = hipMemset(h->status, 0, sizeof(int32_t));
+    if (err != hipSuccess) {
+        std::fprintf(stderr, "mapf_create: %s\n", hipGetErrorString(err));
+        mapf_destroy(h);
+        return MAPF_ERR_HIP;
+    }
+    *out = h;
+    return MAPF_OK;
+}
+
+int mapf_destroy(mapf_env_t *h) {
+    if (!h) return MAPF_ERR_INVALID_ARG;
+    DeviceGuard guard(h->device);
+    (void)hipFree(h->map_rows);
+    (void)hipFree(h->agents);
+    (void)hipFree(h->goals);
+    (void)hipFree(h->navi);
+    (void)hipFree(h->steps);
+    (void)hipFree(h->status);
+    delete h;
+    return MAPF_OK;
+}
+
+int mapf_set_reward_table(mapf_env_t *h, const float table[5]) {
+    if (!h || !table) return MAPF_ERR_INVALID_ARG;
+    std::memcpy(h->rtab, table, sizeof(h->rtab));
+    return MAPF_OK;
+}
+
+int mapf_load(mapf_env_t *h, const int8_t *maps, const int16_t *agents, const int16_t *goals,
+              int src_on_device, void *stream) {
+    if (!h || !maps || !agents || !goals) return MAPF_ERR_INVALID_ARG;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t E = h->E, L = h->L, N = h->N;
+    const size_t pos_bytes = E * N * 2 * sizeof(int16_t);
+    const int8_t *maps_dev = maps;
+    int8_t *tmp = nullptr;
+    if (!src_on_device) {
+        for (size_t k = 0; k < E * N * 2; ++k)
+            if (agents[k] < 0 || agents[k] >= (int)L || goals[k] < 0 || goals[k] >= (int)L) return MAPF_ERR_INVALID_ARG;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), E * L * L));
+        HIP_TRY(hipMemcpyAsync(tmp, maps, E * L * L, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(h->agents, agents, pos_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(h->goals, goals, pos_bytes, hipMemcpyHostToDevice, s));
+        maps_dev = tmp;
+    } else {
+        HIP_TRY(hipMemcpyAsync(h->agents, agents, pos_bytes, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(h->goals, goals, pos_bytes, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(check_positions_kernel, dim3(blocks_for(E * N * 2, 256)), dim3(256), 0, s,
+                           (long long)(E * N * 2), h->L, h->agents, h->goals, h->status);
+    }
+    if (h->wide)
+        hipLaunchKernelGGL(pack_map_kernel<uint64_t>, dim3(blocks_for(E * L, 256)), dim3(256), 0, s, h->E, h->L,
+                           maps_dev, static_cast<uint64_t *>(h->map_rows));
+    else
+        hipLaunchKernelGGL(pack_map_kernel<uint32_t>, dim3(blocks_for(E * L, 256)), dim3(256), 0, s, h->E, h->L,
+                           maps_dev, static_cast<uint32_t *>(h->map_rows));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(h->steps, 0, E * sizeof(int32_t), s));
+    if (tmp) {
+        HIP_TRY(hipStreamSynchronize(s));  // host source buffers and the staging copy may be released on return
+        HIP_TRY(hipFree(tmp));
+    }
+    h->loaded = true;
+    h->navi_ready = false;
+    return MAPF_OK;
+}
+
+int mapf_set_agents(mapf_env_t *h, const int16_t *agents_dev, void *stream) {
+    if (!h || !agents_dev) return MAPF_ERR_INVALID_ARG;
+    if (!h->loaded) return MAPF_ERR_NOT_READY;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t n = (size_t)h->E * h->N * 2;
+    HIP_TRY(hipMemcpyAsync(h->agents, agents_dev, n * sizeof(int16_t), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(check_positions_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, (long long)n, h->L,
+                       h->agents, h->agents, h->status);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(h->steps, 0, (size_t)h->E * sizeof(int32_t), s));
+    return MAPF_OK;
+}
+
+int mapf_build_navi(mapf_env_t *h, void *stream) {
+    if (!h) return MAPF_ERR_INVALID_ARG;
+    if (!h->loaded) return MAPF_ERR_NOT_READY;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long fields = (long long)h->E * h->N;
+    if (h->wide) {
+        const long long waves = fields;
+        hipLaunchKernelGGL(navi_bfs_kernel<uint64_t>, dim3(blocks_for(waves * 64, 256)), dim3(256), 0, s, h->E, h->L,
+                           h->N, static_cast<const uint64_t *>(h->map_rows), h->goals,
+                           static_cast<NaviRec<uint64_t> *>(h->navi), h->status);
+    } else {
+        const long long waves = (fields + 1) / 2;
+        hipLaunchKernelGGL(navi_bfs_kernel<uint32_t>, dim3(blocks_for(waves * 64, 256)), dim3(256), 0, s, h->E, h->L,
+                           h->N, static_cast<const uint32_t *>(h->map_rows), h->goals,
+                           static_cast<NaviRec<uint32_t> *>(h->navi), h->status);
+    }
+    HIP_TRY(hipGetLastError());
+    h->navi_ready = true;
+    return MAPF_OK;
+}
+
+int mapf_step(mapf_env_t *h, const int8_t *actions_dev, uint8_t *obs_dev, int16_t *pos_dev,
+              int8_t *reward_class_dev, float *reward_dev, uint8_t *done_dev, void *stream) {
+    if (!h || !actions_dev) return MAPF_ERR_INVALID_ARG;
+    if (!h->loaded || (obs_dev && !h->navi_ready)) return MAPF_ERR_NOT_READY;
+    DeviceGuard guard(h->device);
+    StepParams p = make_params(h);
+    p.actions = actions_dev;
+    p.obs = obs_dev;
+    p.pos_out = pos_dev;
+    p.rclass = reward_class_dev;
+    p.reward = reward_dev;
+    p.done = done_dev;
+    return launch_step<true>(h, p, static_cast<hipStream_t>(stream));
+}
+
+int mapf_observe(mapf_env_t *h, uint8_t *obs_dev, int16_t *pos_dev, void *stream) {
+    if (!h || !obs_dev) return MAPF_ERR_INVALID_ARG;
+    if (!h->loaded || !h->navi_ready) return MAPF_ERR_NOT_READY;
+    DeviceGuard guard(h->device);
+    StepParams p = make_params(h);
+    p.obs = obs_dev;
+    p.pos_out = pos_dev;
+    return launch_step<false>(h, p, static_cast<hipStream_t>(stream));
+}
+
+int mapf_get_navi(mapf_env_t *h, uint8_t *navi_dev, void *stream) {
+    if (!h || !navi_dev) return MAPF_ERR_INVALID_ARG;
+    if (!h->navi_ready) return MAPF_ERR_NOT_READY;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long fields = (long long)h->E * h->N;
+    const long long total = fields * 4 * h->L * h->L;
+    if (h->wide)
+        hipLaunchKernelGGL(unpack_navi_kernel<uint64_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, fields, h->L,
+                           static_cast<const NaviRec<uint64_t> *>(h->navi), navi_dev);
+    else
+        hipLaunchKernelGGL(unpack_navi_kernel<uint32_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, fields, h->L,
+                           static_cast<const NaviRec<uint32_t> *>(h->navi), navi_dev);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+int mapf_get_agents(mapf_env_t *h, int16_t *agents_dev, void *stream) {
+    if (!h || !agents_dev) return MAPF_ERR_INVALID_ARG;
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipMemcpyAsync(agents_dev, h->agents, (size_t)h->E * h->N * 2 * sizeof(int16_t), hipMemcpyDeviceToDevice,
+                           static_cast<hipStream_t>(stream)));
+    return MAPF_OK;
+}
+
+int mapf_get_goals(mapf_env_t *h, int16_t *goals_dev, void *stream) {
+    if (!h || !goals_dev) return MAPF_ERR_INVALID_ARG;
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipMemcpyAsync(goals_dev, h->goals, (size_t)h->E * h->N * 2 * sizeof(int16_t), hipMemcpyDeviceToDevice,
+                           static_cast<hipStream_t>(stream)));
+    return MAPF_OK;
+}
+
+int mapf_get_maps(mapf_env_t *h, int8_t *maps_dev, void *stream) {
+    if (!h || !maps_dev) return MAPF_ERR_INVALID_ARG;
+    if (!h->loaded) return MAPF_ERR_NOT_READY;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long total = (long long)h->E * h->L * h->L;
+    if (h->wide)
+        hipLaunchKernelGGL(unpack_map_kernel<uint64_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, h->E, h->L,
+                           static_cast<const uint64_t *>(h->map_rows), maps_dev);
+    else
+        hipLaunchKernelGGL(unpack_map_kernel<uint32_t>, dim3(blocks_for(total, 256)), dim3(256), 0, s, h->E, h->L,
+                           static_cast<const uint32_t *>(h->map_rows), maps_dev);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+int mapf_get_steps(mapf_env_t *h, int32_t *steps_dev, void *stream) {
+    if (!h || !steps_dev) return MAPF_ERR_INVALID_ARG;
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipMemcpyAsync(steps_dev, h->steps, (size_t)h->E * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                           static_cast<hipStream_t>(stream)));
+    return MAPF_OK;
+}
+
+int mapf_check_status(mapf_env_t *h, void *stream) {
+    if (!h) return MAPF_ERR_INVALID_ARG;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int32_t st = 0;
+    HIP_TRY(hipMemcpyAsync(&st, h->status, sizeof(st), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (st != 0) {
+        HIP_TRY(hipMemsetAsync(h->status, 0, sizeof(int32_t), s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (st & kStatusRange) return MAPF_ERR_INVALID_ARG;
+    if (st & kStatusAction) return MAPF_ERR_ACTION;
+    if (st & kStatusOverlap) return MAPF_ERR_OVERLAP;
+    return MAPF_OK;
+}
+
+int mapf_num_envs(const mapf_env_t *h) { return h ? h->E : MAPF_ERR_INVALID_ARG; }
+int mapf_map_len(const mapf_env_t *h) { return h ? h->L : MAPF_ERR_INVALID_ARG; }
+int mapf_num_agents(const mapf_env_t *h) { return h ? h->N : MAPF_ERR_INVALID_ARG; }
+int mapf_obs_radius(const mapf_env_t *h) { return h ? h->R : MAPF_ERR_INVALID_ARG; }
+
+int mapf_generate(int num_envs, int map_len, int num_agents, float density, uint64_t seed, int8_t *maps,
+                  int16_t *agents, int16_t *goals, int32_t *redraws) {
+    if (num_envs < 1 || map_len < 2 || num_agents < 1 || !maps || !agents || !goals) return MAPF_ERR_INVALID_ARG;
+    if (density >= 1.0f) return MAPF_ERR_INVALID_ARG;
+    const int L = map_len, N = num_agents;
+    int total_redraws = 0;
+    for (int e = 0; e < num_envs; ++e) {
+        bool ok = false;
+        for (int attempt = 0; attempt < 1000 && !ok; ++attempt) {
+            Rng rng(seed * 0x9E3779B97F4A7C15ull + (uint64_t)e * 1000003ull + (uint64_t)attempt * 0xD1B54A32D192ED03ull);
+            double rho = density;
+            if (density < 0) {  // np.random.triangular(0, 0.33, 0.5), environment.py:100
+                const double a = 0.0, c = 0.33, b = 0.5;
+                double u = rng.uniform();
+                rho = (u < (c - a) / (b - a)) ? a + std::sqrt(u * (b - a) * (c - a)) : b - std::sqrt((1 - u) * (b - a) * (b - c));
+            }
+            ok = generate_one(L, N, rho, rng, maps + (size_t)e * L * L, agents + (size_t)e * N * 2, goals + (size_t)e * N * 2);
+            if (!ok) ++total_redraws;
+        }
+        if (!ok) {
+            if (redraws) *redraws = total_redraws;
+            return MAPF_ERR_NO_SPACE;
+        }
+    }
+    if (redraws) *redraws = total_redraws;
+    return MAPF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol include/mapf_env.h declares;
+host-only entry points (generator, error strings, argument checks) behave."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "mapf_env.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mapf_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from mapf_rl_amd import _lib
+
+    names = _declared_symbols()
+    assert len(names) >= 20
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), "libmapf_env.so does not export %s" % n
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert bound == set(names), (bound ^ set(names))
+
+
+def test_abi_version_and_strerror():
+    from mapf_rl_amd._lib import lib
+
+    assert lib.mapf_abi_version() == 1
+    assert lib.mapf_strerror(0) == b"ok"
+    assert b"action" in lib.mapf_strerror(-2)
+    assert b"unique" in lib.mapf_strerror(-3)
+
+
+def test_create_argument_checks_without_gpu():
+    from mapf_rl_amd import _lib
+
+    h = ctypes.c_void_p()
+    lib = _lib.lib
+    assert lib.mapf_create(0, 8, 2, 4, 0, ctypes.byref(h)) == _lib.ERR_INVALID_ARG
+    assert lib.mapf_create(1, 65, 2, 4, 0, ctypes.byref(h)) == _lib.ERR_UNSUPPORTED
+    assert lib.mapf_create(1, 8, 257, 4, 0, ctypes.byref(h)) == _lib.ERR_UNSUPPORTED
+    assert lib.mapf_create(1, 8, 2, 3, 0, ctypes.byref(h)) == _lib.ERR_UNSUPPORTED
+    if lib.mapf_device_count() == 0:
+        assert lib.mapf_create(1, 8, 2, 4, 0, ctypes.byref(h)) == _lib.ERR_HIP
+        assert not h.value
+
+
+def test_product_does_not_import_oracle():
+    """the product package must never route through oracle/ (it is test infrastructure)"""
+    pkg = os.path.join(ROOT, "mapf_rl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "mapf_oracle" not in text, f
+
+
+def test_vec_environment_fails_loudly_without_gpu():
+    import torch
+
+    import mapf_rl_amd as M
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        M.VecEnvironment(1, 8, 2)

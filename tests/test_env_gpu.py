@@ -1,0 +1,259 @@
+"""GPU parity tests: the HIP path (through the C ABI, via mapf_rl_amd.VecEnvironment / Environment)
+against (1) golden vectors captured from the unmodified reference and (2) the CPU oracle on seeded
+inputs.  Everything here is integer/bit work: the bar is bit-exact."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def M():
+    import mapf_rl_amd
+
+    assert torch.cuda.is_available(), "-m gpu tests need a HIP device"
+    return mapf_rl_amd
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def _run_golden_tapes(M, z, pre, m, a, g):
+    N, L = a.shape[0], m.shape[0]
+    env = M.VecEnvironment(1, L, N)
+    for pol in H.POLICIES:
+        env.load(m[None], a[None], g[None])
+        acts = z[pre + pol + "_actions"]
+        pos = z[pre + pol + "_pos"]
+        rew = z[pre + pol + "_rewards"]
+        done = z[pre + pol + "_done"]
+        sha = z[pre + pol + "_obs_sha"]
+        bits = z[pre + pol + "_obs_bits"]
+        obs, p = env.observe()
+        assert np.array_equal(_np(p)[0], pos[0])
+        assert hashlib.sha256(_np(obs)[0].tobytes()).digest() == sha[0].tobytes(), (pre, pol, "obs0")
+        for t in range(acts.shape[0]):
+            obs, p, r, d, rc = env.step(torch.from_numpy(acts[t][None]).cuda())
+            assert np.array_equal(_np(p)[0], pos[t + 1]), (pre, pol, t)
+            assert H.rewards_match(_np(rc)[0], rew[t]), (pre, pol, t)
+            assert np.array_equal(_np(r)[0], rew[t].astype(np.float32)), (pre, pol, t)
+            assert bool(_np(d)[0]) == bool(done[t])
+            o = _np(obs)[0]
+            assert hashlib.sha256(o.tobytes()).digest() == sha[t + 1].tobytes(), (pre, pol, t)
+            if t + 1 < bits.shape[0]:
+                assert np.array_equal(o, H.unpack_bits(bits[t + 1], (N, 6, 9, 9)))
+        env.check_status()
+        assert int(_np(env.steps())[0]) == acts.shape[0]
+
+
+def test_golden_fixture_navi(M):
+    z = H.load_npz("env_fixtures.npz")
+    for pre, m, a, g in H.fixture_cases(z):
+        N, L = a.shape[0], m.shape[0]
+        env = M.VecEnvironment(1, L, N)
+        env.load(m[None], a[None], g[None])
+        assert np.array_equal(_np(env.navi_map())[0], H.unpack_bits(z[pre + "navi_bits"], (N, 4, L, L))), pre
+        assert np.array_equal(_np(env.maps())[0], m)
+        assert np.array_equal(_np(env.goals_pos())[0], g)
+
+
+def test_golden_fixture_trajectories(M):
+    z = H.load_npz("env_fixtures.npz")
+    for pre, m, a, g in H.fixture_cases(z):
+        _run_golden_tapes(M, z, pre, m, a, g)
+
+
+def test_golden_dense_trajectories(M):
+    z = H.load_npz("env_dense.npz")
+    for pre, m, a, g in H.dense_cases(z):
+        N, L = a.shape[0], m.shape[0]
+        env = M.VecEnvironment(1, L, N)
+        env.load(m[None], a[None], g[None])
+        assert np.array_equal(_np(env.navi_map())[0], H.unpack_bits(z[pre + "navi_bits"], (N, 4, L, L))), pre
+        _run_golden_tapes(M, z, pre, m, a, g)
+
+
+def test_golden_known_answers(M):
+    from tests.test_oracle_golden import KNOWN
+
+    z = H.load_npz("env_known.npz")
+    for name in [str(n) for n in z["names"]]:
+        m, a, g = z[name + "_map"], z[name + "_agents"].astype(np.int16), z[name + "_goals"].astype(np.int16)
+        env = M.VecEnvironment(1, m.shape[0], a.shape[0])
+        env.load(m[None], a[None], g[None])
+        obs, p, r, d, rc = env.step(torch.from_numpy(z[name + "_actions"][None]).cuda())
+        env.check_status()
+        assert np.array_equal(_np(p)[0], z[name + "_pos"]), name
+        assert H.rewards_match(_np(rc)[0], z[name + "_rewards"]), name
+        assert bool(_np(d)[0]) == bool(z[name + "_done"]), name
+        assert np.array_equal(_np(obs)[0], H.unpack_bits(z[name + "_obs_bits"], tuple(obs.shape[1:]))), name
+        if name in KNOWN:
+            pos, rcs, done = KNOWN[name]
+            assert _np(p)[0].tolist() == pos and _np(rc)[0].tolist() == rcs and bool(_np(d)[0]) == done, name
+
+
+def _heuristic_tape_step(obs, rng, p_follow):
+    """numpy policy on a batch: follow a navi flag of the own cell with prob p_follow, else uniform."""
+    E, N = obs.shape[:2]
+    flags = obs[:, :, 2:6, H.R, H.R].astype(bool)  # [E,N,4]
+    score = rng.random_sample((E, N, 4)) * flags
+    follow = np.where(flags.any(-1), 1 + score.argmax(-1), 0)
+    uni = rng.randint(0, 5, size=(E, N))
+    return np.where(rng.random_sample((E, N)) < p_follow, follow, uni).astype(np.int8)
+
+
+@pytest.mark.parametrize("E,L,N,rho,T", [
+    (64, 8, 10, 0.15, 40),     # tiny, dense in agents
+    (64, 16, 40, 0.2, 40),     # BASELINE config 1 literal reading
+    (32, 40, 16, 0.3, 40),     # fixture shape (W = uint64 rows)
+    (128, 32, 40, 0.3, 64),    # BASELINE config 2 shape
+    (16, 64, 40, 0.3, 32),     # config 3
+    (8, 64, 128, 0.3, 32),     # config 5 shape (N > one wavefront)
+    (16, 33, 7, 0.3, 24),      # odd sizes: L just over 32, N odd -> 4/1-byte store path
+    (16, 10, 1, 0.2, 24),      # single agent
+    (16, 12, 3, 0.2, 24),
+    (16, 12, 6, 0.2, 24),      # reference default num_agents
+    (4, 20, 200, 0.1, 16),     # N > 128
+])
+def test_differential_vs_oracle(M, E, L, N, rho, T):
+    maps, agents, goals = H.random_scenarios(E, L, N, rho, seed=E * 1000 + L * 10 + N)
+    env = M.VecEnvironment(E, L, N)
+    env.load(maps, agents, goals)
+    nv = oracle.navi_batch(maps, goals)
+    assert np.array_equal(_np(env.navi_map()), nv)
+    rng = np.random.RandomState(N + L)
+    obs, pos = env.observe()
+    assert np.array_equal(_np(pos), agents)
+    o0 = _np(obs)
+    for e in range(min(E, 4)):
+        assert np.array_equal(o0[e], oracle.observe(maps[e], agents[e], nv[e]))
+    tape = np.zeros((T, E, N), np.int8)
+    got_pos = np.zeros((T, E, N, 2), np.int16)
+    got_rc = np.zeros((T, E, N), np.int8)
+    got_done = np.zeros((T, E), np.uint8)
+    got_hash = []
+    for t in range(T):
+        p_follow = (0.0, 0.8, 1.0)[t % 3]
+        tape[t] = _heuristic_tape_step(_np(obs), rng, p_follow)
+        obs, pos, rew, done, rc = env.step(torch.from_numpy(tape[t]).cuda())
+        got_pos[t], got_rc[t], got_done[t] = _np(pos), _np(rc), _np(done)
+        assert np.array_equal(_np(rew), H.REWARD_VALUES.astype(np.float32)[got_rc[t]])
+    env.check_status()
+    ref = oracle.rollout(maps, agents, goals, nv, tape, want_obs_last=True)
+    assert ref["status"] == 0
+    assert np.array_equal(got_pos, ref["pos"])
+    assert np.array_equal(got_rc, ref["rclass"])
+    assert np.array_equal(got_done, ref["done"])
+    assert np.array_equal(_np(obs), ref["obs_last"])
+    assert np.array_equal(_np(env.steps()), np.full(E, T, np.int32))
+
+
+def test_full_size_config2_properties(M):
+    """BASELINE config 2 at full size (4096 x 32x32 x 40 agents): size-independent invariants on every
+    env (reference environment.py:424-428 uniqueness; obstacles never entered; observation channels
+    consistent with state) + exact oracle comparison on a sample of envs."""
+    E, L, N, T = 4096, 32, 40, 24
+    maps, agents, goals, _ = M.generate_scenarios(E, L, N, 0.3, seed=11)
+    env = M.VecEnvironment(E, L, N)
+    env.load(maps, agents, goals)
+    rng = np.random.RandomState(5)
+    obs, pos = env.observe()
+    tape = np.zeros((T, E, N), np.int8)
+    for t in range(T):
+        tape[t] = _heuristic_tape_step(_np(obs), rng, 0.8)
+        obs, pos, rew, done, rc = env.step(torch.from_numpy(tape[t]).cuda())
+    env.check_status()
+    p = _np(pos).astype(np.int64)
+    assert p.min() >= 0 and p.max() < L
+    keys = p[..., 0] * L + p[..., 1]
+    assert all(len(np.unique(k)) == N for k in keys)  # no two agents on a cell
+    ee = np.arange(E)[:, None]
+    assert maps[ee, p[..., 0], p[..., 1]].sum() == 0  # nobody inside an obstacle
+    o = _np(obs)
+    assert o.max() <= 1
+    assert o[:, :, 0, 4, 4].sum() == 0  # own cell never in the agent channel
+    assert o[:, :, 1, 4, 4].sum() == 0  # standing on a free cell
+    # agent-channel population == number of other agents within the FOV
+    dx = np.abs(p[:, :, None, 0] - p[:, None, :, 0]) <= 4
+    dy = np.abs(p[:, :, None, 1] - p[:, None, :, 1]) <= 4
+    assert np.array_equal(o[:, :, 0].reshape(E, N, -1).sum(-1), (dx & dy).sum(-1) - 1)
+    sample = np.arange(0, E, 64)
+    nv = oracle.navi_batch(maps[sample], goals[sample])
+    ref = oracle.rollout(maps[sample], agents[sample], goals[sample], nv, tape[:, sample], want_obs_last=True)
+    assert np.array_equal(p[sample], ref["final_agents"])
+    assert np.array_equal(o[sample], ref["obs_last"])
+    assert np.array_equal(_np(env.navi_map())[sample], nv)
+
+
+def test_bad_action_raises_assertion(M):
+    maps, agents, goals = H.random_scenarios(2, 8, 4, 0.1, seed=1)
+    env = M.VecEnvironment(2, 8, 4)
+    env.load(maps, agents, goals)
+    acts = torch.zeros((2, 4), dtype=torch.int8, device="cuda")
+    acts[1, 2] = 5
+    env.step(acts)
+    with pytest.raises(AssertionError):
+        env.check_status()
+    env.step(torch.zeros((2, 4), dtype=torch.int8, device="cuda"))
+    env.check_status()  # sticky status was cleared
+
+
+def test_device_side_load_and_rewind(M):
+    maps, agents, goals = H.random_scenarios(8, 16, 12, 0.2, seed=9)
+    env = M.VecEnvironment(8, 16, 12)
+    env.load(torch.from_numpy(maps).cuda(), torch.from_numpy(agents).cuda(), torch.from_numpy(goals).cuda())
+    env.check_status()
+    nv = oracle.navi_batch(maps, goals)
+    assert np.array_equal(_np(env.navi_map()), nv)
+    tape = H.random_tape(10, 8, 12, seed=2)
+    outs = []
+    for rep in range(2):
+        for t in range(10):
+            obs, pos, *_ = env.step(torch.from_numpy(tape[t]).cuda())
+        outs.append((_np(obs).copy(), _np(pos).copy()))
+        env.set_agents(torch.from_numpy(agents).cuda())
+        assert int(_np(env.steps()).max()) == 0
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    bad = agents.copy()
+    bad[0, 0, 0] = 16
+    env.load(torch.from_numpy(maps).cuda(), torch.from_numpy(bad).cuda(), torch.from_numpy(goals).cuda())
+    with pytest.raises(Exception):
+        env.check_status()
+
+
+def test_single_env_facade_matches_reference_api(M):
+    """`Environment` keeps the reference's signatures / return types (environment.py:198,278,433)."""
+    z = H.load_npz("env_fixtures.npz")
+    pre = "fix16_c0_"
+    m, a, g = z[pre + "map"], z[pre + "agents"].astype(np.int64), z[pre + "goals"].astype(np.int64)
+    env = M.Environment()
+    env.load(m, a, g)
+    assert env.num_agents == 16 and env.map_size == (40, 40) and env.steps == 0
+    assert env.navi_map.shape == (16, 4, 48, 48) and env.navi_map.dtype == bool
+    obs, pos = env.observe()
+    assert obs.shape == (16, 6, 9, 9) and obs.dtype == bool and pos.dtype == np.int64
+    acts = z[pre + "mixed_actions"]
+    for t in range(8):
+        (obs, pos), rewards, done, info = env.step([int(x) for x in acts[t]])
+        assert isinstance(rewards, list) and len(rewards) == 16 and isinstance(done, bool)
+        assert info == {"step": t}
+        assert np.array_equal(pos, z[pre + "mixed_pos"][t + 1])
+        assert rewards == z[pre + "mixed_rewards"][t].tolist()
+    assert env.steps == 8
+    with pytest.raises(AssertionError):
+        env.step([0] * 15)
+    with pytest.raises(AssertionError):
+        env.step([5] + [0] * 15)
+    # constructor / reset path: random scenario by the reference's rule
+    env2 = M.Environment(map_length=12, num_agents=5)
+    o, p = env2.reset()
+    assert o.shape == (5, 6, 9, 9) and p.shape == (5, 2)
+    o, p = env2.reset(num_agents=3, map_length=10)
+    assert o.shape == (3, 6, 9, 9) and env2.map_size == (10, 10)
