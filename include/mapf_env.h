@@ -40,7 +40,7 @@ extern "C" {
 #define MAPF_ERR_ACTION (-2)        /* AssertionError 'action index out of range', environment.py:289-290 */
 #define MAPF_ERR_OVERLAP (-3)       /* RuntimeError('unique'): two agents on one cell, environment.py:424-428 */
 #define MAPF_ERR_HIP (-4)           /* a HIP runtime call failed (no GPU, OOM, launch failure) */
-#define MAPF_ERR_UNSUPPORTED (-5)   /* shape outside what the kernels are built for (L > 64, N > 256, r != 4) */
+#define MAPF_ERR_UNSUPPORTED (-5)   /* shape outside what the kernels are built for (L > 64, N > 255, r != 4) */
 #define MAPF_ERR_NO_SPACE (-6)      /* ValueError from placement exhaustion, environment.py:120 */
 #define MAPF_ERR_NOT_READY (-7)     /* step/observe before load + build_navi */
 
@@ -61,7 +61,7 @@ int mapf_device_count(void);
 
 /*
  * Replaces Environment.__init__'s shape arguments (environment.py:75-76): allocates device state for
- * E environments of map side L (2..64), N agents (1..256), FOV radius r (must be 4: the model's
+ * E environments of map side L (2..64), N agents (1..255), FOV radius r (must be 4: the model's
  * obs_shape (6,9,9) is hard-wired, config.py:14, model.py:148,164,235).
  */
 int mapf_create(int num_envs, int map_len, int num_agents, int obs_radius, int device, mapf_env_t **out);

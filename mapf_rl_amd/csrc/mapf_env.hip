@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -55,6 +56,8 @@ struct StepParams {
     float *reward;
     uint8_t *done;
     float rtab[5];
+    int ablate;  // tuning only: bit0 skip navi loads, bit1 skip obs stores
+    unsigned long long *dbg;  // diagnostic builds only: per-block phase stamps [E][8]
 };
 
 // columns y-R .. y+R of a bit row -> bits 0 .. 2R (out-of-range columns read 0)
@@ -80,7 +83,7 @@ __device__ __forceinline__ unsigned expand4(unsigned nib) { return (nib * 0x0020
 //            exactly the byte expansion of the concatenated fields, streamed out with VEC-byte stores.
 // ---------------------------------------------------------------------------------------------
 template <typename W, int R, bool DO_STEP, int VEC>
-__global__ void __launch_bounds__(256) env_step_kernel(StepParams p) {
+__global__ void __launch_bounds__(256) env_step_kernel_v1(StepParams p) {
     constexpr int WW = 2 * R + 1;
     const int e = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
     const int L = p.L, N = p.N;
@@ -293,6 +296,319 @@ __global__ void __launch_bounds__(256) env_step_kernel(StepParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// env_step_kernel (v2): one workgroup per environment, instruction-lean formulation.
+//   * every global load is issued up front: the navi records an agent can need after the step are rows
+//     min(x, x+dx)-R .. max(x, x+dx)+R (<= 2R+2 rows, dx from its action), fetched speculatively into
+//     registers while the step logic runs -- no dependent HBM round trip after the step;
+//   * occupant lookup through a padded id grid in LDS (O(1)); the rivals for a target cell can only be the
+//     occupants of its 4 neighbours, so rule (b) is 4 grid lookups instead of an O(N) scan;
+//   * the observation is assembled as a bit string in LDS (bit b of the string = output byte b of this
+//     env's obs block, because every channel row is a (2R+1)-bit field at bit offset (2R+1)*field), then
+//     expanded 16 bits -> 16 bytes per lane per store.
+// ---------------------------------------------------------------------------------------------
+template <int WW>
+__device__ __forceinline__ void deposit_field(unsigned *bits, unsigned off, unsigned v) {
+    if (v) {
+        unsigned d = off >> 5, sh = off & 31u;
+        atomicOr(&bits[d], v << sh);
+        if (sh > 32u - WW) atomicOr(&bits[d + 1], v >> (32u - sh));
+    }
+}
+
+__device__ __forceinline__ unsigned expand4m(unsigned nib) { return __umul24(nib, 0x00204081u) & 0x01010101u; }
+
+template <int NT>
+__device__ __forceinline__ void block_sync() {
+    __syncthreads();  // NT == 64: one wavefront per block, the compiler drops the s_barrier
+}
+template <int NT>
+__device__ __forceinline__ int block_or(int pred) {
+    if constexpr (NT == 64) return __any(pred);
+    else return __syncthreads_or(pred);
+}
+template <int NT>
+__device__ __forceinline__ int block_and(int pred) {
+    if constexpr (NT == 64) return __all(pred);
+    else return __syncthreads_and(pred);
+}
+
+template <typename W, int R, bool DO_STEP, bool DO_OBS, int VEC, int ITERS, int NT>
+__global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
+    constexpr int WW = 2 * R + 1;
+    constexpr int SPAN = WW + 1;
+    const int e = blockIdx.x, t = threadIdx.x;
+    constexpr int nt = NT;
+    const int L = p.L, N = p.N;
+    const int LP = L + 2 * R;
+    const int GP = L + 2;  // id grid pitch (1-cell border)
+    const int NP = (N + 7) & ~7;
+    const int grid_q = (GP * GP + 15) >> 4;          // uint4 count of the id grid
+    const int bits_q = ((N * 6 * WW * WW + 31) / 32 + 1 + 3) >> 2;  // uint4 count of the bit string (+1 spill dword)
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    W *s_obst = reinterpret_cast<W *>(smem);                             // [LP]
+    W *s_agent = s_obst + LP;                                            // [LP]
+    unsigned char *base = smem + (((size_t)2 * LP * sizeof(W) + 15) & ~(size_t)15);
+    unsigned char *s_id = base;                                          // [grid_q*16]  0xFF = empty
+    unsigned *s_bits = reinterpret_cast<unsigned *>(s_id + (size_t)grid_q * 16);  // [bits_q*4]
+    unsigned short *s_cur = reinterpret_cast<unsigned short *>(s_bits + (size_t)bits_q * 4);  // [NP]
+    unsigned short *s_next = s_cur + NP;                                 // [NP]
+    unsigned short *s_mov = s_next + NP;                                 // [NP]
+
+#define STAMP(k)                                                                       \
+    if (p.dbg && t == 0) {                                                             \
+        unsigned long long _ts;                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_ts)::"memory");   \
+        p.dbg[(size_t)e * 8 + (k)] = _ts;                                              \
+    }
+    STAMP(0)
+    // ---- round 1: every small load, unconditional (clamped indices) so that they all go out back to back ----
+    const bool agent = t < N;
+    const size_t own = (size_t)e * N + (agent ? t : N - 1);
+    const short2 cpos = *reinterpret_cast<const short2 *>(p.agents + own * 2);
+    short2 gpos = make_short2(0, 0);
+    int act = 0;
+    if constexpr (DO_STEP) {
+        gpos = *reinterpret_cast<const short2 *>(p.goals + own * 2);
+        act = p.actions[own];
+    }
+    const W *map_rows = reinterpret_cast<const W *>(p.map_rows) + (size_t)e * L;
+    constexpr int ROW_ITERS = (64 + 2 * R + NT - 1) / NT;  // covers LP <= 64 + 2R
+    W mrow[ROW_ITERS];
+#pragma unroll
+    for (int q = 0; q < ROW_ITERS; ++q) {
+        int rr = t + q * nt - R;
+        rr = rr < 0 ? 0 : (rr >= L ? L - 1 : rr);
+        mrow[q] = map_rows[rr];
+    }
+    int px[ITERS], pdx[ITERS];
+    if constexpr (DO_OBS) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            int k = t + it * nt;
+            k = k < N * SPAN ? k : N * SPAN - 1;
+            const size_t o = (size_t)e * N + k / SPAN;
+            px[it] = p.agents[o * 2];
+            pdx[it] = 0;
+            if constexpr (DO_STEP) pdx[it] = p.actions[o];
+        }
+    }
+    // ---- round 2: the navi records this env can need after the step (speculative, clamped, unconditional) ----
+    NaviRec<W> rec[ITERS];
+    int rrow[ITERS];
+    if constexpr (DO_OBS) {
+        const unsigned navi_mul = (p.ablate & 1) ? 0u : 1u;  // tuning: 0 = every lane reads record 0 (no traffic)
+        const NaviRec<W> *navi = reinterpret_cast<const NaviRec<W> *>(p.navi) + (size_t)e * N * L * navi_mul;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int k = t + it * nt;
+            const int kc = k < N * SPAN ? k : N * SPAN - 1;
+            const int i = kc / SPAN, slot = kc - i * SPAN;
+            const int a = pdx[it];
+            const int dx = (a == 2) - (a == 1);
+            const int row = px[it] + (dx < 0 ? dx : 0) - R + slot;
+            const bool need = k < N * SPAN && slot < WW + (dx != 0) && row >= 0 && row < L;
+            const int rowc = row < 0 ? 0 : (row >= L ? L - 1 : row);
+            rrow[it] = need ? row : -1;
+            rec[it] = navi[(size_t)(i * L + rowc) * navi_mul];
+        }
+    }
+    // ---- LDS init (needs only round 1) ----
+#pragma unroll
+    for (int q = 0; q < ROW_ITERS; ++q) {
+        const int r = t + q * nt;
+        if (r < LP) {
+            const int rr = r - R;
+            s_obst[r] = (rr >= 0 && rr < L) ? mrow[q] : (W)0;
+            s_agent[r] = (W)0;
+        }
+    }
+    if constexpr (DO_STEP) {
+        const uint4 ff = make_uint4(~0u, ~0u, ~0u, ~0u);
+        for (int k = t; k < grid_q; k += nt) reinterpret_cast<uint4 *>(s_id)[k] = ff;
+    }
+    if constexpr (DO_OBS) {
+        const uint4 zz = make_uint4(0u, 0u, 0u, 0u);
+        for (int k = t; k < bits_q; k += nt) reinterpret_cast<uint4 *>(s_bits)[k] = zz;
+    }
+    const int cx = cpos.x, cy = cpos.y, gx = gpos.x, gy = gpos.y;
+    int nx = cx, ny = cy;
+    int rc = MAPF_RC_STAY_ON_GOAL;
+    int all_done = 0;
+    block_sync<NT>();
+    STAMP(1)
+
+    if constexpr (DO_STEP) {
+        bool mover = false;
+        if (agent) {
+            if (act < 0 || act > 4) {  // reference: AssertionError (environment.py:290)
+                atomicOr(p.status, kStatusAction);
+                act = 0;
+            }
+            // S0 (environment.py:298-311)
+            mover = act != 0;
+            nx = cx + (act == 2) - (act == 1);  // action_list, environment.py:12
+            ny = cy + (act == 4) - (act == 3);
+            rc = mover ? MAPF_RC_MOVE : ((cx == gx && cy == gy) ? MAPF_RC_STAY_ON_GOAL : MAPF_RC_STAY_OFF_GOAL);
+            // S1 (environment.py:320-332)
+            if (mover) {
+                bool blocked = nx < 0 || ny < 0 || nx >= L || ny >= L;
+                if (!blocked) blocked = (s_obst[nx + R] >> ny) & 1;
+                if (blocked) {
+                    mover = false;
+                    rc = MAPF_RC_COLLISION;
+                    nx = cx;
+                    ny = cy;
+                }
+            }
+            s_id[(cx + 1) * GP + cy + 1] = (unsigned char)t;
+            s_next[t] = (unsigned short)((nx << 8) | ny);
+            s_mov[t] = mover;
+        }
+        block_sync<NT>();
+
+        // S2 swap (environment.py:335-365)
+        const unsigned my_cur = (unsigned)((cx << 8) | cy);
+        const unsigned my_next = (unsigned)((nx << 8) | ny);
+        int occ = 0xFF;
+        bool swap = false;
+        if (mover) {
+            occ = s_id[(nx + 1) * GP + ny + 1];
+            if (occ != 0xFF) swap = s_mov[occ] && s_next[occ] == my_cur;
+        }
+        block_sync<NT>();
+        if (swap) {
+            mover = false;
+            rc = MAPF_RC_COLLISION;
+            nx = cx;
+            ny = cy;
+            s_next[t] = (unsigned short)my_cur;
+            s_mov[t] = 0;
+        }
+        block_sync<NT>();
+
+        // S3 vertex (environment.py:368-406), rule (b): a lower-id mover claims the same cell.  Rivals can
+        // only stand on the 4 neighbours of the target cell.
+        bool lose = false;
+        if (mover) {
+            const int c = (nx + 1) * GP + ny + 1;
+            const int nb[4] = {c - GP, c + GP, c - 1, c + 1};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = s_id[nb[q]];
+                if (j < t) lose |= (s_mov[j] && s_next[j] == my_next);
+            }
+        }
+        // rule (a) + cascade: target cell held by an agent that is (now) settled
+        for (int round = 0; round <= N; ++round) {
+            bool revert = mover && (lose || (occ != 0xFF && !s_mov[occ]));
+            int any = block_or<NT>(revert);
+            if (revert) {
+                mover = false;
+                rc = MAPF_RC_COLLISION;
+                nx = cx;
+                ny = cy;
+                s_mov[t] = 0;
+            }
+            if (!any) break;
+            block_sync<NT>();
+        }
+
+        // S4 (environment.py:410-430); the result stores are issued at the very end of the kernel
+        all_done = block_and<NT>(!agent || (nx == gx && ny == gy));
+        if (all_done) rc = MAPF_RC_FINISH;
+    }
+
+    // ---- agent occupancy rows after the step (+ the overlap invariant, environment.py:424-428) ----
+    if (agent) {
+        W bit = (W)1 << ny;
+        W old = lds_or(&s_agent[nx + R], bit);
+        if (DO_STEP && (old & bit)) atomicOr(p.status, kStatusOverlap);
+        s_cur[t] = (unsigned short)((nx << 8) | ny);
+    }
+    if constexpr (DO_OBS) {
+        block_sync<NT>();
+        STAMP(2)
+
+        // ---- fields of every prefetched record that lies inside the final window ----
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (rrow[it] >= 0) {
+                const int k = t + it * nt;
+                const int i = k / SPAN;
+                const unsigned key = s_cur[i];
+                const int x = key >> 8, y = key & 255;
+                const int dy = rrow[it] - (x - R);
+                if (dy >= 0 && dy < WW) {
+                    unsigned f_ag = window_bits<W, R>(s_agent[x + dy], y);
+                    if (dy == R) f_ag &= ~(1u << R);  // centre of channel 0 forced to 0 (environment.py:461)
+                    const unsigned f_ob = window_bits<W, R>(s_obst[x + dy], y);
+                    const unsigned off = (unsigned)((i * 6 * WW + dy) * WW);
+                    deposit_field<WW>(s_bits, off, f_ag);
+                    deposit_field<WW>(s_bits, off + WW * WW, f_ob);
+                    deposit_field<WW>(s_bits, off + 2 * WW * WW, window_bits<W, R>(rec[it].w[0], y));
+                    deposit_field<WW>(s_bits, off + 3 * WW * WW, window_bits<W, R>(rec[it].w[1], y));
+                    deposit_field<WW>(s_bits, off + 4 * WW * WW, window_bits<W, R>(rec[it].w[2], y));
+                    deposit_field<WW>(s_bits, off + 5 * WW * WW, window_bits<W, R>(rec[it].w[3], y));
+                }
+            }
+        }
+        block_sync<NT>();
+        STAMP(3)
+
+        // ---- expand the bit string: bit b -> byte b of this env's observation block ----
+        const int total = N * 6 * WW * WW;
+        uint8_t *out = p.obs + (size_t)e * total;
+        if constexpr (VEC == 16) {
+            const unsigned short *b16 = reinterpret_cast<const unsigned short *>(s_bits);
+            const int ntask = total >> 4;
+            for (int task = t; task < ntask; task += nt) {
+                const unsigned bits = b16[task];
+                uint4 v;
+                v.x = expand4m(bits & 15u);
+                v.y = expand4m((bits >> 4) & 15u);
+                v.z = expand4m((bits >> 8) & 15u);
+                v.w = expand4m(bits >> 12);
+                if ((p.ablate & 2) && v.x != 0x77u) continue;  // never true for real data: keeps the work, drops the store
+                reinterpret_cast<uint4 *>(out)[task] = v;
+            }
+        } else if constexpr (VEC == 4) {
+            const int ntask = total >> 2;
+            for (int task = t; task < ntask; task += nt) {
+                const unsigned bits = (s_bits[task >> 3] >> ((task & 7) * 4)) & 15u;
+                reinterpret_cast<unsigned *>(out)[task] = expand4m(bits);
+            }
+        } else {
+            for (int b = t; b < total; b += nt) out[b] = (uint8_t)((s_bits[b >> 5] >> (b & 31)) & 1u);
+        }
+        STAMP(4)
+    }
+
+    // ---- small result stores last (nothing waits on them) ----
+    if (agent) {
+        const size_t o = (size_t)e * N + t;
+        if constexpr (DO_STEP) {
+            *reinterpret_cast<short2 *>(p.agents + o * 2) = make_short2((short)nx, (short)ny);
+            if (p.rclass) p.rclass[o] = (int8_t)rc;
+            if (p.reward) p.reward[o] = p.rtab[rc];
+        }
+        if (p.pos_out) *reinterpret_cast<short2 *>(p.pos_out + o * 2) = make_short2((short)nx, (short)ny);
+    }
+    if constexpr (DO_STEP) {
+        if (t == 0) {
+            if (p.done) p.done[e] = (uint8_t)(all_done != 0);
+            p.steps[e] += 1;
+        }
+    }
+    if (p.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(5)
+    }
+#undef STAMP
+}
+
 // ---------------------------------------------------------------------------------------------
 // navi_bfs_kernel: Environment.get_navi_map (environment.py:217-276) as a bit-parallel BFS.
 // lane = map row, the frontier / visited sets are one W-bit word per row; one BFS level is
@@ -433,6 +749,11 @@ struct mapf_env {
     int32_t *status;
     bool loaded, navi_ready;
     float rtab[5];
+    int tune_threads;  // 0 = default; MAPF_STEP_THREADS (tuning experiments only)
+    int tune_lds_pad;  // extra dynamic LDS bytes per block to cap residency; MAPF_STEP_LDS_PAD
+    int tune_impl;     // 1 = v1 kernel (A/B only); MAPF_STEP_IMPL
+    int tune_ablate;   // MAPF_STEP_ABLATE (timing-only builds; results are wrong)
+    unsigned long long *dbg;  // phase-stamp buffer (diagnostics)
 };
 
 namespace {
@@ -459,34 +780,83 @@ struct DeviceGuard {
     }
 };
 
-size_t step_smem_bytes(const mapf_env *h) {
+size_t step_smem_bytes_v1(const mapf_env *h) {
     const int WW = 2 * h->R + 1;
     size_t LP = h->L + 2 * h->R;
     size_t NP = (h->N + 3) & ~3;
     return 2 * LP * word_bytes(h) + 3 * NP * 2 + ((size_t)h->N * 6 * WW + 8) * 2;
 }
 
+size_t step_smem_bytes(const mapf_env *h) {
+    const int WW = 2 * h->R + 1;
+    size_t LP = h->L + 2 * h->R, GP = h->L + 2, NP = (h->N + 7) & ~7;
+    size_t rows = (2 * LP * word_bytes(h) + 15) & ~(size_t)15;
+    size_t grid_q = (GP * GP + 15) >> 4;
+    size_t bits_q = (((size_t)h->N * 6 * WW * WW + 31) / 32 + 1 + 3) >> 2;
+    return rows + grid_q * 16 + bits_q * 16 + 3 * NP * 2;
+}
+
+// threads per block (one lane per agent in the step phase): 128 measured best on MI355X at N = 40
+// (19.9 us vs 21.6 us for 64 at 4096 envs); MAPF_STEP_THREADS overrides for tuning runs
 int step_block_threads(const mapf_env *h) {
-    int t = 128;
-    while (t < h->N) t += 64;
-    return t;
+    if (h->tune_threads == 64 || h->tune_threads == 128 || h->tune_threads == 256) {
+        if (h->tune_threads >= h->N) return h->tune_threads;
+    }
+    return h->N <= 128 ? 128 : 256;
+}
+
+template <typename W, bool DO_STEP, bool DO_OBS, int VEC, int NT>
+int launch_step_nt(const mapf_env *h, const StepParams &p, hipStream_t s, size_t smem) {
+    const int need = (h->N * 10 + NT - 1) / NT;
+    dim3 g(h->E), b(NT);
+    if constexpr (!DO_OBS) {
+        hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, false, 16, 1, NT>), g, b, smem, s, p);
+    } else if constexpr (NT == 64) {
+        if (need <= 4)
+            hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 4, NT>), g, b, smem, s, p);
+        else if (need <= 7)
+            hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 7, NT>), g, b, smem, s, p);
+        else
+            hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 10, NT>), g, b, smem, s, p);
+    } else {
+        if (need <= 4)
+            hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 4, NT>), g, b, smem, s, p);
+        else
+            hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 10, NT>), g, b, smem, s, p);
+    }
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+template <typename W, bool DO_STEP, bool DO_OBS, int VEC>
+int launch_step_iters(const mapf_env *h, const StepParams &p, hipStream_t s, int threads, size_t smem) {
+    if (threads == 64) return launch_step_nt<W, DO_STEP, DO_OBS, VEC, 64>(h, p, s, smem);
+    if (threads == 128) return launch_step_nt<W, DO_STEP, DO_OBS, VEC, 128>(h, p, s, smem);
+    return launch_step_nt<W, DO_STEP, DO_OBS, VEC, 256>(h, p, s, smem);
 }
 
 template <typename W, bool DO_STEP>
 int launch_step_vec(const mapf_env *h, const StepParams &p, hipStream_t s) {
     const int total = h->N * 6 * 81;
-    const size_t smem = step_smem_bytes(h);
     const int threads = step_block_threads(h);
     const bool a16 = (total % 16 == 0) && ((reinterpret_cast<uintptr_t>(p.obs) & 15) == 0);
     const bool a4 = (total % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.obs) & 3) == 0);
-    if (p.obs == nullptr || a16)
-        hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, 16>), dim3(h->E), dim3(threads), smem, s, p);
-    else if (a4)
-        hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, 4>), dim3(h->E), dim3(threads), smem, s, p);
-    else
-        hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, 1>), dim3(h->E), dim3(threads), smem, s, p);
-    HIP_TRY(hipGetLastError());
-    return MAPF_OK;
+    if (h->tune_impl == 1) {  // v1 kernel kept for A/B measurements only
+        const size_t smem = step_smem_bytes_v1(h) + (size_t)h->tune_lds_pad;
+        if (p.obs == nullptr || a16)
+            hipLaunchKernelGGL((env_step_kernel_v1<W, 4, DO_STEP, 16>), dim3(h->E), dim3(threads), smem, s, p);
+        else if (a4)
+            hipLaunchKernelGGL((env_step_kernel_v1<W, 4, DO_STEP, 4>), dim3(h->E), dim3(threads), smem, s, p);
+        else
+            hipLaunchKernelGGL((env_step_kernel_v1<W, 4, DO_STEP, 1>), dim3(h->E), dim3(threads), smem, s, p);
+        HIP_TRY(hipGetLastError());
+        return MAPF_OK;
+    }
+    const size_t smem = step_smem_bytes(h) + (size_t)h->tune_lds_pad;
+    if (p.obs == nullptr) return launch_step_iters<W, DO_STEP, false, 16>(h, p, s, threads, smem);
+    if (a16) return launch_step_iters<W, DO_STEP, true, 16>(h, p, s, threads, smem);
+    if (a4) return launch_step_iters<W, DO_STEP, true, 4>(h, p, s, threads, smem);
+    return launch_step_iters<W, DO_STEP, true, 1>(h, p, s, threads, smem);
 }
 
 template <bool DO_STEP>
@@ -506,6 +876,8 @@ StepParams make_params(mapf_env *h) {
     p.steps = h->steps;
     p.status = h->status;
     std::memcpy(p.rtab, h->rtab, sizeof(p.rtab));
+    p.ablate = h->tune_ablate;
+    p.dbg = h->dbg;
     return p;
 }
 
@@ -644,7 +1016,7 @@ int mapf_create(int num_envs, int map_len, int num_agents, int obs_radius, int d
     if (!out) return MAPF_ERR_INVALID_ARG;
     *out = nullptr;
     if (num_envs < 1 || map_len < 2 || num_agents < 1 || device < 0) return MAPF_ERR_INVALID_ARG;
-    if (map_len > 64 || num_agents > 256 || obs_radius != 4) return MAPF_ERR_UNSUPPORTED;
+    if (map_len > 64 || num_agents > 255 || obs_radius != 4) return MAPF_ERR_UNSUPPORTED;
     if (device >= mapf_device_count()) return MAPF_ERR_HIP;
     mapf_env *h = new (std::nothrow) mapf_env();
     if (!h) return MAPF_ERR_HIP;
@@ -655,6 +1027,15 @@ int mapf_create(int num_envs, int map_len, int num_agents, int obs_radius, int d
     h->device = device;
     h->wide = map_len > 32;
     h->loaded = h->navi_ready = false;
+    h->dbg = nullptr;
+    const char *tv = std::getenv("MAPF_STEP_THREADS");
+    h->tune_threads = tv ? std::atoi(tv) : 0;
+    tv = std::getenv("MAPF_STEP_LDS_PAD");
+    h->tune_lds_pad = tv ? std::atoi(tv) : 0;
+    tv = std::getenv("MAPF_STEP_IMPL");
+    h->tune_impl = tv ? std::atoi(tv) : 0;
+    tv = std::getenv("MAPF_STEP_ABLATE");
+    h->tune_ablate = tv ? std::atoi(tv) : 0;
     const float def[5] = {-0.075f, 0.0f, -0.075f, -0.5f, 3.0f};
     std::memcpy(h->rtab, def, sizeof(def));
     DeviceGuard guard(device);
@@ -875,6 +1256,13 @@ int mapf_check_status(mapf_env_t *h, void *stream) {
     if (st & kStatusRange) return MAPF_ERR_INVALID_ARG;
     if (st & kStatusAction) return MAPF_ERR_ACTION;
     if (st & kStatusOverlap) return MAPF_ERR_OVERLAP;
+    return MAPF_OK;
+}
+
+// diagnostics only (not part of include/mapf_env.h): device buffer uint64[E][8] receiving s_memtime phase stamps
+int mapf_debug_set_stamps(mapf_env_t *h, unsigned long long *buf_dev) {
+    if (!h) return MAPF_ERR_INVALID_ARG;
+    h->dbg = buf_dev;
     return MAPF_OK;
 }
 

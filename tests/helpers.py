@@ -47,11 +47,13 @@ def random_scenarios(E, L, N, density, seed):
     agents = np.zeros((E, N, 2), np.int16)
     goals = np.zeros((E, N, 2), np.int16)
     for e in range(E):
-        while True:
+        for attempt in range(1000):
             m = (rng.random_sample((L, L)) < density).astype(np.int8)
             free = np.argwhere(m == 0)
             if len(free) >= 2 * N:
                 break
+        else:
+            raise ValueError("random_scenarios: %dx%d at density %.2f cannot host %d agents" % (L, L, density, N))
         pick = free[rng.permutation(len(free))[:2 * N]]
         maps[e], agents[e], goals[e] = m, pick[:N], pick[N:]
     return maps, agents, goals

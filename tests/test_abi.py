@@ -44,7 +44,7 @@ def test_create_argument_checks_without_gpu():
     lib = _lib.lib
     assert lib.mapf_create(0, 8, 2, 4, 0, ctypes.byref(h)) == _lib.ERR_INVALID_ARG
     assert lib.mapf_create(1, 65, 2, 4, 0, ctypes.byref(h)) == _lib.ERR_UNSUPPORTED
-    assert lib.mapf_create(1, 8, 257, 4, 0, ctypes.byref(h)) == _lib.ERR_UNSUPPORTED
+    assert lib.mapf_create(1, 8, 256, 4, 0, ctypes.byref(h)) == _lib.ERR_UNSUPPORTED
     assert lib.mapf_create(1, 8, 2, 3, 0, ctypes.byref(h)) == _lib.ERR_UNSUPPORTED
     if lib.mapf_device_count() == 0:
         assert lib.mapf_create(1, 8, 2, 4, 0, ctypes.byref(h)) == _lib.ERR_HIP

@@ -120,7 +120,7 @@ def _heuristic_tape_step(obs, rng, p_follow):
     (16, 10, 1, 0.2, 24),      # single agent
     (16, 12, 3, 0.2, 24),
     (16, 12, 6, 0.2, 24),      # reference default num_agents
-    (4, 20, 200, 0.1, 16),     # N > 128
+    (4, 24, 200, 0.1, 16),     # N > 128
 ])
 def test_differential_vs_oracle(M, E, L, N, rho, T):
     maps, agents, goals = H.random_scenarios(E, L, N, rho, seed=E * 1000 + L * 10 + N)
