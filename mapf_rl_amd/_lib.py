@@ -36,6 +36,20 @@ SYMBOLS = [
     ("mapf_num_agents", _i, [_vp]),
     ("mapf_obs_radius", _i, [_vp]),
     ("mapf_generate", _i, [_i, _i, _i, _f, _u64, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_int32)]),
+    # include/mapf_replay.h
+    ("mapf_replay_create", _i, [_i, _i, _i, ctypes.POINTER(_vp)]),
+    ("mapf_replay_destroy", _i, [_vp]),
+    ("mapf_replay_row_dwords", _i, [_vp]),
+    ("mapf_replay_capacity", _i, [_vp]),
+    ("mapf_replay_ptr", _i, [_vp]),
+    ("mapf_replay_size", ctypes.c_int64, [_vp]),
+    ("mapf_replay_counter", ctypes.c_int64, [_vp, _i]),
+    ("mapf_replay_tree_update", _i, [_vp, _vp, _vp, _i, ctypes.c_double, _vp]),
+    ("mapf_replay_tree_sample", _i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    ("mapf_replay_tree_read", _i, [_vp, _vp, _vp]),
+    ("mapf_replay_add", _i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("mapf_replay_sample", _i, [_vp, _vp, _i] + [_vp] * 11),
+    ("mapf_replay_update_priorities", _i, [_vp, _vp, _vp, _i, _i, _vp]),
 ]
 
 

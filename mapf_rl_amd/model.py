@@ -1,0 +1,213 @@
+"""Recurrent, communicating dueling DQN of the reference (reference model.py:139-263), re-expressed for
+batched execution on one MI355X: E environments x N agents per actor step, [B, T, N] windows per update.
+
+Compatibility surface kept: `Network()` has the reference's module tree, so `state_dict()` key names and
+shapes are identical (`obs_encoder.{0,2,3,4,5}.*`, `recurrent.*`, `comm.self_attn.W_{Q,K,V,O}.*`,
+`comm.update_cell.*`, `adv.*`, `state.*`; 2,050,582 parameters) and reference checkpoints load unchanged;
+`Network.step(obs, pos)`, `.reset()` and `.bootstrap(obs, steps, hidden, comm_mask)` keep the reference's
+signatures and return types (model.py:180-263).
+
+Declared deviations from the reference:
+  * `bootstrap` / `CommBlock` take the batch size from their inputs (the reference hard-codes
+    config.batch_size, model.py:128,239,245,255 -- quirk Q5).
+  * The 3-nearest-neighbour selection (model.py:203, `topk`) breaks distance ties by LOWEST agent index
+    (deterministic); the reference's CPU topk order on ties is unspecified.  Parity tests inject the
+    reference's comm_mask and check the mask itself on tie-free rows.
+  * On a HIP device the forward runs under bf16 autocast (the reference uses fp16 autocast + GradScaler on
+    CUDA and fp32 on CPU); attention scores / softmax stay fp32 as in model.py:75-78.
+"""
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+OBS_SHAPE = (6, 9, 9)   # reference config.py:14
+LATENT_DIM = 256        # config.py:56
+OBS_RADIUS = 4          # config.py:7
+MAX_COMM_AGENTS = 3     # config.py:59
+NUM_COMM_LAYERS = 2     # config.py:62
+NUM_COMM_HEADS = 2      # config.py:63
+ENC_FEATURES = 16 * 7 * 7
+
+
+class ResBlock(nn.Module):
+    """Two 3x3 pad-1 convolutions with an identity skip, no normalisation (reference model.py:7-42, type='cnn')."""
+
+    def __init__(self, channel):
+        super().__init__()
+        self.block1 = nn.Conv2d(channel, channel, 3, 1, 1)
+        self.block2 = nn.Conv2d(channel, channel, 3, 1, 1)
+
+    def forward(self, x):
+        return F.relu(self.block2(F.relu(self.block1(x))) + x)
+
+
+class MultiHeadAttention(nn.Module):
+    """Masked multi-head attention over the agents of one environment (reference model.py:45-87)."""
+
+    def __init__(self, input_dim, output_dim, num_heads):
+        super().__init__()
+        self.num_heads, self.input_dim, self.output_dim = num_heads, input_dim, output_dim
+        self.W_Q = nn.Linear(input_dim, output_dim * num_heads)
+        self.W_K = nn.Linear(input_dim, output_dim * num_heads)
+        self.W_V = nn.Linear(input_dim, output_dim * num_heads)
+        self.W_O = nn.Linear(output_dim * num_heads, output_dim, bias=False)
+
+    def forward(self, x, blocked):
+        """x [B, N, input_dim]; blocked bool [B, N, N] (True = may NOT attend)."""
+        B, N, _ = x.shape
+        H, D = self.num_heads, self.output_dim
+        q = self.W_Q(x).view(B, N, H, D).transpose(1, 2)
+        k = self.W_K(x).view(B, N, H, D).transpose(1, 2)
+        v = self.W_V(x).view(B, N, H, D).transpose(1, 2)
+        # scores and softmax in fp32 (model.py:75-78)
+        scores = torch.matmul(q.float(), k.float().transpose(-1, -2)) / (D ** 0.5)
+        scores = scores.masked_fill(blocked.unsqueeze(1), -1e9)
+        attn = F.softmax(scores, dim=-1)
+        ctx = torch.matmul(attn.to(v.dtype), v)
+        ctx = ctx.transpose(1, 2).reshape(B, N, H * D)
+        return self.W_O(ctx)
+
+
+class CommBlock(nn.Module):
+    """`NUM_COMM_LAYERS` rounds (shared weights) of attention + GRU update, applied only to agents that have
+    at least one communication partner (reference model.py:89-135)."""
+
+    def __init__(self, input_dim, output_dim=64, num_heads=NUM_COMM_HEADS, num_layers=NUM_COMM_LAYERS):
+        super().__init__()
+        self.input_dim, self.output_dim, self.num_layers = input_dim, output_dim, num_layers
+        self.self_attn = MultiHeadAttention(input_dim, output_dim, num_heads)
+        self.update_cell = nn.GRUCell(output_dim, input_dim)
+
+    def forward(self, latent, comm_mask):
+        """latent [B, N, input_dim]; comm_mask bool [B, N, N] (True = communicates)."""
+        B, N, _ = latent.shape
+        update = (comm_mask.sum(dim=-1) > 1).unsqueeze(-1)  # model.py:103
+        blocked = ~comm_mask
+        for _ in range(self.num_layers):
+            info = self.self_attn(latent, blocked)
+            new = self.update_cell(info.reshape(B * N, self.output_dim), latent.reshape(B * N, self.input_dim))
+            latent = torch.where(update, new.view(B, N, self.input_dim).to(latent.dtype), latent)
+        return latent
+
+
+def comm_mask_from_pos(pos: torch.Tensor, obs_radius: int = OBS_RADIUS, max_comm: int = MAX_COMM_AGENTS) -> torch.Tensor:
+    """pos [E, N, 2] (any integer/float dtype) -> bool [E, N, N]: j is within i's FOV square AND among i's
+    `max_comm` nearest agents by Euclidean distance, itself included (reference model.py:195-208).
+    Distance ties are broken by lowest agent index."""
+    p = pos.to(torch.int64)
+    E, N, _ = p.shape
+    d = (p.unsqueeze(2) - p.unsqueeze(1)).abs()              # [E, N, N, 2]
+    in_fov = (d <= obs_radius).all(-1)
+    d2 = d[..., 0] ** 2 + d[..., 1] ** 2                      # same ordering as the reference's sqrt
+    key = d2 * N + torch.arange(N, device=p.device)           # unique keys: ties -> lowest index first
+    k = min(max_comm, N)
+    nearest = key.topk(k, dim=-1, largest=False).indices
+    near = torch.zeros((E, N, N), dtype=torch.bool, device=p.device)
+    near.scatter_(2, nearest, True)
+    return in_fov & near
+
+
+class Network(nn.Module):
+    def __init__(self, cnn_channel: int = 64):  # `cnn_channel` is accepted and ignored like the reference (model.py:140)
+        super().__init__()
+        self.latent_dim = LATENT_DIM
+        self.obs_encoder = nn.Sequential(
+            nn.Conv2d(OBS_SHAPE[0], 128, 3, 1),
+            nn.ReLU(True),
+            ResBlock(128),
+            ResBlock(128),
+            ResBlock(128),
+            nn.Conv2d(128, 16, 1, 1),
+            nn.ReLU(True),
+            nn.Flatten(),
+        )
+        self.recurrent = nn.GRUCell(ENC_FEATURES, self.latent_dim)
+        self.comm = CommBlock(self.latent_dim)
+        self.adv = nn.Linear(self.latent_dim, 5)
+        self.state = nn.Linear(self.latent_dim, 1)
+        self.hidden = None
+        # model.py:174-178: Xavier-uniform weights / zero bias on Linear and Conv2d only
+        for m in self.modules():
+            if isinstance(m, (nn.Linear, nn.Conv2d)):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    # ------------------------------------------------------------------ building blocks
+    def _autocast(self, device):
+        on_gpu = device.type == "cuda"
+        return torch.autocast(device_type="cuda" if on_gpu else "cpu", dtype=torch.bfloat16, enabled=on_gpu)
+
+    def encode(self, obs):
+        """obs [M, 6, 9, 9] (uint8 / bool / float) -> [M, 784]."""
+        w = self.obs_encoder[0].weight
+        x = obs.to(w.dtype) if obs.dtype != w.dtype else obs
+        return self.obs_encoder(x)
+
+    def q_head(self, hidden):
+        adv = self.adv(hidden)
+        return self.state(hidden) + adv - adv.mean(-1, keepdim=True)  # model.py:218,262
+
+    # ------------------------------------------------------------------ actor side
+    @torch.no_grad()
+    def step_batch(self, obs, pos, hidden: Optional[torch.Tensor], comm_mask: Optional[torch.Tensor] = None):
+        """One actor step for E environments at once.
+        obs [E, N, 6, 9, 9], pos [E, N, 2], hidden [E*N, 256] or None (episode start, model.py:186-189).
+        Returns (actions int64 [E, N], q float32 [E, N, 5], hidden [E*N, 256] (compute dtype), comm_mask bool [E, N, N])."""
+        E, N = obs.shape[:2]
+        with self._autocast(obs.device):
+            latent = self.encode(obs.reshape(E * N, *OBS_SHAPE))
+            hidden = self.recurrent(latent) if hidden is None else self.recurrent(latent, hidden.to(latent.dtype))
+            if comm_mask is None:
+                comm_mask = comm_mask_from_pos(pos)
+            hidden = self.comm(hidden.view(E, N, self.latent_dim), comm_mask).reshape(E * N, self.latent_dim)
+            q = self.q_head(hidden).float().view(E, N, 5)
+        return q.argmax(-1), q, hidden, comm_mask
+
+    @torch.no_grad()
+    def step(self, obs, pos, comm_mask=None):
+        """Reference-compatible single-environment step (model.py:180-222): keeps the recurrent state in
+        `self.hidden`; returns (actions list[int], q ndarray [N,5], hidden ndarray [N,256], comm_mask ndarray [N,N])."""
+        dev = self.adv.weight.device
+        obs = torch.as_tensor(obs).to(dev)
+        pos = torch.as_tensor(pos).to(dev)
+        cm = None if comm_mask is None else torch.as_tensor(comm_mask).to(dev).unsqueeze(0)
+        actions, q, self.hidden, cm = self.step_batch(obs.unsqueeze(0), pos.unsqueeze(0), self.hidden, cm)
+        return (actions[0].tolist(), q[0].cpu().numpy(), self.hidden.float().cpu().numpy(), cm[0].cpu().numpy())
+
+    def reset(self):
+        self.hidden = None
+
+    # ------------------------------------------------------------------ learner side
+    def bootstrap(self, obs, steps, hidden, comm_mask):
+        """Training forward over a [B, T] window of N agents (model.py:227-263).
+        obs [B, T, N, 6, 9, 9]; steps int64 [B] (1-based index of the step whose agent-0 hidden feeds the Q head);
+        hidden [B*N, 256]; comm_mask bool [B, T, N, N].  Returns q [B, 5] (float32)."""
+        B, T, N = obs.shape[:3]
+        with self._autocast(obs.device):
+            latent = self.encode(obs.reshape(B * T * N, *OBS_SHAPE)).view(B, T, N, ENC_FEATURES)
+            hidden = hidden.to(latent.dtype)
+            agent0 = []
+            for t in range(T):
+                hidden = self.recurrent(latent[:, t].reshape(B * N, ENC_FEATURES), hidden)
+                hidden = self.comm(hidden.view(B, N, self.latent_dim), comm_mask[:, t])
+                agent0.append(hidden[:, 0])                      # only agent 0's state is learned from (:248)
+                hidden = hidden.reshape(B * N, self.latent_dim)
+            agent0 = torch.stack(agent0, dim=1)                   # [B, T, 256]
+            sel = agent0[torch.arange(B, device=obs.device), steps.to(obs.device) - 1]
+            q = self.q_head(sel)
+        return q.float()
+
+
+def load_reference_checkpoint(net: Network, path: str, map_location="cpu"):
+    """Loads a `.pth` produced by the reference (worker.py:338) or by this package: same key names."""
+    sd = torch.load(path, map_location=map_location)
+    net.load_state_dict(sd)
+    return net
+
+
+def num_parameters(net: nn.Module) -> int:
+    return sum(p.numel() for p in net.parameters())

@@ -1,0 +1,227 @@
+"""On-device prioritized episode replay: host-side mirror of the reference's `GlobalBuffer`
+(reference worker.py:21-250) and `SumTree` (reference buffer.py:16-105) on top of include/mapf_replay.h.
+
+All episode data and the f64 sum tree live in HBM; `sample_batch` is a tree descent plus one gather kernel.
+The ring pointer / size / counter and the curriculum statistics stay on the host like in the reference.
+PyTorch is used for device memory and streams only."""
+import ctypes
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+MAX_STEPS, BT_STEPS, FORWARD_STEPS = 256, 16, 2
+ALPHA, BETA = 0.6, 0.4  # reference config.py:42-43
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def pack_obs_rows(obs, max_agents, row_dwords):
+    """bool/uint8 [R, na, 6, 9, 9] -> uint32 [R, row_dwords]: bit (a*486 + c*81 + cell), padded agents zero."""
+    obs = np.asarray(obs)
+    R, na = obs.shape[:2]
+    full = np.zeros((R, max_agents, 486), dtype=np.uint8)
+    full[:, :na] = obs.reshape(R, na, 486)
+    bits = np.packbits(full.reshape(R, max_agents * 486), axis=1, bitorder="little")
+    out = np.zeros((R, row_dwords * 4), dtype=np.uint8)
+    out[:, :bits.shape[1]] = bits
+    return out.view(np.uint32)
+
+
+def pack_comm_rows(comm, max_agents):
+    """bool [R, na, na] -> uint32 [R, A, CW]: bit j of word [a][j/32] = comm[r][a][j]."""
+    comm = np.asarray(comm)
+    R, na = comm.shape[:2]
+    cw = (max_agents + 31) // 32
+    full = np.zeros((R, max_agents, cw * 32), dtype=np.uint8)
+    full[:, :na, :na] = comm
+    return np.packbits(full, axis=2, bitorder="little").view(np.uint32).reshape(R, max_agents, cw)
+
+
+class SumTree:
+    """Device sum tree with the reference's interface (buffer.py:16-105), used through `GlobalBuffer` or alone."""
+
+    def __init__(self, replay_handle, leaves, device):
+        self._h, self.capacity, self.device = replay_handle, leaves, device
+
+    def batch_update(self, idxes, priorities, alpha=0.0):
+        idx = torch.as_tensor(idxes, dtype=torch.int64).to(self.device).contiguous()
+        pri = torch.as_tensor(priorities, dtype=torch.float64).to(self.device).contiguous()
+        check(lib.mapf_replay_tree_update(self._h, _ptr(idx), _ptr(pri), idx.numel(), float(alpha), _stream(self.device)),
+              "mapf_replay_tree_update")
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def batch_sample(self, batch_size, uniforms=None):
+        u = self._uniforms(batch_size, uniforms)
+        idx = torch.empty(batch_size, dtype=torch.int64, device=self.device)
+        pri = torch.empty(batch_size, dtype=torch.float64, device=self.device)
+        check(lib.mapf_replay_tree_sample(self._h, _ptr(u), batch_size, _ptr(idx), _ptr(pri), _stream(self.device)),
+              "mapf_replay_tree_sample")
+        return idx, pri
+
+    def _uniforms(self, batch_size, uniforms):
+        if uniforms is not None:
+            return torch.as_tensor(uniforms, dtype=torch.float64).to(self.device).contiguous()
+        # buffer.py:60: U(0, interval) per stratum; interval = sum / batch_size
+        return torch.rand(batch_size, dtype=torch.float64, device=self.device) * (self.sum() / batch_size)
+
+    def tree(self):
+        out = torch.empty(2 * self.capacity - 1, dtype=torch.float64, device=self.device)
+        check(lib.mapf_replay_tree_read(self._h, _ptr(out), _stream(self.device)), "mapf_replay_tree_read")
+        return out
+
+    def sum(self):
+        return float(self.tree()[0].item())
+
+
+class GlobalBuffer:
+    """reference worker.py:21-250 (the Ray plumbing `run/prepare_data/get_data` is replaced by same-device calls)."""
+
+    def __init__(self, capacity, max_agents=6, alpha=ALPHA, beta=BETA, device=None, init_set=(1, 10),
+                 max_map_length=40, pass_rate=0.9):
+        if not torch.cuda.is_available():
+            raise RuntimeError("mapf_rl_amd.GlobalBuffer needs a HIP device (no CPU fallback)")
+        assert abs(alpha - ALPHA) < 1e-12, "the priority exponent 0.6 is compiled into the add/update kernels"
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.capacity, self.max_agents, self.alpha, self.beta = capacity, max_agents, alpha, beta
+        self._h = ctypes.c_void_p()
+        check(lib.mapf_replay_create(capacity, max_agents, self.device.index, ctypes.byref(self._h)), "mapf_replay_create")
+        self.row_dwords = lib.mapf_replay_row_dwords(self._h)
+        self.priority_tree = SumTree(self._h, capacity * MAX_STEPS, self.device)
+        self.lock = threading.Lock()
+        # curriculum statistics (worker.py:32,74-82,205-250)
+        self.init_set, self.max_map_length, self.pass_rate = tuple(init_set), max_map_length, pass_rate
+        self.stat_dict = {self.init_set: []}
+        self.level = [self.init_set]
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            lib.mapf_replay_destroy(h)
+            self._h = ctypes.c_void_p()
+
+    def __len__(self):
+        return int(lib.mapf_replay_size(self._h))
+
+    size = property(lambda self: len(self))
+    ptr = property(lambda self: int(lib.mapf_replay_ptr(self._h)))
+
+    @property
+    def counter(self):
+        return int(lib.mapf_replay_counter(self._h, 0))
+
+    # ------------------------------------------------------------------ add
+    def add_episode_device(self, num_agents, size, done, obs_bits, comm_bits, act, rew, hid, td):
+        """All tensors already on the device in storage layout (see include/mapf_replay.h)."""
+        with self.lock:
+            check(lib.mapf_replay_add(self._h, int(num_agents), int(size), int(bool(done)), _ptr(obs_bits), _ptr(comm_bits),
+                                      _ptr(act), _ptr(rew), _ptr(hid), _ptr(td), _stream(self.device)), "mapf_replay_add")
+
+    def add_episode(self, num_agents, obs, act, rew, hid, td_errors, done, size, comm):
+        """One episode in the reference's array formats (LocalBuffer.finish tuple fields, buffer.py:179)."""
+        d = self.device
+        hid = np.asarray(hid)
+        if hid.ndim == 3:
+            hid = hid[:, 0]  # every agent row holds agent 0's state (quirk Q4)
+        t = dict(
+            obs=torch.from_numpy(pack_obs_rows(np.asarray(obs)[:size + 1], self.max_agents, self.row_dwords).view(np.int32)).to(d),
+            comm=torch.from_numpy(pack_comm_rows(np.asarray(comm)[:size + 1], self.max_agents).view(np.int32)).to(d),
+            act=torch.from_numpy(np.ascontiguousarray(np.asarray(act)[:size], np.uint8)).to(d),
+            rew=torch.from_numpy(np.ascontiguousarray(np.asarray(rew)[:size], np.float16)).to(d),
+            hid=torch.from_numpy(np.ascontiguousarray(hid[:size], np.float16)).to(d),
+            td=torch.from_numpy(np.ascontiguousarray(td_errors, np.float64)).to(d))
+        assert t["td"].numel() == MAX_STEPS
+        self.add_episode_device(num_agents, size, done, t["obs"], t["comm"], t["act"], t["rew"], t["hid"], t["td"])
+        torch.cuda.current_stream(d).synchronize()  # the staging tensors above are temporaries
+
+    def add(self, buffer_list):
+        """reference signature (worker.py:71): list of LocalBuffer.finish() tuples
+        (actor_id, num_agents, map_len, obs, act, rew, hid, td_errors, done, size, comm_mask)."""
+        for b in buffer_list:
+            if b[0] >= 10:  # curriculum statistics only from actors with id >= 10 (worker.py:74)
+                key = (b[1], b[2])
+                if key in self.stat_dict:
+                    if len(self.stat_dict[key]) >= 200:
+                        self.stat_dict[key].pop(0)
+                    self.stat_dict[key].append(b[8])
+        for b in buffer_list:
+            self.add_episode(b[1], b[3], b[4], b[5], b[6], b[7], b[8], b[9], b[10])
+
+    # ------------------------------------------------------------------ sample
+    def sample_batch(self, batch_size, uniforms=None):
+        """Returns the reference's 11-tuple (worker.py:168-182) as device tensors:
+        (obs bf16 [B,18,A,6,9,9], action i64 [B,1], reward f32 [B,1], done f32 [B,1], steps f32 [B,1],
+         bt_steps i64 [B], hidden f16 [B*A,256], comm_mask bool [B,18,A,A], idxes i64 [B], weights f32 [B,1], old_ptr)."""
+        d, A, B = self.device, self.max_agents, batch_size
+        with self.lock:
+            u = self.priority_tree._uniforms(B, uniforms)
+            idx = torch.empty(B, dtype=torch.int64, device=d)
+            pri = torch.empty(B, dtype=torch.float64, device=d)
+            obs = torch.empty((B, 18, A, 6, 9, 9), dtype=torch.bfloat16, device=d)
+            comm = torch.empty((B, 18, A, A), dtype=torch.uint8, device=d)
+            hidden = torch.empty((B * A, 256), dtype=torch.float16, device=d)
+            action = torch.empty(B, dtype=torch.int64, device=d)
+            reward = torch.empty(B, dtype=torch.float32, device=d)
+            done = torch.empty(B, dtype=torch.float32, device=d)
+            steps = torch.empty(B, dtype=torch.float32, device=d)
+            bt = torch.empty(B, dtype=torch.int64, device=d)
+            check(lib.mapf_replay_sample(self._h, _ptr(u), B, _ptr(idx), _ptr(pri), _ptr(obs), _ptr(comm), _ptr(hidden),
+                                         _ptr(action), _ptr(reward), _ptr(done), _ptr(steps), _ptr(bt), _stream(d)),
+                  "mapf_replay_sample")
+            old_ptr = self.ptr
+        weights = torch.pow(pri / pri.min(), -self.beta).to(torch.float32)  # worker.py:165-166
+        return (obs, action.unsqueeze(1), reward.unsqueeze(1), done.unsqueeze(1), steps.unsqueeze(1), bt, hidden,
+                comm.bool(), idx, weights.unsqueeze(1), old_ptr)
+
+    def update_priorities(self, idxes, priorities, old_ptr):
+        """worker.py:186-203; idxes / priorities: device tensors (or array-likes)."""
+        idx = torch.as_tensor(idxes, dtype=torch.int64).to(self.device).contiguous()
+        pri = torch.as_tensor(priorities).to(self.device, torch.float64).contiguous()
+        with self.lock:
+            check(lib.mapf_replay_update_priorities(self._h, _ptr(idx), _ptr(pri), idx.numel(), int(old_ptr), _stream(self.device)),
+                  "mapf_replay_update_priorities")
+        self._keep = (idx, pri)  # keep the (possibly temporary) tensors alive until the next call
+
+    # ------------------------------------------------------------------ curriculum / stats (worker.py:205-250)
+    def stats(self, interval):
+        print("buffer update speed: {}/s".format(int(lib.mapf_replay_counter(self._h, 1)) / interval))
+        print("buffer size: {}".format(len(self)))
+        for key, val in self.stat_dict.copy().items():
+            print("{}: {}/{}".format(key, sum(val), len(val)))
+            if len(val) == 200 and sum(val) >= 200 * self.pass_rate:
+                add_agent_key = (key[0] + 1, key[1])
+                if add_agent_key[0] <= self.max_agents and add_agent_key not in self.stat_dict:
+                    self.stat_dict[add_agent_key] = []
+                if key[1] < self.max_map_length:
+                    add_map_key = (key[0], key[1] + 5)
+                    if add_map_key not in self.stat_dict:
+                        self.stat_dict[add_map_key] = []
+                    del self.stat_dict[key]
+        self.level = list(self.stat_dict.keys())
+
+    def ready(self, learning_starts=50000):
+        return len(self) >= learning_starts
+
+    def get_level(self):
+        return self.level
+
+    def check_done(self):
+        for i in range(self.max_agents):
+            key = (i + 1, self.max_map_length)
+            if key not in self.stat_dict:
+                return False
+            l = self.stat_dict[key]
+            if len(l) < 200 or sum(l) < 200 * self.pass_rate:
+                return False
+        return True

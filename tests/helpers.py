@@ -63,3 +63,31 @@ def random_tape(T, E, N, seed, p_stay=0.2):
     rng = np.random.RandomState(seed)
     tape = rng.randint(0, 5, size=(T, E, N)).astype(np.int8)
     return tape
+
+
+# ---- deterministic network weights (identical on every box; independent of torch's RNG/version) ----
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def det_state_dict(shapes, seed=1234):
+    """shapes: ordered dict name -> shape.  Returns name -> float32 array, values uniform in +-bound with a
+    Xavier-like bound for >=2-d tensors and +-0.05 for 1-d (biases), from a counter-based hash."""
+    out = {}
+    with np.errstate(over="ignore"):
+        for p, (name, shape) in enumerate(shapes.items()):
+            n = int(np.prod(shape))
+            ctr = np.arange(n, dtype=np.uint64) + np.uint64(seed) * np.uint64(1 << 40) + np.uint64(p) * np.uint64(1 << 32)
+            u = (_splitmix64(_splitmix64(ctr)) >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+            if len(shape) >= 2:
+                fan_out = shape[0] * int(np.prod(shape[2:]))
+                fan_in = shape[1] * int(np.prod(shape[2:]))
+                bound = np.sqrt(6.0 / (fan_in + fan_out))
+            else:
+                bound = 0.05
+            out[name] = ((u * 2.0 - 1.0) * bound).astype(np.float32).reshape(shape)
+    return out

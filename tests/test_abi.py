@@ -11,9 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
-    src = open(os.path.join(ROOT, "include", "mapf_env.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(mapf_[a-z_0-9]+)\s*\(", src)))
+    names = set()
+    for h in ("mapf_env.h", "mapf_replay.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(mapf_[a-z_0-9]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_every_declared_symbol_is_exported_and_bound():

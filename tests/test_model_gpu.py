@@ -1,0 +1,72 @@
+"""GPU (bf16 autocast): the product Network against reference goldens.  Tolerance |dQ| <= 2e-2*max(1,|Q|)
+(SURVEY.md 8(c)); greedy-action agreement is asserted only on rows whose top-2 gap exceeds the tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+from tests.test_model_cpu import _net
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-2
+
+
+def _close(a, b, tol=TOL):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.all(np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b)))
+
+
+@pytest.mark.parametrize("nag", [16, 32])
+def test_step_bf16(nag):
+    z = H.load_npz("dqn_model.npz")
+    net, _ = _net()
+    net.cuda()
+    pre = "step%d_" % nag
+    net.reset()
+    for t in range(z[pre + "q"].shape[0]):
+        obs = H.unpack_bits(z[pre + "obs_bits"][t], (nag, 6, 9, 9))
+        actions, q, hidden, cm = net.step(torch.from_numpy(obs), torch.from_numpy(z[pre + "pos"][t].astype(np.int64)),
+                                          comm_mask=z[pre + "comm_mask"][t])
+        assert _close(q, z[pre + "q"][t]), (t, np.abs(q - z[pre + "q"][t]).max())
+        assert _close(hidden, z[pre + "hidden"][t], 3e-2)
+        srt = np.sort(z[pre + "q"][t], axis=1)
+        clear = (srt[:, -1] - srt[:, -2]) > 2 * TOL * np.maximum(1, np.abs(srt[:, -1]))
+        assert np.array_equal(np.array(actions)[clear], z[pre + "actions"][t][clear])
+
+
+def test_bootstrap_bf16_and_fp32_on_gpu():
+    z = H.load_npz("dqn_model.npz")
+    net, _ = _net()
+    net.cuda()
+    B, T, A = z["boot_shape"]
+    obs = torch.from_numpy(H.unpack_bits(z["boot_obs_bits"], (B, T, A, 6, 9, 9))).cuda()
+    args = (torch.from_numpy(z["boot_steps"]).cuda(), torch.from_numpy(z["boot_hidden"]).cuda(), torch.from_numpy(z["boot_comm"]).cuda())
+    with torch.no_grad():
+        q = net.bootstrap(obs.to(torch.bfloat16), *args).cpu().numpy()
+    assert _close(q, z["boot_q"]), np.abs(q - z["boot_q"]).max()
+
+
+def test_batched_step_vs_env_observations():
+    """E envs x N agents straight from the HIP environment (uint8 obs, int16 pos) through step_batch."""
+    import mapf_rl_amd as M
+    from mapf_rl_amd.model import comm_mask_from_pos
+
+    net, _ = _net()
+    net.cuda()
+    E, L, N = 16, 32, 40
+    maps, agents, goals, _ = M.generate_scenarios(E, L, N, 0.3, seed=4)
+    env = M.VecEnvironment(E, L, N)
+    env.load(maps, agents, goals)
+    obs, pos = env.observe()
+    a, q, h, cm = net.step_batch(obs, pos, None)
+    assert a.shape == (E, N) and q.shape == (E, N, 5) and h.shape == (E * N, 256) and cm.shape == (E, N, N)
+    assert torch.equal(cm, comm_mask_from_pos(pos))
+    # same inputs through the CPU fp32 path
+    net_c, _ = _net()
+    a2, q2, h2, cm2 = net_c.step_batch(obs.cpu(), pos.cpu(), None)
+    assert torch.equal(cm.cpu(), cm2)
+    assert _close(q.cpu().numpy(), q2.numpy())
+    obs2, pos2, *_ = env.step(a.to(torch.int8))
+    env.check_status()
+    a3, q3, h3, _ = net.step_batch(obs2, pos2, h)
+    assert torch.isfinite(q3).all()
