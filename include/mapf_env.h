@@ -79,6 +79,15 @@ int mapf_set_reward_table(mapf_env_t *env, const float table[5]);
 int mapf_load(mapf_env_t *env, const int8_t *maps, const int16_t *agents, const int16_t *goals,
               int src_on_device, void *stream);
 
+/*
+ * Partial Environment.load + get_navi_map: environment env_ids[k] (HOST int32 [n]) receives the k-th scenario
+ * of the HOST buffers maps [n][L][L] / agents [n][N][2] / goals [n][N][2]; its step counter is zeroed and only
+ * its N distance fields are rebuilt.  This is the per-environment reset of the actor loop
+ * (reference worker.py:422-428 -> environment.py:146-196).  Synchronises `stream`.
+ */
+int mapf_load_envs(mapf_env_t *env, const int32_t *env_ids, int n, const int8_t *maps, const int16_t *agents,
+                   const int16_t *goals, void *stream);
+
 /* Overwrite agent positions only (e.g. rewind to the start of an action tape); steps := 0. */
 int mapf_set_agents(mapf_env_t *env, const int16_t *agents_dev, void *stream);
 
@@ -90,15 +99,20 @@ int mapf_build_navi(mapf_env_t *env, void *stream);
 
 /*
  * Replaces Environment.step (environment.py:278-430) incl. the observe() it returns (:430 -> :433-467),
- * for all E environments in one launch.  Any output pointer may be NULL (obs_dev == NULL skips the
- * observation build).  Errors detected on the device (action outside [0,5), overlap) are sticky and
+ * for all E environments in one launch.  Any output pointer may be NULL (obs_dev == NULL and
+ * obs_bits_dev == NULL skips the observation build).  obs_bits_dev, uint32 [E][mapf_obs_bits_row_dwords()],
+ * receives the same observation bit-packed (bit a*486 + c*81 + cell of row e = obs[e][a][c][cell]) -- the
+ * storage format of the replay (mapf_replay.h), 8x smaller than obs.  Errors detected on the device (action outside [0,5), overlap) are sticky and
  * reported by mapf_check_status.
  */
-int mapf_step(mapf_env_t *env, const int8_t *actions_dev, uint8_t *obs_dev, int16_t *pos_dev,
+int mapf_step(mapf_env_t *env, const int8_t *actions_dev, uint8_t *obs_dev, uint32_t *obs_bits_dev, int16_t *pos_dev,
               int8_t *reward_class_dev, float *reward_dev, uint8_t *done_dev, void *stream);
 
 /* Replaces Environment.observe (environment.py:433-467) for all E environments. */
-int mapf_observe(mapf_env_t *env, uint8_t *obs_dev, int16_t *pos_dev, void *stream);
+int mapf_observe(mapf_env_t *env, uint8_t *obs_dev, uint32_t *obs_bits_dev, int16_t *pos_dev, void *stream);
+
+/* Dwords per bit-packed observation row: ceil(N*486/32) rounded up to a multiple of 4. */
+int mapf_obs_bits_row_dwords(const mapf_env_t *env);
 
 /* State read-back (device -> caller's device buffers). navi: uint8 [E][N][4][L][L], unpadded. */
 int mapf_get_navi(mapf_env_t *env, uint8_t *navi_dev, void *stream);

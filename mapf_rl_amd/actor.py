@@ -1,0 +1,165 @@
+"""Vectorised actor loop: the reference's `Actor.run` (reference worker.py:368-428) for E lock-step
+environments on one GPU -- policy inference, epsilon-greedy, environment step, per-episode local buffers and
+the flush into the device replay all stay on the device; nothing crosses a process boundary.
+
+Per iteration (= worker.py:376-414 for every environment at once):
+  model.step_batch -> (only agent 0 explores: quirk Q7) -> env.step -> record agent 0's (q, a, r), the next
+  observation (bit-packed straight from the env kernel), agent 0's post-communication hidden state and the
+  comm mask -> environments whose episode ended (done, or 256 steps) compute their initial priorities
+  (LocalBuffer.finish, buffer.py:153-179), are appended to the replay ring (GlobalBuffer.add) and restart
+  on a fresh scenario (Actor.reset, worker.py:422-428).
+
+Quirk Q8 (worker.py:399): on a time-out the reference runs one more model.step on the STALE observation only
+to obtain `comm_mask` for the last buffer row (its q value is never used by the priorities, buffer.py:173).
+The stale positions equal those of the previous step, so the same row is obtained here by repeating the
+previous comm mask -- no extra inference."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import environment as _envmod
+from .environment import VecEnvironment, generate_scenarios
+
+MAX_STEPS = 256      # config.max_steps
+FORWARD_GAMMA = 0.99
+
+
+def epsilon_ladder(num_envs, num_actors=16, base=0.4, alpha=7.0):
+    """train.py:25: eps_i = 0.4 ** (1 + 7 i / 15); environment e plays the role of actor e mod 16."""
+    i = torch.arange(num_envs) % num_actors
+    return base ** (1 + i.double() / (num_actors - 1) * alpha)
+
+
+def pack_comm_device(comm, cw):
+    """bool [E, N, N] -> int32 [E, N, cw] (bit j of word j/32)."""
+    E, N, _ = comm.shape
+    pad = torch.zeros((E, N, cw * 32), dtype=torch.int64, device=comm.device)
+    pad[:, :, :N] = comm
+    w = (pad.view(E, N, cw, 32) << torch.arange(32, device=comm.device)).sum(-1)
+    return (w & 0xFFFFFFFF).to(torch.int64).where(w < 2 ** 31, w - 2 ** 32).to(torch.int32)
+
+
+class VecActor:
+    def __init__(self, env: VecEnvironment, model, buffer, epsilons=None, max_steps=MAX_STEPS, seed=0, density=-1.0,
+                 keep_flushed=False):
+        self.env, self.model, self.buffer = env, model, buffer
+        E, N = env.num_envs, env.num_agents
+        d = env.device
+        self.E, self.N, self.device, self.max_steps, self.density = E, N, d, max_steps, density
+        assert buffer is None or buffer.max_agents == N, "replay rows must use the environment's agent count"
+        self.eps = (epsilon_ladder(E) if epsilons is None else torch.as_tensor(epsilons, dtype=torch.float64).expand(E)).to(d)
+        self.actor_ids = (torch.arange(E) % 16).tolist()
+        self.gen = torch.Generator(device=d)
+        self.gen.manual_seed(seed)
+        self.scenario_seed = seed * 1000003 + 17
+        self.RD = env.obs_bits_row_dwords
+        self.CW = (N + 31) // 32
+        R = max_steps + 1
+        self.lb_obs = torch.zeros((E, R, self.RD), dtype=torch.int32, device=d)
+        self.lb_comm = torch.zeros((E, R, N, self.CW), dtype=torch.int32, device=d)
+        self.lb_act = torch.zeros((E, max_steps), dtype=torch.uint8, device=d)
+        self.lb_rew = torch.zeros((E, max_steps), dtype=torch.float16, device=d)
+        self.lb_hid = torch.zeros((E, max_steps, 256), dtype=torch.float16, device=d)
+        self.lb_q = torch.zeros((E, max_steps, 5), dtype=torch.float32, device=d)
+        self.t = torch.zeros(E, dtype=torch.int64, device=d)
+        self.bits = torch.zeros((E, self.RD), dtype=torch.int32, device=d)
+        self.ar = torch.arange(E, device=d)
+        self.hidden = None
+        self.env_steps = 0
+        self.episodes = 0
+        self.keep_flushed = keep_flushed
+        self.flushed = []
+        self._begin()
+
+    def _begin(self):
+        self.obs, self.pos = self.env.observe(obs_bits_out=self.bits)
+        self.lb_obs[:, 0] = self.bits
+        self.t.zero_()
+        self.hidden = None
+
+    # ------------------------------------------------------------------ one lock-step iteration
+    @torch.no_grad()
+    def step(self):
+        E, N, d = self.E, self.N, self.device
+        actions, q, hidden, comm = self.model.step_batch(self.obs, self.pos, self.hidden)
+        # worker.py:380-382: only agent 0 of an environment explores
+        explore = torch.rand(E, device=d, generator=self.gen, dtype=torch.float64) < self.eps
+        rnd = torch.randint(0, 5, (E,), device=d, generator=self.gen)
+        actions[:, 0] = torch.where(explore, rnd, actions[:, 0])
+        act8 = actions.to(torch.int8).contiguous()
+        obs, pos, reward, done, _ = self.env.step(act8, obs_bits_out=self.bits)
+        # worker.py:388 -> buffer.py:140-151
+        t = self.t
+        self.lb_q[self.ar, t] = q[:, 0]
+        self.lb_act[self.ar, t] = actions[:, 0].to(torch.uint8)
+        self.lb_rew[self.ar, t] = reward[:, 0].to(torch.float16)
+        self.lb_hid[self.ar, t] = hidden.view(E, N, 256)[:, 0].to(torch.float16)
+        self.lb_comm[self.ar, t] = pack_comm_device(comm, self.CW)
+        self.lb_obs[self.ar, t + 1] = self.bits
+        self.t = t + 1
+        self.hidden = hidden
+        self.obs, self.pos = obs, pos
+        self.env_steps += E
+        finished = (done != 0) | (self.t >= self.max_steps)   # worker.py:390
+        if bool(finished.any()):
+            self._flush(finished.nonzero().view(-1), done)
+        return finished
+
+    # ------------------------------------------------------------------ episode end
+    def _finish_priorities(self, ids, sizes):
+        """LocalBuffer.finish (buffer.py:170-177) for the listed environments, f64 on the device."""
+        S = self.max_steps
+        q = self.lb_q[ids].double()                                   # [n, S, 5]
+        rew = self.lb_rew[ids].double()                               # [n, S] (f16 values)
+        steps = torch.arange(S, device=self.device)
+        valid = steps[None, :] < sizes[:, None]
+        rew = torch.where(valid, rew, torch.zeros_like(rew))
+        nxt = torch.cat([rew[:, 1:], torch.zeros_like(rew[:, :1])], dim=1)
+        ret = rew + FORWARD_GAMMA * nxt + q.max(-1).values            # np.convolve(ret, [0.99, 1], 'valid') + q_max
+        qa = q.gather(-1, self.lb_act[ids].long().unsqueeze(-1)).squeeze(-1)
+        td = (ret - qa).abs()
+        return torch.where(valid, td, torch.zeros_like(td))           # zeros past the episode end
+
+    def _flush(self, ids, done):
+        ids_h = ids.tolist()
+        sizes = self.t[ids]
+        dn = (done[ids] != 0)
+        td = self._finish_priorities(ids, sizes)
+        sizes_h, dn_h = sizes.tolist(), dn.tolist()
+        for k, e in enumerate(ids_h):
+            size, is_done = sizes_h[k], dn_h[k]
+            # last comm row: zeros when done (np.zeros init, buffer.py:124), the stale-observation mask on time-out (Q8)
+            if is_done:
+                self.lb_comm[e, size].zero_()
+            else:
+                self.lb_comm[e, size] = self.lb_comm[e, size - 1]
+            if self.buffer is not None:
+                self.buffer.add_episode_device(self.N, size, is_done, self.lb_obs[e], self.lb_comm[e], self.lb_act[e],
+                                               self.lb_rew[e], self.lb_hid[e], td[k].contiguous())
+                if self.actor_ids[e] >= 10:  # curriculum statistics (worker.py:74-82)
+                    key = (self.N, self.env.map_length)
+                    if key in self.buffer.stat_dict:
+                        lst = self.buffer.stat_dict[key]
+                        if len(lst) >= 200:
+                            lst.pop(0)
+                        lst.append(is_done)
+            if self.keep_flushed:
+                self.flushed.append(dict(env=e, size=size, done=is_done, obs=self.lb_obs[e, :size + 1].clone(),
+                                         comm=self.lb_comm[e, :size + 1].clone(), act=self.lb_act[e, :size].clone(),
+                                         rew=self.lb_rew[e, :size].clone(), hid=self.lb_hid[e, :size].clone(),
+                                         q=self.lb_q[e, :size].clone(), td=td[k].clone()))
+        self.episodes += len(ids_h)
+        # Actor.reset (worker.py:422-428): fresh scenario, recurrent state cleared
+        self.scenario_seed += 1
+        maps, agents, goals, _ = generate_scenarios(len(ids_h), self.env.map_length, self.N, self.density, self.scenario_seed)
+        self.env.load_envs(ids_h, maps, agents, goals)
+        self.obs, self.pos = self.env.observe(obs_bits_out=self.bits)
+        self.lb_obs[ids, 0] = self.bits[ids]
+        self.t[ids] = 0
+        self.hidden.view(self.E, self.N, 256)[ids] = 0                # model.reset(): GRUCell(x, None) == zero state
+
+    def run(self, num_iterations):
+        for _ in range(num_iterations):
+            self.step()
+        return self.env_steps

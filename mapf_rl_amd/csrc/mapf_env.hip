@@ -51,6 +51,8 @@ struct StepParams {
     int32_t *status;
     const int8_t *actions;
     uint8_t *obs;
+    uint32_t *obs_bits;  // optional bit-packed observation rows [E][RD]
+    int obs_bits_rd;
     int16_t *pos_out;
     int8_t *rclass;
     float *reward;
@@ -71,234 +73,7 @@ __device__ __forceinline__ unsigned window_bits(W row, int y) {
 __device__ __forceinline__ unsigned expand4(unsigned nib) { return (nib * 0x00204081u) & 0x01010101u; }
 
 // ---------------------------------------------------------------------------------------------
-// env_step_kernel: one workgroup per environment.
-//   phase 0  stage obstacle bit rows in LDS (padded by R zero rows), load agent state
-//   phase 1  (DO_STEP) Environment.step, reference environment.py:278-430, as a parallel fixed point:
-//            S0 move / stay, S1 wall + obstacle, S2 swap (one pass: depends only on post-S1 targets),
-//            S3 vertex: (b) a mover that is not the lowest-id mover into its target reverts,
-//                       (a) a mover whose target cell is held by a settled agent reverts; iterate (a)
-//            until stable (cascade), S4 commit, done, rewards.
-//   phase 2  Environment.observe, reference environment.py:433-467: per (agent, window row) extract
-//            the 6 channel bit-fields of width 2R+1 into LDS; the observation block of the env is then
-//            exactly the byte expansion of the concatenated fields, streamed out with VEC-byte stores.
-// ---------------------------------------------------------------------------------------------
-template <typename W, int R, bool DO_STEP, int VEC>
-__global__ void __launch_bounds__(256) env_step_kernel_v1(StepParams p) {
-    constexpr int WW = 2 * R + 1;
-    const int e = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
-    const int L = p.L, N = p.N;
-    const int LP = L + 2 * R;
-    const int NP = (N + 3) & ~3;
-    const int NF = N * 6 * WW;
-
-    extern __shared__ __align__(16) unsigned char smem[];
-    W *s_obst = reinterpret_cast<W *>(smem);  // [LP] padded obstacle rows
-    W *s_agent = s_obst + LP;                 // [LP] padded agent-occupancy rows (after the step)
-    unsigned short *s_cur = reinterpret_cast<unsigned short *>(s_agent + LP);  // [NP] (x<<8)|y
-    unsigned short *s_next = s_cur + NP;                                      // [NP]
-    unsigned short *s_mov = s_next + NP;                                      // [NP] 1 = still a mover
-    unsigned short *s_F = s_mov + NP;                                         // [NF + 8] channel fields
-
-    const W *map_rows = reinterpret_cast<const W *>(p.map_rows) + (size_t)e * L;
-    for (int r = t; r < LP; r += nt) {
-        int rr = r - R;
-        s_obst[r] = (rr >= 0 && rr < L) ? map_rows[rr] : (W)0;
-        s_agent[r] = (W)0;
-    }
-    if (t < 8) s_F[NF + t] = 0;
-
-    const bool agent = t < N;
-    int cx = 0, cy = 0;
-    if (agent) {
-        const int16_t *a = p.agents + ((size_t)e * N + t) * 2;
-        cx = a[0];
-        cy = a[1];
-    }
-    int nx = cx, ny = cy;
-    __syncthreads();
-
-    if constexpr (DO_STEP) {
-        int gx = 0, gy = 0, act = 0, rc = MAPF_RC_STAY_ON_GOAL;
-        bool mover = false;
-        if (agent) {
-            const int16_t *g = p.goals + ((size_t)e * N + t) * 2;
-            gx = g[0];
-            gy = g[1];
-            act = p.actions[(size_t)e * N + t];
-            if (act < 0 || act > 4) {  // reference: AssertionError (environment.py:290)
-                atomicOr(p.status, kStatusAction);
-                act = 0;
-            }
-            // S0 (environment.py:298-311)
-            mover = act != 0;
-            nx = cx + (act == 2) - (act == 1);  // action_list, environment.py:12
-            ny = cy + (act == 4) - (act == 3);
-            rc = mover ? MAPF_RC_MOVE : ((cx == gx && cy == gy) ? MAPF_RC_STAY_ON_GOAL : MAPF_RC_STAY_OFF_GOAL);
-            // S1 (environment.py:320-332)
-            if (mover) {
-                bool blocked = nx < 0 || ny < 0 || nx >= L || ny >= L;
-                if (!blocked) blocked = (s_obst[nx + R] >> ny) & 1;
-                if (blocked) {
-                    mover = false;
-                    rc = MAPF_RC_COLLISION;
-                    nx = cx;
-                    ny = cy;
-                }
-            }
-            s_cur[t] = (unsigned short)((cx << 8) | cy);
-            s_next[t] = (unsigned short)((nx << 8) | ny);
-            s_mov[t] = mover;
-        }
-        __syncthreads();
-
-        // S2 swap (environment.py:335-365): occupant j of my target, whose own target is my cell
-        const unsigned my_cur = (unsigned)((cx << 8) | cy);
-        const unsigned my_next = (unsigned)((nx << 8) | ny);
-        int occ = -1;
-        bool swap = false;
-        if (mover) {
-            for (int j = 0; j < N; ++j)
-                if (s_cur[j] == my_next) occ = j;  // unique; j != t because my_next != my_cur
-            if (occ >= 0) swap = s_mov[occ] && s_next[occ] == my_cur;
-        }
-        __syncthreads();
-        if (swap) {
-            mover = false;
-            rc = MAPF_RC_COLLISION;
-            nx = cx;
-            ny = cy;
-            s_next[t] = (unsigned short)my_cur;
-            s_mov[t] = 0;
-        }
-        __syncthreads();
-
-        // S3 vertex (environment.py:368-406), rule (b): a lower-id mover claims the same cell
-        bool lose = false;
-        if (mover) {
-            for (int j = 0; j < t; ++j) lose |= (s_mov[j] && s_next[j] == my_next);
-        }
-        // rule (a) + cascade: target cell held by an agent that is (now) settled
-        for (int round = 0; round <= N; ++round) {
-            bool revert = mover && (lose || (occ >= 0 && !s_mov[occ]));
-            int any = __syncthreads_or(revert);
-            if (revert) {
-                mover = false;
-                rc = MAPF_RC_COLLISION;
-                nx = cx;
-                ny = cy;
-                s_mov[t] = 0;
-            }
-            if (!any) break;
-            __syncthreads();
-        }
-
-        // S4 (environment.py:410-430)
-        bool on_goal = !agent || (nx == gx && ny == gy);
-        int all_done = __syncthreads_and(on_goal);
-        if (agent) {
-            if (all_done) rc = MAPF_RC_FINISH;
-            size_t o = (size_t)e * N + t;
-            int16_t *a = p.agents + o * 2;
-            a[0] = (int16_t)nx;
-            a[1] = (int16_t)ny;
-            if (p.pos_out) {
-                p.pos_out[o * 2] = (int16_t)nx;
-                p.pos_out[o * 2 + 1] = (int16_t)ny;
-            }
-            if (p.rclass) p.rclass[o] = (int8_t)rc;
-            if (p.reward) p.reward[o] = p.rtab[rc];
-        }
-        if (t == 0) {
-            if (p.done) p.done[e] = (uint8_t)(all_done != 0);
-            p.steps[e] += 1;
-        }
-    } else {
-        if (agent && p.pos_out) {
-            size_t o = (size_t)e * N + t;
-            p.pos_out[o * 2] = (int16_t)cx;
-            p.pos_out[o * 2 + 1] = (int16_t)cy;
-        }
-    }
-
-    if (p.obs == nullptr) {
-        if constexpr (DO_STEP) {
-            // still run the overlap invariant (environment.py:424-428) on the new positions
-            if (agent) {
-                W bit = (W)1 << ny;
-                W old = lds_or(&s_agent[nx + R], bit);
-                if (old & bit) atomicOr(p.status, kStatusOverlap);
-            }
-        }
-        return;
-    }
-
-    // ---- observe: agent occupancy rows after the step ----
-    if (agent) {
-        W bit = (W)1 << ny;
-        W old = lds_or(&s_agent[nx + R], bit);
-        if (DO_STEP && (old & bit)) atomicOr(p.status, kStatusOverlap);
-        s_cur[t] = (unsigned short)((nx << 8) | ny);
-    }
-    __syncthreads();
-
-    // ---- per (agent, window row): 6 fields of WW bits ----
-    const NaviRec<W> *navi = reinterpret_cast<const NaviRec<W> *>(p.navi) + (size_t)e * N * L;
-    for (int task = t; task < N * WW; task += nt) {
-        int i = task / WW, dy = task - i * WW;
-        unsigned key = s_cur[i];
-        int x = key >> 8, y = key & 255;
-        unsigned f_ag = window_bits<W, R>(s_agent[x + dy], y);
-        if (dy == R) f_ag &= ~(1u << R);  // centre of channel 0 forced to 0 (environment.py:461)
-        unsigned f_ob = window_bits<W, R>(s_obst[x + dy], y);
-        int rr = x + dy - R;
-        unsigned f0 = 0, f1 = 0, f2 = 0, f3 = 0;
-        if (rr >= 0 && rr < L) {
-            NaviRec<W> rec = navi[(size_t)i * L + rr];
-            f0 = window_bits<W, R>(rec.w[0], y);
-            f1 = window_bits<W, R>(rec.w[1], y);
-            f2 = window_bits<W, R>(rec.w[2], y);
-            f3 = window_bits<W, R>(rec.w[3], y);
-        }
-        unsigned short *F = s_F + i * 6 * WW + dy;
-        F[0] = (unsigned short)f_ag;
-        F[WW] = (unsigned short)f_ob;
-        F[2 * WW] = (unsigned short)f0;
-        F[3 * WW] = (unsigned short)f1;
-        F[4 * WW] = (unsigned short)f2;
-        F[5 * WW] = (unsigned short)f3;
-    }
-    __syncthreads();
-
-    // ---- byte expansion of the field string, VEC bytes per lane per store ----
-    const int total = NF * WW;  // bytes of this env's observation block = N*6*WW*WW
-    uint8_t *out = p.obs + (size_t)e * total;
-    constexpr int NFLD = (WW - 1 + VEC + WW - 1) / WW;
-    const int ntask = total / VEC;
-    for (int task = t; task < ntask; task += nt) {
-        int b = task * VEC;
-        int f = b / WW, s = b - f * WW;
-        unsigned long long acc = 0;
-#pragma unroll
-        for (int k = 0; k < NFLD; ++k) acc |= (unsigned long long)s_F[f + k] << (k * WW);
-        unsigned bits = (unsigned)(acc >> s);
-        if constexpr (VEC == 16) {
-            uint4 v;
-            v.x = expand4(bits & 15u);
-            v.y = expand4((bits >> 4) & 15u);
-            v.z = expand4((bits >> 8) & 15u);
-            v.w = expand4((bits >> 12) & 15u);
-            *reinterpret_cast<uint4 *>(out + b) = v;
-        } else if constexpr (VEC == 4) {
-            *reinterpret_cast<unsigned *>(out + b) = expand4(bits & 15u);
-        } else {
-            out[b] = (uint8_t)(bits & 1u);
-        }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// env_step_kernel (v2): one workgroup per environment, instruction-lean formulation.
+// env_step_kernel: one workgroup per environment (Environment.step + observe, reference environment.py:278-467).
 //   * every global load is issued up front: the navi records an agent can need after the step are rows
 //     min(x, x+dx)-R .. max(x, x+dx)+R (<= 2R+2 rows, dx from its action), fetched speculatively into
 //     registers while the step logic runs -- no dependent HBM round trip after the step;
@@ -558,10 +333,18 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
         block_sync<NT>();
         STAMP(3)
 
-        // ---- expand the bit string: bit b -> byte b of this env's observation block ----
         const int total = N * 6 * WW * WW;
+        // ---- optional: the bit string itself (bit-packed observation row for the replay) ----
+        if (p.obs_bits) {
+            uint32_t *ob = p.obs_bits + (size_t)e * p.obs_bits_rd;
+            const int nd = (total + 31) >> 5;
+            for (int k = t; k < p.obs_bits_rd; k += nt) ob[k] = k < nd ? s_bits[k] : 0u;
+        }
+        // ---- expand the bit string: bit b -> byte b of this env's observation block ----
         uint8_t *out = p.obs + (size_t)e * total;
-        if constexpr (VEC == 16) {
+        if (p.obs == nullptr) {
+            // bit-packed output only
+        } else if constexpr (VEC == 16) {
             const unsigned short *b16 = reinterpret_cast<const unsigned short *>(s_bits);
             const int ntask = total >> 4;
             for (int task = t; task < ntask; task += nt) {
@@ -639,15 +422,18 @@ __device__ __forceinline__ W shfl_down_w(W v, int width) {
 
 template <typename W>
 __global__ void __launch_bounds__(256) navi_bfs_kernel(int E, int L, int N, const W *map_rows,
-                                                      const int16_t *goals, NaviRec<W> *navi, int32_t *status) {
+                                                      const int16_t *goals, NaviRec<W> *navi, int32_t *status,
+                                                      const int32_t *env_ids) {
     constexpr int LPF = sizeof(W) == 4 ? 32 : 64;  // lanes per field
     constexpr int FPW = 64 / LPF;                  // fields per wavefront
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long long field = wave * FPW + lane / LPF;
+    const long long slot = wave * FPW + lane / LPF;  // (listed env, agent) pair
     const int row = lane % LPF;
-    const bool valid = field < (long long)E * N;
-    const int e = valid ? (int)(field / N) : 0;
+    const bool valid = slot < (long long)E * N;
+    int e = valid ? (int)(slot / N) : 0;
+    if (env_ids) e = env_ids[e];                      // partial rebuild: E listed environments
+    const long long field = (long long)e * N + (valid ? slot % N : 0);
     const bool in_map = valid && row < L;
     const W lmask = (L == (int)(8 * sizeof(W))) ? ~(W)0 : (((W)1 << L) - 1);
     W freec = 0;
@@ -711,6 +497,32 @@ __global__ void unpack_map_kernel(int E, int L, const W *rows, int8_t *maps) {
     maps[idx] = (int8_t)((rows[r] >> y) & 1);
 }
 
+// partial load: environment ids[k] <- k-th staged scenario (map rows packed on the fly)
+template <typename W>
+__global__ void scatter_load_kernel(int n, int L, int N, const int32_t *ids, const int8_t *maps, const int16_t *agents,
+                                    const int16_t *goals, W *rows, int16_t *dst_agents, int16_t *dst_goals, int32_t *steps,
+                                    int E, int32_t *status) {
+    const int k = blockIdx.x;
+    const int e = ids[k];
+    if (e < 0 || e >= E) {
+        if (threadIdx.x == 0) atomicOr(status, kStatusRange);
+        return;
+    }
+    for (int r = threadIdx.x; r < L; r += blockDim.x) {
+        const int8_t *m = maps + ((size_t)k * L + r) * L;
+        W w = 0;
+        for (int y = 0; y < L; ++y) w |= (W)(m[y] != 0) << y;
+        rows[(size_t)e * L + r] = w;
+    }
+    for (int q = threadIdx.x; q < N * 2; q += blockDim.x) {
+        const int16_t a = agents[(size_t)k * N * 2 + q], g = goals[(size_t)k * N * 2 + q];
+        if (a < 0 || a >= L || g < 0 || g >= L) atomicOr(status, kStatusRange);
+        dst_agents[(size_t)e * N * 2 + q] = a;
+        dst_goals[(size_t)e * N * 2 + q] = g;
+    }
+    if (threadIdx.x == 0) steps[e] = 0;
+}
+
 __global__ void check_positions_kernel(long long n, int L, const int16_t *a, const int16_t *g, int32_t *status) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
@@ -751,7 +563,6 @@ struct mapf_env {
     float rtab[5];
     int tune_threads;  // 0 = default; MAPF_STEP_THREADS (tuning experiments only)
     int tune_lds_pad;  // extra dynamic LDS bytes per block to cap residency; MAPF_STEP_LDS_PAD
-    int tune_impl;     // 1 = v1 kernel (A/B only); MAPF_STEP_IMPL
     int tune_ablate;   // MAPF_STEP_ABLATE (timing-only builds; results are wrong)
     unsigned long long *dbg;  // phase-stamp buffer (diagnostics)
 };
@@ -779,13 +590,6 @@ struct DeviceGuard {
         if (ok && prev >= 0) (void)hipSetDevice(prev);
     }
 };
-
-size_t step_smem_bytes_v1(const mapf_env *h) {
-    const int WW = 2 * h->R + 1;
-    size_t LP = h->L + 2 * h->R;
-    size_t NP = (h->N + 3) & ~3;
-    return 2 * LP * word_bytes(h) + 3 * NP * 2 + ((size_t)h->N * 6 * WW + 8) * 2;
-}
 
 size_t step_smem_bytes(const mapf_env *h) {
     const int WW = 2 * h->R + 1;
@@ -841,19 +645,9 @@ int launch_step_vec(const mapf_env *h, const StepParams &p, hipStream_t s) {
     const int threads = step_block_threads(h);
     const bool a16 = (total % 16 == 0) && ((reinterpret_cast<uintptr_t>(p.obs) & 15) == 0);
     const bool a4 = (total % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.obs) & 3) == 0);
-    if (h->tune_impl == 1) {  // v1 kernel kept for A/B measurements only
-        const size_t smem = step_smem_bytes_v1(h) + (size_t)h->tune_lds_pad;
-        if (p.obs == nullptr || a16)
-            hipLaunchKernelGGL((env_step_kernel_v1<W, 4, DO_STEP, 16>), dim3(h->E), dim3(threads), smem, s, p);
-        else if (a4)
-            hipLaunchKernelGGL((env_step_kernel_v1<W, 4, DO_STEP, 4>), dim3(h->E), dim3(threads), smem, s, p);
-        else
-            hipLaunchKernelGGL((env_step_kernel_v1<W, 4, DO_STEP, 1>), dim3(h->E), dim3(threads), smem, s, p);
-        HIP_TRY(hipGetLastError());
-        return MAPF_OK;
-    }
     const size_t smem = step_smem_bytes(h) + (size_t)h->tune_lds_pad;
-    if (p.obs == nullptr) return launch_step_iters<W, DO_STEP, false, 16>(h, p, s, threads, smem);
+    if (p.obs == nullptr && p.obs_bits == nullptr) return launch_step_iters<W, DO_STEP, false, 16>(h, p, s, threads, smem);
+    if (p.obs == nullptr) return launch_step_iters<W, DO_STEP, true, 16>(h, p, s, threads, smem);
     if (a16) return launch_step_iters<W, DO_STEP, true, 16>(h, p, s, threads, smem);
     if (a4) return launch_step_iters<W, DO_STEP, true, 4>(h, p, s, threads, smem);
     return launch_step_iters<W, DO_STEP, true, 1>(h, p, s, threads, smem);
@@ -1032,8 +826,6 @@ int mapf_create(int num_envs, int map_len, int num_agents, int obs_radius, int d
     h->tune_threads = tv ? std::atoi(tv) : 0;
     tv = std::getenv("MAPF_STEP_LDS_PAD");
     h->tune_lds_pad = tv ? std::atoi(tv) : 0;
-    tv = std::getenv("MAPF_STEP_IMPL");
-    h->tune_impl = tv ? std::atoi(tv) : 0;
     tv = std::getenv("MAPF_STEP_ABLATE");
     h->tune_ablate = tv ? std::atoi(tv) : 0;
     const float def[5] = {-0.075f, 0.0f, -0.075f, -0.5f, 3.0f};
@@ -1124,6 +916,45 @@ int mapf_load(mapf_env_t *h, const int8_t *maps, const int16_t *agents, const in
     return MAPF_OK;
 }
 
+int mapf_load_envs(mapf_env_t *h, const int32_t *env_ids, int n, const int8_t *maps, const int16_t *agents,
+                   const int16_t *goals, void *stream) {
+    if (!h || !env_ids || !maps || !agents || !goals || n < 0) return MAPF_ERR_INVALID_ARG;
+    if (!h->loaded || !h->navi_ready) return MAPF_ERR_NOT_READY;
+    if (n == 0) return MAPF_OK;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t L = h->L, N = h->N;
+    const size_t b_ids = ((size_t)n * 4 + 15) & ~(size_t)15, b_maps = ((size_t)n * L * L + 15) & ~(size_t)15,
+                 b_pos = ((size_t)n * N * 4 + 15) & ~(size_t)15;
+    unsigned char *tmp = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), b_ids + b_maps + 2 * b_pos));
+    int32_t *d_ids = reinterpret_cast<int32_t *>(tmp);
+    int8_t *d_maps = reinterpret_cast<int8_t *>(tmp + b_ids);
+    int16_t *d_ag = reinterpret_cast<int16_t *>(tmp + b_ids + b_maps), *d_go = reinterpret_cast<int16_t *>(tmp + b_ids + b_maps + b_pos);
+    HIP_TRY(hipMemcpyAsync(d_ids, env_ids, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_maps, maps, (size_t)n * L * L, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_ag, agents, (size_t)n * N * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_go, goals, (size_t)n * N * 4, hipMemcpyHostToDevice, s));
+    const long long slots = (long long)n * h->N;
+    if (h->wide) {
+        hipLaunchKernelGGL(scatter_load_kernel<uint64_t>, dim3(n), dim3(128), 0, s, n, h->L, h->N, d_ids, d_maps, d_ag, d_go,
+                           static_cast<uint64_t *>(h->map_rows), h->agents, h->goals, h->steps, h->E, h->status);
+        hipLaunchKernelGGL(navi_bfs_kernel<uint64_t>, dim3(blocks_for(slots * 64, 256)), dim3(256), 0, s, n, h->L, h->N,
+                           static_cast<const uint64_t *>(h->map_rows), h->goals, static_cast<NaviRec<uint64_t> *>(h->navi),
+                           h->status, d_ids);
+    } else {
+        hipLaunchKernelGGL(scatter_load_kernel<uint32_t>, dim3(n), dim3(128), 0, s, n, h->L, h->N, d_ids, d_maps, d_ag, d_go,
+                           static_cast<uint32_t *>(h->map_rows), h->agents, h->goals, h->steps, h->E, h->status);
+        hipLaunchKernelGGL(navi_bfs_kernel<uint32_t>, dim3(blocks_for(((slots + 1) / 2) * 64, 256)), dim3(256), 0, s, n, h->L,
+                           h->N, static_cast<const uint32_t *>(h->map_rows), h->goals,
+                           static_cast<NaviRec<uint32_t> *>(h->navi), h->status, d_ids);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipFree(tmp));
+    return MAPF_OK;
+}
+
 int mapf_set_agents(mapf_env_t *h, const int16_t *agents_dev, void *stream) {
     if (!h || !agents_dev) return MAPF_ERR_INVALID_ARG;
     if (!h->loaded) return MAPF_ERR_NOT_READY;
@@ -1148,26 +979,32 @@ int mapf_build_navi(mapf_env_t *h, void *stream) {
         const long long waves = fields;
         hipLaunchKernelGGL(navi_bfs_kernel<uint64_t>, dim3(blocks_for(waves * 64, 256)), dim3(256), 0, s, h->E, h->L,
                            h->N, static_cast<const uint64_t *>(h->map_rows), h->goals,
-                           static_cast<NaviRec<uint64_t> *>(h->navi), h->status);
+                           static_cast<NaviRec<uint64_t> *>(h->navi), h->status, (const int32_t *)nullptr);
     } else {
         const long long waves = (fields + 1) / 2;
         hipLaunchKernelGGL(navi_bfs_kernel<uint32_t>, dim3(blocks_for(waves * 64, 256)), dim3(256), 0, s, h->E, h->L,
                            h->N, static_cast<const uint32_t *>(h->map_rows), h->goals,
-                           static_cast<NaviRec<uint32_t> *>(h->navi), h->status);
+                           static_cast<NaviRec<uint32_t> *>(h->navi), h->status, (const int32_t *)nullptr);
     }
     HIP_TRY(hipGetLastError());
     h->navi_ready = true;
     return MAPF_OK;
 }
 
-int mapf_step(mapf_env_t *h, const int8_t *actions_dev, uint8_t *obs_dev, int16_t *pos_dev,
+int mapf_obs_bits_row_dwords(const mapf_env_t *h) {
+    return h ? (((h->N * 486 + 31) / 32 + 3) & ~3) : MAPF_ERR_INVALID_ARG;
+}
+
+int mapf_step(mapf_env_t *h, const int8_t *actions_dev, uint8_t *obs_dev, uint32_t *obs_bits_dev, int16_t *pos_dev,
               int8_t *reward_class_dev, float *reward_dev, uint8_t *done_dev, void *stream) {
     if (!h || !actions_dev) return MAPF_ERR_INVALID_ARG;
-    if (!h->loaded || (obs_dev && !h->navi_ready)) return MAPF_ERR_NOT_READY;
+    if (!h->loaded || ((obs_dev || obs_bits_dev) && !h->navi_ready)) return MAPF_ERR_NOT_READY;
     DeviceGuard guard(h->device);
     StepParams p = make_params(h);
     p.actions = actions_dev;
     p.obs = obs_dev;
+    p.obs_bits = obs_bits_dev;
+    p.obs_bits_rd = mapf_obs_bits_row_dwords(h);
     p.pos_out = pos_dev;
     p.rclass = reward_class_dev;
     p.reward = reward_dev;
@@ -1175,12 +1012,14 @@ int mapf_step(mapf_env_t *h, const int8_t *actions_dev, uint8_t *obs_dev, int16_
     return launch_step<true>(h, p, static_cast<hipStream_t>(stream));
 }
 
-int mapf_observe(mapf_env_t *h, uint8_t *obs_dev, int16_t *pos_dev, void *stream) {
-    if (!h || !obs_dev) return MAPF_ERR_INVALID_ARG;
+int mapf_observe(mapf_env_t *h, uint8_t *obs_dev, uint32_t *obs_bits_dev, int16_t *pos_dev, void *stream) {
+    if (!h || (!obs_dev && !obs_bits_dev)) return MAPF_ERR_INVALID_ARG;
     if (!h->loaded || !h->navi_ready) return MAPF_ERR_NOT_READY;
     DeviceGuard guard(h->device);
     StepParams p = make_params(h);
     p.obs = obs_dev;
+    p.obs_bits = obs_bits_dev;
+    p.obs_bits_rd = mapf_obs_bits_row_dwords(h);
     p.pos_out = pos_dev;
     return launch_step<false>(h, p, static_cast<hipStream_t>(stream));
 }

@@ -78,6 +78,7 @@ class VecEnvironment:
         self.reward_class = torch.empty((E, N), dtype=torch.int8, device=d)
         self.reward = torch.empty((E, N), dtype=torch.float32, device=d)
         self.done = torch.empty((E,), dtype=torch.uint8, device=d)
+        self.obs_bits_row_dwords = lib.mapf_obs_bits_row_dwords(self._h)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -117,19 +118,34 @@ class VecEnvironment:
         torch.cuda.current_stream(self.device).synchronize()
 
     # -- the hot path --
-    def step(self, actions, obs_out=None):
+    def step(self, actions, obs_out=None, obs_bits_out=None):
         """actions: int8 tensor [E,N] on this device.  Returns (obs, pos, reward, done, reward_class) --
-        persistent buffers, overwritten by the next call (asynchronous on the current stream)."""
+        persistent buffers, overwritten by the next call (asynchronous on the current stream).
+        obs_bits_out: optional int32/uint32 tensor [E, obs_bits_row_dwords] receiving the bit-packed observation."""
         assert actions.dtype == torch.int8 and actions.is_contiguous() and actions.shape == (self.num_envs, self.num_agents)
         obs = self.obs if obs_out is None else obs_out
-        check(lib.mapf_step(self._h, _ptr(actions), _ptr(obs), _ptr(self.pos), _ptr(self.reward_class),
+        check(lib.mapf_step(self._h, _ptr(actions), _ptr(obs), _ptr(obs_bits_out), _ptr(self.pos), _ptr(self.reward_class),
                             _ptr(self.reward), _ptr(self.done), _stream(self.device)), "mapf_step")
         return obs, self.pos, self.reward, self.done, self.reward_class
 
-    def observe(self, obs_out=None):
+    def observe(self, obs_out=None, obs_bits_out=None):
         obs = self.obs if obs_out is None else obs_out
-        check(lib.mapf_observe(self._h, _ptr(obs), _ptr(self.pos), _stream(self.device)), "mapf_observe")
+        check(lib.mapf_observe(self._h, _ptr(obs), _ptr(obs_bits_out), _ptr(self.pos), _stream(self.device)), "mapf_observe")
         return obs, self.pos
+
+    def load_envs(self, env_ids, maps, agents_pos, goals_pos):
+        """Re-load only the listed environments (numpy host arrays) and rebuild their navi fields."""
+        ids = np.ascontiguousarray(env_ids, dtype=np.int32)
+        n = len(ids)
+        if n == 0:
+            return
+        L, N = self.map_length, self.num_agents
+        m = np.ascontiguousarray(np.asarray(maps) != 0, dtype=np.int8)
+        a = np.ascontiguousarray(agents_pos, dtype=np.int16)
+        g = np.ascontiguousarray(goals_pos, dtype=np.int16)
+        assert m.shape == (n, L, L) and a.shape == (n, N, 2) and g.shape == (n, N, 2)
+        check(lib.mapf_load_envs(self._h, ids.ctypes.data, n, m.ctypes.data, a.ctypes.data, g.ctypes.data,
+                                 _stream(self.device)), "mapf_load_envs")
 
     def check_status(self):
         """Synchronises and raises the reference's exception for any sticky device-side error."""

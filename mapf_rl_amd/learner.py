@@ -1,0 +1,144 @@
+"""DQN batch update of the reference (`Learner.train` body, reference worker.py:282-344) on one MI355X, with
+an optional data-parallel gradient all-reduce across the GPUs of a node.
+
+One `update()` = worker.py:287-338: sample a prioritized batch of [B, 18, A] windows from the device replay,
+target = r + 0.99^steps * (1 - done) * max_a Q_target(window, bt+steps)  (1-step reward even when steps = 2:
+quirk Q2; no double-Q: quirk Q6), Huber(kappa=1) loss weighted by the IS weights, Adam(1e-4) with
+MultiStepLR(100k, 300k, x0.5), global grad-norm clip 40, new priorities |td| back into the sum tree, target
+sync + checkpoint every 2500 updates.
+
+Deviations (declared): bf16 autocast instead of fp16 autocast + GradScaler (bf16 needs no loss scaling;
+on CPU both are fp32); the inner counter that restarts every 10,000 iterations in the reference
+(worker.py:285,336) is the plain update counter here.
+
+Multi-GPU: every rank owns its environments, replay ring and sum tree; the only exchange
+is ONE all-reduce per update of the flat 2,050,582-element fp32 gradient bucket (8.2 MB) over RCCL/xGMI
+(`torch.distributed`, backend "nccl"), averaged over ranks.  Parameter .grad tensors are views into the
+bucket, so there is no flatten/unflatten copy."""
+import os
+from copy import deepcopy
+
+import torch
+import torch.nn as nn
+
+from .model import Network
+
+GAMMA = 0.99          # hard-coded in the reference (worker.py:306), config.gamma is dead
+GRAD_CLIP = 40.0      # worker.py:319
+TARGET_SYNC = 2500    # config.target_network_update_freq (config.py:27)
+FORWARD_STEPS = 2     # config.forward_steps (config.py:65)
+
+
+def huber_loss(td_error, kappa=1.0):
+    """worker.py:341-344"""
+    a = td_error.abs()
+    flag = (a < kappa).to(td_error.dtype)
+    return flag * a.pow(2) * 0.5 + (1 - flag) * (a - 0.5)
+
+
+class FlatGradBucket:
+    """All parameter gradients as views of one contiguous fp32 buffer -> one collective per update."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+        for p, g in zip(self.params, self._views()):  # autograd may have replaced .grad (it does not, but be safe)
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+
+    def _views(self):
+        off = 0
+        for p in self.params:
+            yield self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def all_reduce_mean(self, group=None):
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.div_(dist.get_world_size(group))
+
+
+class Learner:
+    def __init__(self, buffer=None, device=None, batch_size=192, lr=1e-4, milestones=(100000, 300000), save_path="./models",
+                 model=None):
+        self.device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.model = (model if model is not None else Network()).to(self.device)
+        self.tar_model = deepcopy(self.model)
+        for p in self.tar_model.parameters():
+            p.requires_grad_(False)
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr)                       # worker.py:260
+        self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=list(milestones), gamma=0.5)  # :261
+        self.bucket = FlatGradBucket(self.model.parameters())
+        self.buffer, self.batch_size, self.save_path = buffer, batch_size, save_path
+        self.counter = self.last_counter = 0
+        self.loss = 0.0
+        self.done = False
+
+    # ------------------------------------------------------------------ one update
+    def compute_td(self, batch):
+        """worker.py:296-306 on an 11-tuple from GlobalBuffer.sample_batch. Returns (td_error [B,1], q [B,1], q_next [B,1])."""
+        b_obs, b_action, b_reward, b_done, b_steps, b_bt_steps, b_hidden, b_comm_mask = batch[:8]
+        b_next_bt_steps = b_bt_steps + b_steps.view(-1).to(b_bt_steps.dtype)
+        with torch.no_grad():
+            q_next = (1 - b_done) * self.tar_model.bootstrap(b_obs, b_next_bt_steps, b_hidden, b_comm_mask).max(1, keepdim=True)[0]
+        q = self.model.bootstrap(b_obs[:, :-FORWARD_STEPS], b_bt_steps, b_hidden, b_comm_mask[:, :-FORWARD_STEPS]).gather(1, b_action)
+        td = q - (b_reward + (GAMMA ** b_steps) * q_next)
+        return td, q, q_next
+
+    def update(self, batch=None):
+        """One Learner.train iteration (worker.py:287-338).  `batch` defaults to a fresh prioritized sample."""
+        if batch is None:
+            batch = self.buffer.sample_batch(self.batch_size)
+        idxes, weights, old_ptr = batch[8], batch[9], batch[10]
+        td, q, q_next = self.compute_td(batch)
+        priorities = td.detach().view(-1).abs().clamp(1e-6)                                      # worker.py:308
+        loss = (weights * huber_loss(td)).mean()                                                 # worker.py:310
+        self.bucket.zero()
+        loss.backward()
+        self.bucket.all_reduce_mean()                                                            # the only collective
+        grad_norm = nn.utils.clip_grad_norm_(self.model.parameters(), GRAD_CLIP)                 # worker.py:319
+        self.optimizer.step()
+        self.scheduler.step()
+        if self.buffer is not None and idxes is not None:
+            self.buffer.update_priorities(idxes, priorities, old_ptr)                            # worker.py:331
+        self.counter += 1
+        self._last = (loss.detach(), grad_norm.detach())
+        if self.counter % TARGET_SYNC == 0:                                                      # worker.py:336-338
+            self.sync_target()
+            self.save()
+        return dict(loss=loss.detach(), td=td.detach(), priorities=priorities, grad_norm=grad_norm.detach(), q=q.detach(),
+                    q_next=q_next)
+
+    def sync_target(self):
+        self.tar_model.load_state_dict(self.model.state_dict())
+
+    def save(self, path=None):
+        """Checkpoint with the reference's key names (worker.py:338); the directory is created if missing."""
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+            return None
+        os.makedirs(self.save_path, exist_ok=True)
+        path = path or os.path.join(self.save_path, "{}.pth".format(self.counter))
+        torch.save({k: v.detach().cpu() for k, v in self.model.state_dict().items()}, path)
+        return path
+
+    def stats(self, interval):
+        """worker.py:347-352"""
+        if hasattr(self, "_last"):
+            self.loss = float(self._last[0])
+        print("number of updates: {}".format(self.counter))
+        print("update speed: {}/s".format((self.counter - self.last_counter) / interval))
+        print("loss: {}".format(self.loss))
+        self.last_counter = self.counter
+        return self.done
