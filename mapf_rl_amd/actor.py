@@ -47,17 +47,21 @@ class VecActor:
         E, N = env.num_envs, env.num_agents
         d = env.device
         self.E, self.N, self.device, self.max_steps, self.density = E, N, d, max_steps, density
-        assert buffer is None or buffer.max_agents == N, "replay rows must use the environment's agent count"
+        assert buffer is None or buffer.max_agents >= N, "replay rows must hold at least the environment's agents"
         self.eps = (epsilon_ladder(E) if epsilons is None else torch.as_tensor(epsilons, dtype=torch.float64).expand(E)).to(d)
         self.actor_ids = (torch.arange(E) % 16).tolist()
         self.gen = torch.Generator(device=d)
         self.gen.manual_seed(seed)
         self.scenario_seed = seed * 1000003 + 17
         self.RD = env.obs_bits_row_dwords
-        self.CW = (N + 31) // 32
+        # replay rows are laid out for A = buffer.max_agents >= N agents: the N-agent bit row is a prefix of the
+        # A-agent row (bit a*486 + ...), so local rows are simply allocated at the replay's width, zero padded
+        self.A = N if buffer is None else buffer.max_agents
+        self.RDA = self.RD if buffer is None else buffer.row_dwords
+        self.CW = (self.A + 31) // 32
         R = max_steps + 1
-        self.lb_obs = torch.zeros((E, R, self.RD), dtype=torch.int32, device=d)
-        self.lb_comm = torch.zeros((E, R, N, self.CW), dtype=torch.int32, device=d)
+        self.lb_obs = torch.zeros((E, R, self.RDA), dtype=torch.int32, device=d)
+        self.lb_comm = torch.zeros((E, R, self.A, self.CW), dtype=torch.int32, device=d)
         self.lb_act = torch.zeros((E, max_steps), dtype=torch.uint8, device=d)
         self.lb_rew = torch.zeros((E, max_steps), dtype=torch.float16, device=d)
         self.lb_hid = torch.zeros((E, max_steps, 256), dtype=torch.float16, device=d)
@@ -74,7 +78,7 @@ class VecActor:
 
     def _begin(self):
         self.obs, self.pos = self.env.observe(obs_bits_out=self.bits)
-        self.lb_obs[:, 0] = self.bits
+        self.lb_obs[:, 0, :self.RD] = self.bits
         self.t.zero_()
         self.hidden = None
 
@@ -95,8 +99,8 @@ class VecActor:
         self.lb_act[self.ar, t] = actions[:, 0].to(torch.uint8)
         self.lb_rew[self.ar, t] = reward[:, 0].to(torch.float16)
         self.lb_hid[self.ar, t] = hidden.view(E, N, 256)[:, 0].to(torch.float16)
-        self.lb_comm[self.ar, t] = pack_comm_device(comm, self.CW)
-        self.lb_obs[self.ar, t + 1] = self.bits
+        self.lb_comm[self.ar, t, :N] = pack_comm_device(comm, self.CW)
+        self.lb_obs[self.ar, t + 1, :self.RD] = self.bits
         self.t = t + 1
         self.hidden = hidden
         self.obs, self.pos = obs, pos
@@ -155,7 +159,7 @@ class VecActor:
         maps, agents, goals, _ = generate_scenarios(len(ids_h), self.env.map_length, self.N, self.density, self.scenario_seed)
         self.env.load_envs(ids_h, maps, agents, goals)
         self.obs, self.pos = self.env.observe(obs_bits_out=self.bits)
-        self.lb_obs[ids, 0] = self.bits[ids]
+        self.lb_obs[ids, 0, :self.RD] = self.bits[ids]
         self.t[ids] = 0
         self.hidden.view(self.E, self.N, 256)[ids] = 0                # model.reset(): GRUCell(x, None) == zero state
 

@@ -1,0 +1,84 @@
+"""GPU: reference-compatible entry points -- scenario pkl round trip against the reference's own fixture
+format, the vectorised evaluation loop against a sequential evaluation through the single-env facade, and a
+short end-to-end train.py run."""
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tests_from_golden(nag, cases=3):
+    z = H.load_npz("env_fixtures.npz")
+    t = {"maps": [], "agents": [], "goals": []}
+    for c in range(cases):
+        pre = "fix%d_c%d_" % (nag, c)
+        t["maps"].append(z[pre + "map"].astype(np.float32))
+        t["agents"].append(z[pre + "agents"].astype(np.int64))
+        t["goals"].append(z[pre + "goals"].astype(np.int64))
+    return t
+
+
+def test_pkl_round_trip(tmp_path):
+    from mapf_rl_amd import evaluate as EV
+
+    t = _tests_from_golden(16)
+    p = str(tmp_path / "test16_40.pkl")
+    EV.save_tests(p, t["maps"], t["agents"], t["goals"])
+    back = EV.load_tests(p)
+    assert all(np.array_equal(a, b) for a, b in zip(back["maps"], t["maps"]))
+    assert back["agents"][0].dtype == np.int64 and back["agents"][0].shape == (16, 2)
+    plain = pickle.load(open(p, "rb"))  # what the reference's test.py does (test.py:89-90)
+    assert set(plain.keys()) == {"maps", "agents", "goals"}
+    made = EV.create_test(5, 12, test_num=7, density=0.2, seed=3, path=str(tmp_path / "t.pkl"))
+    assert len(made["maps"]) == 7 and made["maps"][0].shape == (12, 12) and made["agents"][0].shape == (5, 2)
+    bad = str(tmp_path / "bad.pkl")
+    pickle.dump({"maps": os.system}, open(bad, "wb"))
+    with pytest.raises(pickle.UnpicklingError):
+        EV.load_tests(bad)
+
+
+def test_vectorised_evaluation_equals_sequential():
+    """test_model's loop (reference test.py:105-143) vectorised over cases == the same loop run case by case
+    through the reference-compatible single-env facade with the same network."""
+    import mapf_rl_amd as M
+    from mapf_rl_amd import evaluate as EV
+    from mapf_rl_amd.model import Network
+
+    torch.manual_seed(3)
+    net = Network().cuda().eval()
+    tests = _tests_from_golden(16)
+    f_rate, mean_steps, steps, ok = EV.evaluate(net, tests, max_steps=12, num_cases=3)
+    for i in range(3):
+        env = M.Environment()
+        env.load(tests["maps"][i], tests["agents"][i], tests["goals"][i])
+        done = False
+        net.reset()
+        while not done and env.steps < 12:
+            obs, pos = env.observe()
+            actions, _, _, _ = net.step(torch.from_numpy(obs.astype(np.float32)), torch.from_numpy(pos.astype(np.float32)))
+            _, _, done, _ = env.step(actions)
+        assert env.steps == steps[i]
+        assert bool(np.array_equal(env.agents_pos, env.goals_pos)) == bool(ok[i])
+    assert 0.0 <= f_rate <= 1.0 and mean_steps <= 12
+
+
+def test_train_entry_point_runs(tmp_path):
+    """`python train.py` for a few seconds on a tiny configuration: collects, starts training, checkpoints."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "train.py"), "--envs", "64", "--agents", "2", "--map", "10", "--capacity", "256",
+           "--learning-starts", "2000", "--batch-size", "16", "--max-updates", "6", "--interval", "2"]
+    out = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "start training" in out.stdout
+    assert os.path.exists(str(tmp_path / "models" / "6.pth"))
+    sd = torch.load(str(tmp_path / "models" / "6.pth"), map_location="cpu")
+    assert "obs_encoder.0.weight" in sd and "comm.self_attn.W_Q.weight" in sd and len(sd) == 35
