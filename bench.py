@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--density", type=float, default=0.3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time")
+    ap.add_argument("--no-dqn", action="store_true", help="skip the secondary learner / actor-loop rates")
+    ap.add_argument("--dqn-updates", type=int, default=5)
+    ap.add_argument("--dqn-actor-iters", type=int, default=3)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -154,33 +157,85 @@ def main():
         except Exception:
             pass
 
-    # ---- CPU baseline: the oracle (C restatement with the reference's sequential semantics) ----
+    # ---- CPU baseline: the oracle (C restatement with the reference's sequential semantics), in a child
+    # process without torch (its OpenMP runtime serialises the oracle's parallel loop) and without the GPU ----
     if rank == 0 and not args.no_cpu_baseline:
-        from oracle import oracle
+        import subprocess
+        import tempfile
 
-        S = min(E, 256)
-        nthreads = oracle.max_threads()
-        tape_h = tape[:, :S].cpu().numpy()
-        nv = oracle.navi_batch(maps[:S], goals[:S], nthreads)
+        nthreads = len(os.sched_getaffinity(0))
+        S = min(E, max(256, 4 * nthreads))
+        with tempfile.TemporaryDirectory() as td:
+            f = os.path.join(td, "sample.npz")
+            np.savez(f, maps=maps[:S], agents=agents[:S], goals=goals[:S], tape=tape[:, :S].cpu().numpy())
+            out = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", f, str(nthreads), str(args.cpu_seconds)],
+                                 cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        cb = json.loads(out.stdout.strip().splitlines()[-1])
         # trajectories must be identical to the GPU's before any number is reported
-        chk = oracle.rollout(maps[:S], agents[:S], goals[:S], nv, tape_h, want_pos=False, want_rclass=False,
-                             want_done=False, want_hash=True, nthreads=nthreads)
-        assert chk["status"] == 0
-        assert np.array_equal(chk["final_agents"], final_pos_first_pass[:S].cpu().numpy()), "CPU/GPU trajectories differ"
-        t1 = time.perf_counter()
-        reps = 0
-        while True:
-            oracle.rollout(maps[:S], agents[:S], goals[:S], nv, tape_h, want_pos=False, want_rclass=False,
-                           want_done=False, want_hash=True, nthreads=nthreads)
-            reps += 1
-            dt = time.perf_counter() - t1
-            if dt >= args.cpu_seconds or reps >= 10000:
-                break
+        assert np.array_equal(np.array(cb["final_agents"], np.int16), final_pos_first_pass[:S].cpu().numpy()), \
+            "CPU/GPU trajectories differ"
         result["cpu_baseline"] = {
-            "value": S * T * reps / dt, "unit": "env-steps/s", "cores": nthreads, "kind": "port",
-            "sample": "first %d envs x %d tape steps x %d repeats (%.1f s), step+observe, OpenMP one env per thread; "
-                      "trajectories verified identical to the GPU run" % (S, T, reps, dt),
+            "value": cb["env_steps_per_sec"], "unit": "env-steps/s", "cores": cb["threads"], "kind": "port",
+            "sample": "first %d envs x %d tape steps x %d repeats (%.1f s), step+observe, OpenMP one env per thread; %d threads = "
+                      "fastest of a scan up to the %d logical CPUs of the box; trajectories verified identical to the GPU run" % (
+                          S, T, cb["reps"], cb["seconds"], cb["threads"], nthreads),
+            "thread_scan": cb.get("scan"),
         }
+    # ---- secondary rates of the same pipeline (BASELINE metric: "env steps/sec + learner updates/sec") ----
+    # learner: Learner.update on 192 x 18 x 40 windows sampled from the device replay (bf16, incl. the flat
+    # gradient all-reduce over RCCL when world > 1); actor loop: policy inference + env step + recording.
+    if not args.no_dqn:
+        try:
+            from mapf_rl_amd.actor import VecActor
+            from mapf_rl_amd.learner import Learner
+            from mapf_rl_amd.replay import GlobalBuffer
+
+            torch.manual_seed(1234)  # identical initial weights on every rank
+            buf = GlobalBuffer(64, max_agents=N, device=dev)
+            g2 = torch.Generator(device=dev)
+            g2.manual_seed(5 + rank)
+            RD, CW, S = buf.row_dwords, (N + 31) // 32, 96
+            for k in range(64):  # synthetic episodes written straight into the ring (random observation bits)
+                td = torch.zeros(256, dtype=torch.float64, device=dev)
+                td[:S] = torch.rand(S, generator=g2, device=dev, dtype=torch.float64) + 0.05
+                buf.add_episode_device(
+                    N, S, k % 2, torch.randint(-2**31, 2**31 - 1, (S + 1, RD), generator=g2, device=dev, dtype=torch.int32) &
+                    torch.randint(-2**31, 2**31 - 1, (S + 1, RD), generator=g2, device=dev, dtype=torch.int32),
+                    torch.randint(0, 2**20, (S + 1, N, CW), generator=g2, device=dev, dtype=torch.int32),
+                    torch.randint(0, 5, (S,), generator=g2, device=dev, dtype=torch.uint8),
+                    (torch.rand(S, generator=g2, device=dev) - 0.5).half(), (torch.randn((S, 256), generator=g2, device=dev) * 0.3).half(), td)
+            learner = Learner(buf, device=dev, batch_size=192)
+            for _ in range(2):
+                learner.update()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.dqn_updates):
+                learner.update()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            dt_upd = (time.perf_counter() - t1) / args.dqn_updates
+            actor = VecActor(env, learner.model, None, seed=rank, density=args.density)
+            actor.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.dqn_actor_iters):
+                actor.step()
+            torch.cuda.synchronize()
+            dt_act = (time.perf_counter() - t1) / args.dqn_actor_iters
+            env.check_status()
+            result["extra"] = {
+                "learner_updates_per_sec": 1.0 / dt_upd, "learner_ms_per_update": dt_upd * 1e3,
+                "learner_config": "B=192 x T=18 x A=%d windows from the device replay, bf16 autocast, Adam, %s" % (
+                    N, "flat-bucket RCCL all-reduce x%d (same update rate on every rank)" % world if world > 1 else "1 GPU"),
+                "actor_loop_env_steps_per_sec": world * E / dt_act, "actor_loop_ms_per_iter": dt_act * 1e3,
+                "actor_loop_config": "Network.step_batch (bf16) + mapf_step + local-buffer recording, %d envs x %d agents per GPU" % (E, N),
+            }
+        except Exception as ex:  # the primary metric must still be reported
+            result["extra"] = {"error": repr(ex)[:300]}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -123,7 +123,10 @@ class VecActor:
         ret = rew + FORWARD_GAMMA * nxt + q.max(-1).values            # np.convolve(ret, [0.99, 1], 'valid') + q_max
         qa = q.gather(-1, self.lb_act[ids].long().unsqueeze(-1)).squeeze(-1)
         td = (ret - qa).abs()
-        return torch.where(valid, td, torch.zeros_like(td))           # zeros past the episode end
+        td = torch.where(valid, td, torch.zeros_like(td))             # zeros past the episode end
+        if S < 256:                                                   # a replay slot always has 256 leaves (worker.py:87,94)
+            td = torch.cat([td, torch.zeros((td.shape[0], 256 - S), dtype=td.dtype, device=td.device)], dim=1)
+        return td.contiguous()
 
     def _flush(self, ids, done):
         ids_h = ids.tolist()

@@ -147,7 +147,9 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherParams p) {
     const long long idx = p.idx[b];
     const long long g = idx / kMaxSteps, l = idx % kMaxSteps;
     const int size = p.size_buf[g];
-    const int steps = (int)min((long long)MAPF_REPLAY_FWD_STEPS, (long long)size - l);      // worker.py:122
+    // worker.py:122; a leaf past the episode end has priority 0 and is never drawn (the reference asserts it,
+    // worker.py:120) -- clamp anyway so that a corrupted tree cannot produce negative window lengths
+    const int steps = (int)max(0ll, min((long long)MAPF_REPLAY_FWD_STEPS, (long long)size - l));
     const long long first_row = g * kRows;
     const long long lo = (l < MAPF_REPLAY_BT_STEPS - 1) ? first_row : idx + g + 1 - MAPF_REPLAY_BT_STEPS;  // :124-136
     const long long hi = idx + g + 1 + steps;

@@ -82,7 +82,7 @@ class VecEnvironment:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h is not None and h.value:
+        if h is not None and h.value and lib is not None:
             lib.mapf_destroy(h)
             self._h = ctypes.c_void_p()
 

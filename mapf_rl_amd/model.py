@@ -141,11 +141,18 @@ class Network(nn.Module):
         on_gpu = device.type == "cuda"
         return torch.autocast(device_type="cuda" if on_gpu else "cpu", dtype=torch.bfloat16, enabled=on_gpu)
 
+    ENCODE_CHUNK = 32768  # observations per convolution call (see encode)
+
     def encode(self, obs):
-        """obs [M, 6, 9, 9] (uint8 / bool / float) -> [M, 784]."""
+        """obs [M, 6, 9, 9] (uint8 / bool / float) -> [M, 784].
+        The batch is processed in chunks of ENCODE_CHUNK observations: MIOpen's convolution for one
+        138,240-observation call (192x18x40, the learner's window batch) returned non-finite rows for finite
+        inputs and weights on ROCm 7.2 / gfx950 (tools/nan_debug.py), and chunking bounds the activation
+        footprint (1.7 GB per layer at 138k observations)."""
         w = self.obs_encoder[0].weight
-        x = obs.to(w.dtype) if obs.dtype != w.dtype else obs
-        return self.obs_encoder(x)
+        if obs.shape[0] <= self.ENCODE_CHUNK:
+            return self.obs_encoder(obs.to(w.dtype) if obs.dtype != w.dtype else obs)
+        return torch.cat([self.obs_encoder(c.to(w.dtype) if c.dtype != w.dtype else c) for c in obs.split(self.ENCODE_CHUNK)], dim=0)
 
     def q_head(self, hidden):
         adv = self.adv(hidden)

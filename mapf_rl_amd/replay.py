@@ -107,7 +107,7 @@ class GlobalBuffer:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h is not None and h.value:
+        if h is not None and h.value and lib is not None:
             lib.mapf_replay_destroy(h)
             self._h = ctypes.c_void_p()
 
@@ -124,6 +124,7 @@ class GlobalBuffer:
     # ------------------------------------------------------------------ add
     def add_episode_device(self, num_agents, size, done, obs_bits, comm_bits, act, rew, hid, td):
         """All tensors already on the device in storage layout (see include/mapf_replay.h)."""
+        assert td.numel() == MAX_STEPS and td.dtype == torch.float64 and td.is_contiguous()
         with self.lock:
             check(lib.mapf_replay_add(self._h, int(num_agents), int(size), int(bool(done)), _ptr(obs_bits), _ptr(comm_bits),
                                       _ptr(act), _ptr(rew), _ptr(hid), _ptr(td), _stream(self.device)), "mapf_replay_add")

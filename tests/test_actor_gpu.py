@@ -51,6 +51,7 @@ def test_actor_records_consistent_episodes():
             rew = ep["rew"].cpu().numpy()
             assert set(np.unique(rew.astype(np.float32))) <= set(np.array([-0.075, -0.5, 0.0, 3.0], np.float16).astype(np.float32))
             td = RO.local_finish(ep["q"].cpu().numpy(), ep["act"].cpu().numpy(), rew, size, capacity=24)
+            assert ep["td"].shape == (256,) and float(ep["td"][24:].abs().sum()) == 0.0
             assert np.allclose(ep["td"].cpu().numpy()[:24], td, rtol=1e-12, atol=1e-12)
             if ep["done"]:
                 assert np.all(rew[-1:] == np.float16(3.0)) and int(ep["comm"][size].abs().sum()) == 0
@@ -63,9 +64,12 @@ def test_actor_records_consistent_episodes():
     assert checked >= E  # every env finished at least one episode (max_steps = 24, 80 iterations)
     assert len(buf) == sum(ep["size"] for ep in actor.flushed[-min(len(actor.flushed), 32):]) or len(actor.flushed) > 32
     assert actor.env_steps == 80 * E
-    # the ring is sampleable and the learner's window gather works on actor-produced data
-    out = buf.sample_batch(16)
-    assert out[0].shape == (16, 18, N, 6, 9, 9) and torch.isfinite(out[9]).all()
+    # the ring is sampleable and the learner's window gather works on actor-produced data: every drawn leaf
+    # lies inside its episode (reference assert, worker.py:120)
+    for _ in range(20):
+        out = buf.sample_batch(64)
+        assert out[0].shape == (64, 18, N, 6, 9, 9) and torch.isfinite(out[9]).all()
+        assert float(out[4].min()) >= 1 and float(out[4].max()) <= 2
 
 
 def _start_of(actor, e, N, L):
