@@ -52,6 +52,9 @@ SYMBOLS = [
     ("mapf_replay_add", _i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_replay_sample", _i, [_vp, _vp, _i] + [_vp] * 11),
     ("mapf_replay_update_priorities", _i, [_vp, _vp, _vp, _i, _i, _vp]),
+    # include/mapf_dqn.h
+    ("mapf_bias_res_relu_fwd", _i, [_vp, _vp, _vp, ctypes.c_int64, _i, _vp]),
+    ("mapf_bias_res_relu_bwd", _i, [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp]),
 ]
 
 

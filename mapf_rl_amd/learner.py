@@ -43,10 +43,17 @@ class FlatGradBucket:
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        for p, g in zip(self.params, self._views()):
+            p.grad = g
+
+    @staticmethod
+    def _view_like(flat_slice, p):
+        """A view of the flat slice with p's shape AND strides (channels_last conv weights keep NHWC strides,
+        so autograd accumulates without a layout-converting copy)."""
+        if p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last):
+            o, i, h, w = p.shape
+            return flat_slice.view(o, h, w, i).permute(0, 3, 1, 2)
+        return flat_slice.view_as(p)
 
     def zero(self):
         self.flat.zero_()
@@ -57,7 +64,7 @@ class FlatGradBucket:
     def _views(self):
         off = 0
         for p in self.params:
-            yield self.flat[off:off + p.numel()].view_as(p)
+            yield self._view_like(self.flat[off:off + p.numel()], p)
             off += p.numel()
 
     def all_reduce_mean(self, group=None):

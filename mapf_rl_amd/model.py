@@ -135,6 +135,10 @@ class Network(nn.Module):
                 nn.init.xavier_uniform_(m.weight)
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
+        # NHWC weights: MIOpen's bf16 NHWC convolutions run 1.5-1.6x faster than NCHW at this shape on MI355X
+        # (418-447 vs 277-279 TFLOP/s for the 128->128 3x3 layers, tools/conv_bench.py).  Shapes and
+        # state_dict values are unaffected (only strides change).
+        self.obs_encoder.to(memory_format=torch.channels_last)
 
     # ------------------------------------------------------------------ building blocks
     def _autocast(self, device):
@@ -142,6 +146,7 @@ class Network(nn.Module):
         return torch.autocast(device_type="cuda" if on_gpu else "cpu", dtype=torch.bfloat16, enabled=on_gpu)
 
     ENCODE_CHUNK = 32768  # observations per convolution call (see encode)
+    FUSED_EPILOGUE = True  # hand-written bias/residual/ReLU epilogue kernels behind every convolution (HIP, bf16)
 
     def encode(self, obs):
         """obs [M, 6, 9, 9] (uint8 / bool / float) -> [M, 784].
@@ -150,14 +155,13 @@ class Network(nn.Module):
         inputs and weights on ROCm 7.2 / gfx950 (tools/nan_debug.py), and chunking bounds the activation
         footprint (1.7 GB per layer at 138k observations)."""
         w = self.obs_encoder[0].weight
-        nhwc = w.device.type == "cuda"
-        if nhwc and not getattr(self, "_nhwc_weights", False):
-            # MIOpen's bf16 NHWC convolutions run 1.5-1.6x faster than NCHW at this shape on MI355X
-            # (418-447 vs 277-279 TFLOP/s for the 128->128 3x3 layers, tools/conv_bench.py)
-            self.obs_encoder.to(memory_format=torch.channels_last)
-            self._nhwc_weights = True
+        nhwc = w.device.type == "cuda"  # weights are stored channels_last (see __init__)
+
+        fused = nhwc and self.FUSED_EPILOGUE and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
 
         def run(x):
+            if fused:
+                return self._encode_fused(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
             x = x.to(w.dtype) if x.dtype != w.dtype else x
             if nhwc:
                 x = x.contiguous(memory_format=torch.channels_last)
@@ -166,6 +170,19 @@ class Network(nn.Module):
         if obs.shape[0] <= self.ENCODE_CHUNK:
             return run(obs)
         return torch.cat([run(c) for c in obs.split(self.ENCODE_CHUNK)], dim=0)
+
+    def _encode_fused(self, x):
+        """The encoder (model.py:147-162) with every bias / residual / ReLU fused behind its convolution by the
+        hand-written epilogue kernel (mapf_rl_amd/fused.py): bf16, NHWC, under autocast."""
+        from .fused import bias_res_relu
+
+        enc = self.obs_encoder
+        h = bias_res_relu(F.conv2d(x, enc[0].weight, None), enc[0].bias)
+        for blk in (enc[2], enc[3], enc[4]):
+            t = bias_res_relu(F.conv2d(h, blk.block1.weight, None, 1, 1), blk.block1.bias)
+            h = bias_res_relu(F.conv2d(t, blk.block2.weight, None, 1, 1), blk.block2.bias, h)
+        h = bias_res_relu(F.conv2d(h, enc[5].weight, None), enc[5].bias)
+        return h.flatten(1)
 
     def q_head(self, hidden):
         adv = self.adv(hidden)
