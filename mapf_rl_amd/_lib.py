@@ -5,7 +5,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmapf_env.so")
+LIB_PATH = os.environ.get("MAPF_LIB_OVERRIDE") or os.path.join(_HERE, "libmapf_env.so")  # override: A/B tuning of two builds only
 
 OK = 0
 ERR_INVALID_ARG, ERR_ACTION, ERR_OVERLAP, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_SPACE, ERR_NOT_READY = (
