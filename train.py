@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--interval", type=float, default=30.0, help="statistics interval in seconds (train.py:39)")
     ap.add_argument("--learning-starts", type=int, default=config.learning_starts)
     ap.add_argument("--batch-size", type=int, default=config.batch_size)
+    ap.add_argument("--curriculum", action="store_true", help="reference schedule: start at config.init_set and promote levels "
+                    "at config.pass_rate (worker.py:205-250); --envs is then the number of environments PER LEVEL")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -53,17 +55,26 @@ def main():
     from mapf_rl_amd.learner import Learner
     from mapf_rl_amd.replay import GlobalBuffer
 
-    env = M.VecEnvironment(a.envs, a.map, a.agents, config.obs_radius, config.reward_fn, device=dev)
-    maps, agents, goals, _ = M.generate_scenarios(a.envs, a.map, a.agents, -1.0, seed=rank)
-    env.load(maps, agents, goals)
-    buffer = GlobalBuffer(a.capacity, max_agents=max(a.agents, config.max_num_agetns), device=dev,
-                          init_set=(a.agents, a.map), max_map_length=config.max_map_lenght, pass_rate=config.pass_rate)
+    if a.curriculum:
+        from mapf_rl_amd.curriculum import CurriculumActors
+
+        buffer = GlobalBuffer(a.capacity, max_agents=config.max_num_agetns, device=dev, init_set=config.init_set,
+                              max_map_length=config.max_map_lenght, pass_rate=config.pass_rate)
+    else:
+        env = M.VecEnvironment(a.envs, a.map, a.agents, config.obs_radius, config.reward_fn, device=dev)
+        maps, agents, goals, _ = M.generate_scenarios(a.envs, a.map, a.agents, -1.0, seed=rank)
+        env.load(maps, agents, goals)
+        buffer = GlobalBuffer(a.capacity, max_agents=max(a.agents, config.max_num_agetns), device=dev,
+                              init_set=(a.agents, a.map), max_map_length=config.max_map_lenght, pass_rate=config.pass_rate)
     learner = Learner(buffer, device=dev, batch_size=a.batch_size, save_path=config.save_path)
     if world > 1:  # identical initial weights on every rank
         for p in learner.model.parameters():
             dist.broadcast(p.data, src=0)
         learner.sync_target()
-    actor = VecActor(env, learner.model, buffer, seed=rank)
+    if a.curriculum:
+        actor = CurriculumActors(learner.model, buffer, envs_per_level=a.envs, device=dev, seed=rank, reward_fn=config.reward_fn)
+    else:
+        actor = VecActor(env, learner.model, buffer, seed=rank)
 
     t_start = t_last = time.time()
     debt = 0.0
@@ -85,8 +96,16 @@ def main():
                 learner.stats(now - t_last)
                 buffer.stats(now - t_last)
                 print()
-            else:
-                buffer.stats.__func__  # (per-rank buffers keep their own counters; only rank 0 prints)
+            else:  # per-rank buffers keep their own counters and levels; only rank 0 prints
+                import contextlib
+                import io
+
+                with contextlib.redirect_stdout(io.StringIO()):
+                    buffer.stats(now - t_last)
+            if a.curriculum:
+                actor.sync_levels()
+                if buffer.check_done():  # worker.py:237-250, train.py:41-43
+                    break
             t_last = now
         if a.minutes > 0 and (now - t_start) > a.minutes * 60:
             break
