@@ -8,8 +8,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MAPF_LIB_OVERRIDE") or os.path.join(_HERE, "libmapf_env.so")  # override: A/B tuning of two builds only
 
 OK = 0
-ERR_INVALID_ARG, ERR_ACTION, ERR_OVERLAP, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_SPACE, ERR_NOT_READY = (
-    -1, -2, -3, -4, -5, -6, -7)
+ERR_INVALID_ARG, ERR_ACTION, ERR_OVERLAP, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_SPACE, ERR_NOT_READY, ERR_TIMEOUT = (
+    -1, -2, -3, -4, -5, -6, -7, -8)
 
 # every symbol include/mapf_env.h declares: (name, restype, argtypes)
 _vp, _i, _u64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_float
@@ -55,6 +55,9 @@ SYMBOLS = [
     # include/mapf_dqn.h
     ("mapf_bias_res_relu_fwd", _i, [_vp, _vp, _vp, ctypes.c_int64, _i, _vp]),
     ("mapf_bias_res_relu_bwd", _i, [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp]),
+    # include/mapf_search.h
+    ("mapf_find_path", _i, [_i, _i, _vp, _vp, _vp, ctypes.c_double, _i, _vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    ("mapf_distance_field", _i, [_i, _vp, _i, _i, _vp]),
 ]
 
 

@@ -46,12 +46,30 @@ def save_tests(path, maps, agents, goals, extra=None):
     return tests
 
 
-def create_test(agent_range, map_range, test_num=TEST_NUM, density=-1.0, seed=1, path=None):
-    """reference test.py:23-79 without the CBS labelling: writes ./test{agents}_{map}.pkl"""
+def create_test(agent_range, map_range, test_num=TEST_NUM, density=-1.0, seed=1, path=None, with_opt_steps=False,
+                time_limit=5.0):
+    """reference test.py:23-79: writes ./test{agents}_{map}.pkl.  with_opt_steps=True labels every scenario with the
+    makespan of the expert plan (`opt_steps`, test.py:50-58); a scenario the planner cannot solve within
+    `time_limit` seconds is re-drawn, like the reference's `while actions is None: env.reset()` loop."""
     assert isinstance(agent_range, int) and isinstance(map_range, int), "fixed sizes only (the shipped fixtures' case)"
     path = path or "./test{}_{}.pkl".format(agent_range, map_range)
     maps, agents, goals, _ = generate_scenarios(test_num, map_range, agent_range, density, seed)
-    return save_tests(path, list(maps.astype(np.float32)), list(agents), list(goals))
+    extra = None
+    if with_opt_steps:
+        from .search import plan
+
+        opt = []
+        redraw_seed = seed * 100003
+        for k in range(test_num):
+            res = plan(maps[k], agents[k], goals[k], time_limit)
+            while res is None:
+                redraw_seed += 1
+                m1, a1, g1, _ = generate_scenarios(1, map_range, agent_range, density, redraw_seed)
+                maps[k], agents[k], goals[k] = m1[0], a1[0], g1[0]
+                res = plan(maps[k], agents[k], goals[k], time_limit)
+            opt.append(len(res[0]))
+        extra = {"opt_steps": opt, "opt_mean_steps": sum(opt) / len(opt)}  # test.py:58,76
+    return save_tests(path, list(maps.astype(np.float32)), list(agents), list(goals), extra)
 
 
 @torch.no_grad()

@@ -2,7 +2,7 @@
 checkpoints in ./models on a scenario fixture.  The work runs through mapf_rl_amd (GPU, 200 cases in lock-step).
 
     python3 test.py [--test-case test32_40_0.3.pkl] [--model-dir ./models] [--start 190000]
-    python3 test.py --create 32 40     # writes ./test32_40.pkl (reference create_test, without CBS labels)
+    python3 test.py --create 32 40     # writes ./test32_40.pkl incl. opt_steps from the CBS expert (reference create_test)
 """
 import argparse
 import random
@@ -19,7 +19,7 @@ test_num = 200
 def create_test(agent_range, map_range):
     from mapf_rl_amd.evaluate import create_test as _create
 
-    return _create(agent_range, map_range, test_num)
+    return _create(agent_range, map_range, test_num, with_opt_steps=True)
 
 
 def test_model(test_case="test32_40_0.3.pkl", model_dir="./models", start=190000):

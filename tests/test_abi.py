@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     names = set()
-    for h in ("mapf_env.h", "mapf_replay.h", "mapf_dqn.h"):
+    for h in ("mapf_env.h", "mapf_replay.h", "mapf_dqn.h", "mapf_search.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names |= set(re.findall(r"\b(mapf_[a-z_0-9]+)\s*\(", src))
