@@ -88,6 +88,15 @@ int mapf_load(mapf_env_t *env, const int8_t *maps, const int16_t *agents, const 
 int mapf_load_envs(mapf_env_t *env, const int32_t *env_ids, int n, const int8_t *maps, const int16_t *agents,
                    const int16_t *goals, void *stream);
 
+/*
+ * On-device Environment.reset (environment.py:146-196) for every environment e with mask_dev[e] != 0
+ * (mask_dev == NULL: all): new Bernoulli map, placement by the reference's rule, navi fields, step counter 0 --
+ * one launch, no host round trip (the actor loop's auto-reset).  Own counter-based RNG keyed by
+ * (seed, environment, per-environment reset count): statistical, not bitwise, parity with the reference.
+ * density < 0 draws rho ~ triangular(0, 0.33, 0.5) per reset.  A map that cannot host the agents is re-drawn.
+ */
+int mapf_reset_envs(mapf_env_t *env, const uint8_t *mask_dev, float density, uint64_t seed, void *stream);
+
 /* Overwrite agent positions only (e.g. rewind to the start of an action tape); steps := 0. */
 int mapf_set_agents(mapf_env_t *env, const int16_t *agents_dev, void *stream);
 

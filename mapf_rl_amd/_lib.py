@@ -22,6 +22,7 @@ SYMBOLS = [
     ("mapf_set_reward_table", _i, [_vp, ctypes.POINTER(_f)]),
     ("mapf_load", _i, [_vp, _vp, _vp, _vp, _i, _vp]),
     ("mapf_set_agents", _i, [_vp, _vp, _vp]),
+    ("mapf_reset_envs", _i, [_vp, _vp, _f, _u64, _vp]),
     ("mapf_build_navi", _i, [_vp, _vp]),
     ("mapf_step", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_observe", _i, [_vp, _vp, _vp, _vp, _vp]),

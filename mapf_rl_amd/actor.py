@@ -42,7 +42,7 @@ def pack_comm_device(comm, cw):
 
 class VecActor:
     def __init__(self, env: VecEnvironment, model, buffer, epsilons=None, max_steps=MAX_STEPS, seed=0, density=-1.0,
-                 keep_flushed=False):
+                 keep_flushed=False, on_device_reset=True):
         self.env, self.model, self.buffer = env, model, buffer
         E, N = env.num_envs, env.num_agents
         d = env.device
@@ -73,6 +73,7 @@ class VecActor:
         self.env_steps = 0
         self.episodes = 0
         self.keep_flushed = keep_flushed
+        self.on_device_reset = on_device_reset
         self.flushed = []
         self._begin()
 
@@ -159,8 +160,13 @@ class VecActor:
         self.episodes += len(ids_h)
         # Actor.reset (worker.py:422-428): fresh scenario, recurrent state cleared
         self.scenario_seed += 1
-        maps, agents, goals, _ = generate_scenarios(len(ids_h), self.env.map_length, self.N, self.density, self.scenario_seed)
-        self.env.load_envs(ids_h, maps, agents, goals)
+        if self.on_device_reset:   # mapf_reset_envs: generation + placement + navi in one launch, no host round trip
+            mask = torch.zeros(self.E, dtype=torch.uint8, device=self.device)
+            mask[ids] = 1
+            self.env.reset_envs(mask, self.density, self.scenario_seed)
+        else:                      # host generator + partial load
+            maps, agents, goals, _ = generate_scenarios(len(ids_h), self.env.map_length, self.N, self.density, self.scenario_seed)
+            self.env.load_envs(ids_h, maps, agents, goals)
         self.obs, self.pos = self.env.observe(obs_bits_out=self.bits)
         self.lb_obs[ids, 0, :self.RD] = self.bits[ids]
         self.t[ids] = 0

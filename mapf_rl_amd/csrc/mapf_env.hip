@@ -477,6 +477,165 @@ __global__ void __launch_bounds__(256) navi_bfs_kernel(int E, int L, int N, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// reset_kernel: on-device scenario generation + navi build for the environments flagged in `mask`
+// (Environment.reset, reference environment.py:146-196 / __init__ :100-143, statistical parity only: own
+// counter-based RNG).  One wavefront per environment, lane = map row.
+//   map      Bernoulli(rho) per cell, rho = density or ~ triangular(0, 0.33, 0.5)               (:156-157)
+//   placement  the reference picks a partition with probability proportional to its remaining cells, then two
+//            distinct cells of it uniformly (:118-138)  ==  the first cell uniform over all remaining cells of
+//            partitions that still hold >= 2 cells, the second uniform over the rest of the same partition.
+//            Here the first cell drawn is the GOAL: the navi BFS from it (needed anyway) yields the partition
+//            as its visited set, so one BFS per agent does both jobs; cells of partitions found too small are
+//            dropped from the candidate set (rejection keeps the draw uniform).
+//   a map that cannot host N agents is re-drawn (the reference raises ValueError there, :120).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ float u01(uint64_t h) { return (float)(h >> 40) * (1.0f / 16777216.0f); }
+
+template <typename W>
+__device__ __forceinline__ int popc_w(W v) {
+    if constexpr (sizeof(W) == 4) return __popc((unsigned)v);
+    else return __popcll((unsigned long long)v);
+}
+template <typename W>
+__device__ __forceinline__ int ctz_w(W v) {
+    if constexpr (sizeof(W) == 4) return __ffs((unsigned)v) - 1;
+    else return __ffsll((unsigned long long)v) - 1;
+}
+
+// wave-wide: picks the r-th (0-based) set bit of the per-lane words `bits` in (row, column) order; every lane returns (x, y)
+template <typename W>
+__device__ __forceinline__ void select_bit(W bits, int r, int lane, int &x, int &y) {
+    int cnt = popc_w<W>(bits), incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    const int excl = incl - cnt;
+    const bool mine = r >= excl && r < incl;
+    int yy = 0;
+    if (mine) {
+        W w = bits;
+        for (int k = r - excl; k > 0; --k) w &= w - 1;
+        yy = ctz_w<W>(w);
+    }
+    const unsigned long long who = __ballot(mine);
+    const int src = who ? (int)__ffsll(who) - 1 : 0;
+    x = src;
+    y = __shfl(yy, src, 64);
+}
+
+template <typename W>
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+template <typename W>
+__global__ void __launch_bounds__(64) reset_kernel(int E, int L, int N, const uint8_t *mask, float density, uint64_t seed,
+                                                   W *map_rows, int16_t *agents, int16_t *goals, NaviRec<W> *navi,
+                                                   int32_t *steps, int32_t *epochs, int32_t *status) {
+    const int e = blockIdx.x, lane = threadIdx.x;
+    if (e >= E || (mask && !mask[e])) return;
+    const int row = lane;
+    const bool in_map = row < L;
+    const W lmask = (L == (int)(8 * sizeof(W))) ? ~(W)0 : (((W)1 << L) - 1);
+    int epoch = 0;
+    if (lane == 0) epoch = atomicAdd(&epochs[e], 1) + 1;
+    epoch = __shfl(epoch, 0, 64);
+    const uint64_t base = mix64(seed ^ mix64(((uint64_t)e << 32) | (uint32_t)epoch));
+    bool ok = false;
+    for (int attempt = 0; attempt < 64 && !ok; ++attempt) {
+        const uint64_t akey = mix64(base + (uint64_t)attempt);
+        float rho = density;
+        if (density < 0.f) {  // np.random.triangular(0, 0.33, 0.5)
+            const float u = u01(mix64(akey ^ 0x7269616E67ull));
+            const float a = 0.f, c = 0.33f, b = 0.5f;
+            rho = (u < (c - a) / (b - a)) ? a + sqrtf(u * (b - a) * (c - a)) : b - sqrtf((1.f - u) * (b - a) * (b - c));
+        }
+        W obst = 0;
+        if (in_map)
+            for (int y = 0; y < L; ++y) obst |= (W)(u01(mix64(akey + 0x100 + (uint64_t)(row * L + y))) < rho) << y;
+        const W freec = in_map ? (~obst & lmask) : (W)0;
+        W avail = freec, elig = freec;
+        ok = true;
+        uint64_t draw = akey ^ 0x64726177ull;
+        for (int i = 0; i < N && ok; ++i) {
+            int gx = 0, gy = 0, cnt = 0;
+            W vis = 0, up = 0, down = 0, left = 0, right = 0;
+            for (;;) {  // rejection over candidate goal cells; every rejection removes >= 1 candidate
+                const int total = wave_sum<W>(popc_w<W>(elig));
+                if (total == 0) {
+                    ok = false;
+                    break;
+                }
+                draw = mix64(draw);
+                select_bit<W>(elig, (int)(draw % (uint64_t)total), lane, gx, gy);
+                vis = (row == gx) ? ((W)1 << gy) : (W)0;
+                W fr = vis;
+                up = down = left = right = 0;
+                for (int it = 0; it < L * L; ++it) {  // same level-synchronous BFS as navi_bfs_kernel
+                    W fu = shfl_up_w<W>(fr, 64);
+                    if (row == 0) fu = 0;
+                    W fd = shfl_down_w<W>(fr, 64);
+                    if (row == 63) fd = 0;
+                    const W fl = fr << 1, frr = fr >> 1;
+                    const W nw = (fu | fd | fl | frr) & freec & ~vis;
+                    up |= nw & fu;
+                    down |= nw & fd;
+                    left |= nw & fl;
+                    right |= nw & frr;
+                    vis |= nw;
+                    fr = nw;
+                    if (__ballot(nw != 0) == 0ull) break;
+                }
+                cnt = wave_sum<W>(popc_w<W>(vis & avail));
+                if (cnt >= 2) break;
+                elig &= ~vis;  // this partition holds < 2 remaining cells: never a candidate again
+            }
+            if (!ok) break;
+            const W gbit = (row == gx) ? ((W)1 << gy) : (W)0;
+            avail &= ~gbit;
+            elig &= ~gbit;
+            int sx, sy;
+            draw = mix64(draw);
+            select_bit<W>(vis & avail, (int)(draw % (uint64_t)(cnt - 1)), lane, sx, sy);
+            const W sbit = (row == sx) ? ((W)1 << sy) : (W)0;
+            avail &= ~sbit;
+            elig &= ~sbit;
+            if (cnt - 2 < 2) elig &= ~vis;
+            const size_t o = (size_t)e * N + i;
+            if (lane == 0) {
+                goals[o * 2] = (int16_t)gx;
+                goals[o * 2 + 1] = (int16_t)gy;
+                agents[o * 2] = (int16_t)sx;
+                agents[o * 2 + 1] = (int16_t)sy;
+            }
+            if (in_map) {
+                NaviRec<W> rec;
+                rec.w[0] = up;
+                rec.w[1] = down;
+                rec.w[2] = left;
+                rec.w[3] = right;
+                navi[o * L + row] = rec;
+            }
+        }
+        if (ok && in_map) map_rows[(size_t)e * L + row] = obst;
+    }
+    if (lane == 0) {
+        if (ok) steps[e] = 0;
+        else atomicOr(status, kStatusRange);
+    }
+}
+
 // int8 map [E][L][L] -> bit rows; also range-checks agent/goal positions of a device-side load
 template <typename W>
 __global__ void pack_map_kernel(int E, int L, const int8_t *maps, W *rows) {
@@ -559,6 +718,7 @@ struct mapf_env {
     void *navi;
     int32_t *steps;
     int32_t *status;
+    int32_t *epochs;  // per-environment reset counter (RNG stream of mapf_reset_envs)
     bool loaded, navi_ready;
     float rtab[5];
     int tune_threads;  // 0 = default; MAPF_STEP_THREADS (tuning experiments only)
@@ -846,8 +1006,10 @@ int mapf_create(int num_envs, int map_len, int num_agents, int obs_radius, int d
     alloc(&h->navi, E * N * L * 4 * wb);
     alloc(reinterpret_cast<void **>(&h->steps), E * sizeof(int32_t));
     alloc(reinterpret_cast<void **>(&h->status), sizeof(int32_t));
+    alloc(reinterpret_cast<void **>(&h->epochs), E * sizeof(int32_t));
     if (err == hipSuccess) err = hipMemset(h->steps, 0, E * sizeof(int32_t));
     if (err == hipSuccess) err = hipMemset(h->status, 0, sizeof(int32_t));
+    if (err == hipSuccess) err = hipMemset(h->epochs, 0, E * sizeof(int32_t));
     if (err != hipSuccess) {
         std::fprintf(stderr, "mapf_create: %s\n", hipGetErrorString(err));
         mapf_destroy(h);
@@ -866,6 +1028,7 @@ int mapf_destroy(mapf_env_t *h) {
     (void)hipFree(h->navi);
     (void)hipFree(h->steps);
     (void)hipFree(h->status);
+    (void)hipFree(h->epochs);
     delete h;
     return MAPF_OK;
 }
@@ -952,6 +1115,23 @@ int mapf_load_envs(mapf_env_t *h, const int32_t *env_ids, int n, const int8_t *m
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipFree(tmp));
+    return MAPF_OK;
+}
+
+int mapf_reset_envs(mapf_env_t *h, const uint8_t *mask_dev, float density, uint64_t seed, void *stream) {
+    if (!h || density >= 1.0f) return MAPF_ERR_INVALID_ARG;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (h->wide)
+        hipLaunchKernelGGL(reset_kernel<uint64_t>, dim3(h->E), dim3(64), 0, s, h->E, h->L, h->N, mask_dev, density, seed,
+                           static_cast<uint64_t *>(h->map_rows), h->agents, h->goals, static_cast<NaviRec<uint64_t> *>(h->navi),
+                           h->steps, h->epochs, h->status);
+    else
+        hipLaunchKernelGGL(reset_kernel<uint32_t>, dim3(h->E), dim3(64), 0, s, h->E, h->L, h->N, mask_dev, density, seed,
+                           static_cast<uint32_t *>(h->map_rows), h->agents, h->goals, static_cast<NaviRec<uint32_t> *>(h->navi),
+                           h->steps, h->epochs, h->status);
+    HIP_TRY(hipGetLastError());
+    if (!mask_dev) h->loaded = h->navi_ready = true;  // every environment now holds a complete scenario
     return MAPF_OK;
 }
 

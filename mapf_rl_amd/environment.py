@@ -112,6 +112,17 @@ class VecEnvironment:
         self.load(maps, agents, goals)
         return self.observe()
 
+    def reset_envs(self, mask=None, density=-1.0, seed=0):
+        """On-device reset of the environments flagged in `mask` (uint8/bool tensor [E]; None = all): new map,
+        placement, navi fields, steps = 0.  Asynchronous, no host round trip."""
+        m = None
+        if mask is not None:
+            m = mask.to(self.device, torch.uint8).contiguous()
+            assert m.shape == (self.num_envs,)
+        check(lib.mapf_reset_envs(self._h, _ptr(m), float(density), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream(self.device)),
+              "mapf_reset_envs")
+        self._keep_mask = m
+
     def set_agents(self, agents_pos):
         a = agents_pos.to(self.device, torch.int16).contiguous()
         check(lib.mapf_set_agents(self._h, _ptr(a), _stream(self.device)), "mapf_set_agents")

@@ -1,0 +1,111 @@
+"""GPU: on-device scenario generation / auto-reset (mapf_reset_envs; reference Environment.reset,
+environment.py:146-196).  The RNG differs from the reference's, so parity is structural + statistical:
+every invariant the reference guarantees by construction, the navi fields bit-exact against the oracle for the
+generated scenario, and placement statistics against the host generator that implements the same rule."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def _check_invariants(maps, agents, goals, L, N):
+    E = maps.shape[0]
+    assert set(np.unique(maps)) <= {0, 1}
+    for e in range(E):
+        cells = np.concatenate([agents[e], goals[e]]).astype(np.int64)
+        assert cells.min() >= 0 and cells.max() < L
+        assert len(np.unique(cells[:, 0] * L + cells[:, 1])) == 2 * N          # all 2N cells distinct
+        assert maps[e][cells[:, 0], cells[:, 1]].sum() == 0                     # and free
+
+
+@pytest.mark.parametrize("E,L,N,rho", [(256, 32, 40, 0.3), (64, 40, 16, -1.0), (64, 10, 1, -1.0), (32, 64, 40, 0.3), (64, 16, 40, 0.3)])
+def test_reset_all_invariants_and_navi(E, L, N, rho):
+    import mapf_rl_amd as M
+
+    env = M.VecEnvironment(E, L, N)
+    env.reset_envs(None, rho, seed=7)
+    env.check_status()
+    maps, agents, goals = _np(env.maps()), _np(env.agents_pos()), _np(env.goals_pos())
+    _check_invariants(maps, agents, goals, L, N)
+    nv = oracle.navi_batch(maps, goals)
+    assert np.array_equal(_np(env.navi_map()), nv)                               # fused BFS == oracle BFS
+    for e in range(min(E, 16)):                                                  # goal reachable from start
+        for i in range(min(N, 6)):
+            d = oracle.dist(maps[e], goals[e, i])
+            assert d[agents[e, i, 0], agents[e, i, 1]] < 2147483647
+    assert int(_np(env.steps()).max()) == 0
+    # the generated state is steppable and matches the oracle
+    tape = H.random_tape(8, E, N, seed=3)
+    for t in range(8):
+        obs, pos, *_ = env.step(torch.from_numpy(tape[t]).cuda())
+    env.check_status()
+    ref = oracle.rollout(maps, agents, goals, nv, tape, want_obs_last=True)
+    assert np.array_equal(_np(pos), ref["final_agents"]) and np.array_equal(_np(obs), ref["obs_last"])
+    if rho > 0:
+        assert abs(maps.mean() - rho) < 0.02
+
+
+def test_masked_reset_touches_only_flagged_envs():
+    import mapf_rl_amd as M
+
+    E, L, N = 32, 20, 6
+    env = M.VecEnvironment(E, L, N)
+    env.reset_envs(None, 0.25, seed=1)
+    tape = H.random_tape(3, E, N, seed=1)
+    for t in range(3):
+        env.step(torch.from_numpy(tape[t]).cuda())
+    m0, a0, g0, s0, n0 = _np(env.maps()), _np(env.agents_pos()), _np(env.goals_pos()), _np(env.steps()), _np(env.navi_map())
+    mask = torch.zeros(E, dtype=torch.uint8)
+    mask[[3, 4, 17]] = 1
+    env.reset_envs(mask.cuda(), 0.25, seed=2)
+    env.check_status()
+    m1, a1, g1, s1, n1 = _np(env.maps()), _np(env.agents_pos()), _np(env.goals_pos()), _np(env.steps()), _np(env.navi_map())
+    keep = np.ones(E, bool)
+    keep[[3, 4, 17]] = False
+    assert np.array_equal(m0[keep], m1[keep]) and np.array_equal(a0[keep], a1[keep]) and np.array_equal(g0[keep], g1[keep])
+    assert np.array_equal(n0[keep], n1[keep]) and np.array_equal(s1[keep], np.full(keep.sum(), 3)) and np.all(s1[~keep] == 0)
+    assert not np.array_equal(m0[~keep], m1[~keep])
+    # a second reset of the same env with the same seed draws a NEW scenario (per-env reset counter)
+    env.reset_envs(mask.cuda(), 0.25, seed=2)
+    assert not np.array_equal(_np(env.maps())[~keep], m1[~keep])
+
+
+def test_statistics_match_host_generator():
+    """Same rule as mapf_generate (host): map density, triangular density, start-goal distance distribution."""
+    import mapf_rl_amd as M
+
+    E, L, N = 512, 24, 8
+    env = M.VecEnvironment(E, L, N)
+    env.reset_envs(None, -1.0, seed=11)
+    maps, agents, goals = _np(env.maps()), _np(env.agents_pos()), _np(env.goals_pos())
+    hm, ha, hg, _ = M.generate_scenarios(E, L, N, -1.0, seed=12)
+    assert abs(maps.mean() - hm.mean()) < 0.02 and abs(maps.mean() - (0.33 + 0.5) / 3) < 0.03
+
+    def mean_dist(mm, aa, gg):
+        tot, cnt = 0, 0
+        for e in range(0, E, 4):
+            for i in range(N):
+                d = oracle.dist(mm[e], gg[e, i])[aa[e, i, 0], aa[e, i, 1]]
+                tot += d
+                cnt += 1
+        return tot / cnt
+
+    d_dev, d_host = mean_dist(maps, agents, goals), mean_dist(hm, ha, hg)
+    assert abs(d_dev - d_host) < 0.12 * d_host, (d_dev, d_host)
+
+
+def test_infeasible_shape_sets_status():
+    import mapf_rl_amd as M
+
+    env = M.VecEnvironment(2, 4, 40)   # 16 cells cannot host 80 distinct positions
+    env.reset_envs(None, 0.3, seed=0)
+    with pytest.raises(Exception):
+        env.check_status()
