@@ -12,6 +12,24 @@
 //                             word k = "neighbour k of (row, y) is strictly closer to the agent's goal"
 //   steps    int32[E]
 // All integer/bit work: the kernels are HBM-bound (obs write 486 B/agent dominates), not MFMA work.
+//
+// Why the parallel conflict resolution equals the reference's sequential one (environment.py:368-406).
+// After S0-S2 every agent is a *mover* (wants cell next != cur) or *settled* (next == cur).  The reference
+// repeatedly takes the first mover (id order) whose target cell is also claimed by somebody else and resolves
+// that cell: if a settled agent is among the claimants every mover into the cell reverts, otherwise all but
+// the lowest-id mover revert (stable sort on identical keys, :392); a reverted agent becomes settled on its
+// own cell, which may evict movers into that cell in a later pass.  Two facts make the outcome independent
+// of the processing order:
+//   (1) a mover only ever reverts because of its OWN target cell, so all original movers into a cell are
+//       still movers when that cell is first resolved; hence every mover that is not the lowest id into its
+//       cell reverts no matter what (rule b), and the lowest-id mover M(c) of a cell c can only revert through
+//       rule (a): the agent standing on c ends up settled there;
+//   (2) rule (a) is monotone -- the set of settled agents only grows -- so "M(c) reverts iff the occupant of c
+//       is settled in the end" has a unique least fixed point, reached by iterating rule (a) from the state
+//       left by rule (b) until nothing changes (chains revert back to front, rotations with no outside
+//       intruder never start reverting and go through).
+// The kernel computes exactly that fixed point; tests compare it with the sequential oracle on >100k steps
+// (tests/test_env_gpu.py) including the hand-built cascade cases K5, K8, K8b, K8c, K13.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -68,9 +86,6 @@ __device__ __forceinline__ unsigned window_bits(W row, int y) {
     constexpr unsigned M = (1u << (2 * R + 1)) - 1u;
     return (y >= R) ? ((unsigned)(row >> (y - R)) & M) : (((unsigned)row << (R - y)) & M);
 }
-
-// 4 bits -> 4 bytes of 0/1 (bit k -> byte k)
-__device__ __forceinline__ unsigned expand4(unsigned nib) { return (nib * 0x00204081u) & 0x01010101u; }
 
 // ---------------------------------------------------------------------------------------------
 // env_step_kernel: one workgroup per environment (Environment.step + observe, reference environment.py:278-467).

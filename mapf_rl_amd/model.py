@@ -167,9 +167,11 @@ class Network(nn.Module):
                 x = x.contiguous(memory_format=torch.channels_last)
             return self.obs_encoder(x)
 
-        if obs.shape[0] <= self.ENCODE_CHUNK:
+        M = obs.shape[0]
+        if M <= self.ENCODE_CHUNK:
             return run(obs)
-        return torch.cat([run(c) for c in obs.split(self.ENCODE_CHUNK)], dim=0)
+        parts = -(-M // self.ENCODE_CHUNK)          # equal-sized chunks: one convolution shape per call site
+        return torch.cat([run(c) for c in obs.split(-(-M // parts))], dim=0)
 
     def _encode_fused(self, x):
         """The encoder (model.py:147-162) with every bias / residual / ReLU fused behind its convolution by the
