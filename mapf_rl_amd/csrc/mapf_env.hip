@@ -775,12 +775,14 @@ size_t step_smem_bytes(const mapf_env *h) {
     return rows + grid_q * 16 + bits_q * 16 + 3 * NP * 2;
 }
 
-// threads per block (one lane per agent in the step phase): 128 measured best on MI355X at N = 40
-// (19.9 us vs 21.6 us for 64 at 4096 envs); MAPF_STEP_THREADS overrides for tuning runs
+// threads per block (one lane per agent in the step phase), measured on MI355X (tools/shape_sweep.py):
+// 32x32 / 40 agents 20.5 us @128 vs 22.0 us @64; 64x64 / 40 agents 23.5 us @64 vs 26.4 us @128; few agents
+// (N <= 24) prefer one wavefront per environment.  MAPF_STEP_THREADS overrides for tuning runs.
 int step_block_threads(const mapf_env *h) {
     if (h->tune_threads == 64 || h->tune_threads == 128 || h->tune_threads == 256) {
         if (h->tune_threads >= h->N) return h->tune_threads;
     }
+    if (h->N <= 64 && (h->N <= 24 || h->L > 32)) return 64;
     return h->N <= 128 ? 128 : 256;
 }
 
