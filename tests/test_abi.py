@@ -73,3 +73,21 @@ def test_vec_environment_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         M.VecEnvironment(1, 8, 2)
+
+
+def test_config_attribute_compatibility():
+    """config.py keeps every attribute name and value of the reference's config.py (values listed here so the
+    check also runs where the reference is absent)."""
+    import config
+
+    expect = dict(env_level=0, map_length=20, num_agents=6, obs_radius=4, obs_shape=(6, 9, 9), training_times=1000000,
+                  save_interval=2500, gamma=0.99, batch_size=192, learning_starts=50000, target_network_update_freq=2500,
+                  save_path='./models', max_steps=256, bt_steps=16, load_model=None, local_buffer_size=256,
+                  global_buffer_size=1024 * 256, actor_update_steps=400, grad_norm_dqn=40, prioritized_replay_alpha=0.6,
+                  prioritized_replay_beta=0.4, double_q=False, init_set=(1, 10), max_num_agetns=6, max_map_lenght=40,
+                  pass_rate=0.9, cnn_channel=64, latent_dim=256, max_comm_agents=3, num_comm_layers=2, num_comm_heads=2,
+                  forward_steps=2)
+    for k, v in expect.items():
+        assert getattr(config, k) == v, k
+    assert config.reward_fn == dict(move=-0.075, stay_on_goal=0, stay_off_goal=-0.075, collision=-0.5, finish=3)
+    assert list(config.reward_fn) == ["move", "stay_on_goal", "stay_off_goal", "collision", "finish"]
