@@ -25,6 +25,35 @@ int mapf_bias_res_relu_fwd(uint16_t *y_dev, const float *bias_dev, const uint16_
 int mapf_bias_res_relu_bwd(const uint16_t *g_dev, const uint16_t *y_dev, uint16_t *gx_dev, float *gbias_dev,
                            int64_t n, int C, void *stream);
 
+/*
+ * Fused observation encoder, inference only (no autograd): replaces the reference's
+ * `self.obs_encoder(obs)` in `Network.step` (model.py:184) and in the target network's `bootstrap`
+ * (model.py:237, called without gradients at worker.py:300-303) by ONE kernel that keeps the activations of
+ * 8 observations per workgroup in LDS across all 8 convolutions (csrc/mapf_encoder.hip).  bf16 MFMA, fp32
+ * accumulation, one rounding to bf16 per layer output.
+ *
+ * Packed weights (produced by mapf_encoder_pack from the 8 convolutions of `Network.obs_encoder`, in module
+ * order: [0], [2].block1, [2].block2, [3].block1, [3].block2, [4].block1, [4].block2, [5]; each weight fp32
+ * contiguous [co][ci][kh][kw], each bias fp32 [co]): bf16 A-operand fragments of v_mfma_f32_16x16x32_bf16,
+ *   conv0   [s=2 ][c=8][lane=64][j=8]   k = 32 s + 8 (lane>>4) + j = ci*9 + kh*3 + kw  (k >= 54 -> 0)
+ *   3x3 x6  [s=36][c=8][lane=64][j=8]   s = (kh*3+kw)*4 + chunk, ci = 32 chunk + 8 (lane>>4) + j
+ *   1x1     [s=4 ]     [lane=64][j=8]   ci = 32 s + 8 (lane>>4) + j
+ * with co = 16 c + (lane & 15); MAPF_ENC_PACKED_ELEMS bf16 in total.  Biases: MAPF_ENC_BIAS_ELEMS fp32,
+ * concatenated in the same order.  Both buffers must be 16-byte aligned.
+ */
+#define MAPF_ENC_OBS_PER_BLOCK 8
+#define MAPF_ENC_PACKED_ELEMS 894976 /* 8192 + 6*147456 + 2048 */
+#define MAPF_ENC_BIAS_ELEMS 912      /* 7*128 + 16 */
+#define MAPF_ENC_OBS_U8 0            /* obs elements are bytes (0/1, any 0..255 is exact) */
+#define MAPF_ENC_OBS_BF16 1          /* obs elements are bf16 */
+
+/* w_dev / b_dev: HOST arrays of 8 DEVICE pointers (see above). */
+int mapf_encoder_pack(const float *const *w_dev, const float *const *b_dev, uint16_t *packed_dev, float *bias_dev,
+                      void *stream);
+/* obs [M][6][9][9] (u8 or bf16, 16-byte aligned) -> latent bf16 [M][784] (= Flatten of [16][7][7]). */
+int mapf_encoder_forward(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev,
+                         const float *bias_dev, uint16_t *latent_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

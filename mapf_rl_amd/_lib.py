@@ -56,6 +56,8 @@ SYMBOLS = [
     # include/mapf_dqn.h
     ("mapf_bias_res_relu_fwd", _i, [_vp, _vp, _vp, ctypes.c_int64, _i, _vp]),
     ("mapf_bias_res_relu_bwd", _i, [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp]),
+    ("mapf_encoder_pack", _i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp, _vp]),
+    ("mapf_encoder_forward", _i, [_vp, _i, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     # include/mapf_search.h
     ("mapf_find_path", _i, [_i, _i, _vp, _vp, _vp, ctypes.c_double, _i, _vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     ("mapf_distance_field", _i, [_i, _vp, _i, _i, _vp]),

@@ -1,0 +1,373 @@
+// mapf_encoder.hip -- the observation encoder of the DQN (reference model.py:147-162: Conv(6->128,3x3,valid)+ReLU,
+// 3 x ResBlock(128) (model.py:30-42, two 3x3 pad-1 convolutions + identity skip, no normalisation),
+// Conv(128->16,1x1)+ReLU, Flatten) as ONE inference kernel for gfx950 (see include/mapf_dqn.h).
+//
+// Why one kernel: per observation the encoder is 87.6 MFLOP over activations of only 7x7x128 bf16 = 12.5 KB.
+// Layer-by-layer (MIOpen implicit GEMM + an epilogue pass per layer) every layer round-trips that activation
+// through HBM and pays a launch; here a workgroup keeps the activations of G = 8 observations resident in LDS for
+// all 8 layers and only the packed weights (1.8 MB, L2-resident) stream in.  MFMA-bound.
+//
+// Mapping (512 threads = 8 waves, 2 per SIMD, <= 256 VGPR each; 146 KB LDS -> one workgroup per CU):
+//  * Each 3x3 layer is the GEMM  out[co][p] = sum_{tap,ci} W[co][ci][tap] * act[p + tap][ci]  with M = 128 output
+//    channels, N = 49*G positions, K = 9*128, on v_mfma_f32_16x16x32_bf16: A = weights, B = activations, so a lane's
+//    4 accumulator registers are 4 consecutive output channels of one position -> one 8-byte LDS store.
+//  * Wave w owns output channels [32*(w&3), +32) (two 16-row A tiles) and position tiles (w>>2)*13 .. +13
+//    (16 positions each; 26 tiles cover the 392 positions): 104 accumulator registers.
+//  * Activations live in LDS as rows of 128 channels (256 B + 16 B pad = 272 B: conflict-free ds_read_b128 over
+//    16 consecutive rows).  Row index = 64*obs + 8*(y+1) + (x+1): an 8-wide zero-bordered image in which the right
+//    border of one image row IS the left border of the next and the bottom border of one observation IS the top
+//    border of the next, so a 3x3 tap is a constant row offset (8*ky + kx) -- an immediate in the ds_read -- and
+//    the zero padding costs no selects.  Border rows are zeroed once and never written.
+//  * The A operand is pre-packed in exact fragment order (mapf_encoder_pack): one k-step of one 16-channel tile is a
+//    contiguous 1 KiB, read straight into registers with global_load_dwordx4 (no LDS round trip; each weight byte
+//    is used by exactly one co-block wave pair).
+//  * ResBlock: the skip input of this wave's own (co, position) elements is read from LDS as packed bf16 before
+//    conv1's output overwrites it and becomes the initial accumulator of conv2 -> a single activation buffer.
+//  * conv0 (K = 54, padded to 64) builds its B fragments directly from the raw observation bytes staged in LDS.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+
+#include "mapf_dqn.h"
+#include "mapf_env.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int G = MAPF_ENC_OBS_PER_BLOCK;  // observations per workgroup
+constexpr int ROWB = 272;                  // bytes per activation row (128 bf16 + 16 B pad)
+constexpr int ACT_ROWS = 64 * G + 9;
+constexpr int ACT_BYTES = ACT_ROWS * ROWB;  // 141,712
+constexpr int OBS_ELEMS = 6 * 9 * 9;        // 486
+constexpr int RAW_BYTES = ((G * OBS_ELEMS * 2 + 15) / 16) * 16;  // sized for 2-byte inputs
+constexpr int NT = 13;                      // position tiles per wave
+constexpr int NPOS = 49 * G;
+static_assert(2 * NT * 16 >= NPOS, "tiles must cover all positions");
+static_assert(ACT_BYTES % 16 == 0, "");
+static_assert(ACT_BYTES + RAW_BYTES <= 160 * 1024, "LDS budget");
+
+// packed-weight element offsets (bf16 elements), see mapf_dqn.h
+constexpr int WP_L0 = 0;
+constexpr int WP_L0_SIZE = 2 * 8 * 512;
+constexpr int WP_RES = WP_L0 + WP_L0_SIZE;
+constexpr int WP_RES_SIZE = 36 * 8 * 512;
+constexpr int WP_L7 = WP_RES + 6 * WP_RES_SIZE;
+constexpr int WP_L7_SIZE = 4 * 512;
+constexpr int WP_TOTAL = WP_L7 + WP_L7_SIZE;
+static_assert(WP_TOTAL == MAPF_ENC_PACKED_ELEMS, "header constant out of date");
+constexpr int BIAS_TOTAL = 128 * 7 + 16;
+static_assert(BIAS_TOTAL == MAPF_ENC_BIAS_ELEMS, "header constant out of date");
+
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {  // round to nearest even (finite inputs)
+    uint32_t u = __float_as_uint(f);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+
+__device__ __forceinline__ uint16_t raw_to_bf16(uint8_t v) { return (uint16_t)f32_to_bf16_bits((float)v); }  // exact for 0..255
+__device__ __forceinline__ uint16_t raw_to_bf16(uint16_t v) { return v; }                                   // already bf16 bits
+
+// relu(acc + bias) for the 4 consecutive channels of one lane, packed to 4 bf16
+__device__ __forceinline__ uint2 pack_relu(const f32x4 &a, const float4 &b) {
+    const float v0 = fmaxf(a[0] + b.x, 0.f), v1 = fmaxf(a[1] + b.y, 0.f), v2 = fmaxf(a[2] + b.z, 0.f), v3 = fmaxf(a[3] + b.w, 0.f);
+    return make_uint2(f32_to_bf16_bits(v0) | (f32_to_bf16_bits(v1) << 16), f32_to_bf16_bits(v2) | (f32_to_bf16_bits(v3) << 16));
+}
+
+// One 3x3 pad-1 128->128 convolution over the LDS-resident activations: acc[a][n] += W(a) * act(n).
+// `wv` points at this lane's element of this wave's first co tile of the layer: index (s*8 + a)*64.
+// The 36 k-steps x 13 position tiles are one flat software-pipelined sequence: the B fragment of tile-step t + PB is
+// read from LDS while tile-step t's two MFMAs issue, and the A fragments of k-step s + PA are loaded from L2 at the
+// start of k-step s.  hipcc on its own emits each load right before its use (s_waitcnt 0 per tile); the
+// sched_barrier pins the order written here, and the wait-count pass then inserts counted lgkmcnt / vmcnt.
+constexpr int PB = 4, RB = PB + 1;  // B prefetch distance in tile-steps / ring size
+constexpr int PA = 2, RA = PA + 1;  // A prefetch distance in k-steps / ring size
+
+__device__ __forceinline__ int tap_off(int s) {
+    const int tap = s >> 2, chunk = s & 3;
+    return (8 * (tap / 3) + (tap % 3)) * ROWB + chunk * 64;
+}
+
+__device__ __forceinline__ void conv3x3(const unsigned char *act, const bf16x8 *__restrict__ wv, const int (&addr)[NT],
+                                        f32x4 (&acc)[2][NT]) {
+    bf16x8 ar[RA][2], br[RB];
+#pragma unroll
+    for (int s = 0; s < PA; ++s) {
+        ar[s][0] = wv[(s * 8 + 0) * 64];
+        ar[s][1] = wv[(s * 8 + 1) * 64];
+    }
+#pragma unroll
+    for (int t = 0; t < PB; ++t) br[t] = *reinterpret_cast<const bf16x8 *>(act + addr[t % NT] + tap_off(t / NT));
+#pragma unroll
+    for (int s = 0; s < 36; ++s) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int t = s * NT + n, tn = t + PB;
+            if (tn < 36 * NT) br[tn % RB] = *reinterpret_cast<const bf16x8 *>(act + addr[tn % NT] + tap_off(tn / NT));
+            if (n == 0 && s + PA < 36) {
+                ar[(s + PA) % RA][0] = wv[((s + PA) * 8 + 0) * 64];
+                ar[(s + PA) % RA][1] = wv[((s + PA) * 8 + 1) * 64];
+            }
+            acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[s % RA][0], br[t % RB], acc[0][n], 0, 0, 0);
+            acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[s % RA][1], br[t % RB], acc[1][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <typename InT>
+__global__ void __launch_bounds__(512) encoder_fwd_kernel(const InT *__restrict__ obs, long long M,
+                                                          const uint16_t *__restrict__ wp, const float *__restrict__ bias,
+                                                          uint16_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ACT_BYTES + RAW_BYTES];
+    unsigned char *const act = smem;
+    const InT *const raw = reinterpret_cast<const InT *>(smem + ACT_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int cb = w & 3, ph = w >> 2;
+    const int lr = lane & 15, lh = lane >> 4;
+    const long long obs0 = (long long)blockIdx.x * G;
+    const long long left = M - obs0;
+    const int nobs = left < G ? (int)left : G;  // >= 1 by the grid size
+
+    // ---- zero the activation image (its border rows must be zero; they are never written afterwards) ----
+    for (int i = tid; i < ACT_BYTES / 16; i += 512) reinterpret_cast<uint4 *>(act)[i] = make_uint4(0, 0, 0, 0);
+    // ---- stage the raw observations of this block (contiguous in global memory); missing ones read as zero ----
+    {
+        constexpr int DW = G * OBS_ELEMS * (int)sizeof(InT) / 4;
+        static_assert((G * OBS_ELEMS * sizeof(InT)) % 16 == 0, "block input must stay 16-byte aligned");
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(obs + obs0 * OBS_ELEMS);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(smem + ACT_BYTES);
+        const int have = nobs * OBS_ELEMS * (int)sizeof(InT) / 4;  // 486*sizeof(InT) is a multiple of 4 only for even sizes...
+        const int have_bytes = nobs * OBS_ELEMS * (int)sizeof(InT);
+        for (int i = tid; i < DW; i += 512) {
+            uint32_t v = 0;
+            if (i < have) {
+                v = src[i];
+            } else if (i * 4 < have_bytes) {  // ragged last dword (odd number of 486-byte observations)
+                const unsigned char *sb = reinterpret_cast<const unsigned char *>(src);
+                for (int k = 0; k < 4; ++k)
+                    if (i * 4 + k < have_bytes) v |= (uint32_t)sb[i * 4 + k] << (8 * k);
+            }
+            dst[i] = v;
+        }
+    }
+
+    // ---- per-tile geometry of this lane: byte address of (row(p) - 9) + this lane's 16-byte k slice ----
+    int addr[NT];
+    uint32_t vmask = 0;  // bit n: position of tile n exists
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int p = (ph * NT + n) * 16 + lr;
+        const bool v = p < 49 * nobs;
+        const int o = p / 49, q = p - 49 * o, y = q / 7, x = q - 7 * y;
+        addr[n] = (v ? (64 * o + 8 * y + x) * ROWB : 0) + lh * 16;
+        vmask |= (v ? 1u : 0u) << n;
+    }
+    __syncthreads();
+
+    f32x4 acc[2][NT];
+    const float *bl = bias;
+    const int co_lane = cb * 32 + 4 * lh;  // + 16*a: first of this lane's 4 output channels
+
+    // =========================== conv0: 6 -> 128, 3x3 valid on 9x9 (K = 54 -> 64) ===========================
+    {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bf16x8 *wv = reinterpret_cast<const bf16x8 *>(wp + WP_L0) + (2 * cb) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 a0 = wv[(s * 8 + 0) * 64];
+            const bf16x8 a1 = wv[(s * 8 + 1) * 64];
+            int koff[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = s * 32 + lh * 8 + j;
+                const int ci = k / 9, t = k - 9 * ci, ky = t / 3, kx = t - 3 * ky;
+                koff[j] = k < 54 ? ci * 81 + ky * 9 + kx : -1;
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int p = (ph * NT + n) * 16 + lr;
+                const bool v = (vmask >> n) & 1u;
+                const int o = p / 49, q = p - 49 * o, y = q / 7, x = q - 7 * y;
+                const int rb = v ? o * OBS_ELEMS + y * 9 + x : 0;
+                union {
+                    bf16x8 v8;
+                    uint16_t u[8];
+                } b;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b.u[j] = koff[j] >= 0 ? raw_to_bf16(raw[rb + koff[j]]) : (uint16_t)0;
+                acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b.v8, acc[0][n], 0, 0, 0);
+                acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b.v8, acc[1][n], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(bl + co_lane + 16 * a);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                if ((vmask >> n) & 1u)
+                    *reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2) = pack_relu(acc[a][n], b4);
+        }
+        bl += 128;
+        __syncthreads();
+    }
+
+    // =========================== 3 residual blocks ===========================
+    for (int blk = 0; blk < 3; ++blk) {
+        const bf16x8 *wv1 = reinterpret_cast<const bf16x8 *>(wp + WP_RES + (2 * blk) * WP_RES_SIZE) + (2 * cb) * 64 + lane;
+        const bf16x8 *wv2 = wv1 + WP_RES_SIZE / 8;
+        // ---- block1: t = relu(conv(x) + b1) ----
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        conv3x3(act, wv1, addr, acc);
+        __syncthreads();  // every wave has finished reading x
+        uint2 xres[2][NT];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(bl + co_lane + 16 * a);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                uint2 *cell = reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2);
+                xres[a][n] = *cell;  // this lane's skip input (lanes without a position read row 9 and drop it)
+                if ((vmask >> n) & 1u) *cell = pack_relu(acc[a][n], b4);
+            }
+        }
+        __syncthreads();
+        // ---- block2: x' = relu(conv(t) + b2 + x): the skip input is the initial accumulator ----
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[a][n] = f32x4{bf16_bits_to_f32(xres[a][n].x & 0xFFFFu), bf16_bits_to_f32(xres[a][n].x >> 16),
+                                  bf16_bits_to_f32(xres[a][n].y & 0xFFFFu), bf16_bits_to_f32(xres[a][n].y >> 16)};
+        conv3x3(act, wv2, addr, acc);
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(bl + 128 + co_lane + 16 * a);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                if ((vmask >> n) & 1u)
+                    *reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2) = pack_relu(acc[a][n], b4);
+        }
+        bl += 256;
+        __syncthreads();
+    }
+
+    // =========================== conv 1x1: 128 -> 16, ReLU, NCHW flatten ===========================
+    {
+        const bf16x8 *wv = reinterpret_cast<const bf16x8 *>(wp + WP_L7) + lane;
+        bf16x8 a7[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a7[s] = wv[s * 64];
+        const float4 b4 = *reinterpret_cast<const float4 *>(bl + 4 * lh);
+        for (int n = w; n < 2 * NT; n += 8) {
+            const int p = n * 16 + lr;
+            const bool v = p < 49 * nobs;
+            const int o = p / 49, q = p - 49 * o, y = q / 7, x = q - 7 * y;
+            const unsigned char *rowp = act + (v ? (64 * o + 8 * y + x + 9) * ROWB : 0) + lh * 16;
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a7[s], *reinterpret_cast<const bf16x8 *>(rowp + s * 64), c, 0, 0, 0);
+            if (v) {
+                uint16_t *dst = out + (obs0 + o) * 784 + (4 * lh) * 49 + q;  // latent[obs][co*49 + y*7 + x]
+                dst[0] = (uint16_t)f32_to_bf16_bits(fmaxf(c[0] + b4.x, 0.f));
+                dst[49] = (uint16_t)f32_to_bf16_bits(fmaxf(c[1] + b4.y, 0.f));
+                dst[98] = (uint16_t)f32_to_bf16_bits(fmaxf(c[2] + b4.z, 0.f));
+                dst[147] = (uint16_t)f32_to_bf16_bits(fmaxf(c[3] + b4.w, 0.f));
+            }
+        }
+    }
+}
+
+// ---- weight packing: fp32 [co][ci][kh][kw] (contiguous) -> bf16 MFMA A fragments, biases concatenated ----
+struct PackArgs {
+    const float *w[8];
+    const float *b[8];
+};
+
+__global__ void __launch_bounds__(256) encoder_pack_kernel(PackArgs pa, uint16_t *__restrict__ wp, float *__restrict__ bias) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < BIAS_TOTAL) {
+        const int layer = i < 896 ? i / 128 : 7;
+        bias[i] = pa.b[layer][i - layer * 128];
+    }
+    if (i >= WP_TOTAL) return;
+    const int j = i & 7, l = (i >> 3) & 63;
+    const int r = l & 15, h = l >> 4;
+    float v = 0.f;
+    if (i < WP_RES) {  // conv0: [s=2][c=8][l][j], k = 32 s + 8 h + j = ci*9 + tap
+        const int c = (i >> 9) & 7, s = i >> 12;
+        const int k = 32 * s + 8 * h + j, co = 16 * c + r;
+        if (k < 54) v = pa.w[0][co * 54 + k];
+    } else if (i < WP_L7) {  // 3x3 layers: [s=36][c=8][l][j], s = tap*4 + chunk, ci = 32 chunk + 8 h + j
+        const int e = i - WP_RES, layer = e / WP_RES_SIZE, f = e - layer * WP_RES_SIZE;
+        const int c = (f >> 9) & 7, s = f >> 12;
+        const int tap = s >> 2, chunk = s & 3;
+        const int ci = 32 * chunk + 8 * h + j, co = 16 * c + r;
+        v = pa.w[1 + layer][(co * 128 + ci) * 9 + tap];
+    } else {  // 1x1: [s=4][l][j], ci = 32 s + 8 h + j, co = r
+        const int f = i - WP_L7, s = f >> 9;
+        v = pa.w[7][r * 128 + 32 * s + 8 * h + j];
+    }
+    wp[i] = (uint16_t)f32_to_bf16_bits(v);
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            std::fprintf(stderr, "mapf_encoder: %s failed: %s\n", #expr, hipGetErrorString(_e)); \
+            return MAPF_ERR_HIP;                                                               \
+        }                                                                                      \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int mapf_encoder_pack(const float *const *w_dev, const float *const *b_dev, uint16_t *packed_dev, float *bias_dev, void *stream) {
+    if (!w_dev || !b_dev || !packed_dev || !bias_dev) return MAPF_ERR_INVALID_ARG;
+    PackArgs pa;
+    for (int i = 0; i < 8; ++i) {
+        if (!w_dev[i] || !b_dev[i]) return MAPF_ERR_INVALID_ARG;
+        pa.w[i] = w_dev[i];
+        pa.b[i] = b_dev[i];
+    }
+    hipLaunchKernelGGL(encoder_pack_kernel, dim3((WP_TOTAL + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), pa,
+                       packed_dev, bias_dev);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+int mapf_encoder_forward(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev, const float *bias_dev,
+                         uint16_t *latent_dev, void *stream) {
+    if (M < 0 || !packed_dev || !bias_dev || (M > 0 && (!obs_dev || !latent_dev))) return MAPF_ERR_INVALID_ARG;
+    if (obs_dtype != MAPF_ENC_OBS_U8 && obs_dtype != MAPF_ENC_OBS_BF16) return MAPF_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(obs_dev) & 15) || (reinterpret_cast<uintptr_t>(packed_dev) & 15) ||
+        (reinterpret_cast<uintptr_t>(bias_dev) & 15) || (reinterpret_cast<uintptr_t>(latent_dev) & 1))
+        return MAPF_ERR_INVALID_ARG;
+    if (M == 0) return MAPF_OK;
+    const long long blocks = (M + G - 1) / G;
+    if (blocks > 0x7FFFFFFFLL) return MAPF_ERR_INVALID_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (obs_dtype == MAPF_ENC_OBS_U8)
+        hipLaunchKernelGGL(encoder_fwd_kernel<uint8_t>, dim3((unsigned)blocks), dim3(512), 0, st,
+                           static_cast<const uint8_t *>(obs_dev), (long long)M, packed_dev, bias_dev, latent_dev);
+    else
+        hipLaunchKernelGGL(encoder_fwd_kernel<uint16_t>, dim3((unsigned)blocks), dim3(512), 0, st,
+                           static_cast<const uint16_t *>(obs_dev), (long long)M, packed_dev, bias_dev, latent_dev);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+}  // extern "C"

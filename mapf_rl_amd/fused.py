@@ -48,3 +48,62 @@ def bias_res_relu(conv_out, bias, res=None):
     if res is not None:
         assert res.dtype == torch.bfloat16 and _is_nhwc(res) and res.shape == conv_out.shape
     return _BiasResReLU.apply(conv_out, bias.contiguous(), res)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Fused inference encoder (include/mapf_dqn.h: mapf_encoder_pack / mapf_encoder_forward)
+# ---------------------------------------------------------------------------------------------------------
+ENC_PACKED_ELEMS = 894976
+ENC_BIAS_ELEMS = 912
+_ENC_OBS_U8, _ENC_OBS_BF16 = 0, 1
+
+
+def encoder_convs(obs_encoder):
+    """The 8 convolutions of `Network.obs_encoder` (reference model.py:147-162) in the order the packer expects."""
+    e = obs_encoder
+    return [e[0], e[2].block1, e[2].block2, e[3].block1, e[3].block2, e[4].block1, e[4].block2, e[5]]
+
+
+class PackedEncoder:
+    """bf16 MFMA-fragment image of an encoder's weights; re-packed (one small kernel) whenever a parameter changed
+    (optimizer step, load_state_dict, .to()), detected through the tensors' version counters and storage pointers."""
+
+    def __init__(self):
+        self.key = None
+        self.weights = None
+        self.bias = None
+
+    def get(self, obs_encoder):
+        convs = encoder_convs(obs_encoder)
+        params = [c.weight for c in convs] + [c.bias for c in convs]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if key != self.key:
+            dev = params[0].device
+            assert dev.type == "cuda", "the fused encoder needs a HIP device"
+            ws = [c.weight.detach().to(torch.float32).contiguous() for c in convs]  # standard [co][ci][kh][kw] order
+            bs = [c.bias.detach().to(torch.float32).contiguous() for c in convs]
+            assert [tuple(w.shape) for w in ws] == [(128, 6, 3, 3)] + [(128, 128, 3, 3)] * 6 + [(16, 128, 1, 1)]
+            if self.weights is None or self.weights.device != dev:
+                self.weights = torch.empty(ENC_PACKED_ELEMS, dtype=torch.bfloat16, device=dev)
+                self.bias = torch.empty(ENC_BIAS_ELEMS, dtype=torch.float32, device=dev)
+            wp = (ctypes.c_void_p * 8)(*[w.data_ptr() for w in ws])
+            bp = (ctypes.c_void_p * 8)(*[b.data_ptr() for b in bs])
+            check(lib.mapf_encoder_pack(wp, bp, _ptr(self.weights), _ptr(self.bias), _stream(dev)), "mapf_encoder_pack")
+            self.key = key  # `ws`/`bs` temporaries stay alive until the stream has consumed them (caching allocator)
+        return self.weights, self.bias
+
+
+def encoder_forward(obs, packed_weights, packed_bias):
+    """obs [M, 6, 9, 9] uint8 / bool / bf16 on a HIP device -> latent bf16 [M, 784]; no autograd."""
+    assert obs.dim() == 4 and tuple(obs.shape[1:]) == (6, 9, 9) and obs.is_cuda
+    if obs.dtype == torch.bool:
+        obs = obs.view(torch.uint8)
+    if obs.dtype not in (torch.uint8, torch.bfloat16):
+        obs = obs.to(torch.bfloat16)
+    obs = obs.contiguous()
+    M = obs.shape[0]
+    out = torch.empty((M, 784), dtype=torch.bfloat16, device=obs.device)
+    kind = _ENC_OBS_U8 if obs.dtype == torch.uint8 else _ENC_OBS_BF16
+    check(lib.mapf_encoder_forward(_ptr(obs), kind, M, _ptr(packed_weights), _ptr(packed_bias), _ptr(out), _stream(obs.device)),
+          "mapf_encoder_forward")
+    return out

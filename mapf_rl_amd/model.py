@@ -129,6 +129,7 @@ class Network(nn.Module):
         self.adv = nn.Linear(self.latent_dim, 5)
         self.state = nn.Linear(self.latent_dim, 1)
         self.hidden = None
+        self._packed = None  # PackedEncoder of the fused inference kernel, built on first use
         # model.py:174-178: Xavier-uniform weights / zero bias on Linear and Conv2d only
         for m in self.modules():
             if isinstance(m, (nn.Linear, nn.Conv2d)):
@@ -147,6 +148,7 @@ class Network(nn.Module):
 
     ENCODE_CHUNK = 32768  # observations per convolution call (see encode)
     FUSED_EPILOGUE = True  # hand-written bias/residual/ReLU epilogue kernels behind every convolution (HIP, bf16)
+    FUSED_INFERENCE = True  # without autograd: the whole encoder as one hand-written MFMA kernel (csrc/mapf_encoder.hip)
 
     def encode(self, obs):
         """obs [M, 6, 9, 9] (uint8 / bool / float) -> [M, 784].
@@ -156,8 +158,17 @@ class Network(nn.Module):
         footprint (1.7 GB per layer at 138k observations)."""
         w = self.obs_encoder[0].weight
         nhwc = w.device.type == "cuda"  # weights are stored channels_last (see __init__)
+        bf16_autocast = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+        if nhwc and self.FUSED_INFERENCE and bf16_autocast and not torch.is_grad_enabled():
+            # actor steps and the target network's bootstrap: the whole encoder in one LDS-resident MFMA kernel
+            from .fused import PackedEncoder, encoder_forward
 
-        fused = nhwc and self.FUSED_EPILOGUE and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            if self._packed is None:
+                self._packed = PackedEncoder()
+            wp, bp = self._packed.get(self.obs_encoder)
+            return encoder_forward(obs, wp, bp)
+
+        fused = nhwc and self.FUSED_EPILOGUE and bf16_autocast
 
         def run(x):
             if fused:

@@ -1,0 +1,172 @@
+"""GPU: the fused inference encoder (include/mapf_dqn.h: mapf_encoder_pack / mapf_encoder_forward,
+csrc/mapf_encoder.hip) against plain PyTorch fp32 math of the same network (reference model.py:147-162).
+
+Two references:
+  * `ref_fp32`: the encoder in fp32 -- the tolerance is the bf16 one stated in SURVEY 8(c): 2e-2 * max(1, |x|);
+  * `ref_emulated`: fp32 convolutions of bf16-rounded weights with the layer outputs rounded to bf16 at exactly
+    the kernel's rounding points; what is left is fp32 summation order, i.e. occasional 1-ulp bf16 flips.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(seed, bias_scale=0.1):
+    from mapf_rl_amd.model import Network
+
+    torch.manual_seed(seed)
+    net = Network().cuda()
+    with torch.no_grad():  # the reference initialises biases to zero; give them values so that they are tested
+        for m in net.obs_encoder.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                m.bias.uniform_(-bias_scale, bias_scale)
+    return net
+
+
+def _convs(net):
+    from mapf_rl_amd.fused import encoder_convs
+
+    return encoder_convs(net.obs_encoder)
+
+
+def ref_fp32(net, obs):
+    x = obs.float()
+    c = _convs(net)
+    w = [m.weight.detach().float().contiguous() for m in c]
+    b = [m.bias.detach().float() for m in c]
+    h = F.relu(F.conv2d(x, w[0], b[0]))
+    for i in (1, 3, 5):
+        t = F.relu(F.conv2d(h, w[i], b[i], padding=1))
+        h = F.relu(F.conv2d(t, w[i + 1], b[i + 1], padding=1) + h)
+    return F.relu(F.conv2d(h, w[7], b[7])).flatten(1)
+
+
+def ref_emulated(net, obs):
+    r = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    x = obs.float()
+    c = _convs(net)
+    w = [r(m.weight.detach().float().contiguous()) for m in c]
+    b = [m.bias.detach().float() for m in c]
+    h = r(F.relu(F.conv2d(x, w[0], b[0])))
+    for i in (1, 3, 5):
+        t = r(F.relu(F.conv2d(h, w[i], b[i], padding=1)))
+        h = r(F.relu(F.conv2d(t, w[i + 1], b[i + 1], padding=1) + h))
+    return r(F.relu(F.conv2d(h, w[7], b[7]))).flatten(1)
+
+
+def _run(net, obs):
+    from mapf_rl_amd.fused import PackedEncoder, encoder_forward
+
+    wp, bp = PackedEncoder().get(net.obs_encoder)
+    return encoder_forward(obs, wp, bp)
+
+
+@pytest.fixture(autouse=True)
+def _fp32_reference_math():
+    old = torch.backends.cudnn.allow_tf32
+    torch.backends.cudnn.allow_tf32 = False
+    yield
+    torch.backends.cudnn.allow_tf32 = old
+
+
+@pytest.mark.parametrize("M", [1, 7, 8, 9, 16, 63, 200, 1029])
+def test_encoder_u8_against_fp32(M):
+    net = _net(M)
+    g = torch.Generator(device="cuda").manual_seed(M)
+    obs = (torch.rand((M, 6, 9, 9), device="cuda", generator=g) < 0.35).to(torch.uint8)
+    out = _run(net, obs)
+    assert out.shape == (M, 784) and out.dtype == torch.bfloat16
+    ref = ref_fp32(net, obs)
+    err = (out.float() - ref).abs()
+    tol = 2e-2 * torch.clamp(ref.abs(), min=1.0)
+    assert bool((err <= tol).all()), "max err %.4g (ref max %.4g)" % (float(err.max()), float(ref.abs().max()))
+    emu = ref_emulated(net, obs)
+    e2 = (out.float() - emu).abs()
+    # same rounding points: almost every element identical; the rest are single-ulp flips (2^-8 relative) of an
+    # intermediate activation carried through the later layers -- bounded here by 4 bf16 ulps
+    assert float((e2 > 0).float().mean()) < 0.25
+    assert bool((e2 <= 2.0 ** -6 * torch.clamp(emu.abs(), min=0.25)).all()), float(e2.max())
+    assert float(ref.abs().max()) > 0.05  # the test is not vacuous
+
+
+def test_encoder_layout_is_position_and_channel_exact():
+    """Weights that make every stage a pure copy/shift, so a transposed tap, a swapped channel or a wrong
+    flatten order shows up as an exact mismatch (all values are small integers: exact in bf16)."""
+    net = _net(3, bias_scale=0.0)
+    c = _convs(net)
+    with torch.no_grad():
+        for m in c:
+            m.weight.zero_()
+            m.bias.zero_()
+        # conv0: channel co <- input channel (co % 6) at tap (co // 6) % 9 (asymmetric in kh/kw), weight 1 + co % 3
+        for co in range(128):
+            t = (co // 6) % 9
+            c[0].weight[co, co % 6, t // 3, t % 3] = 1 + co % 3
+        # res layers: block1 = shift by tap (1,2) from channel (co+1)%128; block2 = tap (2,0) from channel (co+5)%128
+        for i in (1, 3, 5):
+            for co in range(128):
+                c[i].weight[co, (co + 1) % 128, 1, 2] = 1
+                c[i + 1].weight[co, (co + 5) % 128, 2, 0] = 1
+        for co in range(16):
+            c[7].weight[co, (7 * co + 3) % 128, 0, 0] = 1
+            c[7].bias[co] = co
+    g = torch.Generator(device="cuda").manual_seed(5)
+    obs = (torch.rand((37, 6, 9, 9), device="cuda", generator=g) < 0.5).to(torch.uint8)
+    out = _run(net, obs)
+    ref = ref_fp32(net, obs)
+    assert float(ref.max()) <= 256  # integers that bf16 holds exactly
+    assert torch.equal(out.float(), ref)
+
+
+def test_encoder_bf16_input_and_model_path():
+    """bf16 observations (the replay gather's output type) and the `Network.encode` switch: without autograd under
+    bf16 autocast the fused kernel runs; with autograd the MIOpen path runs; both agree within bf16 tolerance."""
+    from mapf_rl_amd.model import Network
+
+    net = _net(11)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    obs = (torch.rand((300, 6, 9, 9), device="cuda", generator=g) < 0.3)
+    a = _run(net, obs.to(torch.uint8))
+    b = _run(net, obs.to(torch.bfloat16))
+    c = _run(net, obs)  # bool
+    assert torch.equal(a, b) and torch.equal(a, c)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.no_grad():
+            fused = net.encode(obs.to(torch.uint8))
+        unfused = net.encode(obs.to(torch.uint8))
+    assert torch.equal(fused, a)
+    assert unfused.requires_grad and not fused.requires_grad
+    assert torch.allclose(fused.float(), unfused.float(), rtol=3e-2, atol=3e-2)
+    # weight updates are picked up (version counter of the parameters)
+    with torch.no_grad():
+        net.obs_encoder[5].bias.add_(1.0)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            fused2 = net.encode(obs.to(torch.uint8))
+    d = fused2.float() - fused.float()  # relu(x + 1) - relu(x) lies in [0, 1] and is 1 wherever x > 0
+    assert float(d.min()) >= 0 and float(d.max()) <= 1.01 and float(d[fused > 0].min()) > 0.98
+    # switch off -> MIOpen path also without autograd
+    Network.FUSED_INFERENCE = False
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            plain = net.encode(obs.to(torch.uint8))
+    finally:
+        Network.FUSED_INFERENCE = True
+    assert torch.allclose(fused2.float(), plain.float(), rtol=3e-2, atol=3e-2)
+
+
+def test_encoder_argument_checks():
+    from mapf_rl_amd._lib import ERR_INVALID_ARG, lib
+
+    assert lib.mapf_encoder_forward(None, 0, 8, None, None, None, None) == ERR_INVALID_ARG
+    assert lib.mapf_encoder_forward(None, 0, 0, None, None, None, None) == ERR_INVALID_ARG  # weights are always required
+    w = torch.zeros(894976, dtype=torch.bfloat16, device="cuda")
+    b = torch.zeros(912, dtype=torch.float32, device="cuda")
+    o = torch.zeros((8, 6, 9, 9), dtype=torch.uint8, device="cuda")
+    out = torch.zeros((8, 784), dtype=torch.bfloat16, device="cuda")
+    assert lib.mapf_encoder_forward(o.data_ptr(), 7, 8, w.data_ptr(), b.data_ptr(), out.data_ptr(), None) == ERR_INVALID_ARG
+    assert lib.mapf_encoder_forward(o.data_ptr() + 1, 0, 1, w.data_ptr(), b.data_ptr(), out.data_ptr(), None) == ERR_INVALID_ARG
+    assert lib.mapf_encoder_forward(o.data_ptr(), 0, 0, w.data_ptr(), b.data_ptr(), out.data_ptr(), None) == 0
+    assert lib.mapf_encoder_forward(o.data_ptr(), 0, -1, w.data_ptr(), b.data_ptr(), out.data_ptr(), None) == ERR_INVALID_ARG
