@@ -54,6 +54,16 @@ int mapf_encoder_pack(const float *const *w_dev, const float *const *b_dev, uint
 int mapf_encoder_forward(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev,
                          const float *bias_dev, uint16_t *latent_dev, void *stream);
 
+/*
+ * Communication mask of `Network.step` (reference model.py:195-208): mask[e][i][j] = j lies inside i's FOV square
+ * (|drow| <= r and |dcol| <= r) AND j is among i's `max_comm` nearest agents by Euclidean distance, i itself
+ * included; distance ties go to the LOWEST agent index (the reference's CPU topk leaves ties unspecified).
+ * pos int16 [E][N][2]; mask_dev u8 [E][N][N] and/or packed_dev int32 [E][N][cw] (bit j of word j/32, the
+ * replay's comm-row format, include/mapf_replay.h); either output may be NULL.  N <= 128, max_comm <= 8.
+ */
+int mapf_comm_mask(const int16_t *pos_dev, int E, int N, int obs_radius, int max_comm, uint8_t *mask_dev,
+                   int32_t *packed_dev, int cw, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

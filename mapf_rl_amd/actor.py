@@ -87,7 +87,13 @@ class VecActor:
     @torch.no_grad()
     def step(self):
         E, N, d = self.E, self.N, self.device
-        actions, q, hidden, comm = self.model.step_batch(self.obs, self.pos, self.hidden)
+        if self.pos.dtype == torch.int16 and N <= 128:  # mask + the replay's packed comm row from one kernel
+            from .fused import comm_mask
+
+            comm, comm_packed = comm_mask(self.pos, packed_words=self.CW)
+        else:
+            comm, comm_packed = None, None
+        actions, q, hidden, comm = self.model.step_batch(self.obs, self.pos, self.hidden, comm)
         # worker.py:380-382: only agent 0 of an environment explores
         explore = torch.rand(E, device=d, generator=self.gen, dtype=torch.float64) < self.eps
         rnd = torch.randint(0, 5, (E,), device=d, generator=self.gen)
@@ -100,7 +106,7 @@ class VecActor:
         self.lb_act[self.ar, t] = actions[:, 0].to(torch.uint8)
         self.lb_rew[self.ar, t] = reward[:, 0].to(torch.float16)
         self.lb_hid[self.ar, t] = hidden.view(E, N, 256)[:, 0].to(torch.float16)
-        self.lb_comm[self.ar, t, :N] = pack_comm_device(comm, self.CW)
+        self.lb_comm[self.ar, t, :N] = comm_packed if comm_packed is not None else pack_comm_device(comm, self.CW)
         self.lb_obs[self.ar, t + 1, :self.RD] = self.bits
         self.t = t + 1
         self.hidden = hidden

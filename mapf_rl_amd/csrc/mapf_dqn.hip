@@ -81,6 +81,58 @@ __global__ void __launch_bounds__(256) bias_res_relu_bwd_kernel(const uint4 *g, 
     }
 }
 
+
+// ---- communication mask (reference model.py:195-208): j is inside i's FOV square AND among i's `max_comm`
+// nearest agents by Euclidean distance (itself included, ties -> lowest index).  One block per environment,
+// one thread per agent i; the environment's positions sit in LDS.  Replaces a [E,N,N] int64 topk + scatter
+// (1.3 ms per 4096x40 actor step) by one ~10 us pass. ----
+constexpr int COMM_MAX_K = 8;
+
+__global__ void __launch_bounds__(128) comm_mask_kernel(const short2 *__restrict__ pos, int N, int radius, int k,
+                                                        uint8_t *__restrict__ mask, int32_t *__restrict__ packed, int cw) {
+    __shared__ short2 s_pos[128];
+    const int e = blockIdx.x, i = threadIdx.x;
+    if (i < N) s_pos[i] = pos[(long long)e * N + i];
+    __syncthreads();
+    if (i >= N) return;
+    const int px = s_pos[i].x, py = s_pos[i].y;
+    int best[COMM_MAX_K];  // the k smallest keys d2*N + j, ascending
+#pragma unroll
+    for (int t = 0; t < COMM_MAX_K; ++t) best[t] = 0x7FFFFFFF;
+    for (int j = 0; j < N; ++j) {
+        const int dx = px - s_pos[j].x, dy = py - s_pos[j].y;
+        int key = (dx * dx + dy * dy) * N + j;
+#pragma unroll
+        for (int t = 0; t < COMM_MAX_K; ++t) {  // insertion into the sorted list
+            if (t < k) {
+                const int lo = min(best[t], key);
+                key = max(best[t], key);
+                best[t] = lo;
+            }
+        }
+    }
+    int kth = 0;
+#pragma unroll
+    for (int t = 0; t < COMM_MAX_K; ++t)
+        if (t == k - 1) kth = best[t];
+    uint8_t *mrow = mask ? mask + ((long long)e * N + i) * N : nullptr;
+    int32_t *prow = packed ? packed + ((long long)e * N + i) * cw : nullptr;
+    uint32_t word = 0;
+    for (int j = 0; j < N; ++j) {
+        const int dx = px - s_pos[j].x, dy = py - s_pos[j].y;
+        const bool in_fov = abs(dx) <= radius && abs(dy) <= radius;
+        const bool on = in_fov && ((dx * dx + dy * dy) * N + j) <= kth;
+        if (mrow) mrow[j] = on ? 1 : 0;
+        word |= (on ? 1u : 0u) << (j & 31);
+        if ((j & 31) == 31 || j == N - 1) {
+            if (prow) prow[j >> 5] = (int32_t)word;
+            word = 0;
+        }
+    }
+    if (prow)
+        for (int w = (N + 31) / 32; w < cw; ++w) prow[w] = 0;
+}
+
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \
         hipError_t _e = (expr);                                                            \
@@ -127,6 +179,20 @@ int mapf_bias_res_relu_bwd(const uint16_t *g_dev, const uint16_t *y_dev, uint16_
     hipLaunchKernelGGL(bias_res_relu_bwd_kernel, dim3(pick_grid(nvec, C / 8)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const uint4 *>(g_dev), reinterpret_cast<const uint4 *>(y_dev),
                        reinterpret_cast<uint4 *>(gx_dev), gbias_dev, nvec, C);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+int mapf_comm_mask(const int16_t *pos_dev, int E, int N, int obs_radius, int max_comm, uint8_t *mask_dev, int32_t *packed_dev,
+                   int cw, void *stream) {
+    if (!pos_dev || E < 0 || N < 1 || N > 128 || obs_radius < 0 || max_comm < 1 || max_comm > COMM_MAX_K) return MAPF_ERR_INVALID_ARG;
+    if (!mask_dev && !packed_dev) return MAPF_ERR_INVALID_ARG;
+    if (packed_dev && cw < (N + 31) / 32) return MAPF_ERR_INVALID_ARG;
+    if (reinterpret_cast<uintptr_t>(pos_dev) & 3) return MAPF_ERR_INVALID_ARG;
+    if (E == 0) return MAPF_OK;
+    const int k = max_comm < N ? max_comm : N;
+    hipLaunchKernelGGL(comm_mask_kernel, dim3(E), dim3(128), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const short2 *>(pos_dev), N, obs_radius, k, mask_dev, packed_dev, cw);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }

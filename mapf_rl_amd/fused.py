@@ -107,3 +107,16 @@ def encoder_forward(obs, packed_weights, packed_bias):
     check(lib.mapf_encoder_forward(_ptr(obs), kind, M, _ptr(packed_weights), _ptr(packed_bias), _ptr(out), _stream(obs.device)),
           "mapf_encoder_forward")
     return out
+
+
+def comm_mask(pos, obs_radius=4, max_comm=3, packed_words=0):
+    """pos int16 [E, N, 2] on a HIP device -> (bool [E, N, N], int32 [E, N, packed_words] or None):
+    include/mapf_dqn.h mapf_comm_mask (reference model.py:195-208)."""
+    assert pos.is_cuda and pos.dtype == torch.int16 and pos.dim() == 3 and pos.shape[2] == 2
+    pos = pos.contiguous()
+    E, N, _ = pos.shape
+    mask = torch.empty((E, N, N), dtype=torch.bool, device=pos.device)
+    packed = torch.empty((E, N, packed_words), dtype=torch.int32, device=pos.device) if packed_words else None
+    check(lib.mapf_comm_mask(_ptr(pos), E, N, obs_radius, max_comm, _ptr(mask), _ptr(packed), packed_words, _stream(pos.device)),
+          "mapf_comm_mask")
+    return mask, packed

@@ -97,6 +97,10 @@ def comm_mask_from_pos(pos: torch.Tensor, obs_radius: int = OBS_RADIUS, max_comm
     """pos [E, N, 2] (any integer/float dtype) -> bool [E, N, N]: j is within i's FOV square AND among i's
     `max_comm` nearest agents by Euclidean distance, itself included (reference model.py:195-208).
     Distance ties are broken by lowest agent index."""
+    if pos.is_cuda and pos.dtype == torch.int16 and pos.shape[1] <= 128 and max_comm <= 8:
+        from .fused import comm_mask  # one small HIP kernel instead of an [E, N, N] int64 topk + scatter
+
+        return comm_mask(pos, obs_radius, max_comm)[0]
     p = pos.to(torch.int64)
     E, N, _ = p.shape
     d = (p.unsqueeze(2) - p.unsqueeze(1)).abs()              # [E, N, N, 2]

@@ -60,3 +60,25 @@ def test_fused_encoder_matches_unfused():
     for k in grads[0]:
         a, b = grads[0][k], grads[1][k]
         assert torch.allclose(a, b, rtol=5e-2, atol=5e-2 * float(b.abs().max()) + 1e-8), k
+
+
+@pytest.mark.parametrize("E,N,L,k", [(1, 1, 5, 3), (3, 2, 4, 3), (64, 40, 32, 3), (17, 128, 64, 3), (9, 33, 12, 5), (5, 6, 20, 1)])
+def test_comm_mask_kernel_matches_torch_rule(E, N, L, k):
+    """mapf_comm_mask against the torch formulation of model.py:195-208 (int64 path of comm_mask_from_pos), incl.
+    distance ties (dense small maps) and the replay's packed row format."""
+    from mapf_rl_amd.actor import pack_comm_device
+    from mapf_rl_amd.fused import comm_mask
+    from mapf_rl_amd.model import comm_mask_from_pos
+
+    g = torch.Generator().manual_seed(E * 1000 + N)
+    # distinct cells per environment, like real agent positions
+    cells = torch.stack([torch.randperm(L * L, generator=g)[:N] for _ in range(E)])
+    pos = torch.stack([cells // L, cells % L], dim=-1)
+    ref = comm_mask_from_pos(pos.cuda().to(torch.int64), 4, k)          # torch path
+    cw = (N + 31) // 32 + 1
+    mask, packed = comm_mask(pos.cuda().to(torch.int16), 4, k, packed_words=cw)
+    assert mask.dtype == torch.bool and torch.equal(mask, ref)
+    assert torch.equal(comm_mask_from_pos(pos.cuda().to(torch.int16), 4, k), ref)  # dispatches to the kernel
+    assert torch.equal(packed, pack_comm_device(ref, cw))
+    assert bool(mask.diagonal(dim1=1, dim2=2).all())                      # an agent always hears itself
+    assert int(mask.sum(-1).max()) <= min(k, N)

@@ -1,0 +1,11 @@
+# kernel breakdown of the actor loop and of the learner update (rocprofv3 --kernel-trace --stats)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rm -rf $R/gpurun_out/prof_actor $R/gpurun_out/prof_learner
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_actor -- python3 $R/tools/profile_actor.py > $R/gpurun_out/prof_actor.log 2>&1; echo actor=$?
+TUPD=6 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_learner -- python3 $R/tools/profile_update.py > $R/gpurun_out/prof_learner.log 2>&1; echo learner=$?
+cd $R
+python tools/summarize_rocprof.py gpurun_out/prof_actor actor > gpurun_out/prof_actor.md
+python tools/summarize_rocprof.py gpurun_out/prof_learner learner > gpurun_out/prof_learner.md
+find gpurun_out/prof_actor gpurun_out/prof_learner -name "*kernel_trace.csv" -size +20M -delete
+head -30 gpurun_out/prof_actor.md | cut -c1-160

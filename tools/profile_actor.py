@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Runs a few actor-loop iterations (Network.step_batch + mapf_step + recording) at the config-2 shape for
+rocprofv3 (kernel breakdown of the end-to-end env-steps/s)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import mapf_rl_amd as M  # noqa: E402
+from mapf_rl_amd.actor import VecActor  # noqa: E402
+from mapf_rl_amd.model import Network  # noqa: E402
+
+N, E = 40, 4096
+torch.manual_seed(0)
+model = Network().cuda()
+maps, agents, goals, _ = M.generate_scenarios(E, 32, N, 0.3, seed=1)
+env = M.VecEnvironment(E, 32, N)
+env.load(maps, agents, goals)
+actor = VecActor(env, model, None, seed=0, density=0.3)
+for _ in range(int(os.environ.get("TACT", 6))):
+    actor.step()
+torch.cuda.synchronize()
