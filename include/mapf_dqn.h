@@ -29,7 +29,7 @@ int mapf_bias_res_relu_bwd(const uint16_t *g_dev, const uint16_t *y_dev, uint16_
  * Fused observation encoder, inference only (no autograd): replaces the reference's
  * `self.obs_encoder(obs)` in `Network.step` (model.py:184) and in the target network's `bootstrap`
  * (model.py:237, called without gradients at worker.py:300-303) by ONE kernel that keeps the activations of
- * 8 observations per workgroup in LDS across all 8 convolutions (csrc/mapf_encoder.hip).  bf16 MFMA, fp32
+ * 4 observations per workgroup in LDS across all 8 convolutions (csrc/mapf_encoder.hip).  bf16 MFMA, fp32
  * accumulation, one rounding to bf16 per layer output.
  *
  * Packed weights (produced by mapf_encoder_pack from the 8 convolutions of `Network.obs_encoder`, in module
@@ -41,7 +41,7 @@ int mapf_bias_res_relu_bwd(const uint16_t *g_dev, const uint16_t *y_dev, uint16_
  * with co = 16 c + (lane & 15); MAPF_ENC_PACKED_ELEMS bf16 in total.  Biases: MAPF_ENC_BIAS_ELEMS fp32,
  * concatenated in the same order.  Both buffers must be 16-byte aligned.
  */
-#define MAPF_ENC_OBS_PER_BLOCK 8
+#define MAPF_ENC_OBS_PER_BLOCK 4
 #define MAPF_ENC_PACKED_ELEMS 894976 /* 8192 + 6*147456 + 2048 */
 #define MAPF_ENC_BIAS_ELEMS 912      /* 7*128 + 16 */
 #define MAPF_ENC_OBS_U8 0            /* obs elements are bytes (0/1, any 0..255 is exact) */
@@ -50,7 +50,7 @@ int mapf_bias_res_relu_bwd(const uint16_t *g_dev, const uint16_t *y_dev, uint16_
 /* w_dev / b_dev: HOST arrays of 8 DEVICE pointers (see above). */
 int mapf_encoder_pack(const float *const *w_dev, const float *const *b_dev, uint16_t *packed_dev, float *bias_dev,
                       void *stream);
-/* obs [M][6][9][9] (u8 or bf16, 16-byte aligned) -> latent bf16 [M][784] (= Flatten of [16][7][7]). */
+/* obs [M][6][9][9] (u8 or bf16, 4-byte aligned) -> latent bf16 [M][784] (= Flatten of [16][7][7]). */
 int mapf_encoder_forward(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev,
                          const float *bias_dev, uint16_t *latent_dev, void *stream);
 

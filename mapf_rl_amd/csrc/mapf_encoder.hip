@@ -4,15 +4,16 @@
 //
 // Why one kernel: per observation the encoder is 87.6 MFLOP over activations of only 7x7x128 bf16 = 12.5 KB.
 // Layer-by-layer (MIOpen implicit GEMM + an epilogue pass per layer) every layer round-trips that activation
-// through HBM and pays a launch; here a workgroup keeps the activations of G = 8 observations resident in LDS for
+// through HBM and pays a launch; here a workgroup keeps the activations of G = 4 observations resident in LDS for
 // all 8 layers and only the packed weights (1.8 MB, L2-resident) stream in.  MFMA-bound.
 //
-// Mapping (512 threads = 8 waves, 2 per SIMD, <= 256 VGPR each; 146 KB LDS -> one workgroup per CU):
+// Mapping (256 threads = 4 waves, <= 256 VGPR each; 76 KB LDS -> TWO independent workgroups per CU, 2 waves per
+// SIMD: while one workgroup is in a layer epilogue / at a barrier the other one keeps the MFMA pipe busy):
 //  * Each 3x3 layer is the GEMM  out[co][p] = sum_{tap,ci} W[co][ci][tap] * act[p + tap][ci]  with M = 128 output
 //    channels, N = 49*G positions, K = 9*128, on v_mfma_f32_16x16x32_bf16: A = weights, B = activations, so a lane's
 //    4 accumulator registers are 4 consecutive output channels of one position -> one 8-byte LDS store.
-//  * Wave w owns output channels [32*(w&3), +32) (two 16-row A tiles) and position tiles (w>>2)*13 .. +13
-//    (16 positions each; 26 tiles cover the 392 positions): 104 accumulator registers.
+//  * Wave w owns output channels [32*w, +32) (two 16-row A tiles) and all 13 position tiles (16 positions each,
+//    208 >= 196): 104 accumulator registers.
 //  * Activations live in LDS as rows of 128 channels (256 B + 16 B pad = 272 B: conflict-free ds_read_b128 over
 //    16 consecutive rows).  Row index = 64*obs + 8*(y+1) + (x+1): an 8-wide zero-bordered image in which the right
 //    border of one image row IS the left border of the next and the bottom border of one observation IS the top
@@ -20,7 +21,7 @@
 //    the zero padding costs no selects.  Border rows are zeroed once and never written.
 //  * The A operand is pre-packed in exact fragment order (mapf_encoder_pack): one k-step of one 16-channel tile is a
 //    contiguous 1 KiB, read straight into registers with global_load_dwordx4 (no LDS round trip; each weight byte
-//    is used by exactly one co-block wave pair).
+//    is used by exactly one wave of the workgroup).
 //  * ResBlock: the skip input of this wave's own (co, position) elements is read from LDS as packed bf16 before
 //    conv1's output overwrites it and becomes the initial accumulator of conv2 -> a single activation buffer.
 //  * conv0 (K = 54, padded to 64) builds its B fragments directly from the raw observation bytes staged in LDS.
@@ -43,11 +44,12 @@ constexpr int ACT_ROWS = 64 * G + 9;
 constexpr int ACT_BYTES = ACT_ROWS * ROWB;  // 141,712
 constexpr int OBS_ELEMS = 6 * 9 * 9;        // 486
 constexpr int RAW_BYTES = ((G * OBS_ELEMS * 2 + 15) / 16) * 16;  // sized for 2-byte inputs
-constexpr int NT = 13;                      // position tiles per wave
+constexpr int NT = 13;                      // position tiles (16 positions each)
+constexpr int NTHREADS = 256;
 constexpr int NPOS = 49 * G;
-static_assert(2 * NT * 16 >= NPOS, "tiles must cover all positions");
+static_assert(NT * 16 >= NPOS, "tiles must cover all positions");
 static_assert(ACT_BYTES % 16 == 0, "");
-static_assert(ACT_BYTES + RAW_BYTES <= 160 * 1024, "LDS budget");
+static_assert(2 * (ACT_BYTES + RAW_BYTES) <= 160 * 1024, "LDS budget: two workgroups per CU");
 
 // packed-weight element offsets (bf16 elements), see mapf_dqn.h
 constexpr int WP_L0 = 0;
@@ -70,10 +72,15 @@ __device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as
 __device__ __forceinline__ uint16_t raw_to_bf16(uint8_t v) { return (uint16_t)f32_to_bf16_bits((float)v); }  // exact for 0..255
 __device__ __forceinline__ uint16_t raw_to_bf16(uint16_t v) { return v; }                                   // already bf16 bits
 
-// relu(acc + bias) for the 4 consecutive channels of one lane, packed to 4 bf16
+// relu(acc + bias) for the 4 consecutive channels of one lane, packed to 4 bf16 (v_cvt_pk_bf16_f32: RNE)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
 __device__ __forceinline__ uint2 pack_relu(const f32x4 &a, const float4 &b) {
-    const float v0 = fmaxf(a[0] + b.x, 0.f), v1 = fmaxf(a[1] + b.y, 0.f), v2 = fmaxf(a[2] + b.z, 0.f), v3 = fmaxf(a[3] + b.w, 0.f);
-    return make_uint2(f32_to_bf16_bits(v0) | (f32_to_bf16_bits(v1) << 16), f32_to_bf16_bits(v2) | (f32_to_bf16_bits(v3) << 16));
+    return make_uint2(pack2_bf16(fmaxf(a[0] + b.x, 0.f), fmaxf(a[1] + b.y, 0.f)),
+                      pack2_bf16(fmaxf(a[2] + b.z, 0.f), fmaxf(a[3] + b.w, 0.f)));
 }
 
 // One 3x3 pad-1 128->128 convolution over the LDS-resident activations: acc[a][n] += W(a) * act(n).
@@ -118,7 +125,7 @@ __device__ __forceinline__ void conv3x3(const unsigned char *act, const bf16x8 *
 }
 
 template <typename InT>
-__global__ void __launch_bounds__(512) encoder_fwd_kernel(const InT *__restrict__ obs, long long M,
+__global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__restrict__ obs, long long M,
                                                           const uint16_t *__restrict__ wp, const float *__restrict__ bias,
                                                           uint16_t *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[ACT_BYTES + RAW_BYTES];
@@ -126,23 +133,23 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const InT *__restrict_
     const InT *const raw = reinterpret_cast<const InT *>(smem + ACT_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int cb = w & 3, ph = w >> 2;
+    const int cb = w;
     const int lr = lane & 15, lh = lane >> 4;
     const long long obs0 = (long long)blockIdx.x * G;
     const long long left = M - obs0;
     const int nobs = left < G ? (int)left : G;  // >= 1 by the grid size
 
     // ---- zero the activation image (its border rows must be zero; they are never written afterwards) ----
-    for (int i = tid; i < ACT_BYTES / 16; i += 512) reinterpret_cast<uint4 *>(act)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < ACT_BYTES / 16; i += NTHREADS) reinterpret_cast<uint4 *>(act)[i] = make_uint4(0, 0, 0, 0);
     // ---- stage the raw observations of this block (contiguous in global memory); missing ones read as zero ----
     {
         constexpr int DW = G * OBS_ELEMS * (int)sizeof(InT) / 4;
-        static_assert((G * OBS_ELEMS * sizeof(InT)) % 16 == 0, "block input must stay 16-byte aligned");
+        static_assert((G * OBS_ELEMS * sizeof(InT)) % 4 == 0, "block input must stay 4-byte aligned");
         const uint32_t *src = reinterpret_cast<const uint32_t *>(obs + obs0 * OBS_ELEMS);
         uint32_t *dst = reinterpret_cast<uint32_t *>(smem + ACT_BYTES);
         const int have = nobs * OBS_ELEMS * (int)sizeof(InT) / 4;  // 486*sizeof(InT) is a multiple of 4 only for even sizes...
         const int have_bytes = nobs * OBS_ELEMS * (int)sizeof(InT);
-        for (int i = tid; i < DW; i += 512) {
+        for (int i = tid; i < DW; i += NTHREADS) {
             uint32_t v = 0;
             if (i < have) {
                 v = src[i];
@@ -160,7 +167,7 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const InT *__restrict_
     uint32_t vmask = 0;  // bit n: position of tile n exists
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        const int p = (ph * NT + n) * 16 + lr;
+        const int p = n * 16 + lr;
         const bool v = p < 49 * nobs;
         const int o = p / 49, q = p - 49 * o, y = q / 7, x = q - 7 * y;
         addr[n] = (v ? (64 * o + 8 * y + x) * ROWB : 0) + lh * 16;
@@ -192,7 +199,7 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const InT *__restrict_
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                const int p = (ph * NT + n) * 16 + lr;
+                const int p = n * 16 + lr;
                 const bool v = (vmask >> n) & 1u;
                 const int o = p / 49, q = p - 49 * o, y = q / 7, x = q - 7 * y;
                 const int rb = v ? o * OBS_ELEMS + y * 9 + x : 0;
@@ -269,7 +276,7 @@ __global__ void __launch_bounds__(512) encoder_fwd_kernel(const InT *__restrict_
 #pragma unroll
         for (int s = 0; s < 4; ++s) a7[s] = wv[s * 64];
         const float4 b4 = *reinterpret_cast<const float4 *>(bl + 4 * lh);
-        for (int n = w; n < 2 * NT; n += 8) {
+        for (int n = w; n < NT; n += NTHREADS / 64) {
             const int p = n * 16 + lr;
             const bool v = p < 49 * nobs;
             const int o = p / 49, q = p - 49 * o, y = q / 7, x = q - 7 * y;
@@ -353,7 +360,7 @@ int mapf_encoder_forward(const void *obs_dev, int obs_dtype, int64_t M, const ui
                          uint16_t *latent_dev, void *stream) {
     if (M < 0 || !packed_dev || !bias_dev || (M > 0 && (!obs_dev || !latent_dev))) return MAPF_ERR_INVALID_ARG;
     if (obs_dtype != MAPF_ENC_OBS_U8 && obs_dtype != MAPF_ENC_OBS_BF16) return MAPF_ERR_INVALID_ARG;
-    if ((reinterpret_cast<uintptr_t>(obs_dev) & 15) || (reinterpret_cast<uintptr_t>(packed_dev) & 15) ||
+    if ((reinterpret_cast<uintptr_t>(obs_dev) & 3) || (reinterpret_cast<uintptr_t>(packed_dev) & 15) ||
         (reinterpret_cast<uintptr_t>(bias_dev) & 15) || (reinterpret_cast<uintptr_t>(latent_dev) & 1))
         return MAPF_ERR_INVALID_ARG;
     if (M == 0) return MAPF_OK;
@@ -361,10 +368,10 @@ int mapf_encoder_forward(const void *obs_dev, int obs_dtype, int64_t M, const ui
     if (blocks > 0x7FFFFFFFLL) return MAPF_ERR_INVALID_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (obs_dtype == MAPF_ENC_OBS_U8)
-        hipLaunchKernelGGL(encoder_fwd_kernel<uint8_t>, dim3((unsigned)blocks), dim3(512), 0, st,
+        hipLaunchKernelGGL(encoder_fwd_kernel<uint8_t>, dim3((unsigned)blocks), dim3(NTHREADS), 0, st,
                            static_cast<const uint8_t *>(obs_dev), (long long)M, packed_dev, bias_dev, latent_dev);
     else
-        hipLaunchKernelGGL(encoder_fwd_kernel<uint16_t>, dim3((unsigned)blocks), dim3(512), 0, st,
+        hipLaunchKernelGGL(encoder_fwd_kernel<uint16_t>, dim3((unsigned)blocks), dim3(NTHREADS), 0, st,
                            static_cast<const uint16_t *>(obs_dev), (long long)M, packed_dev, bias_dev, latent_dev);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
