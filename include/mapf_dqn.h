@@ -54,6 +54,12 @@ int mapf_encoder_pack(const float *const *w_dev, const float *const *b_dev, uint
 int mapf_encoder_forward(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev,
                          const float *bias_dev, uint16_t *latent_dev, void *stream);
 
+/* Training forward: the same kernel, additionally storing the 7 post-ReLU layer outputs that the backward pass
+ * needs (ReLU masks and the inputs of the weight gradients): acts_dev bf16 [7][M][7][7][128] (NHWC), in order
+ * conv0, res1.block1, res1, res2.block1, res2, res3.block1, res3 (16-byte aligned, 7*M*6272 elements). */
+int mapf_encoder_forward_save(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev,
+                              const float *bias_dev, uint16_t *latent_dev, uint16_t *acts_dev, void *stream);
+
 /*
  * Communication mask of `Network.step` (reference model.py:195-208): mask[e][i][j] = j lies inside i's FOV square
  * (|drow| <= r and |dcol| <= r) AND j is among i's `max_comm` nearest agents by Euclidean distance, i itself

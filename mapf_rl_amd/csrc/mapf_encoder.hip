@@ -124,10 +124,21 @@ __device__ __forceinline__ void conv3x3(const unsigned char *act, const bf16x8 *
     }
 }
 
-template <typename InT>
+// Training forward: copy the layer output that is now resident in LDS (valid rows only) to its saved-activation
+// tensor [M][49][128] (NHWC) -- 49*nobs rows of 256 B, contiguous in global memory for the block's observations.
+__device__ __forceinline__ void save_rows(const unsigned char *act, uint16_t *__restrict__ dst, int nobs, int tid) {
+    const int total = nobs * 49 * 16;  // 16-byte chunks
+    for (int c = tid; c < total; c += NTHREADS) {
+        const int rowi = c >> 4, ch = c & 15;
+        const int o = rowi / 49, q = rowi - 49 * o, y = q / 7, x = q - 7 * y;
+        reinterpret_cast<uint4 *>(dst)[c] = *reinterpret_cast<const uint4 *>(act + (64 * o + 8 * y + x + 9) * ROWB + ch * 16);
+    }
+}
+
+template <typename InT, bool SAVE>
 __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__restrict__ obs, long long M,
                                                           const uint16_t *__restrict__ wp, const float *__restrict__ bias,
-                                                          uint16_t *__restrict__ out) {
+                                                          uint16_t *__restrict__ out, uint16_t *__restrict__ save) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[ACT_BYTES + RAW_BYTES];
     unsigned char *const act = smem;
     const InT *const raw = reinterpret_cast<const InT *>(smem + ACT_BYTES);
@@ -223,6 +234,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
         }
         bl += 128;
         __syncthreads();
+        if (SAVE) save_rows(act, save + obs0 * 6272, nobs, tid);
     }
 
     // =========================== 3 residual blocks ===========================
@@ -248,6 +260,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
             }
         }
         __syncthreads();
+        if (SAVE) save_rows(act, save + ((1 + 2 * blk) * M + obs0) * 6272, nobs, tid);
         // ---- block2: x' = relu(conv(t) + b2 + x): the skip input is the initial accumulator ----
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -267,6 +280,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
         }
         bl += 256;
         __syncthreads();
+        if (SAVE) save_rows(act, save + ((2 + 2 * blk) * M + obs0) * 6272, nobs, tid);
     }
 
     // =========================== conv 1x1: 128 -> 16, ReLU, NCHW flatten ===========================
@@ -356,25 +370,41 @@ int mapf_encoder_pack(const float *const *w_dev, const float *const *b_dev, uint
     return MAPF_OK;
 }
 
-int mapf_encoder_forward(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev, const float *bias_dev,
-                         uint16_t *latent_dev, void *stream) {
-    if (M < 0 || !packed_dev || !bias_dev || (M > 0 && (!obs_dev || !latent_dev))) return MAPF_ERR_INVALID_ARG;
+static int encoder_launch(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev, const float *bias_dev,
+                          uint16_t *latent_dev, uint16_t *save_dev, bool save, void *stream) {
+    if (M < 0 || !packed_dev || !bias_dev || (M > 0 && (!obs_dev || !latent_dev || (save && !save_dev)))) return MAPF_ERR_INVALID_ARG;
     if (obs_dtype != MAPF_ENC_OBS_U8 && obs_dtype != MAPF_ENC_OBS_BF16) return MAPF_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(obs_dev) & 3) || (reinterpret_cast<uintptr_t>(packed_dev) & 15) ||
-        (reinterpret_cast<uintptr_t>(bias_dev) & 15) || (reinterpret_cast<uintptr_t>(latent_dev) & 1))
+        (reinterpret_cast<uintptr_t>(bias_dev) & 15) || (reinterpret_cast<uintptr_t>(latent_dev) & 1) ||
+        (reinterpret_cast<uintptr_t>(save_dev) & 15))
         return MAPF_ERR_INVALID_ARG;
     if (M == 0) return MAPF_OK;
     const long long blocks = (M + G - 1) / G;
     if (blocks > 0x7FFFFFFFLL) return MAPF_ERR_INVALID_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (obs_dtype == MAPF_ENC_OBS_U8)
-        hipLaunchKernelGGL(encoder_fwd_kernel<uint8_t>, dim3((unsigned)blocks), dim3(NTHREADS), 0, st,
-                           static_cast<const uint8_t *>(obs_dev), (long long)M, packed_dev, bias_dev, latent_dev);
+    const dim3 grid((unsigned)blocks), block(NTHREADS);
+    const uint8_t *o8 = static_cast<const uint8_t *>(obs_dev);
+    const uint16_t *o16 = static_cast<const uint16_t *>(obs_dev);
+    if (obs_dtype == MAPF_ENC_OBS_U8 && !save)
+        hipLaunchKernelGGL((encoder_fwd_kernel<uint8_t, false>), grid, block, 0, st, o8, (long long)M, packed_dev, bias_dev, latent_dev, save_dev);
+    else if (obs_dtype == MAPF_ENC_OBS_U8)
+        hipLaunchKernelGGL((encoder_fwd_kernel<uint8_t, true>), grid, block, 0, st, o8, (long long)M, packed_dev, bias_dev, latent_dev, save_dev);
+    else if (!save)
+        hipLaunchKernelGGL((encoder_fwd_kernel<uint16_t, false>), grid, block, 0, st, o16, (long long)M, packed_dev, bias_dev, latent_dev, save_dev);
     else
-        hipLaunchKernelGGL(encoder_fwd_kernel<uint16_t>, dim3((unsigned)blocks), dim3(NTHREADS), 0, st,
-                           static_cast<const uint16_t *>(obs_dev), (long long)M, packed_dev, bias_dev, latent_dev);
+        hipLaunchKernelGGL((encoder_fwd_kernel<uint16_t, true>), grid, block, 0, st, o16, (long long)M, packed_dev, bias_dev, latent_dev, save_dev);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
+}
+
+int mapf_encoder_forward(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev, const float *bias_dev,
+                         uint16_t *latent_dev, void *stream) {
+    return encoder_launch(obs_dev, obs_dtype, M, packed_dev, bias_dev, latent_dev, nullptr, false, stream);
+}
+
+int mapf_encoder_forward_save(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev, const float *bias_dev,
+                              uint16_t *latent_dev, uint16_t *acts_dev, void *stream) {
+    return encoder_launch(obs_dev, obs_dtype, M, packed_dev, bias_dev, latent_dev, acts_dev, true, stream);
 }
 
 }  // extern "C"

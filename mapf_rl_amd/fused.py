@@ -120,3 +120,88 @@ def comm_mask(pos, obs_radius=4, max_comm=3, packed_words=0):
     check(lib.mapf_comm_mask(_ptr(pos), E, N, obs_radius, max_comm, _ptr(mask), _ptr(packed), packed_words, _stream(pos.device)),
           "mapf_comm_mask")
     return mask, packed
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Training forward of the encoder through the fused kernel (it also stores the 7 layer outputs); the backward
+# chain runs layer by layer on those saved activations (MIOpen data / weight gradients + the fused ReLU-mask /
+# bias-gradient pass above).
+# ---------------------------------------------------------------------------------------------------------
+_BWD_CHUNK = 32768  # observations per MIOpen call (see Network.encode: very large batches misbehave on ROCm 7.2)
+
+
+def _conv_bwd(gz, x, w, pad, need_input):
+    gi, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                    [need_input, True, False])
+    return gi, gw
+
+
+def _mask_bias(g, y, gb):
+    """gx = g where y > 0 else 0 (bf16 NHWC); gb += per-channel sum of gx (f32)."""
+    gx = torch.empty_like(y)
+    check(lib.mapf_bias_res_relu_bwd(_ptr(g), _ptr(y), _ptr(gx), _ptr(gb), y.numel(), y.shape[1], _stream(y.device)),
+          "mapf_bias_res_relu_bwd")
+    return gx
+
+
+class _EncoderTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, obs, packed_w, packed_b, *params):
+        M = obs.shape[0]
+        acts = torch.empty((7, M, 7, 7, 128), dtype=torch.bfloat16, device=obs.device)
+        out = torch.empty((M, 784), dtype=torch.bfloat16, device=obs.device)
+        kind = _ENC_OBS_U8 if obs.dtype == torch.uint8 else _ENC_OBS_BF16
+        check(lib.mapf_encoder_forward_save(_ptr(obs), kind, M, _ptr(packed_w), _ptr(packed_b), _ptr(out), _ptr(acts),
+                                            _stream(obs.device)), "mapf_encoder_forward_save")
+        ctx.save_for_backward(obs, acts, out, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        obs, acts, out = ctx.saved_tensors[:3]
+        params = ctx.saved_tensors[3:]
+        cl = torch.channels_last
+        ws = [params[2 * i].detach().to(torch.bfloat16) for i in range(8)]  # keeps the channels_last strides
+        gws = [torch.zeros(w.shape, dtype=torch.float32, device=w.device).contiguous(memory_format=cl) for w in ws]
+        gbs = [torch.zeros(w.shape[0], dtype=torch.float32, device=w.device) for w in ws]
+        M = obs.shape[0]
+        g = g.to(torch.bfloat16)
+        parts = -(-M // _BWD_CHUNK)
+        step = -(-M // parts)
+        for lo in range(0, M, step):
+            hi = min(M, lo + step)
+            a = [acts[k, lo:hi].permute(0, 3, 1, 2) for k in range(7)]  # [m,128,7,7] views with NHWC strides
+            o4 = out[lo:hi].view(-1, 16, 7, 7).contiguous(memory_format=cl)
+            g4 = g[lo:hi].reshape(-1, 16, 7, 7).contiguous(memory_format=cl)
+            gz = _mask_bias(g4, o4, gbs[7])
+            gh, gw = _conv_bwd(gz, a[6], ws[7], 0, True)
+            gws[7] += gw
+            for blk in (2, 1, 0):  # y = relu(x + conv2(t) + b2), t = relu(conv1(x) + b1)
+                x_in, t, y = a[2 * blk], a[2 * blk + 1], a[2 * blk + 2]
+                gz2 = _mask_bias(gh.contiguous(memory_format=cl), y, gbs[2 + 2 * blk])
+                gt, gw = _conv_bwd(gz2, t, ws[2 + 2 * blk], 1, True)
+                gws[2 + 2 * blk] += gw
+                gz1 = _mask_bias(gt.contiguous(memory_format=cl), t, gbs[1 + 2 * blk])
+                gx, gw = _conv_bwd(gz1, x_in, ws[1 + 2 * blk], 1, True)
+                gws[1 + 2 * blk] += gw
+                gh = gx + gz2
+            gz0 = _mask_bias(gh.contiguous(memory_format=cl), a[0], gbs[0])
+            x0 = obs[lo:hi].to(torch.bfloat16).contiguous(memory_format=cl)
+            _, gw = _conv_bwd(gz0, x0, ws[0], 0, False)
+            gws[0] += gw
+        grads = []
+        for i in range(8):
+            grads += [gws[i].to(params[2 * i].dtype), gbs[i].to(params[2 * i + 1].dtype)]
+        return (None, None, None, *grads)
+
+
+def encoder_forward_train(obs, obs_encoder, packed: PackedEncoder):
+    """obs [M, 6, 9, 9] uint8 / bool / bf16 -> latent bf16 [M, 784] with autograd into the encoder's parameters."""
+    assert obs.dim() == 4 and tuple(obs.shape[1:]) == (6, 9, 9) and obs.is_cuda
+    if obs.dtype == torch.bool:
+        obs = obs.view(torch.uint8)
+    if obs.dtype not in (torch.uint8, torch.bfloat16):
+        obs = obs.to(torch.bfloat16)
+    wp, bp = packed.get(obs_encoder)
+    params = [t for c in encoder_convs(obs_encoder) for t in (c.weight, c.bias)]
+    return _EncoderTrain.apply(obs.contiguous(), wp, bp, *params)

@@ -152,6 +152,7 @@ class Network(nn.Module):
 
     ENCODE_CHUNK = 32768  # observations per convolution call (see encode)
     FUSED_EPILOGUE = True  # hand-written bias/residual/ReLU epilogue kernels behind every convolution (HIP, bf16)
+    FUSED_TRAINING = True   # with autograd: fused forward that saves the layer outputs + layer-wise backward on them
     FUSED_INFERENCE = True  # without autograd: the whole encoder as one hand-written MFMA kernel (csrc/mapf_encoder.hip)
 
     def encode(self, obs):
@@ -171,6 +172,13 @@ class Network(nn.Module):
                 self._packed = PackedEncoder()
             wp, bp = self._packed.get(self.obs_encoder)
             return encoder_forward(obs, wp, bp)
+        if nhwc and self.FUSED_TRAINING and bf16_autocast and torch.is_grad_enabled():
+            # learner: the same kernel also stores the layer outputs the backward chain needs
+            from .fused import PackedEncoder, encoder_forward_train
+
+            if self._packed is None:
+                self._packed = PackedEncoder()
+            return encoder_forward_train(obs, self.obs_encoder, self._packed)
 
         fused = nhwc and self.FUSED_EPILOGUE and bf16_autocast
 

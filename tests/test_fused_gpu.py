@@ -45,6 +45,7 @@ def test_fused_encoder_matches_unfused():
     net = Network().cuda()
     obs = (torch.rand(513, 6, 9, 9, device="cuda") < 0.3).to(torch.uint8)
     outs, grads = [], []
+    Network.FUSED_TRAINING = False  # this test is about the epilogue kernels of the layer-by-layer path
     for fused in (True, False):
         Network.FUSED_EPILOGUE = fused
         net.zero_grad()
@@ -55,6 +56,7 @@ def test_fused_encoder_matches_unfused():
         outs.append(lat.float().detach().clone())
         grads.append({k: p.grad.detach().clone() for k, p in net.obs_encoder.named_parameters()})
     Network.FUSED_EPILOGUE = True
+    Network.FUSED_TRAINING = True
     assert outs[0].shape == (513, 784)
     assert torch.allclose(outs[0], outs[1], rtol=3e-2, atol=3e-2)
     for k in grads[0]:
