@@ -61,6 +61,21 @@ int mapf_encoder_forward_save(const void *obs_dev, int obs_dtype, int64_t M, con
                               const float *bias_dev, uint16_t *latent_dev, uint16_t *acts_dev, void *stream);
 
 /*
+ * Backward-data chain of the encoder in one kernel (the mirror image of the forward: the transposed convolutions are
+ * the same LDS-resident implicit GEMMs on weights packed by mapf_encoder_pack_bwd -- channels swapped, taps
+ * flipped; MAPF_ENC_PACKED_BWD_ELEMS bf16).
+ *   gz7_dev  bf16 [M][7][7][16]   gradient w.r.t. the 1x1 convolution's pre-activation (ReLU mask already applied)
+ *   acts_dev bf16 [7][M][7][7][128] the layer outputs saved by mapf_encoder_forward_save
+ *   gz_dev   bf16 [7][M][7][7][128] OUT: gradient w.r.t. each 128-channel layer's pre-activation (ReLU-masked), same
+ *            order as acts_dev; its per-channel sums are the bias gradients and conv_k's weight gradient is the
+ *            correlation of gz_dev[k] with the layer's input (acts_dev[k-1], or the observation for k = 0).
+ */
+#define MAPF_ENC_PACKED_BWD_ELEMS 888832 /* 6*147456 + 4096 */
+int mapf_encoder_pack_bwd(const float *const *w_dev, uint16_t *packed_bwd_dev, void *stream);
+int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint16_t *acts_dev,
+                               const uint16_t *packed_bwd_dev, uint16_t *gz_dev, void *stream);
+
+/*
  * Communication mask of `Network.step` (reference model.py:195-208): mask[e][i][j] = j lies inside i's FOV square
  * (|drow| <= r and |dcol| <= r) AND j is among i's `max_comm` nearest agents by Euclidean distance, i itself
  * included; distance ties go to the LOWEST agent index (the reference's CPU topk leaves ties unspecified).

@@ -343,6 +343,183 @@ __global__ void __launch_bounds__(256) encoder_pack_kernel(PackArgs pa, uint16_t
     wp[i] = (uint16_t)f32_to_bf16_bits(v);
 }
 
+// =====================================================================================================
+// Backward-data chain of the encoder in ONE kernel (the mirror image of encoder_fwd_kernel).
+//
+// In: gz7 = gradient w.r.t. the 1x1 convolution's pre-activation (already ReLU-masked), bf16 [M][49][16];
+// the saved layer outputs acts [7][M][49][128] of the training forward; weights packed for the TRANSPOSED
+// convolutions (mapf_encoder_pack_bwd: channels swapped, taps flipped), so that every step
+//     g_in[ci][p] = sum_{co,tap} W[co][ci][tap] * gz[co][p - tap]
+// is the same LDS-resident implicit GEMM as the forward (conv3x3 above).
+// Out: gz [7][M][49][128] = the gradient w.r.t. every 128-channel layer's PRE-activation (ReLU-masked with the
+// saved outputs) -- exactly what the weight-/bias-gradient reductions consume.
+// Residual block backward (y = relu(x + conv2(t) + b2), t = relu(conv1(x) + b1)):
+//     gz2 = g_y * (y > 0);  g_t = conv2^T(gz2);  gz1 = g_t * (t > 0);  g_x = conv1^T(gz1) + gz2
+// -- the skip term gz2 is what LDS holds when gz1 overwrites it, so, as in the forward, each lane reads its own
+// elements back as the initial accumulator of conv1^T.
+// =====================================================================================================
+constexpr int GZ7_BYTES = G * 49 * 16 * 2;  // 6272
+static_assert(2 * (ACT_BYTES + GZ7_BYTES) <= 160 * 1024, "LDS budget: two workgroups per CU");
+constexpr int WPT_L7 = 6 * WP_RES_SIZE;
+constexpr int WPT_TOTAL = WPT_L7 + 8 * 512;
+static_assert(WPT_TOTAL == MAPF_ENC_PACKED_BWD_ELEMS, "header constant out of date");
+
+// bit r of the result: the r-th of the 4 bf16 values in `y` (a ReLU output) is > 0
+__device__ __forceinline__ uint32_t positive4(const uint2 y) {
+    auto pos = [](uint32_t h) -> uint32_t { return ((h & 0x7FFFu) != 0u && !(h & 0x8000u)) ? 1u : 0u; };
+    return pos(y.x & 0xFFFFu) | (pos(y.x >> 16) << 1) | (pos(y.y & 0xFFFFu) << 2) | (pos(y.y >> 16) << 3);
+}
+__device__ __forceinline__ uint2 pack_masked(const f32x4 &a, uint32_t m) {
+    return make_uint2(pack2_bf16((m & 1u) ? a[0] : 0.f, (m & 2u) ? a[1] : 0.f), pack2_bf16((m & 4u) ? a[2] : 0.f, (m & 8u) ? a[3] : 0.f));
+}
+
+__global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t *__restrict__ gz7, long long M,
+                                                                  const uint16_t *__restrict__ acts,
+                                                                  const uint16_t *__restrict__ wpt, uint16_t *__restrict__ gz) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ACT_BYTES + GZ7_BYTES];
+    unsigned char *const act = smem;
+    const unsigned char *const raw = smem + ACT_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, cb = tid >> 6;
+    const int lr = lane & 15, lh = lane >> 4;
+    const long long obs0 = (long long)blockIdx.x * G;
+    const long long left = M - obs0;
+    const int nobs = left < G ? (int)left : G;
+
+    for (int i = tid; i < ACT_BYTES / 16; i += NTHREADS) reinterpret_cast<uint4 *>(act)[i] = make_uint4(0, 0, 0, 0);
+    {   // gz7 rows of this block: contiguous, 32 B per position
+        const uint4 *src = reinterpret_cast<const uint4 *>(gz7 + obs0 * (49 * 16));
+        uint4 *dst = reinterpret_cast<uint4 *>(smem + ACT_BYTES);
+        const int have = nobs * 49 * 2;
+        for (int i = tid; i < GZ7_BYTES / 16; i += NTHREADS) dst[i] = i < have ? src[i] : make_uint4(0, 0, 0, 0);
+    }
+    int addr[NT];
+    uint32_t vmask = 0;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int p = n * 16 + lr;
+        const bool v = p < 49 * nobs;
+        const int o = p / 49, q = p - 49 * o, y = q / 7, x = q - 7 * y;
+        addr[n] = (v ? (64 * o + 8 * y + x) * ROWB : 0) + lh * 16;
+        vmask |= (v ? 1u : 0u) << n;
+    }
+    __syncthreads();
+
+    const int co_lane = cb * 32 + 4 * lh;
+    // this lane's element (a, n) of a saved activation / gz tensor of layer k: 4 channels = 8 bytes
+    auto cell_off = [&](int a, int n) -> long long { return ((obs0 * 49 + n * 16 + lr) * 128 + co_lane + 16 * a); };
+    const long long LSTRIDE = M * 6272;
+
+    f32x4 acc[2][NT];
+    // ---- 1x1^T: g_y3[ci][p] = sum_co W7[co][ci] gz7[co][p]  (K = 16, zero-padded to 32) ----
+    {
+        const bf16x8 *wv = reinterpret_cast<const bf16x8 *>(wpt + WPT_L7) + (2 * cb) * 64 + lane;
+        const bf16x8 a0 = wv[0], a1 = wv[64];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int p = n * 16 + lr;
+            bf16x8 b = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (((vmask >> n) & 1u) && lh < 2) b = *reinterpret_cast<const bf16x8 *>(raw + p * 32 + lh * 16);
+            acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+    }
+
+    for (int blk = 2; blk >= 0; --blk) {
+        const bf16x8 *wv1 = reinterpret_cast<const bf16x8 *>(wpt + (2 * blk) * WP_RES_SIZE) + (2 * cb) * 64 + lane;
+        const bf16x8 *wv2 = wv1 + WP_RES_SIZE / 8;
+        // ---- gz2 = g_y * (y > 0) -> LDS (input of conv2^T) ----
+        {
+            const uint16_t *yk = acts + (2 + 2 * blk) * LSTRIDE;
+            uint2 yv[2][NT];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    yv[a][n] = ((vmask >> n) & 1u) ? *reinterpret_cast<const uint2 *>(yk + cell_off(a, n)) : make_uint2(0, 0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    if ((vmask >> n) & 1u)
+                        *reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2) =
+                            pack_masked(acc[a][n], positive4(yv[a][n]));
+        }
+        __syncthreads();
+        save_rows(act, gz + (2 + 2 * blk) * LSTRIDE + obs0 * 6272, nobs, tid);
+        // ---- g_t = conv2^T(gz2) ----
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        conv3x3(act, wv2, addr, acc);
+        __syncthreads();
+        // ---- gz1 = g_t * (t > 0) -> LDS; the gz2 it overwrites is the skip term of g_x ----
+        uint2 skip[2][NT];
+        {
+            const uint16_t *tk = acts + (1 + 2 * blk) * LSTRIDE;
+            uint2 tv[2][NT];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    tv[a][n] = ((vmask >> n) & 1u) ? *reinterpret_cast<const uint2 *>(tk + cell_off(a, n)) : make_uint2(0, 0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    uint2 *cell = reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2);
+                    skip[a][n] = *cell;
+                    if ((vmask >> n) & 1u) *cell = pack_masked(acc[a][n], positive4(tv[a][n]));
+                }
+        }
+        __syncthreads();
+        save_rows(act, gz + (1 + 2 * blk) * LSTRIDE + obs0 * 6272, nobs, tid);
+        // ---- g_x = conv1^T(gz1) + gz2 ----
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[a][n] = f32x4{bf16_bits_to_f32(skip[a][n].x & 0xFFFFu), bf16_bits_to_f32(skip[a][n].x >> 16),
+                                  bf16_bits_to_f32(skip[a][n].y & 0xFFFFu), bf16_bits_to_f32(skip[a][n].y >> 16)};
+        conv3x3(act, wv1, addr, acc);
+        __syncthreads();
+    }
+    // ---- gz0 = g_y0 * (y0 > 0): straight to global memory (conv0 has no data gradient) ----
+    {
+        uint16_t *g0 = gz;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                if ((vmask >> n) & 1u) {
+                    const long long off = cell_off(a, n);
+                    const uint2 yv = *reinterpret_cast<const uint2 *>(acts + off);
+                    *reinterpret_cast<uint2 *>(g0 + off) = pack_masked(acc[a][n], positive4(yv));
+                }
+    }
+}
+
+// transposed-convolution weight image: [6 layers][s=36][c=8][lane][j] with o = 16c + (lane&15) the INPUT channel of
+// the forward layer, i = 32 chunk + 8 (lane>>4) + j its OUTPUT channel, tap flipped; then W7^T [c=8][lane][j]
+__global__ void __launch_bounds__(256) encoder_pack_bwd_kernel(PackArgs pa, uint16_t *__restrict__ wpt) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= WPT_TOTAL) return;
+    const int j = idx & 7, l = (idx >> 3) & 63, r = l & 15, h = l >> 4;
+    float v = 0.f;
+    if (idx < WPT_L7) {
+        const int layer = idx / WP_RES_SIZE, f = idx - layer * WP_RES_SIZE;
+        const int c = (f >> 9) & 7, s = f >> 12;
+        const int tap = s >> 2, chunk = s & 3;
+        const int i = 32 * chunk + 8 * h + j, o = 16 * c + r;
+        v = pa.w[1 + layer][(i * 128 + o) * 9 + (8 - tap)];
+    } else {
+        const int c = ((idx - WPT_L7) >> 9) & 7, k = 8 * h + j, o = 16 * c + r;
+        if (k < 16) v = pa.w[7][k * 128 + o];
+    }
+    wpt[idx] = (uint16_t)f32_to_bf16_bits(v);
+}
+
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \
@@ -405,6 +582,35 @@ int mapf_encoder_forward(const void *obs_dev, int obs_dtype, int64_t M, const ui
 int mapf_encoder_forward_save(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev, const float *bias_dev,
                               uint16_t *latent_dev, uint16_t *acts_dev, void *stream) {
     return encoder_launch(obs_dev, obs_dtype, M, packed_dev, bias_dev, latent_dev, acts_dev, true, stream);
+}
+
+int mapf_encoder_pack_bwd(const float *const *w_dev, uint16_t *packed_bwd_dev, void *stream) {
+    if (!w_dev || !packed_bwd_dev || (reinterpret_cast<uintptr_t>(packed_bwd_dev) & 15)) return MAPF_ERR_INVALID_ARG;
+    PackArgs pa;
+    for (int i = 0; i < 8; ++i) {
+        if (!w_dev[i]) return MAPF_ERR_INVALID_ARG;
+        pa.w[i] = w_dev[i];
+        pa.b[i] = nullptr;
+    }
+    hipLaunchKernelGGL(encoder_pack_bwd_kernel, dim3((WPT_TOTAL + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), pa,
+                       packed_bwd_dev);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint16_t *acts_dev, const uint16_t *packed_bwd_dev,
+                               uint16_t *gz_dev, void *stream) {
+    if (M < 0 || !packed_bwd_dev || (M > 0 && (!gz7_dev || !acts_dev || !gz_dev))) return MAPF_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(gz7_dev) & 15) || (reinterpret_cast<uintptr_t>(acts_dev) & 15) ||
+        (reinterpret_cast<uintptr_t>(packed_bwd_dev) & 15) || (reinterpret_cast<uintptr_t>(gz_dev) & 15))
+        return MAPF_ERR_INVALID_ARG;
+    if (M == 0) return MAPF_OK;
+    const long long blocks = (M + G - 1) / G;
+    if (blocks > 0x7FFFFFFFLL) return MAPF_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(encoder_bwd_kernel, dim3((unsigned)blocks), dim3(NTHREADS), 0, static_cast<hipStream_t>(stream), gz7_dev,
+                       (long long)M, acts_dev, packed_bwd_dev, gz_dev);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
 }
 
 }  // extern "C"

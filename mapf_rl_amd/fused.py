@@ -55,6 +55,7 @@ def bias_res_relu(conv_out, bias, res=None):
 # ---------------------------------------------------------------------------------------------------------
 ENC_PACKED_ELEMS = 894976
 ENC_BIAS_ELEMS = 912
+ENC_PACKED_BWD_ELEMS = 888832
 _ENC_OBS_U8, _ENC_OBS_BF16 = 0, 1
 
 
@@ -123,9 +124,9 @@ def comm_mask(pos, obs_radius=4, max_comm=3, packed_words=0):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# Training forward of the encoder through the fused kernel (it also stores the 7 layer outputs); the backward
-# chain runs layer by layer on those saved activations (MIOpen data / weight gradients + the fused ReLU-mask /
-# bias-gradient pass above).
+# Training forward of the encoder through the fused kernel (it also stores the 7 layer outputs); the backward-data
+# chain is one more kernel of the same structure (mapf_encoder_backward_data) that emits the ReLU-masked
+# pre-activation gradient of every layer; weight gradients = MIOpen wrw on (layer input, that gradient).
 # ---------------------------------------------------------------------------------------------------------
 _BWD_CHUNK = 32768  # observations per MIOpen call (see Network.encode: very large batches misbehave on ROCm 7.2)
 
@@ -161,34 +162,36 @@ class _EncoderTrain(torch.autograd.Function):
         obs, acts, out = ctx.saved_tensors[:3]
         params = ctx.saved_tensors[3:]
         cl = torch.channels_last
-        ws = [params[2 * i].detach().to(torch.bfloat16) for i in range(8)]  # keeps the channels_last strides
-        gws = [torch.zeros(w.shape, dtype=torch.float32, device=w.device).contiguous(memory_format=cl) for w in ws]
-        gbs = [torch.zeros(w.shape[0], dtype=torch.float32, device=w.device) for w in ws]
+        dev = obs.device
         M = obs.shape[0]
-        g = g.to(torch.bfloat16)
+        ws = [params[2 * i].detach().to(torch.bfloat16) for i in range(8)]  # keeps the channels_last strides
+        gws = [torch.zeros(w.shape, dtype=torch.float32, device=dev).contiguous(memory_format=cl) for w in ws]
+        gb7 = torch.zeros(16, dtype=torch.float32, device=dev)
+        # 1x1 layer: ReLU mask + bias gradient in one pass; [M,16,7,7] channels_last == memory [M][49][16]
+        o4 = out.view(M, 16, 7, 7).contiguous(memory_format=cl)
+        g4 = g.to(torch.bfloat16).reshape(M, 16, 7, 7).contiguous(memory_format=cl)
+        gz7 = _mask_bias(g4, o4, gb7)
+        # the whole backward-data chain: one kernel, masked pre-activation gradients of all 7 layers out
+        w32 = [params[2 * i].detach().to(torch.float32).contiguous() for i in range(8)]
+        wpt = torch.empty(ENC_PACKED_BWD_ELEMS, dtype=torch.bfloat16, device=dev)
+        check(lib.mapf_encoder_pack_bwd((ctypes.c_void_p * 8)(*[w.data_ptr() for w in w32]), _ptr(wpt), _stream(dev)),
+              "mapf_encoder_pack_bwd")
+        gz = torch.empty_like(acts)
+        check(lib.mapf_encoder_backward_data(_ptr(gz7), M, _ptr(acts), _ptr(wpt), _ptr(gz), _stream(dev)),
+              "mapf_encoder_backward_data")
+        gbs = [gz[k].sum(dim=(0, 1, 2), dtype=torch.float32) for k in range(7)] + [gb7]
+        # weight gradients: correlation of each layer's input with its gz (MIOpen wrw), in chunks of observations
         parts = -(-M // _BWD_CHUNK)
         step = -(-M // parts)
         for lo in range(0, M, step):
             hi = min(M, lo + step)
             a = [acts[k, lo:hi].permute(0, 3, 1, 2) for k in range(7)]  # [m,128,7,7] views with NHWC strides
-            o4 = out[lo:hi].view(-1, 16, 7, 7).contiguous(memory_format=cl)
-            g4 = g[lo:hi].reshape(-1, 16, 7, 7).contiguous(memory_format=cl)
-            gz = _mask_bias(g4, o4, gbs[7])
-            gh, gw = _conv_bwd(gz, a[6], ws[7], 0, True)
-            gws[7] += gw
-            for blk in (2, 1, 0):  # y = relu(x + conv2(t) + b2), t = relu(conv1(x) + b1)
-                x_in, t, y = a[2 * blk], a[2 * blk + 1], a[2 * blk + 2]
-                gz2 = _mask_bias(gh.contiguous(memory_format=cl), y, gbs[2 + 2 * blk])
-                gt, gw = _conv_bwd(gz2, t, ws[2 + 2 * blk], 1, True)
-                gws[2 + 2 * blk] += gw
-                gz1 = _mask_bias(gt.contiguous(memory_format=cl), t, gbs[1 + 2 * blk])
-                gx, gw = _conv_bwd(gz1, x_in, ws[1 + 2 * blk], 1, True)
-                gws[1 + 2 * blk] += gw
-                gh = gx + gz2
-            gz0 = _mask_bias(gh.contiguous(memory_format=cl), a[0], gbs[0])
+            z = [gz[k, lo:hi].permute(0, 3, 1, 2) for k in range(7)]
             x0 = obs[lo:hi].to(torch.bfloat16).contiguous(memory_format=cl)
-            _, gw = _conv_bwd(gz0, x0, ws[0], 0, False)
-            gws[0] += gw
+            gws[0] += _conv_bwd(z[0], x0, ws[0], 0, False)[1]
+            for k in range(1, 7):
+                gws[k] += _conv_bwd(z[k], a[k - 1], ws[k], 1, False)[1]
+            gws[7] += _conv_bwd(gz7[lo:hi], a[6], ws[7], 0, False)[1]
         grads = []
         for i in range(8):
             grads += [gws[i].to(params[2 * i].dtype), gbs[i].to(params[2 * i + 1].dtype)]
