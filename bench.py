@@ -233,7 +233,24 @@ def main():
             torch.cuda.synchronize()
             dt_act = (time.perf_counter() - t1) / args.dqn_actor_iters
             env.check_status()
+            # the dominant kernel of the actor loop: the fused inference encoder (MFMA-bound), timed alone on the
+            # actor's batch with HIP events on the launch stream
+            obs_flat = actor.obs.reshape(E * N, 6, 9, 9)
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                learner.model.encode(obs_flat)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    learner.model.encode(obs_flat)
+                e1.record()
+            torch.cuda.synchronize()
+            enc_s = e0.elapsed_time(e1) * 1e-3 / 5
+            enc_flop = 2.0 * (49 * 128 * 54 + 6 * 49 * 128 * 1152 + 49 * 16 * 128) * E * N  # 87.6 MFLOP per observation
             result["extra"] = {
+                "encoder_roofline": {"bound": "mfma", "kernel": "encoder_fwd_kernel", "achieved": enc_flop / enc_s / 1e12,
+                                     "peak": 2500.0, "unit": "TFLOP/s", "frac": enc_flop / enc_s / 1e12 / 2500.0,
+                                     "flop_per_launch": enc_flop, "kernel_avg_ms": enc_s * 1e3,
+                                     "observations": E * N},
                 "learner_updates_per_sec": 1.0 / dt_upd, "learner_ms_per_update": dt_upd * 1e3,
                 "learner_config": "B=192 x T=18 x A=%d windows from the device replay, bf16 autocast, Adam, %s" % (
                     N, "flat-bucket RCCL all-reduce x%d (same update rate on every rank)" % world if world > 1 else "1 GPU"),

@@ -93,6 +93,67 @@ class CommBlock(nn.Module):
         return latent
 
 
+class _WGradSink:
+    """Weight gradients of the linears inside the T-step recurrence, deferred to the end of the backward pass.
+
+    Autograd would run one small GEMM per (time step, weight) -- [out, in] = dy_t^T x_t with K = B*N = 7,680 rows,
+    224 launches of ~55 us per update that each fill a fraction of the chip -- and then add each result into
+    .grad.  The sink keeps (x_t, dy_t) instead and, from an end-of-backward callback (the hook DDP finalises in),
+    runs ONE GEMM per weight over the concatenated K = T*B*N rows and accumulates straight into .grad."""
+
+    def __init__(self):
+        self.items = {}
+        self.queued = False
+
+    def add(self, key, x, dy):
+        ent = self.items.get(id(key))
+        if ent is None:
+            ent = self.items[id(key)] = (key, [], [])
+        ent[1].append(x)
+        ent[2].append(dy)
+        if not self.queued:
+            self.queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
+    def flush(self):
+        items, self.items, self.queued = self.items, {}, False
+        for key, xs, dys in items.values():
+            X = torch.cat(xs, dim=0) if len(xs) > 1 else xs[0]
+            DY = torch.cat(dys, dim=0) if len(dys) > 1 else dys[0]
+            gw = torch.mm(DY.t(), X)  # [out, in], fp32 accumulation inside the GEMM
+            gb = DY.sum(dim=0, dtype=torch.float32)
+            for w, b, lo, hi in key:
+                _accumulate(w, gw[lo:hi])
+                if b is not None:
+                    _accumulate(b, gb[lo:hi])
+
+
+def _accumulate(p, g):
+    if p.grad is None:
+        p.grad = g.to(p.dtype).reshape(p.shape).clone()
+    else:
+        p.grad.add_(g.reshape(p.shape))
+
+
+class _TimeLinear(torch.autograd.Function):
+    """y = x W^T (+ b) for one time step of the recurrence; dx in backward, dW/db deferred to `sink`."""
+
+    @staticmethod
+    def forward(ctx, x, w_lp, b_lp, sink, key, anchor):
+        # `anchor` (the fp32 weight Parameter) only makes autograd record this node when x itself carries no
+        # gradient (the first time step); it receives no gradient here -- the sink accumulates into .grad directly
+        ctx.save_for_backward(x, w_lp)
+        ctx.sink, ctx.key = sink, key
+        return F.linear(x, w_lp, b_lp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_lp = ctx.saved_tensors
+        dy = dy.contiguous()
+        ctx.sink.add(ctx.key, x, dy)
+        return (torch.mm(dy, w_lp) if ctx.needs_input_grad[0] else None), None, None, None, None, None
+
+
 def comm_mask_from_pos(pos: torch.Tensor, obs_radius: int = OBS_RADIUS, max_comm: int = MAX_COMM_AGENTS) -> torch.Tensor:
     """pos [E, N, 2] (any integer/float dtype) -> bool [E, N, N]: j is within i's FOV square AND among i's
     `max_comm` nearest agents by Euclidean distance, itself included (reference model.py:195-208).
@@ -244,6 +305,8 @@ class Network(nn.Module):
         self.hidden = None
 
     # ------------------------------------------------------------------ learner side
+    FAST_RECURRENCE = True  # HIP device: hoisted input projection, fused QKV, deferred weight gradients (see _recur_fast)
+
     def bootstrap(self, obs, steps, hidden, comm_mask):
         """Training forward over a [B, T] window of N agents (model.py:227-263).
         obs [B, T, N, 6, 9, 9]; steps int64 [B] (1-based index of the step whose agent-0 hidden feeds the Q head);
@@ -252,16 +315,78 @@ class Network(nn.Module):
         with self._autocast(obs.device):
             latent = self.encode(obs.reshape(B * T * N, *OBS_SHAPE)).view(B, T, N, ENC_FEATURES)
             hidden = hidden.to(latent.dtype)
-            agent0 = []
-            for t in range(T):
-                hidden = self.recurrent(latent[:, t].reshape(B * N, ENC_FEATURES), hidden)
-                hidden = self.comm(hidden.view(B, N, self.latent_dim), comm_mask[:, t])
-                agent0.append(hidden[:, 0])                      # only agent 0's state is learned from (:248)
-                hidden = hidden.reshape(B * N, self.latent_dim)
-            agent0 = torch.stack(agent0, dim=1)                   # [B, T, 256]
+            if self.FAST_RECURRENCE and latent.is_cuda and latent.dtype == torch.bfloat16:
+                agent0 = self._recur_fast(latent, hidden, comm_mask)
+            else:
+                agent0 = []
+                for t in range(T):
+                    hidden = self.recurrent(latent[:, t].reshape(B * N, ENC_FEATURES), hidden)
+                    hidden = self.comm(hidden.view(B, N, self.latent_dim), comm_mask[:, t])
+                    agent0.append(hidden[:, 0])                      # only agent 0's state is learned from (:248)
+                    hidden = hidden.reshape(B * N, self.latent_dim)
+                agent0 = torch.stack(agent0, dim=1)                   # [B, T, 256]
             sel = agent0[torch.arange(B, device=obs.device), steps.to(obs.device) - 1]
             q = self.q_head(sel)
         return q.float()
+
+    def _recur_fast(self, latent, hidden, comm_mask):
+        """The T-step GRU + CommBlock recurrence of `bootstrap` (model.py:242-249), same math as the module path,
+        arranged for the GPU:
+          * the GRU's input projection W_ih x_t does not depend on the recurrence -> ONE GEMM over all T steps;
+          * W_Q, W_K, W_V share their input -> one [384, 256] GEMM per communication round;
+          * every weight is cast to bf16 once per call (not once per step);
+          * with autograd, the per-step weight gradients are deferred to one GEMM per weight (_WGradSink).
+        latent bf16 [B, T, N, 784]; hidden bf16 [B*N, 256]; comm_mask bool [B, T, N, N] -> agent-0 states [B, T, 256]."""
+        B, T, N, _ = latent.shape
+        D, H, A = self.latent_dim, NUM_COMM_HEADS, self.comm.output_dim
+        lp = torch.bfloat16
+        grad = torch.is_grad_enabled()
+        sink = _WGradSink() if grad else None
+        rc, at, uc = self.recurrent, self.comm.self_attn, self.comm.update_cell
+
+        def cast(*ps):
+            return torch.cat([p.detach() for p in ps], dim=0).to(lp) if len(ps) > 1 else ps[0].detach().to(lp)
+
+        w_hh, w_qkv, b_qkv, w_o = cast(rc.weight_hh), cast(at.W_Q.weight, at.W_K.weight, at.W_V.weight), \
+            cast(at.W_Q.bias, at.W_K.bias, at.W_V.bias), cast(at.W_O.weight)
+        u_ih, u_hh = cast(uc.weight_ih), cast(uc.weight_hh)
+        HA = H * A
+        keys = {
+            "hh": [(rc.weight_hh, None, 0, 3 * D)],
+            "qkv": [(at.W_Q.weight, at.W_Q.bias, 0, HA), (at.W_K.weight, at.W_K.bias, HA, 2 * HA), (at.W_V.weight, at.W_V.bias, 2 * HA, 3 * HA)],
+            "o": [(at.W_O.weight, None, 0, A)],
+            "uih": [(uc.weight_ih, None, 0, 3 * D)],
+            "uhh": [(uc.weight_hh, None, 0, 3 * D)],
+        }
+
+        def lin(x, w, b, name):
+            if grad:
+                return _TimeLinear.apply(x, w, b, sink, keys[name], keys[name][0][0])
+            return F.linear(x, w, b)
+
+        # all T input projections at once, time-major so that step t is a contiguous [B*N, 768] slab
+        lat_t = latent.transpose(0, 1).reshape(T, B * N, ENC_FEATURES)
+        gi_all = F.linear(lat_t, rc.weight_ih.to(lp) if grad else cast(rc.weight_ih))
+        blocked = (~comm_mask).unsqueeze(2)                              # [B, T, 1, N, N]
+        update = (comm_mask.sum(dim=-1) > 1).unsqueeze(-1)               # [B, T, N, 1]  (model.py:103)
+        scale = 1.0 / (A ** 0.5)
+        agent0 = []
+        for t in range(T):
+            gh = lin(hidden, w_hh, None, "hh")
+            hidden = torch.ops.aten._thnn_fused_gru_cell(gi_all[t], gh, hidden, rc.bias_ih, rc.bias_hh)[0]
+            for _ in range(self.comm.num_layers):
+                qkv = lin(hidden, w_qkv, b_qkv, "qkv").view(B, N, 3, H, A)
+                q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2)
+                scores = torch.matmul(q.float(), k.float().transpose(-1, -2)) * scale   # fp32 (model.py:75-78)
+                attn = F.softmax(scores.masked_fill(blocked[:, t], -1e9), dim=-1)
+                ctx = torch.matmul(attn.to(lp), v).transpose(1, 2).reshape(B * N, HA)
+                info = lin(ctx, w_o, None, "o")
+                gi = lin(info, u_ih, None, "uih")
+                gh = lin(hidden, u_hh, None, "uhh")
+                new = torch.ops.aten._thnn_fused_gru_cell(gi, gh, hidden, uc.bias_ih, uc.bias_hh)[0]
+                hidden = torch.where(update[:, t], new.view(B, N, D), hidden.view(B, N, D)).reshape(B * N, D)
+            agent0.append(hidden.view(B, N, D)[:, 0])                    # only agent 0's state is learned from (:248)
+        return torch.stack(agent0, dim=1)
 
 
 def load_reference_checkpoint(net: Network, path: str, map_location="cpu"):

@@ -70,3 +70,46 @@ def test_batched_step_vs_env_observations():
     env.check_status()
     a3, q3, h3, _ = net.step_batch(obs2, pos2, h)
     assert torch.isfinite(q3).all()
+
+
+def test_fast_recurrence_matches_module_path():
+    """`Network._recur_fast` (hoisted input projection, fused QKV, weight gradients deferred to one GEMM per weight
+    at the end of backward) against the plain module loop of `bootstrap` at the same bf16 precision: Q-values and
+    every parameter gradient."""
+    from mapf_rl_amd.model import Network
+
+    torch.manual_seed(3)
+    net = Network().cuda()
+    with torch.no_grad():  # non-zero biases so that their deferred gradients are exercised
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.1, 0.1)
+    B, T, N = 6, 5, 7
+    g = torch.Generator(device="cuda").manual_seed(4)
+    obs = (torch.rand((B, T, N, 6, 9, 9), device="cuda", generator=g) < 0.3).to(torch.bfloat16)
+    steps = torch.randint(1, T + 1, (B,), device="cuda", generator=g)
+    hidden = (torch.randn((B * N, 256), device="cuda", generator=g) * 0.3).to(torch.bfloat16)
+    comm = torch.rand((B, T, N, N), device="cuda", generator=g) < 0.3
+    comm |= torch.eye(N, dtype=torch.bool, device="cuda")
+    comm[0, :, 1] = torch.eye(N, dtype=torch.bool, device="cuda")[1]   # an agent without partners (no update)
+    r = torch.randn((B, 5), device="cuda", generator=g)
+    res = {}
+    for fast in (True, False):
+        Network.FAST_RECURRENCE = fast
+        try:
+            net.zero_grad()
+            q = net.bootstrap(obs, steps, hidden, comm)
+            (q * r).sum().backward()
+            res[fast] = (q.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+            with torch.no_grad():
+                q_ng = net.bootstrap(obs, steps, hidden, comm)
+            assert torch.allclose(q_ng, q.detach(), rtol=3e-2, atol=3e-2)
+        finally:
+            Network.FAST_RECURRENCE = True
+    assert torch.allclose(res[True][0], res[False][0], rtol=3e-2, atol=3e-2)
+    scale = max(float(b.norm()) for b in res[False][1].values())
+    for k in res[True][1]:
+        a, b = res[True][1][k], res[False][1][k]
+        # W_K.bias has an exactly-zero true gradient (softmax is shift-invariant): both sides are rounding noise,
+        # hence the absolute floor relative to the largest parameter gradient
+        assert float((a - b).norm()) <= 6e-2 * float(b.norm()) + 1e-4 * scale, (k, float((a - b).norm()), float(b.norm()))
