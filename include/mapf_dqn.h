@@ -76,6 +76,17 @@ int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint16_
                                const uint16_t *packed_bwd_dev, uint16_t *gz_dev, void *stream);
 
 /*
+ * Weight gradient of one 3x3 128->128 convolution of the encoder (csrc/mapf_wgrad.hip):
+ *   dW[co][ky][kx][ci] = sum_m sum_(y,x) gz[m][y][x][co] * in[m][y+ky-1][x+kx-1][ci]
+ * gz_dev = the layer's slice of mapf_encoder_backward_data's output, in_dev = the layer's input (the matching slice
+ * of mapf_encoder_forward_save's acts), both bf16 [M][7][7][128].  The kernel writes MAPF_ENC_WGRAD_PARTS partial
+ * sums, fp32 [MAPF_ENC_WGRAD_PARTS][128][3][3][128] (co, ky, kx, ci -- the channels_last order of a [co][ci][3][3]
+ * weight); the weight gradient is their sum over the first axis (deterministic, no atomics).
+ */
+#define MAPF_ENC_WGRAD_PARTS 80
+int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M, float *partial_dev, void *stream);
+
+/*
  * Communication mask of `Network.step` (reference model.py:195-208): mask[e][i][j] = j lies inside i's FOV square
  * (|drow| <= r and |dcol| <= r) AND j is among i's `max_comm` nearest agents by Euclidean distance, i itself
  * included; distance ties go to the LOWEST agent index (the reference's CPU topk leaves ties unspecified).

@@ -56,6 +56,7 @@ def bias_res_relu(conv_out, bias, res=None):
 ENC_PACKED_ELEMS = 894976
 ENC_BIAS_ELEMS = 912
 ENC_PACKED_BWD_ELEMS = 888832
+ENC_WGRAD_PARTS = 80
 _ENC_OBS_U8, _ENC_OBS_BF16 = 0, 1
 
 
@@ -126,7 +127,8 @@ def comm_mask(pos, obs_radius=4, max_comm=3, packed_words=0):
 # ---------------------------------------------------------------------------------------------------------
 # Training forward of the encoder through the fused kernel (it also stores the 7 layer outputs); the backward-data
 # chain is one more kernel of the same structure (mapf_encoder_backward_data) that emits the ReLU-masked
-# pre-activation gradient of every layer; weight gradients = MIOpen wrw on (layer input, that gradient).
+# pre-activation gradient of every layer; the weight gradients of the 3x3 128->128 layers are a third kernel
+# (mapf_encoder_wgrad) on (layer input, that gradient).
 # ---------------------------------------------------------------------------------------------------------
 _BWD_CHUNK = 32768  # observations per MIOpen call (see Network.encode: very large batches misbehave on ROCm 7.2)
 
@@ -164,8 +166,8 @@ class _EncoderTrain(torch.autograd.Function):
         cl = torch.channels_last
         dev = obs.device
         M = obs.shape[0]
-        ws = [params[2 * i].detach().to(torch.bfloat16) for i in range(8)]  # keeps the channels_last strides
-        gws = [torch.zeros(w.shape, dtype=torch.float32, device=dev).contiguous(memory_format=cl) for w in ws]
+        ws_bf = [params[2 * i].detach().to(torch.bfloat16) for i in range(8)]  # keeps the channels_last strides
+        gws = [torch.zeros(w.shape, dtype=torch.float32, device=dev).contiguous(memory_format=cl) for w in ws_bf]
         gb7 = torch.zeros(16, dtype=torch.float32, device=dev)
         # 1x1 layer: ReLU mask + bias gradient in one pass; [M,16,7,7] channels_last == memory [M][49][16]
         o4 = out.view(M, 16, 7, 7).contiguous(memory_format=cl)
@@ -180,18 +182,20 @@ class _EncoderTrain(torch.autograd.Function):
         check(lib.mapf_encoder_backward_data(_ptr(gz7), M, _ptr(acts), _ptr(wpt), _ptr(gz), _stream(dev)),
               "mapf_encoder_backward_data")
         gbs = [gz[k].sum(dim=(0, 1, 2), dtype=torch.float32) for k in range(7)] + [gb7]
-        # weight gradients: correlation of each layer's input with its gz (MIOpen wrw), in chunks of observations
+        # weight gradients of the six 3x3 128->128 layers: one streaming MFMA kernel per layer (mapf_encoder_wgrad),
+        # partial sums per observation partition, added here
+        ws = torch.empty((ENC_WGRAD_PARTS, 128, 3, 3, 128), dtype=torch.float32, device=dev)
+        for k in range(1, 7):
+            check(lib.mapf_encoder_wgrad(_ptr(gz[k]), _ptr(acts[k - 1]), M, _ptr(ws), _stream(dev)), "mapf_encoder_wgrad")
+            gws[k] = ws.sum(dim=0).permute(0, 3, 1, 2)  # [co][ky][kx][ci] memory == channels_last [co, ci, 3, 3]
+        # conv0 (6 input channels) and the 1x1 layer (16 output channels) are 1 % of the work: MIOpen, chunked
         parts = -(-M // _BWD_CHUNK)
         step = -(-M // parts)
         for lo in range(0, M, step):
             hi = min(M, lo + step)
-            a = [acts[k, lo:hi].permute(0, 3, 1, 2) for k in range(7)]  # [m,128,7,7] views with NHWC strides
-            z = [gz[k, lo:hi].permute(0, 3, 1, 2) for k in range(7)]
             x0 = obs[lo:hi].to(torch.bfloat16).contiguous(memory_format=cl)
-            gws[0] += _conv_bwd(z[0], x0, ws[0], 0, False)[1]
-            for k in range(1, 7):
-                gws[k] += _conv_bwd(z[k], a[k - 1], ws[k], 1, False)[1]
-            gws[7] += _conv_bwd(gz7[lo:hi], a[6], ws[7], 0, False)[1]
+            gws[0] += _conv_bwd(gz[0, lo:hi].permute(0, 3, 1, 2), x0, ws_bf[0], 0, False)[1]
+            gws[7] += _conv_bwd(gz7[lo:hi], acts[6, lo:hi].permute(0, 3, 1, 2), ws_bf[7], 0, False)[1]
         grads = []
         for i in range(8):
             grads += [gws[i].to(params[2 * i].dtype), gbs[i].to(params[2 * i + 1].dtype)]

@@ -219,6 +219,23 @@ def test_encoder_training_path_gradients(M, chunk):
         assert rel_fused <= 0.15, (k, rel_fused)
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 161, 1000])
+def test_wgrad_kernel_against_fp32(M):
+    """mapf_encoder_wgrad on random bf16 operands against the fp32 weight gradient of a 3x3 pad-1 convolution
+    (the products are exact in fp32, so only the summation order differs)."""
+    from mapf_rl_amd._lib import check, lib
+
+    g = torch.Generator(device="cuda").manual_seed(M)
+    gz = (torch.randn((M, 7, 7, 128), device="cuda", generator=g) * (torch.rand((M, 7, 7, 128), device="cuda", generator=g) < 0.5)).to(torch.bfloat16)
+    a = torch.relu(torch.randn((M, 7, 7, 128), device="cuda", generator=g)).to(torch.bfloat16)
+    ws = torch.full((80, 128, 3, 3, 128), float("nan"), dtype=torch.float32, device="cuda")
+    check(lib.mapf_encoder_wgrad(gz.data_ptr(), a.data_ptr(), M, ws.data_ptr(), None), "mapf_encoder_wgrad")
+    got = ws.sum(0).permute(0, 3, 1, 2)                                         # [co, ci, ky, kx]
+    ref = torch.nn.grad.conv2d_weight(a.float().permute(0, 3, 1, 2), (128, 128, 3, 3), gz.float().permute(0, 3, 1, 2), padding=1)
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), float((got - ref).abs().max())
+
+
 def test_encoder_argument_checks():
     from mapf_rl_amd._lib import ERR_INVALID_ARG, lib
 

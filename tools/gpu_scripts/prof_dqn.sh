@@ -7,5 +7,7 @@ TUPD=6 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d
 cd $R
 python tools/summarize_rocprof.py gpurun_out/prof_actor actor > gpurun_out/prof_actor.md
 python tools/summarize_rocprof.py gpurun_out/prof_learner learner > gpurun_out/prof_learner.md
-find gpurun_out/prof_actor gpurun_out/prof_learner -name "*kernel_trace.csv" -size +20M -delete
-head -30 gpurun_out/prof_actor.md | cut -c1-160
+python tools/trace_breakdown.py gpurun_out/prof_actor comm_mask_kernel 20 > gpurun_out/prof_actor_iter.md
+python tools/trace_breakdown.py gpurun_out/prof_learner encoder_bwd_kernel 30 > gpurun_out/prof_learner_iter.md
+find gpurun_out/prof_actor gpurun_out/prof_learner -name "*kernel_trace.csv" -delete
+cat gpurun_out/prof_learner_iter.md gpurun_out/prof_actor_iter.md
