@@ -67,13 +67,16 @@ int mapf_encoder_forward_save(const void *obs_dev, int obs_dtype, int64_t M, con
  *   gz7_dev  bf16 [M][7][7][16]   gradient w.r.t. the 1x1 convolution's pre-activation (ReLU mask already applied)
  *   acts_dev bf16 [7][M][7][7][128] the layer outputs saved by mapf_encoder_forward_save
  *   gz_dev   bf16 [7][M][7][7][128] OUT: gradient w.r.t. each 128-channel layer's pre-activation (ReLU-masked), same
- *            order as acts_dev; its per-channel sums are the bias gradients and conv_k's weight gradient is the
- *            correlation of gz_dev[k] with the layer's input (acts_dev[k-1], or the observation for k = 0).
+ *            order as acts_dev; conv_k's weight gradient is the correlation of gz_dev[k] with the layer's input
+ *            (acts_dev[k-1], or the observation for k = 0).
+ *   gbias_partial_dev f32 [7][ceil(M / MAPF_ENC_OBS_PER_BLOCK)][128] OUT: per-workgroup sums of gz over its
+ *            positions; the bias gradient of layer k is the sum of slab k over its middle axis (no atomics).
  */
 #define MAPF_ENC_PACKED_BWD_ELEMS 888832 /* 6*147456 + 4096 */
 int mapf_encoder_pack_bwd(const float *const *w_dev, uint16_t *packed_bwd_dev, void *stream);
 int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint16_t *acts_dev,
-                               const uint16_t *packed_bwd_dev, uint16_t *gz_dev, void *stream);
+                               const uint16_t *packed_bwd_dev, uint16_t *gz_dev, float *gbias_partial_dev,
+                               void *stream);
 
 /*
  * Weight gradient of one 3x3 128->128 convolution of the encoder (csrc/mapf_wgrad.hip):

@@ -369,13 +369,36 @@ __device__ __forceinline__ uint32_t positive4(const uint2 y) {
     auto pos = [](uint32_t h) -> uint32_t { return ((h & 0x7FFFu) != 0u && !(h & 0x8000u)) ? 1u : 0u; };
     return pos(y.x & 0xFFFFu) | (pos(y.x >> 16) << 1) | (pos(y.y & 0xFFFFu) << 2) | (pos(y.y >> 16) << 3);
 }
-__device__ __forceinline__ uint2 pack_masked(const f32x4 &a, uint32_t m) {
-    return make_uint2(pack2_bf16((m & 1u) ? a[0] : 0.f, (m & 2u) ? a[1] : 0.f), pack2_bf16((m & 4u) ? a[2] : 0.f, (m & 8u) ? a[3] : 0.f));
+// masked gradient of 4 channels, packed to bf16; `bs` accumulates this lane's share of the bias gradient
+__device__ __forceinline__ uint2 pack_masked(const f32x4 &a, uint32_t m, float (&bs)[4]) {
+    const float v0 = (m & 1u) ? a[0] : 0.f, v1 = (m & 2u) ? a[1] : 0.f, v2 = (m & 4u) ? a[2] : 0.f, v3 = (m & 8u) ? a[3] : 0.f;
+    bs[0] += v0;
+    bs[1] += v1;
+    bs[2] += v2;
+    bs[3] += v3;
+    return make_uint2(pack2_bf16(v0, v1), pack2_bf16(v2, v3));
+}
+// Sum the per-lane bias shares over the 16 lanes that hold the same channels (different positions) and store this
+// workgroup's partial bias gradient of one layer: dst[co] for co = co_lane + 16 a + r (each written by one lane).
+__device__ __forceinline__ void store_bias_partial(float (&bs)[2][4], float *__restrict__ dst, int co_lane, int lr) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = bs[a][r];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8);
+            if (lr == 0) dst[co_lane + 16 * a + r] = v;
+            bs[a][r] = 0.f;
+        }
 }
 
 __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t *__restrict__ gz7, long long M,
                                                                   const uint16_t *__restrict__ acts,
-                                                                  const uint16_t *__restrict__ wpt, uint16_t *__restrict__ gz) {
+                                                                  const uint16_t *__restrict__ wpt, uint16_t *__restrict__ gz,
+                                                                  float *__restrict__ gb_part) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[ACT_BYTES + GZ7_BYTES];
     unsigned char *const act = smem;
     const unsigned char *const raw = smem + ACT_BYTES;
@@ -409,6 +432,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
     // this lane's element (a, n) of a saved activation / gz tensor of layer k: 4 channels = 8 bytes
     auto cell_off = [&](int a, int n) -> long long { return ((obs0 * 49 + n * 16 + lr) * 128 + co_lane + 16 * a); };
     const long long LSTRIDE = M * 6272;
+    float bs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // bias-gradient partials: gb_part[layer][block][128]
+    auto gb_dst = [&](int layer) -> float * { return gb_part + ((long long)layer * gridDim.x + blockIdx.x) * 128; };
 
     f32x4 acc[2][NT];
     // ---- 1x1^T: g_y3[ci][p] = sum_co W7[co][ci] gz7[co][p]  (K = 16, zero-padded to 32) ----
@@ -443,7 +469,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
                 for (int n = 0; n < NT; ++n)
                     if ((vmask >> n) & 1u)
                         *reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2) =
-                            pack_masked(acc[a][n], positive4(yv[a][n]));
+                            pack_masked(acc[a][n], positive4(yv[a][n]), bs[a]);
+            store_bias_partial(bs, gb_dst(2 + 2 * blk), co_lane, lr);
         }
         __syncthreads();
         save_rows(act, gz + (2 + 2 * blk) * LSTRIDE + obs0 * 6272, nobs, tid);
@@ -470,8 +497,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
                 for (int n = 0; n < NT; ++n) {
                     uint2 *cell = reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2);
                     skip[a][n] = *cell;
-                    if ((vmask >> n) & 1u) *cell = pack_masked(acc[a][n], positive4(tv[a][n]));
+                    if ((vmask >> n) & 1u) *cell = pack_masked(acc[a][n], positive4(tv[a][n]), bs[a]);
                 }
+            store_bias_partial(bs, gb_dst(1 + 2 * blk), co_lane, lr);
         }
         __syncthreads();
         save_rows(act, gz + (1 + 2 * blk) * LSTRIDE + obs0 * 6272, nobs, tid);
@@ -495,8 +523,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
                 if ((vmask >> n) & 1u) {
                     const long long off = cell_off(a, n);
                     const uint2 yv = *reinterpret_cast<const uint2 *>(acts + off);
-                    *reinterpret_cast<uint2 *>(g0 + off) = pack_masked(acc[a][n], positive4(yv));
+                    *reinterpret_cast<uint2 *>(g0 + off) = pack_masked(acc[a][n], positive4(yv), bs[a]);
                 }
+        store_bias_partial(bs, gb_dst(0), co_lane, lr);
     }
 }
 
@@ -599,8 +628,8 @@ int mapf_encoder_pack_bwd(const float *const *w_dev, uint16_t *packed_bwd_dev, v
 }
 
 int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint16_t *acts_dev, const uint16_t *packed_bwd_dev,
-                               uint16_t *gz_dev, void *stream) {
-    if (M < 0 || !packed_bwd_dev || (M > 0 && (!gz7_dev || !acts_dev || !gz_dev))) return MAPF_ERR_INVALID_ARG;
+                               uint16_t *gz_dev, float *gbias_partial_dev, void *stream) {
+    if (M < 0 || !packed_bwd_dev || (M > 0 && (!gz7_dev || !acts_dev || !gz_dev || !gbias_partial_dev))) return MAPF_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(gz7_dev) & 15) || (reinterpret_cast<uintptr_t>(acts_dev) & 15) ||
         (reinterpret_cast<uintptr_t>(packed_bwd_dev) & 15) || (reinterpret_cast<uintptr_t>(gz_dev) & 15))
         return MAPF_ERR_INVALID_ARG;
@@ -608,7 +637,7 @@ int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint16_
     const long long blocks = (M + G - 1) / G;
     if (blocks > 0x7FFFFFFFLL) return MAPF_ERR_INVALID_ARG;
     hipLaunchKernelGGL(encoder_bwd_kernel, dim3((unsigned)blocks), dim3(NTHREADS), 0, static_cast<hipStream_t>(stream), gz7_dev,
-                       (long long)M, acts_dev, packed_bwd_dev, gz_dev);
+                       (long long)M, acts_dev, packed_bwd_dev, gz_dev, gbias_partial_dev);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }

@@ -57,6 +57,7 @@ ENC_PACKED_ELEMS = 894976
 ENC_BIAS_ELEMS = 912
 ENC_PACKED_BWD_ELEMS = 888832
 ENC_WGRAD_PARTS = 80
+ENC_OBS_PER_BLOCK = 4
 _ENC_OBS_U8, _ENC_OBS_BF16 = 0, 1
 
 
@@ -179,9 +180,10 @@ class _EncoderTrain(torch.autograd.Function):
         check(lib.mapf_encoder_pack_bwd((ctypes.c_void_p * 8)(*[w.data_ptr() for w in w32]), _ptr(wpt), _stream(dev)),
               "mapf_encoder_pack_bwd")
         gz = torch.empty_like(acts)
-        check(lib.mapf_encoder_backward_data(_ptr(gz7), M, _ptr(acts), _ptr(wpt), _ptr(gz), _stream(dev)),
+        gb_part = torch.empty((7, -(-M // ENC_OBS_PER_BLOCK), 128), dtype=torch.float32, device=dev)
+        check(lib.mapf_encoder_backward_data(_ptr(gz7), M, _ptr(acts), _ptr(wpt), _ptr(gz), _ptr(gb_part), _stream(dev)),
               "mapf_encoder_backward_data")
-        gbs = [gz[k].sum(dim=(0, 1, 2), dtype=torch.float32) for k in range(7)] + [gb7]
+        gbs = list(gb_part.sum(dim=1).unbind(0)) + [gb7]  # per-workgroup partial bias gradients -> [7][128]
         # weight gradients of the six 3x3 128->128 layers: one streaming MFMA kernel per layer (mapf_encoder_wgrad),
         # partial sums per observation partition, added here
         ws = torch.empty((ENC_WGRAD_PARTS, 128, 3, 3, 128), dtype=torch.float32, device=dev)
