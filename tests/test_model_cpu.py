@@ -101,3 +101,46 @@ def test_step_batch_equals_per_env_steps():
         assert _close(qe, q[e].numpy()) and np.array_equal(cme, cm[e].numpy())
         ae, qe, he, cme = net.step(obs[e], pos[e])
         assert _close(qe, q2[e].numpy(), 1e-4)
+
+
+def test_deferred_weight_gradients_match_autograd():
+    """`_TimeLinear` + `_WGradSink` (mapf_rl_amd/model.py): a T-step recurrence whose per-step weight gradients are
+    deferred to one GEMM per weight at the end of backward gives the same gradients as plain autograd -- including
+    the first step (input without grad), a fused two-parameter key with row slices, and gradient accumulation
+    into an existing .grad."""
+    import torch
+    import torch.nn.functional as F
+
+    from mapf_rl_amd.model import _TimeLinear, _WGradSink
+
+    torch.manual_seed(0)
+    T, R, D = 5, 7, 6
+    lin_a, lin_b = torch.nn.Linear(D, D), torch.nn.Linear(D, D)
+    lin_o = torch.nn.Linear(2 * D, D, bias=False)
+    x0 = torch.randn(R, D)
+    target = torch.randn(R, D)
+
+    def run(deferred):
+        for p in list(lin_a.parameters()) + list(lin_b.parameters()) + list(lin_o.parameters()):
+            p.grad = torch.ones_like(p)                      # accumulation into an existing gradient
+        sink = _WGradSink()
+        w_ab = torch.cat([lin_a.weight, lin_b.weight]).detach()
+        b_ab = torch.cat([lin_a.bias, lin_b.bias]).detach()
+        key_ab = [(lin_a.weight, lin_a.bias, 0, D), (lin_b.weight, lin_b.bias, D, 2 * D)]
+        key_o = [(lin_o.weight, None, 0, D)]
+        h = x0
+        for _ in range(T):
+            if deferred:
+                ab = _TimeLinear.apply(h, w_ab, b_ab, sink, key_ab, lin_a.weight)
+                h = torch.tanh(_TimeLinear.apply(torch.relu(ab), lin_o.weight.detach(), None, sink, key_o, lin_o.weight))
+            else:
+                ab = torch.cat([lin_a(h), lin_b(h)], dim=-1)
+                h = torch.tanh(lin_o(torch.relu(ab)))
+        ((h - target) ** 2).sum().backward()
+        assert not sink.items and not sink.queued            # flushed by the end-of-backward callback
+        return [p.grad.clone() for p in (lin_a.weight, lin_a.bias, lin_b.weight, lin_b.bias, lin_o.weight)]
+
+    ref, got = run(False), run(True)
+    for a, b in zip(ref, got):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+        assert float((a - 1).abs().max()) > 1e-3             # a real gradient was added to the ones
