@@ -54,27 +54,30 @@ int mapf_encoder_pack(const float *const *w_dev, const float *const *b_dev, uint
 int mapf_encoder_forward(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev,
                          const float *bias_dev, uint16_t *latent_dev, void *stream);
 
-/* Training forward: the same kernel, additionally storing the 7 post-ReLU layer outputs that the backward pass
- * needs (ReLU masks and the inputs of the weight gradients): acts_dev bf16 [7][M][7][7][128] (NHWC), in order
- * conv0, res1.block1, res1, res2.block1, res2, res3.block1, res3 (16-byte aligned, 7*M*6272 elements). */
+/* Training forward: the same kernel, additionally storing what the backward pass needs:
+ *   acts_dev bf16 [7][M][7][7][128] (NHWC) the 7 post-ReLU layer outputs, in order conv0, res1.block1, res1,
+ *            res2.block1, res2, res3.block1, res3 -- the inputs of the weight gradients (16-byte aligned);
+ *   relu_bits_dev uint32 [7][M][49][4] their sign bits: bit c % 32 of word c / 32 is set iff channel c of that
+ *            position is > 0 -- the ReLU masks of the backward-data chain (16 bytes per position instead of 256). */
 int mapf_encoder_forward_save(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev,
-                              const float *bias_dev, uint16_t *latent_dev, uint16_t *acts_dev, void *stream);
+                              const float *bias_dev, uint16_t *latent_dev, uint16_t *acts_dev,
+                              uint32_t *relu_bits_dev, void *stream);
 
 /*
  * Backward-data chain of the encoder in one kernel (the mirror image of the forward: the transposed convolutions are
  * the same LDS-resident implicit GEMMs on weights packed by mapf_encoder_pack_bwd -- channels swapped, taps
  * flipped; MAPF_ENC_PACKED_BWD_ELEMS bf16).
  *   gz7_dev  bf16 [M][7][7][16]   gradient w.r.t. the 1x1 convolution's pre-activation (ReLU mask already applied)
- *   acts_dev bf16 [7][M][7][7][128] the layer outputs saved by mapf_encoder_forward_save
+ *   relu_bits_dev uint32 [7][M][49][4] the ReLU sign bits written by mapf_encoder_forward_save
  *   gz_dev   bf16 [7][M][7][7][128] OUT: gradient w.r.t. each 128-channel layer's pre-activation (ReLU-masked), same
- *            order as acts_dev; conv_k's weight gradient is the correlation of gz_dev[k] with the layer's input
- *            (acts_dev[k-1], or the observation for k = 0).
+ *            layer order; conv_k's weight gradient is the correlation of gz_dev[k] with the layer's input
+ *            (acts_dev[k-1] of the forward, or the observation for k = 0).
  *   gbias_partial_dev f32 [7][ceil(M / MAPF_ENC_OBS_PER_BLOCK)][128] OUT: per-workgroup sums of gz over its
  *            positions; the bias gradient of layer k is the sum of slab k over its middle axis (no atomics).
  */
 #define MAPF_ENC_PACKED_BWD_ELEMS 888832 /* 6*147456 + 4096 */
 int mapf_encoder_pack_bwd(const float *const *w_dev, uint16_t *packed_bwd_dev, void *stream);
-int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint16_t *acts_dev,
+int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint32_t *relu_bits_dev,
                                const uint16_t *packed_bwd_dev, uint16_t *gz_dev, float *gbias_partial_dev,
                                void *stream);
 

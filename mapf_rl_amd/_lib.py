@@ -62,7 +62,7 @@ SYMBOLS = [
     ("mapf_encoder_pack_bwd", _i, [ctypes.POINTER(_vp), _vp, _vp]),
     ("mapf_encoder_backward_data", _i, [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_encoder_wgrad", _i, [_vp, _vp, ctypes.c_int64, _vp, _vp]),
-    ("mapf_encoder_forward_save", _i, [_vp, _i, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp]),
+    ("mapf_encoder_forward_save", _i, [_vp, _i, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]),
     # include/mapf_search.h
     ("mapf_find_path", _i, [_i, _i, _vp, _vp, _vp, ctypes.c_double, _i, _vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     ("mapf_distance_field", _i, [_i, _vp, _i, _i, _vp]),

@@ -83,6 +83,26 @@ __device__ __forceinline__ uint2 pack_relu(const f32x4 &a, const float4 &b) {
                       pack2_bf16(fmaxf(a[2] + b.z, 0.f), fmaxf(a[3] + b.w, 0.f)));
 }
 
+// bit r of the result: the r-th of the 4 bf16 values in `y` (a ReLU output) is > 0
+__device__ __forceinline__ uint32_t positive4(const uint2 y) {
+    auto pos = [](uint32_t h) -> uint32_t { return ((h & 0x7FFFu) != 0u && !(h & 0x8000u)) ? 1u : 0u; };
+    return pos(y.x & 0xFFFFu) | (pos(y.x >> 16) << 1) | (pos(y.y & 0xFFFFu) << 2) | (pos(y.y >> 16) << 3);
+}
+
+// Training forward: ReLU sign bits of a layer output, one uint32 per (position, 32-channel block): this lane's two
+// nibbles (tiles a = 0, 1; 4 channels each at bit 16 a + 4 lh) are ORed with those of the three lanes that hold the
+// other channels of the same position (lane ^ 16, lane ^ 32); the lh = 0 lane stores the word.  The backward kernel
+// reads these 16 bytes per position instead of the 256-byte activation rows.
+__device__ __forceinline__ void store_relu_bits(uint32_t nib[NT], uint32_t vmask, uint32_t *__restrict__ dst, int cb, int lr, int lh) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        uint32_t wbits = nib[n];
+        wbits |= (uint32_t)__shfl_xor((int)wbits, 16);
+        wbits |= (uint32_t)__shfl_xor((int)wbits, 32);
+        if (lh == 0 && ((vmask >> n) & 1u)) dst[(n * 16 + lr) * 4 + cb] = wbits;
+    }
+}
+
 // One 3x3 pad-1 128->128 convolution over the LDS-resident activations: acc[a][n] += W(a) * act(n).
 // `wv` points at this lane's element of this wave's first co tile of the layer: index (s*8 + a)*64.
 // The 36 k-steps x 13 position tiles are one flat software-pipelined sequence: the B fragment of tile-step t + PB is
@@ -138,7 +158,8 @@ __device__ __forceinline__ void save_rows(const unsigned char *act, uint16_t *__
 template <typename InT, bool SAVE>
 __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__restrict__ obs, long long M,
                                                           const uint16_t *__restrict__ wp, const float *__restrict__ bias,
-                                                          uint16_t *__restrict__ out, uint16_t *__restrict__ save) {
+                                                          uint16_t *__restrict__ out, uint16_t *__restrict__ save,
+                                                          uint32_t *__restrict__ relu_bits) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[ACT_BYTES + RAW_BYTES];
     unsigned char *const act = smem;
     const InT *const raw = reinterpret_cast<const InT *>(smem + ACT_BYTES);
@@ -187,6 +208,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
     __syncthreads();
 
     f32x4 acc[2][NT];
+    uint32_t nib[NT];  // training forward: this lane's ReLU sign nibbles of the layer being finished
     const float *bl = bias;
     const int co_lane = cb * 32 + 4 * lh;  // + 16*a: first of this lane's 4 output channels
 
@@ -228,10 +250,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
         for (int a = 0; a < 2; ++a) {
             const float4 b4 = *reinterpret_cast<const float4 *>(bl + co_lane + 16 * a);
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
-                if ((vmask >> n) & 1u)
-                    *reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2) = pack_relu(acc[a][n], b4);
+            for (int n = 0; n < NT; ++n) {
+                const uint2 v = pack_relu(acc[a][n], b4);
+                if (SAVE) nib[n] = (a ? nib[n] : 0u) | (((vmask >> n) & 1u) ? positive4(v) << (16 * a + 4 * lh) : 0u);
+                if ((vmask >> n) & 1u) *reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2) = v;
+            }
         }
+        if (SAVE) store_relu_bits(nib, vmask, relu_bits + obs0 * 196, cb, lr, lh);
         bl += 128;
         __syncthreads();
         if (SAVE) save_rows(act, save + obs0 * 6272, nobs, tid);
@@ -256,9 +281,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
             for (int n = 0; n < NT; ++n) {
                 uint2 *cell = reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2);
                 xres[a][n] = *cell;  // this lane's skip input (lanes without a position read row 9 and drop it)
-                if ((vmask >> n) & 1u) *cell = pack_relu(acc[a][n], b4);
+                const uint2 v = pack_relu(acc[a][n], b4);
+                if (SAVE) nib[n] = (a ? nib[n] : 0u) | (((vmask >> n) & 1u) ? positive4(v) << (16 * a + 4 * lh) : 0u);
+                if ((vmask >> n) & 1u) *cell = v;
             }
         }
+        if (SAVE) store_relu_bits(nib, vmask, relu_bits + ((1 + 2 * blk) * M + obs0) * 196, cb, lr, lh);
         __syncthreads();
         if (SAVE) save_rows(act, save + ((1 + 2 * blk) * M + obs0) * 6272, nobs, tid);
         // ---- block2: x' = relu(conv(t) + b2 + x): the skip input is the initial accumulator ----
@@ -274,10 +302,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
         for (int a = 0; a < 2; ++a) {
             const float4 b4 = *reinterpret_cast<const float4 *>(bl + 128 + co_lane + 16 * a);
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
-                if ((vmask >> n) & 1u)
-                    *reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2) = pack_relu(acc[a][n], b4);
+            for (int n = 0; n < NT; ++n) {
+                const uint2 v = pack_relu(acc[a][n], b4);
+                if (SAVE) nib[n] = (a ? nib[n] : 0u) | (((vmask >> n) & 1u) ? positive4(v) << (16 * a + 4 * lh) : 0u);
+                if ((vmask >> n) & 1u) *reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2) = v;
+            }
         }
+        if (SAVE) store_relu_bits(nib, vmask, relu_bits + ((2 + 2 * blk) * M + obs0) * 196, cb, lr, lh);
         bl += 256;
         __syncthreads();
         if (SAVE) save_rows(act, save + ((2 + 2 * blk) * M + obs0) * 6272, nobs, tid);
@@ -347,12 +378,12 @@ __global__ void __launch_bounds__(256) encoder_pack_kernel(PackArgs pa, uint16_t
 // Backward-data chain of the encoder in ONE kernel (the mirror image of encoder_fwd_kernel).
 //
 // In: gz7 = gradient w.r.t. the 1x1 convolution's pre-activation (already ReLU-masked), bf16 [M][49][16];
-// the saved layer outputs acts [7][M][49][128] of the training forward; weights packed for the TRANSPOSED
+// the ReLU sign bits of the 7 layer outputs written by the training forward (uint32 [7][M][49][4]); weights packed for the TRANSPOSED
 // convolutions (mapf_encoder_pack_bwd: channels swapped, taps flipped), so that every step
 //     g_in[ci][p] = sum_{co,tap} W[co][ci][tap] * gz[co][p - tap]
 // is the same LDS-resident implicit GEMM as the forward (conv3x3 above).
-// Out: gz [7][M][49][128] = the gradient w.r.t. every 128-channel layer's PRE-activation (ReLU-masked with the
-// saved outputs) -- exactly what the weight-/bias-gradient reductions consume.
+// Out: gz [7][M][49][128] = the gradient w.r.t. every 128-channel layer's PRE-activation (ReLU-masked with those
+// sign bits) -- exactly what the weight-/bias-gradient reductions consume.
 // Residual block backward (y = relu(x + conv2(t) + b2), t = relu(conv1(x) + b1)):
 //     gz2 = g_y * (y > 0);  g_t = conv2^T(gz2);  gz1 = g_t * (t > 0);  g_x = conv1^T(gz1) + gz2
 // -- the skip term gz2 is what LDS holds when gz1 overwrites it, so, as in the forward, each lane reads its own
@@ -364,11 +395,6 @@ constexpr int WPT_L7 = 6 * WP_RES_SIZE;
 constexpr int WPT_TOTAL = WPT_L7 + 8 * 512;
 static_assert(WPT_TOTAL == MAPF_ENC_PACKED_BWD_ELEMS, "header constant out of date");
 
-// bit r of the result: the r-th of the 4 bf16 values in `y` (a ReLU output) is > 0
-__device__ __forceinline__ uint32_t positive4(const uint2 y) {
-    auto pos = [](uint32_t h) -> uint32_t { return ((h & 0x7FFFu) != 0u && !(h & 0x8000u)) ? 1u : 0u; };
-    return pos(y.x & 0xFFFFu) | (pos(y.x >> 16) << 1) | (pos(y.y & 0xFFFFu) << 2) | (pos(y.y >> 16) << 3);
-}
 // masked gradient of 4 channels, packed to bf16; `bs` accumulates this lane's share of the bias gradient
 __device__ __forceinline__ uint2 pack_masked(const f32x4 &a, uint32_t m, float (&bs)[4]) {
     const float v0 = (m & 1u) ? a[0] : 0.f, v1 = (m & 2u) ? a[1] : 0.f, v2 = (m & 4u) ? a[2] : 0.f, v3 = (m & 8u) ? a[3] : 0.f;
@@ -396,7 +422,7 @@ __device__ __forceinline__ void store_bias_partial(float (&bs)[2][4], float *__r
 }
 
 __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t *__restrict__ gz7, long long M,
-                                                                  const uint16_t *__restrict__ acts,
+                                                                  const uint32_t *__restrict__ relu_bits,
                                                                   const uint16_t *__restrict__ wpt, uint16_t *__restrict__ gz,
                                                                   float *__restrict__ gb_part) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[ACT_BYTES + GZ7_BYTES];
@@ -436,6 +462,16 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
     // bias-gradient partials: gb_part[layer][block][128]
     auto gb_dst = [&](int layer) -> float * { return gb_part + ((long long)layer * gridDim.x + blockIdx.x) * 128; };
 
+    // ReLU sign words of the layer whose mask comes next (one uint32 per tile: this wave's 32 channels of the lane's
+    // position); loaded one convolution ahead, so the 16-byte-per-position reads are long finished when needed
+    uint32_t mk[NT];
+    auto load_masks = [&](int layer) {
+        const uint32_t *src = relu_bits + ((long long)layer * M + obs0) * 196 + cb;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) mk[n] = ((vmask >> n) & 1u) ? src[(n * 16 + lr) * 4] : 0u;
+    };
+    load_masks(6);
+
     f32x4 acc[2][NT];
     // ---- 1x1^T: g_y3[ci][p] = sum_co W7[co][ci] gz7[co][p]  (K = 16, zero-padded to 32) ----
     {
@@ -455,23 +491,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
         const bf16x8 *wv1 = reinterpret_cast<const bf16x8 *>(wpt + (2 * blk) * WP_RES_SIZE) + (2 * cb) * 64 + lane;
         const bf16x8 *wv2 = wv1 + WP_RES_SIZE / 8;
         // ---- gz2 = g_y * (y > 0) -> LDS (input of conv2^T) ----
-        {
-            const uint16_t *yk = acts + (2 + 2 * blk) * LSTRIDE;
-            uint2 yv[2][NT];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    yv[a][n] = ((vmask >> n) & 1u) ? *reinterpret_cast<const uint2 *>(yk + cell_off(a, n)) : make_uint2(0, 0);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    if ((vmask >> n) & 1u)
-                        *reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2) =
-                            pack_masked(acc[a][n], positive4(yv[a][n]), bs[a]);
-            store_bias_partial(bs, gb_dst(2 + 2 * blk), co_lane, lr);
-        }
+            for (int n = 0; n < NT; ++n)
+                if ((vmask >> n) & 1u)
+                    *reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2) =
+                        pack_masked(acc[a][n], (mk[n] >> (16 * a + 4 * lh)) & 0xFu, bs[a]);
+        store_bias_partial(bs, gb_dst(2 + 2 * blk), co_lane, lr);
+        load_masks(1 + 2 * blk);
         __syncthreads();
         save_rows(act, gz + (2 + 2 * blk) * LSTRIDE + obs0 * 6272, nobs, tid);
         // ---- g_t = conv2^T(gz2) ----
@@ -483,24 +511,16 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
         __syncthreads();
         // ---- gz1 = g_t * (t > 0) -> LDS; the gz2 it overwrites is the skip term of g_x ----
         uint2 skip[2][NT];
-        {
-            const uint16_t *tk = acts + (1 + 2 * blk) * LSTRIDE;
-            uint2 tv[2][NT];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    tv[a][n] = ((vmask >> n) & 1u) ? *reinterpret_cast<const uint2 *>(tk + cell_off(a, n)) : make_uint2(0, 0);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    uint2 *cell = reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2);
-                    skip[a][n] = *cell;
-                    if ((vmask >> n) & 1u) *cell = pack_masked(acc[a][n], positive4(tv[a][n]), bs[a]);
-                }
-            store_bias_partial(bs, gb_dst(1 + 2 * blk), co_lane, lr);
-        }
+            for (int n = 0; n < NT; ++n) {
+                uint2 *cell = reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2);
+                skip[a][n] = *cell;
+                if ((vmask >> n) & 1u) *cell = pack_masked(acc[a][n], (mk[n] >> (16 * a + 4 * lh)) & 0xFu, bs[a]);
+            }
+        store_bias_partial(bs, gb_dst(1 + 2 * blk), co_lane, lr);
+        load_masks(2 * blk);  // y of the previous block, or conv0's output for blk = 0
         __syncthreads();
         save_rows(act, gz + (1 + 2 * blk) * LSTRIDE + obs0 * 6272, nobs, tid);
         // ---- g_x = conv1^T(gz1) + gz2 ----
@@ -520,11 +540,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
-                if ((vmask >> n) & 1u) {
-                    const long long off = cell_off(a, n);
-                    const uint2 yv = *reinterpret_cast<const uint2 *>(acts + off);
-                    *reinterpret_cast<uint2 *>(g0 + off) = pack_masked(acc[a][n], positive4(yv), bs[a]);
-                }
+                if ((vmask >> n) & 1u)
+                    *reinterpret_cast<uint2 *>(g0 + cell_off(a, n)) = pack_masked(acc[a][n], (mk[n] >> (16 * a + 4 * lh)) & 0xFu, bs[a]);
         store_bias_partial(bs, gb_dst(0), co_lane, lr);
     }
 }
@@ -577,12 +594,12 @@ int mapf_encoder_pack(const float *const *w_dev, const float *const *b_dev, uint
 }
 
 static int encoder_launch(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev, const float *bias_dev,
-                          uint16_t *latent_dev, uint16_t *save_dev, bool save, void *stream) {
-    if (M < 0 || !packed_dev || !bias_dev || (M > 0 && (!obs_dev || !latent_dev || (save && !save_dev)))) return MAPF_ERR_INVALID_ARG;
+                          uint16_t *latent_dev, uint16_t *save_dev, uint32_t *bits_dev, bool save, void *stream) {
+    if (M < 0 || !packed_dev || !bias_dev || (M > 0 && (!obs_dev || !latent_dev || (save && (!save_dev || !bits_dev))))) return MAPF_ERR_INVALID_ARG;
     if (obs_dtype != MAPF_ENC_OBS_U8 && obs_dtype != MAPF_ENC_OBS_BF16) return MAPF_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(obs_dev) & 3) || (reinterpret_cast<uintptr_t>(packed_dev) & 15) ||
         (reinterpret_cast<uintptr_t>(bias_dev) & 15) || (reinterpret_cast<uintptr_t>(latent_dev) & 1) ||
-        (reinterpret_cast<uintptr_t>(save_dev) & 15))
+        (reinterpret_cast<uintptr_t>(save_dev) & 15) || (reinterpret_cast<uintptr_t>(bits_dev) & 15))
         return MAPF_ERR_INVALID_ARG;
     if (M == 0) return MAPF_OK;
     const long long blocks = (M + G - 1) / G;
@@ -592,25 +609,25 @@ static int encoder_launch(const void *obs_dev, int obs_dtype, int64_t M, const u
     const uint8_t *o8 = static_cast<const uint8_t *>(obs_dev);
     const uint16_t *o16 = static_cast<const uint16_t *>(obs_dev);
     if (obs_dtype == MAPF_ENC_OBS_U8 && !save)
-        hipLaunchKernelGGL((encoder_fwd_kernel<uint8_t, false>), grid, block, 0, st, o8, (long long)M, packed_dev, bias_dev, latent_dev, save_dev);
+        hipLaunchKernelGGL((encoder_fwd_kernel<uint8_t, false>), grid, block, 0, st, o8, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev);
     else if (obs_dtype == MAPF_ENC_OBS_U8)
-        hipLaunchKernelGGL((encoder_fwd_kernel<uint8_t, true>), grid, block, 0, st, o8, (long long)M, packed_dev, bias_dev, latent_dev, save_dev);
+        hipLaunchKernelGGL((encoder_fwd_kernel<uint8_t, true>), grid, block, 0, st, o8, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev);
     else if (!save)
-        hipLaunchKernelGGL((encoder_fwd_kernel<uint16_t, false>), grid, block, 0, st, o16, (long long)M, packed_dev, bias_dev, latent_dev, save_dev);
+        hipLaunchKernelGGL((encoder_fwd_kernel<uint16_t, false>), grid, block, 0, st, o16, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev);
     else
-        hipLaunchKernelGGL((encoder_fwd_kernel<uint16_t, true>), grid, block, 0, st, o16, (long long)M, packed_dev, bias_dev, latent_dev, save_dev);
+        hipLaunchKernelGGL((encoder_fwd_kernel<uint16_t, true>), grid, block, 0, st, o16, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }
 
 int mapf_encoder_forward(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev, const float *bias_dev,
                          uint16_t *latent_dev, void *stream) {
-    return encoder_launch(obs_dev, obs_dtype, M, packed_dev, bias_dev, latent_dev, nullptr, false, stream);
+    return encoder_launch(obs_dev, obs_dtype, M, packed_dev, bias_dev, latent_dev, nullptr, nullptr, false, stream);
 }
 
 int mapf_encoder_forward_save(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev, const float *bias_dev,
-                              uint16_t *latent_dev, uint16_t *acts_dev, void *stream) {
-    return encoder_launch(obs_dev, obs_dtype, M, packed_dev, bias_dev, latent_dev, acts_dev, true, stream);
+                              uint16_t *latent_dev, uint16_t *acts_dev, uint32_t *relu_bits_dev, void *stream) {
+    return encoder_launch(obs_dev, obs_dtype, M, packed_dev, bias_dev, latent_dev, acts_dev, relu_bits_dev, true, stream);
 }
 
 int mapf_encoder_pack_bwd(const float *const *w_dev, uint16_t *packed_bwd_dev, void *stream) {
@@ -627,17 +644,17 @@ int mapf_encoder_pack_bwd(const float *const *w_dev, uint16_t *packed_bwd_dev, v
     return MAPF_OK;
 }
 
-int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint16_t *acts_dev, const uint16_t *packed_bwd_dev,
+int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint32_t *relu_bits_dev, const uint16_t *packed_bwd_dev,
                                uint16_t *gz_dev, float *gbias_partial_dev, void *stream) {
-    if (M < 0 || !packed_bwd_dev || (M > 0 && (!gz7_dev || !acts_dev || !gz_dev || !gbias_partial_dev))) return MAPF_ERR_INVALID_ARG;
-    if ((reinterpret_cast<uintptr_t>(gz7_dev) & 15) || (reinterpret_cast<uintptr_t>(acts_dev) & 15) ||
+    if (M < 0 || !packed_bwd_dev || (M > 0 && (!gz7_dev || !relu_bits_dev || !gz_dev || !gbias_partial_dev))) return MAPF_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(gz7_dev) & 15) || (reinterpret_cast<uintptr_t>(relu_bits_dev) & 15) ||
         (reinterpret_cast<uintptr_t>(packed_bwd_dev) & 15) || (reinterpret_cast<uintptr_t>(gz_dev) & 15))
         return MAPF_ERR_INVALID_ARG;
     if (M == 0) return MAPF_OK;
     const long long blocks = (M + G - 1) / G;
     if (blocks > 0x7FFFFFFFLL) return MAPF_ERR_INVALID_ARG;
     hipLaunchKernelGGL(encoder_bwd_kernel, dim3((unsigned)blocks), dim3(NTHREADS), 0, static_cast<hipStream_t>(stream), gz7_dev,
-                       (long long)M, acts_dev, packed_bwd_dev, gz_dev, gbias_partial_dev);
+                       (long long)M, relu_bits_dev, packed_bwd_dev, gz_dev, gbias_partial_dev);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }

@@ -154,16 +154,17 @@ class _EncoderTrain(torch.autograd.Function):
         M = obs.shape[0]
         acts = torch.empty((7, M, 7, 7, 128), dtype=torch.bfloat16, device=obs.device)
         out = torch.empty((M, 784), dtype=torch.bfloat16, device=obs.device)
+        bits = torch.empty((7, M, 49, 4), dtype=torch.int32, device=obs.device)  # ReLU sign bits for the backward chain
         kind = _ENC_OBS_U8 if obs.dtype == torch.uint8 else _ENC_OBS_BF16
         check(lib.mapf_encoder_forward_save(_ptr(obs), kind, M, _ptr(packed_w), _ptr(packed_b), _ptr(out), _ptr(acts),
-                                            _stream(obs.device)), "mapf_encoder_forward_save")
-        ctx.save_for_backward(obs, acts, out, *params)
+                                            _ptr(bits), _stream(obs.device)), "mapf_encoder_forward_save")
+        ctx.save_for_backward(obs, acts, out, bits, *params)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        obs, acts, out = ctx.saved_tensors[:3]
-        params = ctx.saved_tensors[3:]
+        obs, acts, out, bits = ctx.saved_tensors[:4]
+        params = ctx.saved_tensors[4:]
         cl = torch.channels_last
         dev = obs.device
         M = obs.shape[0]
@@ -181,7 +182,7 @@ class _EncoderTrain(torch.autograd.Function):
               "mapf_encoder_pack_bwd")
         gz = torch.empty_like(acts)
         gb_part = torch.empty((7, -(-M // ENC_OBS_PER_BLOCK), 128), dtype=torch.float32, device=dev)
-        check(lib.mapf_encoder_backward_data(_ptr(gz7), M, _ptr(acts), _ptr(wpt), _ptr(gz), _ptr(gb_part), _stream(dev)),
+        check(lib.mapf_encoder_backward_data(_ptr(gz7), M, _ptr(bits), _ptr(wpt), _ptr(gz), _ptr(gb_part), _stream(dev)),
               "mapf_encoder_backward_data")
         gbs = list(gb_part.sum(dim=1).unbind(0)) + [gb7]  # per-workgroup partial bias gradients -> [7][128]
         # weight gradients of the six 3x3 128->128 layers: one streaming MFMA kernel per layer (mapf_encoder_wgrad),

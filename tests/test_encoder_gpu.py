@@ -219,6 +219,43 @@ def test_encoder_training_path_gradients(M, chunk):
         assert rel_fused <= 0.15, (k, rel_fused)
 
 
+@pytest.mark.parametrize("M", [5, 64, 203])
+def test_forward_save_outputs(M):
+    """mapf_encoder_forward_save: the latent equals the inference kernel's bit for bit, the saved activations are the
+    layer outputs (last one reproduces the latent through the 1x1 layer), and relu_bits are exactly their sign bits."""
+    from mapf_rl_amd._lib import check, lib
+    from mapf_rl_amd.fused import PackedEncoder, encoder_forward
+
+    net = _net(M)
+    g = torch.Generator(device="cuda").manual_seed(M)
+    obs = (torch.rand((M, 6, 9, 9), device="cuda", generator=g) < 0.35).to(torch.uint8)
+    wp, bp = PackedEncoder().get(net.obs_encoder)
+    lat = torch.empty((M, 784), dtype=torch.bfloat16, device="cuda")
+    acts = torch.full((7, M, 49, 128), float("nan"), dtype=torch.bfloat16, device="cuda")
+    bits = torch.full((7, M, 49, 4), -1, dtype=torch.int32, device="cuda")
+    check(lib.mapf_encoder_forward_save(obs.data_ptr(), 0, M, wp.data_ptr(), bp.data_ptr(), lat.data_ptr(), acts.data_ptr(),
+                                        bits.data_ptr(), None), "mapf_encoder_forward_save")
+    assert torch.equal(lat, encoder_forward(obs, wp, bp))
+    assert torch.isfinite(acts.float()).all() and float(acts.float().min()) >= 0
+    # sign bits: bit c % 32 of word c / 32
+    pos = (acts.float() > 0).view(7, M, 49, 4, 32).to(torch.int64)
+    words = (pos << torch.arange(32, device="cuda")).sum(-1)
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
+    assert torch.equal(bits, words)
+    # the layer outputs against the fp32 network, layer by layer (bf16 tolerance)
+    c = _convs(net)
+    x = obs.float()
+    h = F.relu(F.conv2d(x, c[0].weight.float(), c[0].bias))
+    outs = [h]
+    for i in (1, 3, 5):
+        t = F.relu(F.conv2d(h, c[i].weight.float(), c[i].bias, padding=1))
+        h = F.relu(F.conv2d(t, c[i + 1].weight.float(), c[i + 1].bias, padding=1) + h)
+        outs += [t, h]
+    for k, ref in enumerate(outs):
+        got = acts[k].float().view(M, 7, 7, 128).permute(0, 3, 1, 2)
+        assert bool(((got - ref).abs() <= 2e-2 * torch.clamp(ref.abs(), min=1.0)).all()), k
+
+
 @pytest.mark.parametrize("M", [1, 2, 3, 161, 1000])
 def test_wgrad_kernel_against_fp32(M):
     """mapf_encoder_wgrad on random bf16 operands against the fp32 weight gradient of a 3x3 pad-1 convolution
