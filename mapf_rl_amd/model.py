@@ -62,6 +62,10 @@ class MultiHeadAttention(nn.Module):
         q = self.W_Q(x).view(B, N, H, D).transpose(1, 2)
         k = self.W_K(x).view(B, N, H, D).transpose(1, 2)
         v = self.W_V(x).view(B, N, H, D).transpose(1, 2)
+        if Network.SDPA and x.is_cuda and q.dtype == torch.bfloat16:
+            # fused kernel, fp32 accumulation of scores / softmax from the bf16 q, k (see Network._recur_fast)
+            ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=(~blocked).unsqueeze(1))
+            return self.W_O(ctx.transpose(1, 2).reshape(B, N, H * D))
         # scores and softmax in fp32 (model.py:75-78)
         scores = torch.matmul(q.float(), k.float().transpose(-1, -2)) / (D ** 0.5)
         scores = scores.masked_fill(blocked.unsqueeze(1), -1e9)
@@ -305,6 +309,7 @@ class Network(nn.Module):
         self.hidden = None
 
     # ------------------------------------------------------------------ learner side
+    SDPA = True  # fused scaled-dot-product attention inside _recur_fast
     FAST_RECURRENCE = True  # HIP device: hoisted input projection, fused QKV, deferred weight gradients (see _recur_fast)
 
     def bootstrap(self, obs, steps, hidden, comm_mask):
@@ -368,6 +373,7 @@ class Network(nn.Module):
         lat_t = latent.transpose(0, 1).reshape(T, B * N, ENC_FEATURES)
         gi_all = F.linear(lat_t, rc.weight_ih.to(lp) if grad else cast(rc.weight_ih))
         blocked = (~comm_mask).unsqueeze(2)                              # [B, T, 1, N, N]
+        allowed = comm_mask.unsqueeze(2)
         update = (comm_mask.sum(dim=-1) > 1).unsqueeze(-1)               # [B, T, N, 1]  (model.py:103)
         scale = 1.0 / (A ** 0.5)
         agent0 = []
@@ -377,9 +383,14 @@ class Network(nn.Module):
             for _ in range(self.comm.num_layers):
                 qkv = lin(hidden, w_qkv, b_qkv, "qkv").view(B, N, 3, H, A)
                 q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2)
-                scores = torch.matmul(q.float(), k.float().transpose(-1, -2)) * scale   # fp32 (model.py:75-78)
-                attn = F.softmax(scores.masked_fill(blocked[:, t], -1e9), dim=-1)
-                ctx = torch.matmul(attn.to(lp), v).transpose(1, 2).reshape(B * N, HA)
+                if self.SDPA:
+                    # one fused kernel: scores and softmax accumulate in fp32 from the bf16 q/k (model.py:75-78 keeps them
+                    # in fp32 too); every agent hears itself, so no row is fully masked and -inf == the reference's -1e9
+                    ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=allowed[:, t]).transpose(1, 2).reshape(B * N, HA)
+                else:
+                    scores = torch.matmul(q.float(), k.float().transpose(-1, -2)) * scale   # fp32 (model.py:75-78)
+                    attn = F.softmax(scores.masked_fill(blocked[:, t], -1e9), dim=-1)
+                    ctx = torch.matmul(attn.to(lp), v).transpose(1, 2).reshape(B * N, HA)
                 info = lin(ctx, w_o, None, "o")
                 gi = lin(info, u_ih, None, "uih")
                 gh = lin(hidden, u_hh, None, "uhh")
