@@ -131,21 +131,25 @@ def comm_mask(pos, obs_radius=4, max_comm=3, packed_words=0):
 # pre-activation gradient of every layer; the weight gradients of the 3x3 128->128 layers are a third kernel
 # (mapf_encoder_wgrad) on (layer input, that gradient).
 # ---------------------------------------------------------------------------------------------------------
-_BWD_CHUNK = 32768  # observations per MIOpen call (see Network.encode: very large batches misbehave on ROCm 7.2)
-
-
-def _conv_bwd(gz, x, w, pad, need_input):
-    gi, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
-                                                    [need_input, True, False])
-    return gi, gw
-
-
 def _mask_bias(g, y, gb):
     """gx = g where y > 0 else 0 (bf16 NHWC); gb += per-channel sum of gx (f32)."""
     gx = torch.empty_like(y)
     check(lib.mapf_bias_res_relu_bwd(_ptr(g), _ptr(y), _ptr(gx), _ptr(gb), y.numel(), y.shape[1], _stream(y.device)),
           "mapf_bias_res_relu_bwd")
     return gx
+
+
+def _tall_tn(a, b, rows=4096):
+    """a^T b for a [K, m], b [K, n] with K in the millions and m, n tiny: BLAS libraries run such a shape as ONE
+    workgroup walking all of K (0.5 s here), so K is split into batches of `rows` (bmm), summed in fp32."""
+    K, m = a.shape
+    S = K // rows
+    out = torch.zeros((m, b.shape[1]), dtype=torch.float32, device=a.device)
+    if S:
+        out += torch.bmm(a[:S * rows].view(S, rows, m).transpose(1, 2), b[:S * rows].view(S, rows, -1)).sum(dim=0, dtype=torch.float32)
+    if K > S * rows:
+        out += torch.mm(a[S * rows:].t(), b[S * rows:]).float()
+    return out
 
 
 class _EncoderTrain(torch.autograd.Function):
@@ -168,8 +172,7 @@ class _EncoderTrain(torch.autograd.Function):
         cl = torch.channels_last
         dev = obs.device
         M = obs.shape[0]
-        ws_bf = [params[2 * i].detach().to(torch.bfloat16) for i in range(8)]  # keeps the channels_last strides
-        gws = [torch.zeros(w.shape, dtype=torch.float32, device=dev).contiguous(memory_format=cl) for w in ws_bf]
+        gws = [None] * 8
         gb7 = torch.zeros(16, dtype=torch.float32, device=dev)
         # 1x1 layer: ReLU mask + bias gradient in one pass; [M,16,7,7] channels_last == memory [M][49][16]
         o4 = out.view(M, 16, 7, 7).contiguous(memory_format=cl)
@@ -191,14 +194,12 @@ class _EncoderTrain(torch.autograd.Function):
         for k in range(1, 7):
             check(lib.mapf_encoder_wgrad(_ptr(gz[k]), _ptr(acts[k - 1]), M, _ptr(ws), _stream(dev)), "mapf_encoder_wgrad")
             gws[k] = ws.sum(dim=0).permute(0, 3, 1, 2)  # [co][ky][kx][ci] memory == channels_last [co, ci, 3, 3]
-        # conv0 (6 input channels) and the 1x1 layer (16 output channels) are 1 % of the work: MIOpen, chunked
-        parts = -(-M // _BWD_CHUNK)
-        step = -(-M // parts)
-        for lo in range(0, M, step):
-            hi = min(M, lo + step)
-            x0 = obs[lo:hi].to(torch.bfloat16).contiguous(memory_format=cl)
-            gws[0] += _conv_bwd(gz[0, lo:hi].permute(0, 3, 1, 2), x0, ws_bf[0], 0, False)[1]
-            gws[7] += _conv_bwd(gz7[lo:hi], acts[6, lo:hi].permute(0, 3, 1, 2), ws_bf[7], 0, False)[1]
+        # conv0 (K = 54) and the 1x1 layer (16 output channels) are 1 % of the work: plain GEMMs over all positions
+        # (im2col of the 9x9 observation for conv0) -- no MIOpen anywhere in this path
+        # (a strided window view, not F.unfold: its bf16 im2col kernel takes 0.5 s at this shape)
+        cols = obs.to(torch.bfloat16).unfold(2, 3, 1).unfold(3, 3, 1).permute(0, 2, 3, 1, 4, 5).reshape(M * 49, 54)  # [position, ci*9 + ky*3 + kx]
+        gws[0] = _tall_tn(gz[0].reshape(M * 49, 128), cols).view(128, 6, 3, 3)
+        gws[7] = _tall_tn(gz7.permute(0, 2, 3, 1).reshape(M * 49, 16), acts[6].reshape(M * 49, 128)).view(16, 128, 1, 1)
         grads = []
         for i in range(8):
             grads += [gws[i].to(params[2 * i].dtype), gbs[i].to(params[2 * i + 1].dtype)]
