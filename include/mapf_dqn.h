@@ -93,6 +93,30 @@ int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint32_
 int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M, float *partial_dev, void *stream);
 
 /*
+ * Inference recurrence behind the encoder (csrc/mapf_recur.hip): for T steps and E environments of N <= 48 agents
+ *   hidden = GRUCell(latent_t, hidden)                                   (reference model.py:186-189 / :244)
+ *   2 x: info = MultiHeadAttention(hidden, comm_mask_t); hidden = where(partners > 1, GRUCell(info, hidden), hidden)
+ *                                                                        (CommBlock, model.py:99-135)
+ * with one workgroup per environment keeping the hidden states in LDS across all steps.  No autograd.
+ *   gi_dev      bf16 [T][E][N][768]  the GRU's input projection W_ih latent (no bias), one GEMM done by the caller
+ *   h0_dev      bf16 [E][N][256] or NULL (zeros: episode start)
+ *   comm_dev    u8   [T][E][N][N]    communication masks (non-zero = j talks to i)
+ *   weights_dev bf16 MAPF_RECUR_WEIGHT_ELEMS: recurrent.weight_hh [768][256] | W_Q;W_K;W_V [384][256] | W_O [64][128] |
+ *               update_cell.weight_ih [768][64] | update_cell.weight_hh [768][256], each matrix [O][K] stored in MFMA
+ *               A-fragment order [O/16][K/32][lane = 64][8]: element (o, k) at tile o/16, k-step k/32,
+ *               lane 16*((k%32)/8) + o%16, slot k%8
+ *   bias_dev    f32  MAPF_RECUR_BIAS_ELEMS: recurrent.bias_ih | recurrent.bias_hh | b_Q;b_K;b_V | update_cell.bias_ih |
+ *               update_cell.bias_hh
+ *   h_out_dev   bf16 [E][N][256] hidden state after the last step;  agent0_out_dev bf16 [T][E][256] or NULL: agent 0's
+ *               state after every step (what `bootstrap` feeds the Q head, model.py:248).
+ */
+#define MAPF_RECUR_WEIGHT_ELEMS 548864 /* 196608 + 98304 + 8192 + 49152 + 196608 */
+#define MAPF_RECUR_BIAS_ELEMS 3456     /* 768 + 768 + 384 + 768 + 768 */
+int mapf_recurrent_infer(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev,
+                         const uint16_t *weights_dev, const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev,
+                         uint16_t *agent0_out_dev, void *stream);
+
+/*
  * Communication mask of `Network.step` (reference model.py:195-208): mask[e][i][j] = j lies inside i's FOV square
  * (|drow| <= r and |dcol| <= r) AND j is among i's `max_comm` nearest agents by Euclidean distance, i itself
  * included; distance ties go to the LOWEST agent index (the reference's CPU topk leaves ties unspecified).

@@ -1,0 +1,375 @@
+// mapf_recur.hip -- inference recurrence of the DQN behind the encoder (reference model.py:186-218 `Network.step`
+// and the no-gradient `bootstrap` of the target network, model.py:242-249 called from worker.py:300-303):
+//     hidden = GRUCell(latent, hidden);  2 x [ info = MultiHeadAttention(hidden, comm_mask);
+//                                              hidden = where(has_partner, GRUCell(info, hidden), hidden) ]
+// for T consecutive steps, ONE workgroup per environment (see include/mapf_dqn.h: mapf_recurrent_infer).
+//
+// Everything after the GRU's input projection is independent between environments (attention only mixes the <= 48
+// agents of one environment), so a workgroup keeps its environment's hidden states in LDS for all T steps and only
+// streams the weights (1.1 MB, L2-resident).  Through PyTorch this is ~14 small launches per step (GEMMs on 160 K x
+// 256 rows, a fused GRU cell that also writes a 5x workspace, SDPA, where, copies): 1.9 ms of a 12 ms actor
+// iteration, 18 x that in the target network's bootstrap.
+//
+// Conventions (as in csrc/mapf_encoder.hip): v_mfma_f32_16x16x32_bf16 with A = weights (16 output channels x 32 k,
+// pre-packed in fragment order so that one wave load is a contiguous 1 KiB) and
+// B = activations (32 k x 16 agents, rows of an LDS image with one row per agent), so an accumulator lane holds
+// 4 consecutive channels of one agent = one 8-byte LDS store.  LDS rows are 32 bytes longer than a multiple of 256
+// (conflict-free ds_read_b128 over 16 consecutive rows, tools/micro/lds_b128_bank.hip).
+// The GRU gates of a 16-channel block (r, z, n) are accumulated by the same wave, so the cell's pointwise math runs
+// on registers; gi (the input projection W_ih x, one large GEMM over all steps) is an input.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+
+#include "mapf_dqn.h"
+#include "mapf_env.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+#ifndef MAPF_RECUR_ABLATE  // diagnostic builds only (tools/micro/recur_ablate.py): 1 GRU, 2 QKV, 4 attention, 8 W_O, 16 update cell
+#define MAPF_RECUR_ABLATE 0
+#endif
+constexpr int NT = 3;            // agent tiles of 16: up to 48 agents per environment
+constexpr int NA = 16 * NT;
+constexpr int D = 256;           // hidden size (config.latent_dim)
+constexpr int HD = 64;           // attention head dim (comm output_dim)
+constexpr int NTHR = 256;        // 4 waves, one per SIMD (up to 512 VGPRs: the A fragments of a whole call stay in flight)
+
+// LDS image (bytes)
+constexpr int H_ROW = D * 2 + 32;          // 544
+constexpr int H_BYTES = NA * H_ROW;        // one hidden buffer
+constexpr int QK_ROW = 256 * 2 + 32;       // q (2 heads x 64) | k (2 heads x 64)
+constexpr int VT_ROW = 64 * 2 + 32;        // v transposed: row = (head, d), 64 agent slots
+constexpr int P_ROW = 64 * 2 + 32;         // softmax weights bf16: row = (head, agent i), 64 agent slots j
+constexpr int CTX_ROW = 128 * 2 + 32;
+constexpr int INFO_ROW = 64 * 2 + 32;
+constexpr int S_ROW = NA + 1;              // scores fp32: row = (head, agent i)
+constexpr int OFF_H0 = 0, OFF_H1 = OFF_H0 + H_BYTES;
+constexpr int OFF_QK = OFF_H1 + H_BYTES;
+constexpr int OFF_VT = OFF_QK + NA * QK_ROW;
+constexpr int OFF_P = OFF_VT + 128 * VT_ROW;
+constexpr int OFF_CTX = OFF_P + 2 * NA * P_ROW;
+constexpr int OFF_INFO = OFF_CTX + NA * CTX_ROW;
+constexpr int OFF_S = OFF_INFO + NA * INFO_ROW;
+constexpr int OFF_UPD = OFF_S + 2 * NA * S_ROW * 4;
+constexpr int OFF_MB = OFF_UPD + 64 * 4;     // comm mask of the step as bits: 2 words per agent row
+constexpr int LDS_BYTES = OFF_MB + NA * 2 * 4;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(OFF_S % 16 == 0 && OFF_UPD % 16 == 0, "");
+
+// weight buffer (bf16 elements) and bias buffer (f32 elements), see mapf_dqn.h
+constexpr int W_HH = 0, W_QKV = W_HH + 768 * 256, W_O = W_QKV + 384 * 256, U_IH = W_O + 64 * 128, U_HH = U_IH + 768 * 64;
+constexpr int W_TOTAL = U_HH + 768 * 256;
+static_assert(W_TOTAL == MAPF_RECUR_WEIGHT_ELEMS, "header constant out of date");
+constexpr int B_IH = 0, B_HH = 768, B_QKV = 1536, UB_IH = 1920, UB_HH = 2688, B_TOTAL = 3456;
+static_assert(B_TOTAL == MAPF_RECUR_BIAS_ELEMS, "header constant out of date");
+
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 2.f / (1.f + __expf(-2.f * x)) - 1.f; }
+
+// acc[n] += (tile `t` of 16 rows of W) * X^T for the NT agent tiles; W packed [tile][k-step][lane][8] (see gemm3x16),
+// X an LDS image with `xrow` bytes per agent row.  All KS A fragments are loaded before the first MFMA.
+template <int KS>
+__device__ __forceinline__ void gemm16(f32x4 (&acc)[NT], const uint16_t *__restrict__ W, int t, const unsigned char *X, int xrow, int lane) {
+    const int lr = lane & 15, lh = lane >> 4;
+    bf16x8 a[KS];
+    const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(W) + (long long)t * KS * 64 + lane;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) a[kk] = wp[kk * 64];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8 *>(X + (16 * n + lr) * xrow + (32 * kk + 8 * lh) * 2);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk], b, acc[n], 0, 0, 0);
+        }
+}
+
+// Three output tiles at once (tiles t0, t1, t2 of 16 rows of W), sharing every B fragment.  W is packed in MFMA
+// A-fragment order, [tile][k-step][lane][8]: one wave load = one contiguous 1 KiB = 8 full cache lines (row-major
+// weights cost 16 half lines per load and ran the L2 -> CU path at a quarter of its rate).
+template <int KS>
+__device__ __forceinline__ void gemm3x16(f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], f32x4 (&acc2)[NT], const uint16_t *__restrict__ W, int t0,
+                                         int t1, int t2, const unsigned char *X, int xrow, int lane) {
+    const int lr = lane & 15, lh = lane >> 4;
+    const bf16x8 *w0 = reinterpret_cast<const bf16x8 *>(W) + (long long)t0 * KS * 64 + lane;
+    const bf16x8 *w1 = reinterpret_cast<const bf16x8 *>(W) + (long long)t1 * KS * 64 + lane;
+    const bf16x8 *w2 = reinterpret_cast<const bf16x8 *>(W) + (long long)t2 * KS * 64 + lane;
+    // ALL A fragments of the call are requested before the first MFMA (up to 96 VGPRs; one wave per SIMD, 512 available)
+    bf16x8 a[KS][3];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        a[kk][0] = w0[kk * 64];
+        a[kk][1] = w1[kk * 64];
+        a[kk][2] = w2[kk * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8 *>(X + (16 * n + lr) * xrow + (32 * kk + 8 * lh) * 2);
+            acc0[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][0], b, acc0[n], 0, 0, 0);
+            acc1[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][1], b, acc1[n], 0, 0, 0);
+            acc2[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][2], b, acc2[n], 0, 0, 0);
+        }
+    }
+}
+
+// One GRU cell for the 16-channel block `cblk`, all agents: gates from registers, pointwise math, new state to Hout.
+//   r = s(gi_r + b_ir + W_hr h + b_hr), z likewise, n = tanh(gi_n + b_in + r (W_hn h + b_hn)), h' = (1-z) n + z h
+// gi_* comes either from global memory (GI_GLOBAL: precomputed input projection, bf16 [agent][768]) or from a GEMM of
+// W_i (ldwi = KI*32 columns) with the LDS image Xi.  `upd` (LDS int per agent, or nullptr): keep h where it is 0.
+template <bool GI_GLOBAL, int KI>
+__device__ __forceinline__ void gru_block(int cblk, const uint16_t *__restrict__ gi_glob, const uint16_t *__restrict__ Wi,
+                                          const unsigned char *Xi, int xirow, const uint16_t *__restrict__ Wh, const float *__restrict__ bi,
+                                          const float *__restrict__ bh, const unsigned char *Hin, unsigned char *Hout, const int *upd,
+                                          int nagents, int lr, int lh) {
+    f32x4 ar[NT], az[NT], ani[NT], anh[NT];
+    const int c0 = 16 * cblk + 4 * lh;  // this lane's 4 channels
+    const float4 bir = *reinterpret_cast<const float4 *>(bi + c0), biz = *reinterpret_cast<const float4 *>(bi + 256 + c0),
+                 bin = *reinterpret_cast<const float4 *>(bi + 512 + c0);
+    const float4 bhr = *reinterpret_cast<const float4 *>(bh + c0), bhz = *reinterpret_cast<const float4 *>(bh + 256 + c0),
+                 bhn = *reinterpret_cast<const float4 *>(bh + 512 + c0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        ar[n] = f32x4{bir.x + bhr.x, bir.y + bhr.y, bir.z + bhr.z, bir.w + bhr.w};
+        az[n] = f32x4{biz.x + bhz.x, biz.y + bhz.y, biz.z + bhz.z, biz.w + bhz.w};
+        ani[n] = f32x4{bin.x, bin.y, bin.z, bin.w};
+        anh[n] = f32x4{bhn.x, bhn.y, bhn.z, bhn.w};
+        if (GI_GLOBAL) {
+            const int agent = 16 * n + lr;
+            if (agent < nagents) {
+                const uint16_t *g = gi_glob + (long long)agent * 768 + c0;
+                const uint2 gr = *reinterpret_cast<const uint2 *>(g), gz = *reinterpret_cast<const uint2 *>(g + 256),
+                            gn = *reinterpret_cast<const uint2 *>(g + 512);
+                ar[n] += f32x4{bf16_lo(gr.x), bf16_hi(gr.x), bf16_lo(gr.y), bf16_hi(gr.y)};
+                az[n] += f32x4{bf16_lo(gz.x), bf16_hi(gz.x), bf16_lo(gz.y), bf16_hi(gz.y)};
+                ani[n] += f32x4{bf16_lo(gn.x), bf16_hi(gn.x), bf16_lo(gn.y), bf16_hi(gn.y)};
+            }
+        }
+    }
+    if (!GI_GLOBAL) gemm3x16<KI>(ar, az, ani, Wi, cblk, 16 + cblk, 32 + cblk, Xi, xirow, 16 * lh + lr);
+    gemm3x16<8>(ar, az, anh, Wh, cblk, 16 + cblk, 32 + cblk, Hin, H_ROW, 16 * lh + lr);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int agent = 16 * n + lr;
+        const uint2 hv = *reinterpret_cast<const uint2 *>(Hin + agent * H_ROW + c0 * 2);
+        const float h[4] = {bf16_lo(hv.x), bf16_hi(hv.x), bf16_lo(hv.y), bf16_hi(hv.y)};
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float rg = sigmoidf_(ar[n][r]), zg = sigmoidf_(az[n][r]);
+            const float ng = tanhf_(ani[n][r] + rg * anh[n][r]);
+            o[r] = (1.f - zg) * ng + zg * h[r];
+        }
+        const bool keep = upd != nullptr && upd[agent] == 0;
+        *reinterpret_cast<uint2 *>(Hout + agent * H_ROW + c0 * 2) = keep ? hv : make_uint2(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]));
+    }
+}
+
+__global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t *__restrict__ gi, const uint16_t *__restrict__ h0,
+                                                                  const uint8_t *__restrict__ comm, const uint16_t *__restrict__ W,
+                                                                  const float *__restrict__ bias, int T, int E, int N,
+                                                                  uint16_t *__restrict__ h_out, uint16_t *__restrict__ agent0_out) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lh = lane >> 4;
+    const int e = blockIdx.x;
+    const int rot = blockIdx.x;  // workgroups walk the weight tiles in rotated order: they run in step, and would otherwise all
+                                 // request the same cache lines at the same moment
+
+    // hidden state of this environment (rows >= N stay zero: they are computed like real agents and never stored)
+    for (int i = tid; i < LDS_BYTES / 16; i += NTHR) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (h0 != nullptr)
+        for (int i = tid; i < N * 32; i += NTHR) {  // 32 chunks of 16 B per agent
+            const int a = i >> 5, ch = i & 31;
+            *reinterpret_cast<uint4 *>(smem + OFF_H0 + a * H_ROW + ch * 16) =
+                *reinterpret_cast<const uint4 *>(h0 + ((long long)e * N + a) * D + ch * 8);
+        }
+    __syncthreads();
+
+    unsigned char *Hc = smem + OFF_H0, *Hn = smem + OFF_H1;
+    int *upd = reinterpret_cast<int *>(smem + OFF_UPD);
+    float *S = reinterpret_cast<float *>(smem + OFF_S);
+    uint32_t *mb = reinterpret_cast<uint32_t *>(smem + OFF_MB);
+    const float scale = 0.125f;  // 1 / sqrt(64)
+
+    for (int t = 0; t < T; ++t) {
+        // ---------------- this step's communication mask -> bit rows in LDS (the softmax loops must not touch global memory:
+        // 120 dependent byte loads per row made the first version 10x slower than its MFMAs) ----------------
+        const uint8_t *comm_t = comm + ((long long)t * E + e) * N * N;
+        if (tid < NA * 2) mb[tid] = 0u;
+        __syncthreads();
+        for (int idx = tid; idx < N * N; idx += NTHR)
+            if (comm_t[idx] != 0) {
+                const int i = idx / N, j = idx - i * N;
+                atomicOr(&mb[2 * i + (j >> 5)], 1u << (j & 31));
+            }
+        // ---------------- recurrent GRU cell: Hc -> Hn (the barrier behind it also publishes the mask bits) ----------------
+        const uint16_t *gi_t = gi + ((long long)t * E + e) * N * 768;
+        for (int c = w; c < 16 && !(MAPF_RECUR_ABLATE & 1); c += NTHR / 64)
+            gru_block<true, 1>((c + rot) & 15, gi_t, nullptr, nullptr, 0, W + W_HH, bias + B_IH, bias + B_HH, Hc, Hn, nullptr, N, lr, lh);
+        __syncthreads();
+        {
+            unsigned char *tmp = Hc;
+            Hc = Hn;
+            Hn = tmp;
+        }
+        // ---------------- two communication rounds (shared weights): Hc -> Hn -> swap ----------------
+        for (int round = 0; round < 2; ++round) {
+            // q | k | v = W_qkv h + b: 24 output tiles of 16
+            for (int wq0 = w; wq0 < 8 && !(MAPF_RECUR_ABLATE & 2); wq0 += NTHR / 64) {
+                const int wq = (wq0 + rot) & 7;
+                f32x4 acc[3][NT];  // tiles wq (q), wq + 8 (k), wq + 16 (v)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const float4 b4 = *reinterpret_cast<const float4 *>(bias + B_QKV + 16 * (wq + 8 * g) + 4 * lh);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[g][n] = f32x4{b4.x, b4.y, b4.z, b4.w};
+                }
+                gemm3x16<8>(acc[0], acc[1], acc[2], W + W_QKV, wq, wq + 8, wq + 16, Hc, H_ROW, lane);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int agent = 16 * n + lr, c0 = 16 * wq + 4 * lh;
+                    // q (channels 0..127) and k (128..255): [agent][channel]
+                    *reinterpret_cast<uint2 *>(smem + OFF_QK + agent * QK_ROW + c0 * 2) =
+                        make_uint2(pack2_bf16(acc[0][n][0], acc[0][n][1]), pack2_bf16(acc[0][n][2], acc[0][n][3]));
+                    *reinterpret_cast<uint2 *>(smem + OFF_QK + agent * QK_ROW + (128 + c0) * 2) =
+                        make_uint2(pack2_bf16(acc[1][n][0], acc[1][n][1]), pack2_bf16(acc[1][n][2], acc[1][n][3]));
+                    // v transposed: row (head, d) = c0 + r, column = agent
+                    const uint32_t p01 = pack2_bf16(acc[2][n][0], acc[2][n][1]), p23 = pack2_bf16(acc[2][n][2], acc[2][n][3]);
+                    uint16_t *vt = reinterpret_cast<uint16_t *>(smem + OFF_VT + c0 * VT_ROW) + agent;
+                    vt[0] = (uint16_t)(p01 & 0xFFFFu);
+                    vt[VT_ROW / 2] = (uint16_t)(p01 >> 16);
+                    vt[2 * (VT_ROW / 2)] = (uint16_t)(p23 & 0xFFFFu);
+                    vt[3 * (VT_ROW / 2)] = (uint16_t)(p23 >> 16);
+                }
+            }
+            __syncthreads();
+            // scores S[head][i][j] = q_i . k_j / 8: 2 heads x 3 x 3 tiles, K = 64
+            for (int job = w; job < 2 * NT * NT && !(MAPF_RECUR_ABLATE & 4); job += NTHR / 64) {
+                const int hd = job / (NT * NT), ti = (job / NT) % NT, tj = job % NT;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(smem + OFF_QK + (16 * ti + lr) * QK_ROW + (hd * HD + 32 * kk + 8 * lh) * 2);
+                    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(smem + OFF_QK + (16 * tj + lr) * QK_ROW + (128 + hd * HD + 32 * kk + 8 * lh) * 2);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[(hd * NA + 16 * ti + 4 * lh + r) * S_ROW + 16 * tj + lr] = acc[r] * scale;
+            }
+            __syncthreads();
+            // masked softmax per (head, agent i) row -> P bf16 (zero for j >= N and for rows i >= N); update flags
+            if (tid < 2 * NA && !(MAPF_RECUR_ABLATE & 4)) {
+                const int hd = tid / NA, i = tid % NA;
+                uint16_t *prow = reinterpret_cast<uint16_t *>(smem + OFF_P + (hd * NA + i) * P_ROW);
+                if (i < N) {
+                    const uint64_t bits = (uint64_t)mb[2 * i] | ((uint64_t)mb[2 * i + 1] << 32);
+                    float *srow = S + (hd * NA + i) * S_ROW;
+                    float mx = -3.0e38f;
+                    for (int j = 0; j < N; ++j) mx = fmaxf(mx, ((bits >> j) & 1ull) ? srow[j] : -1e9f);
+                    float sum = 0.f;
+                    for (int j = 0; j < N; ++j) {
+                        const float ex = __expf((((bits >> j) & 1ull) ? srow[j] : -1e9f) - mx);
+                        srow[j] = ex;
+                        sum += ex;
+                    }
+                    const float inv = 1.f / sum;
+                    for (int j = 0; j < N; ++j) prow[j] = (uint16_t)(pack2_bf16(srow[j] * inv, 0.f) & 0xFFFFu);
+                    if (hd == 0) upd[i] = __popcll(bits) > 1 ? 1 : 0;  // model.py:103
+                } else if (hd == 0) {
+                    upd[i] = 0;
+                }
+            }
+            __syncthreads();
+            // ctx^T[d][i] = sum_j vT[d][j] P[i][j]: 2 heads x 4 d-tiles, K = 64 agent slots -> CTX[agent][head*64 + d]
+            for (int job = w; job < 8 && !(MAPF_RECUR_ABLATE & 4); job += NTHR / 64) {
+                const int hd = job >> 2, td = job & 3;
+                f32x4 acc[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(smem + OFF_VT + (hd * HD + 16 * td + lr) * VT_ROW + (32 * kk + 8 * lh) * 2);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(smem + OFF_P + (hd * NA + 16 * n + lr) * P_ROW + (32 * kk + 8 * lh) * 2);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[n], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    *reinterpret_cast<uint2 *>(smem + OFF_CTX + (16 * n + lr) * CTX_ROW + (hd * HD + 16 * td + 4 * lh) * 2) =
+                        make_uint2(pack2_bf16(acc[n][0], acc[n][1]), pack2_bf16(acc[n][2], acc[n][3]));
+            }
+            __syncthreads();
+            // info = W_O ctx (no bias): 4 output tiles, K = 128
+            for (int ot = w; ot < 4 && !(MAPF_RECUR_ABLATE & 8); ot += NTHR / 64) {
+                f32x4 acc[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                gemm16<4>(acc, W + W_O, ot, smem + OFF_CTX, CTX_ROW, lane);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    *reinterpret_cast<uint2 *>(smem + OFF_INFO + (16 * n + lr) * INFO_ROW + (16 * ot + 4 * lh) * 2) =
+                        make_uint2(pack2_bf16(acc[n][0], acc[n][1]), pack2_bf16(acc[n][2], acc[n][3]));
+            }
+            __syncthreads();
+            // update cell: Hc -> Hn where the agent has a partner
+            for (int c = w; c < 16 && !(MAPF_RECUR_ABLATE & 16); c += NTHR / 64)
+                gru_block<false, 2>((c + rot) & 15, nullptr, W + U_IH, smem + OFF_INFO, INFO_ROW, W + U_HH, bias + UB_IH, bias + UB_HH, Hc, Hn, upd, N, lr, lh);
+            __syncthreads();
+            unsigned char *tmp = Hc;
+            Hc = Hn;
+            Hn = tmp;
+        }
+        if (agent0_out != nullptr && tid < 32)  // agent 0's state after this step (model.py:248)
+            *reinterpret_cast<uint4 *>(agent0_out + ((long long)t * E + e) * D + tid * 8) = *reinterpret_cast<const uint4 *>(Hc + tid * 16);
+    }
+    for (int i = tid; i < N * 32; i += NTHR) {
+        const int a = i >> 5, ch = i & 31;
+        *reinterpret_cast<uint4 *>(h_out + ((long long)e * N + a) * D + ch * 8) = *reinterpret_cast<const uint4 *>(Hc + a * H_ROW + ch * 16);
+    }
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            std::fprintf(stderr, "mapf_recur: %s failed: %s\n", #expr, hipGetErrorString(_e)); \
+            return MAPF_ERR_HIP;                                                             \
+        }                                                                                    \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int mapf_recurrent_infer(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
+                         const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev, void *stream) {
+    if (T < 1 || E < 0 || N < 1 || N > NA || !gi_dev || !comm_dev || !weights_dev || !bias_dev || !h_out_dev) return MAPF_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(gi_dev) & 7) || (reinterpret_cast<uintptr_t>(h0_dev) & 15) || (reinterpret_cast<uintptr_t>(weights_dev) & 15) ||
+        (reinterpret_cast<uintptr_t>(bias_dev) & 15) || (reinterpret_cast<uintptr_t>(h_out_dev) & 15) ||
+        (reinterpret_cast<uintptr_t>(agent0_out_dev) & 15))
+        return MAPF_ERR_INVALID_ARG;
+    if (E == 0) return MAPF_OK;
+    hipLaunchKernelGGL(recurrent_infer_kernel, dim3(E), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
+                       weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+}  // extern "C"

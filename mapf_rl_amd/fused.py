@@ -216,3 +216,53 @@ def encoder_forward_train(obs, obs_encoder, packed: PackedEncoder):
     wp, bp = packed.get(obs_encoder)
     params = [t for c in encoder_convs(obs_encoder) for t in (c.weight, c.bias)]
     return _EncoderTrain.apply(obs.contiguous(), wp, bp, *params)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Inference recurrence behind the encoder (include/mapf_dqn.h: mapf_recurrent_infer)
+# ---------------------------------------------------------------------------------------------------------
+RECUR_MAX_AGENTS = 48
+
+
+class PackedRecurrence:
+    """bf16 row-major weight image + f32 biases of Network.recurrent / Network.comm for mapf_recurrent_infer;
+    rebuilt when a parameter changed (same rule as PackedEncoder)."""
+
+    def __init__(self):
+        self.key = None
+        self.weights = None
+        self.bias = None
+
+    def get(self, net):
+        rc, at, uc = net.recurrent, net.comm.self_attn, net.comm.update_cell
+        ws = [rc.weight_hh, at.W_Q.weight, at.W_K.weight, at.W_V.weight, at.W_O.weight, uc.weight_ih, uc.weight_hh]
+        bs = [rc.bias_ih, rc.bias_hh, at.W_Q.bias, at.W_K.bias, at.W_V.bias, uc.bias_ih, uc.bias_hh]
+        key = tuple((p.data_ptr(), p._version) for p in ws + bs)
+        if key != self.key:
+            # each [O, K] matrix in MFMA A-fragment order [O/16][K/32][lane = 16*(k%32)//8 + o%16][k%8]
+            qkv = torch.cat([w.detach() for w in ws[1:4]], dim=0)
+            mats = [ws[0].detach(), qkv, ws[4].detach(), ws[5].detach(), ws[6].detach()]
+            self.weights = torch.cat([m.reshape(m.shape[0] // 16, 16, m.shape[1] // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1)
+                                      for m in mats]).to(torch.bfloat16).contiguous()
+            self.bias = torch.cat([b.detach().reshape(-1) for b in bs]).to(torch.float32).contiguous()
+            assert self.weights.numel() == 548864 and self.bias.numel() == 3456
+            self.key = key
+        return self.weights, self.bias
+
+
+def recurrent_infer(gi, h0, comm, weights, bias, want_agent0=False):
+    """gi bf16 [T, E, N, 768]; h0 bf16 [E, N, 256] or None; comm bool/u8 [T, E, N, N]
+    -> (hidden bf16 [E, N, 256], agent-0 states bf16 [T, E, 256] or None)."""
+    T, E, N, _ = gi.shape
+    assert gi.is_cuda and gi.dtype == torch.bfloat16 and gi.shape[3] == 768 and N <= RECUR_MAX_AGENTS
+    assert tuple(comm.shape) == (T, E, N, N)
+    gi = gi.contiguous()
+    comm = comm.contiguous()
+    comm = comm.view(torch.uint8) if comm.dtype == torch.bool else comm.to(torch.uint8)
+    if h0 is not None:
+        h0 = h0.to(torch.bfloat16).reshape(E, N, 256).contiguous()
+    h_out = torch.empty((E, N, 256), dtype=torch.bfloat16, device=gi.device)
+    a0 = torch.empty((T, E, 256), dtype=torch.bfloat16, device=gi.device) if want_agent0 else None
+    check(lib.mapf_recurrent_infer(_ptr(gi), _ptr(h0), _ptr(comm), _ptr(weights), _ptr(bias), T, E, N, _ptr(h_out), _ptr(a0),
+                                   _stream(gi.device)), "mapf_recurrent_infer")
+    return h_out, a0

@@ -199,6 +199,7 @@ class Network(nn.Module):
         self.state = nn.Linear(self.latent_dim, 1)
         self.hidden = None
         self._packed = None  # PackedEncoder of the fused inference kernel, built on first use
+        self._packed_recur = None  # PackedRecurrence of the fused recurrence kernel
         # model.py:174-178: Xavier-uniform weights / zero bias on Linear and Conv2d only
         for m in self.modules():
             if isinstance(m, (nn.Linear, nn.Conv2d)):
@@ -287,10 +288,15 @@ class Network(nn.Module):
         E, N = obs.shape[:2]
         with self._autocast(obs.device):
             latent = self.encode(obs.reshape(E * N, *OBS_SHAPE))
-            hidden = self.recurrent(latent) if hidden is None else self.recurrent(latent, hidden.to(latent.dtype))
             if comm_mask is None:
                 comm_mask = comm_mask_from_pos(pos)
-            hidden = self.comm(hidden.view(E, N, self.latent_dim), comm_mask).reshape(E * N, self.latent_dim)
+            if self.FUSED_RECURRENCE and latent.is_cuda and latent.dtype == torch.bfloat16 and N <= 48:
+                # GRU cell + both communication rounds in one kernel, one workgroup per environment (csrc/mapf_recur.hip)
+                hidden = self._recur_kernel(latent.view(1, E, N, ENC_FEATURES), hidden, comm_mask.unsqueeze(0), False)[0]
+                hidden = hidden.view(E * N, self.latent_dim)
+            else:
+                hidden = self.recurrent(latent) if hidden is None else self.recurrent(latent, hidden.to(latent.dtype))
+                hidden = self.comm(hidden.view(E, N, self.latent_dim), comm_mask).reshape(E * N, self.latent_dim)
             q = self.q_head(hidden).float().view(E, N, 5)
         return q.argmax(-1), q, hidden, comm_mask
 
@@ -309,6 +315,7 @@ class Network(nn.Module):
         self.hidden = None
 
     # ------------------------------------------------------------------ learner side
+    FUSED_RECURRENCE = True  # without autograd: GRU + CommBlock of all steps in one kernel (csrc/mapf_recur.hip), N <= 48
     SDPA = True  # fused scaled-dot-product attention inside _recur_fast
     FAST_RECURRENCE = True  # HIP device: hoisted input projection, fused QKV, deferred weight gradients (see _recur_fast)
 
@@ -334,6 +341,19 @@ class Network(nn.Module):
             q = self.q_head(sel)
         return q.float()
 
+    def _recur_kernel(self, latent_t, hidden, comm_t, want_agent0):
+        """latent_t bf16 [T, E, N, 784] (time-major); hidden [E*N, 256] or None; comm_t bool [T, E, N, N]
+        -> (hidden bf16 [E, N, 256], agent-0 states [T, E, 256] or None) through mapf_recurrent_infer."""
+        from .fused import PackedRecurrence, recurrent_infer
+
+        if self._packed_recur is None:
+            self._packed_recur = PackedRecurrence()
+        w, b = self._packed_recur.get(self)
+        T, E, N, _ = latent_t.shape
+        gi = F.linear(latent_t.reshape(T * E * N, ENC_FEATURES), self.recurrent.weight_ih.detach().to(torch.bfloat16)).view(T, E, N, 768)
+        h0 = None if hidden is None else hidden.reshape(E, N, self.latent_dim)
+        return recurrent_infer(gi, h0, comm_t, w, b, want_agent0)
+
     def _recur_fast(self, latent, hidden, comm_mask):
         """The T-step GRU + CommBlock recurrence of `bootstrap` (model.py:242-249), same math as the module path,
         arranged for the GPU:
@@ -346,6 +366,9 @@ class Network(nn.Module):
         D, H, A = self.latent_dim, NUM_COMM_HEADS, self.comm.output_dim
         lp = torch.bfloat16
         grad = torch.is_grad_enabled()
+        if not grad and self.FUSED_RECURRENCE and N <= 48:  # target network: all T steps in one kernel launch
+            a0 = self._recur_kernel(latent.transpose(0, 1), hidden, comm_mask.transpose(0, 1), True)[1]
+            return a0.transpose(0, 1)
         sink = _WGradSink() if grad else None
         rc, at, uc = self.recurrent, self.comm.self_attn, self.comm.update_cell
 

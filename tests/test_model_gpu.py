@@ -113,3 +113,41 @@ def test_fast_recurrence_matches_module_path():
         # W_K.bias has an exactly-zero true gradient (softmax is shift-invariant): both sides are rounding noise,
         # hence the absolute floor relative to the largest parameter gradient
         assert float((a - b).norm()) <= 6e-2 * float(b.norm()) + 1e-4 * scale, (k, float((a - b).norm()), float(b.norm()))
+
+
+@pytest.mark.parametrize("E,N,T", [(5, 7, 1), (3, 40, 4), (2, 48, 2), (4, 1, 3), (3, 17, 2)])
+def test_fused_recurrence_kernel_matches_module_path(E, N, T):
+    """mapf_recurrent_infer (GRU cell + two communication rounds per step, all T steps in one launch) against the
+    PyTorch module path at the same bf16 precision: actor step (T = 1, with and without an incoming hidden state) and
+    the no-gradient bootstrap (agent-0 states of every step -> Q-values)."""
+    from mapf_rl_amd.model import Network
+
+    torch.manual_seed(E * 100 + N)
+    net = Network().cuda()
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.1, 0.1)
+    g = torch.Generator(device="cuda").manual_seed(N)
+    obs = (torch.rand((E, T, N, 6, 9, 9), device="cuda", generator=g) < 0.3).to(torch.uint8)
+    comm = torch.rand((E, T, N, N), device="cuda", generator=g) < 0.25
+    comm |= torch.eye(N, dtype=torch.bool, device="cuda")
+    if N > 2:
+        comm[0, :, 1] = torch.eye(N, dtype=torch.bool, device="cuda")[1]   # an agent without partners keeps its state
+    hidden = (torch.randn((E * N, 256), device="cuda", generator=g) * 0.3).to(torch.bfloat16)
+    steps = torch.randint(1, T + 1, (E,), device="cuda", generator=g)
+    pos = torch.zeros((E, N, 2), dtype=torch.int16, device="cuda")
+    out = {}
+    for fused in (True, False):
+        Network.FUSED_RECURRENCE = fused
+        try:
+            a = net.step_batch(obs[:, 0], pos, None, comm[:, 0])
+            b = net.step_batch(obs[:, 0], pos, hidden, comm[:, 0])
+            with torch.no_grad():
+                q = net.bootstrap(obs, steps, hidden, comm)
+            out[fused] = (a[1], a[2].float(), b[1], b[2].float(), q)
+        finally:
+            Network.FUSED_RECURRENCE = True
+    for x, y in zip(out[True], out[False]):
+        assert x.shape == y.shape
+        assert torch.allclose(x, y, rtol=3e-2, atol=3e-2), float((x - y).abs().max())
