@@ -39,7 +39,7 @@ constexpr int NT = 3;            // agent tiles of 16: up to 48 agents per envir
 constexpr int NA = 16 * NT;
 constexpr int D = 256;           // hidden size (config.latent_dim)
 constexpr int HD = 64;           // attention head dim (comm output_dim)
-constexpr int NTHR = 256;        // 4 waves, one per SIMD (up to 512 VGPRs: the A fragments of a whole call stay in flight)
+constexpr int NTHR = 512;        // 8 waves: twice the weight loads in flight per CU (the kernel is bound by the L2 -> CU weight stream)
 
 // LDS image (bytes)
 constexpr int H_ROW = D * 2 + 32;          // 544
@@ -49,7 +49,7 @@ constexpr int VT_ROW = 64 * 2 + 32;        // v transposed: row = (head, d), 64 
 constexpr int P_ROW = 64 * 2 + 32;         // softmax weights bf16: row = (head, agent i), 64 agent slots j
 constexpr int CTX_ROW = 128 * 2 + 32;
 constexpr int INFO_ROW = 64 * 2 + 32;
-constexpr int S_ROW = NA + 1;              // scores fp32: row = (head, agent i)
+constexpr int S_ROW = NA + 4;              // scores fp32: row = (head, agent i), 16-byte aligned rows (float4 reads)
 constexpr int OFF_H0 = 0, OFF_H1 = OFF_H0 + H_BYTES;
 constexpr int OFF_QK = OFF_H1 + H_BYTES;
 constexpr int OFF_VT = OFF_QK + NA * QK_ROW;
@@ -277,18 +277,37 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                 const int hd = tid / NA, i = tid % NA;
                 uint16_t *prow = reinterpret_cast<uint16_t *>(smem + OFF_P + (hd * NA + i) * P_ROW);
                 if (i < N) {
-                    const uint64_t bits = (uint64_t)mb[2 * i] | ((uint64_t)mb[2 * i + 1] << 32);
-                    float *srow = S + (hd * NA + i) * S_ROW;
+                    const uint64_t bits = (uint64_t)mb[2 * i] | ((uint64_t)mb[2 * i + 1] << 32);  // bits >= N are 0
+                    const float4 *srow = reinterpret_cast<const float4 *>(S + (hd * NA + i) * S_ROW);
+                    // the whole row in registers (12 x 16-byte LDS reads; a scalar loop over j waits ~100 cycles per element)
+                    float v[NA];
+#pragma unroll
+                    for (int q = 0; q < NA / 4; ++q) {
+                        const float4 x = srow[q];
+                        v[4 * q] = x.x;
+                        v[4 * q + 1] = x.y;
+                        v[4 * q + 2] = x.z;
+                        v[4 * q + 3] = x.w;
+                    }
                     float mx = -3.0e38f;
-                    for (int j = 0; j < N; ++j) mx = fmaxf(mx, ((bits >> j) & 1ull) ? srow[j] : -1e9f);
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) {
+                        // model.py:77 masked_fill(-1e9), columns >= N likewise (weight 0 below); as a bit select, not a
+                        // predicate: 48 compile-time lane masks would live in scalar registers and spill
+                        const uint32_t m = 0u - (uint32_t)((bits >> j) & 1ull);
+                        v[j] = __uint_as_float((__float_as_uint(v[j]) & m) | (__float_as_uint(-1e9f) & ~m));
+                        mx = fmaxf(mx, v[j]);
+                    }
                     float sum = 0.f;
-                    for (int j = 0; j < N; ++j) {
-                        const float ex = __expf((((bits >> j) & 1ull) ? srow[j] : -1e9f) - mx);
-                        srow[j] = ex;
-                        sum += ex;
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) {
+                        v[j] = __expf(v[j] - mx);  // masked and padded columns: exp(-1e9 - mx) == 0 (a row always holds its own agent)
+                        sum += v[j];
                     }
                     const float inv = 1.f / sum;
-                    for (int j = 0; j < N; ++j) prow[j] = (uint16_t)(pack2_bf16(srow[j] * inv, 0.f) & 0xFFFFu);
+                    uint32_t *p32 = reinterpret_cast<uint32_t *>(prow);
+#pragma unroll
+                    for (int j = 0; j < NA; j += 2) p32[j / 2] = pack2_bf16(v[j] * inv, v[j + 1] * inv);
                     if (hd == 0) upd[i] = __popcll(bits) > 1 ? 1 : 0;  // model.py:103
                 } else if (hd == 0) {
                     upd[i] = 0;
