@@ -144,3 +144,16 @@ def test_deferred_weight_gradients_match_autograd():
     for a, b in zip(ref, got):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
         assert float((a - 1).abs().max()) > 1e-3             # a real gradient was added to the ones
+
+
+def test_fragment_packing_layouts():
+    """The MFMA A-fragment order documented in include/mapf_dqn.h for mapf_recurrent_infer's weights: element (o, k) of an
+    [O, K] matrix sits at tile o/16, k-step k/32, lane 16*((k%32)//8) + o%16, slot k%8 (pure index check, no GPU)."""
+    import torch
+
+    O, K = 48, 96
+    m = torch.arange(O * K, dtype=torch.float32).reshape(O, K)
+    packed = m.reshape(O // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1)   # the expression in fused.PackedRecurrence
+    for o, k in [(0, 0), (5, 7), (17, 40), (47, 95), (16, 32), (31, 63)]:
+        tile, ks, lane, slot = o // 16, k // 32, 16 * ((k % 32) // 8) + o % 16, k % 8
+        assert float(packed[((tile * (K // 32) + ks) * 64 + lane) * 8 + slot]) == float(m[o, k])
