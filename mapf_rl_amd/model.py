@@ -223,10 +223,12 @@ class Network(nn.Module):
 
     def encode(self, obs):
         """obs [M, 6, 9, 9] (uint8 / bool / float) -> [M, 784].
-        The batch is processed in chunks of ENCODE_CHUNK observations: MIOpen's convolution for one
-        138,240-observation call (192x18x40, the learner's window batch) returned non-finite rows for finite
-        inputs and weights on ROCm 7.2 / gfx950 (tools/nan_debug.py), and chunking bounds the activation
-        footprint (1.7 GB per layer at 138k observations)."""
+        On a HIP device under bf16 autocast the hand-written kernels run (csrc/mapf_encoder.hip, mapf_wgrad.hip): one
+        launch without autograd, forward-with-saved-activations + backward-data + weight-gradient launches with it.
+        Otherwise (CPU, fp32, the FUSED_* switches off) the layer-by-layer module path runs; on the GPU it is processed
+        in chunks of ENCODE_CHUNK observations: MIOpen's convolution for one 138,240-observation call (192x18x40, the
+        learner's window batch) returned non-finite rows for finite inputs and weights on ROCm 7.2 / gfx950, and
+        chunking bounds the activation footprint (1.7 GB per layer at 138k observations)."""
         w = self.obs_encoder[0].weight
         nhwc = w.device.type == "cuda"  # weights are stored channels_last (see __init__)
         bf16_autocast = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
