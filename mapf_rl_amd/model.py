@@ -382,11 +382,11 @@ class Network(nn.Module):
         u_ih, u_hh = cast(uc.weight_ih), cast(uc.weight_hh)
         HA = H * A
         keys = {
-            "hh": [(rc.weight_hh, None, 0, 3 * D)],
+            "hh": [(rc.weight_hh, rc.bias_hh, 0, 3 * D)],
             "qkv": [(at.W_Q.weight, at.W_Q.bias, 0, HA), (at.W_K.weight, at.W_K.bias, HA, 2 * HA), (at.W_V.weight, at.W_V.bias, 2 * HA, 3 * HA)],
             "o": [(at.W_O.weight, None, 0, A)],
-            "uih": [(uc.weight_ih, None, 0, 3 * D)],
-            "uhh": [(uc.weight_hh, None, 0, 3 * D)],
+            "uih": [(uc.weight_ih, uc.bias_ih, 0, 3 * D)],
+            "uhh": [(uc.weight_hh, uc.bias_hh, 0, 3 * D)],
         }
 
         def lin(x, w, b, name):
@@ -396,15 +396,18 @@ class Network(nn.Module):
 
         # all T input projections at once, time-major so that step t is a contiguous [B*N, 768] slab
         lat_t = latent.transpose(0, 1).reshape(T, B * N, ENC_FEATURES)
-        gi_all = F.linear(lat_t, rc.weight_ih.to(lp) if grad else cast(rc.weight_ih))
+        # biases are added by the linears (the GRU cell gets none): with autograd their gradients are then ONE deferred
+        # column sum per bias instead of a reduction per (step, cell) inside the fused cell's backward (96 launches)
+        b_hh, ub_ih, ub_hh = cast(rc.bias_hh), cast(uc.bias_ih), cast(uc.bias_hh)
+        gi_all = F.linear(lat_t, rc.weight_ih.to(lp), rc.bias_ih.to(lp)) if grad else F.linear(lat_t, cast(rc.weight_ih), cast(rc.bias_ih))
         blocked = (~comm_mask).unsqueeze(2)                              # [B, T, 1, N, N]
         allowed = comm_mask.unsqueeze(2)
         update = (comm_mask.sum(dim=-1) > 1).unsqueeze(-1)               # [B, T, N, 1]  (model.py:103)
         scale = 1.0 / (A ** 0.5)
         agent0 = []
         for t in range(T):
-            gh = lin(hidden, w_hh, None, "hh")
-            hidden = torch.ops.aten._thnn_fused_gru_cell(gi_all[t], gh, hidden, rc.bias_ih, rc.bias_hh)[0]
+            gh = lin(hidden, w_hh, b_hh, "hh")
+            hidden = torch.ops.aten._thnn_fused_gru_cell(gi_all[t], gh, hidden)[0]
             for _ in range(self.comm.num_layers):
                 qkv = lin(hidden, w_qkv, b_qkv, "qkv").view(B, N, 3, H, A)
                 q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2)
@@ -417,9 +420,9 @@ class Network(nn.Module):
                     attn = F.softmax(scores.masked_fill(blocked[:, t], -1e9), dim=-1)
                     ctx = torch.matmul(attn.to(lp), v).transpose(1, 2).reshape(B * N, HA)
                 info = lin(ctx, w_o, None, "o")
-                gi = lin(info, u_ih, None, "uih")
-                gh = lin(hidden, u_hh, None, "uhh")
-                new = torch.ops.aten._thnn_fused_gru_cell(gi, gh, hidden, uc.bias_ih, uc.bias_hh)[0]
+                gi = lin(info, u_ih, ub_ih, "uih")
+                gh = lin(hidden, u_hh, ub_hh, "uhh")
+                new = torch.ops.aten._thnn_fused_gru_cell(gi, gh, hidden)[0]
                 hidden = torch.where(update[:, t], new.view(B, N, D), hidden.view(B, N, D)).reshape(B * N, D)
             agent0.append(hidden.view(B, N, D)[:, 0])                    # only agent 0's state is learned from (:248)
         return torch.stack(agent0, dim=1)
