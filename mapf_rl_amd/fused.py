@@ -139,19 +139,6 @@ def _mask_bias(g, y, gb):
     return gx
 
 
-def _tall_tn(a, b, rows=4096):
-    """a^T b for a [K, m], b [K, n] with K in the millions and m, n tiny: BLAS libraries run such a shape as ONE
-    workgroup walking all of K (0.5 s here), so K is split into batches of `rows` (bmm), summed in fp32."""
-    K, m = a.shape
-    S = K // rows
-    out = torch.zeros((m, b.shape[1]), dtype=torch.float32, device=a.device)
-    if S:
-        out += torch.bmm(a[:S * rows].view(S, rows, m).transpose(1, 2), b[:S * rows].view(S, rows, -1)).sum(dim=0, dtype=torch.float32)
-    if K > S * rows:
-        out += torch.mm(a[S * rows:].t(), b[S * rows:]).float()
-    return out
-
-
 class _EncoderTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, obs, packed_w, packed_b, *params):
@@ -198,6 +185,8 @@ class _EncoderTrain(torch.autograd.Function):
         # (im2col of the 9x9 observation for conv0) -- no MIOpen anywhere in this path
         # (a strided window view, not F.unfold: its bf16 im2col kernel takes 0.5 s at this shape)
         cols = obs.to(torch.bfloat16).unfold(2, 3, 1).unfold(3, 3, 1).permute(0, 2, 3, 1, 4, 5).reshape(M * 49, 54)  # [position, ci*9 + ky*3 + kx]
+        from .model import _tall_tn  # split-K GEMM for [K, m]^T [K, n] with huge K
+
         gws[0] = _tall_tn(gz[0].reshape(M * 49, 128), cols).view(128, 6, 3, 3)
         gws[7] = _tall_tn(gz7.permute(0, 2, 3, 1).reshape(M * 49, 16), acts[6].reshape(M * 49, 128)).view(16, 128, 1, 1)
         grads = []

@@ -124,12 +124,27 @@ class _WGradSink:
         for key, xs, dys in items.values():
             X = torch.cat(xs, dim=0) if len(xs) > 1 else xs[0]
             DY = torch.cat(dys, dim=0) if len(dys) > 1 else dys[0]
-            gw = torch.mm(DY.t(), X)  # [out, in], fp32 accumulation inside the GEMM
+            gw = _tall_tn(DY, X)  # [out, in] fp32
             gb = DY.sum(dim=0, dtype=torch.float32)
             for w, b, lo, hi in key:
                 _accumulate(w, gw[lo:hi])
                 if b is not None:
                     _accumulate(b, gb[lo:hi])
+
+
+def _tall_tn(a, b, rows=8192):
+    """a^T b for a [K, m], b [K, n] with K in the 10^5..10^6 range and m, n a few hundred at most: one GEMM call gives the
+    BLAS library an output of a handful of tiles (a fraction of the chip walking all of K), so K is split into
+    batches of `rows` (bmm, bf16 in / fp32 accumulate inside each batch) that are then summed in fp32."""
+    K, m = a.shape
+    S = K // rows
+    out = None
+    if S > 1:
+        out = torch.bmm(a[:S * rows].view(S, rows, m).transpose(1, 2), b[:S * rows].view(S, rows, -1)).sum(dim=0, dtype=torch.float32)
+        if K > S * rows:
+            out += torch.mm(a[S * rows:].t(), b[S * rows:]).float()
+        return out
+    return torch.mm(a.t(), b).float()
 
 
 def _accumulate(p, g):
