@@ -173,6 +173,21 @@ class _TimeLinear(torch.autograd.Function):
         return (torch.mm(dy, w_lp) if ctx.needs_input_grad[0] else None), None, None, None, None, None
 
 
+class _Select(torch.autograd.Function):
+    """torch.where(cond, a, b) whose backward is two masked multiplies (autograd's own makes two zero tensors and two
+    more where-kernels per call; this runs 32 times per update)."""
+
+    @staticmethod
+    def forward(ctx, cond, a, b):
+        ctx.save_for_backward(cond)
+        return torch.where(cond, a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        (cond,) = ctx.saved_tensors
+        return None, g * cond, g * ~cond
+
+
 def comm_mask_from_pos(pos: torch.Tensor, obs_radius: int = OBS_RADIUS, max_comm: int = MAX_COMM_AGENTS) -> torch.Tensor:
     """pos [E, N, 2] (any integer/float dtype) -> bool [E, N, N]: j is within i's FOV square AND among i's
     `max_comm` nearest agents by Euclidean distance, itself included (reference model.py:195-208).
@@ -438,7 +453,7 @@ class Network(nn.Module):
                 gi = lin(info, u_ih, ub_ih, "uih")
                 gh = lin(hidden, u_hh, ub_hh, "uhh")
                 new = torch.ops.aten._thnn_fused_gru_cell(gi, gh, hidden)[0]
-                hidden = torch.where(update[:, t], new.view(B, N, D), hidden.view(B, N, D)).reshape(B * N, D)
+                hidden = _Select.apply(update[:, t], new.view(B, N, D), hidden.view(B, N, D)).reshape(B * N, D)
             agent0.append(hidden.view(B, N, D)[:, 0])                    # only agent 0's state is learned from (:248)
         return torch.stack(agent0, dim=1)
 
