@@ -266,6 +266,25 @@ def test_wgrad_kernel_against_fp32(M):
     assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), float((got - ref).abs().max())
 
 
+def test_training_step_is_bitwise_repeatable():
+    """No atomics anywhere in the fused training path (bias and weight gradients are per-workgroup / per-partition
+    partial sums added in a fixed order): two runs give bit-identical latents and parameter gradients."""
+    net = _net(31)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    obs = (torch.rand((777, 6, 9, 9), device="cuda", generator=g) < 0.3).to(torch.uint8)
+    gl = torch.randn((777, 784), device="cuda", generator=g)
+    runs = []
+    for _ in range(2):
+        net.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            lat = net.encode(obs)
+        (lat.float() * gl).sum().backward()
+        runs.append((lat.detach().clone(), [p.grad.detach().clone() for p in net.obs_encoder.parameters()]))
+    assert torch.equal(runs[0][0], runs[1][0])
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(a, b)
+
+
 def test_encoder_argument_checks():
     from mapf_rl_amd._lib import ERR_INVALID_ARG, lib
 
