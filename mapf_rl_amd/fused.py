@@ -165,6 +165,7 @@ class _EncoderTrain(torch.autograd.Function):
         o4 = out.view(M, 16, 7, 7).contiguous(memory_format=cl)
         g4 = g.to(torch.bfloat16).reshape(M, 16, 7, 7).contiguous(memory_format=cl)
         gz7 = _mask_bias(g4, o4, gb7)
+        gb7 = gz7.sum(dim=(0, 2, 3), dtype=torch.float32)  # (the mask kernel's own bias sum uses float atomics: not repeatable)
         # the whole backward-data chain: one kernel, masked pre-activation gradients of all 7 layers out
         w32 = [params[2 * i].detach().to(torch.float32).contiguous() for i in range(8)]
         wpt = torch.empty(ENC_PACKED_BWD_ELEMS, dtype=torch.bfloat16, device=dev)
