@@ -89,7 +89,8 @@ int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint32_
  * sums, fp32 [MAPF_ENC_WGRAD_PARTS][128][3][3][128] (co, ky, kx, ci -- the channels_last order of a [co][ci][3][3]
  * weight); the weight gradient is their sum over the first axis (deterministic, no atomics).
  */
-#define MAPF_ENC_WGRAD_PARTS 80
+#define MAPF_ENC_WGRAD_PARTS 128
+#define MAPF_ENC_WGRAD_SLABS 2 /* internal: column slabs of the output, one workgroup each per partition */
 int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M, float *partial_dev, void *stream);
 
 /*

@@ -9,10 +9,14 @@
 // (mapf_encoder_forward_save), both bf16 [M][49][128].  As a GEMM: 128 (co) x 1152 (tap, ci) outputs, K = all
 // positions of all observations -- tiny output, enormous K, so the output is held in registers and the
 // operands stream through LDS:
-//  * A workgroup (256 threads, ONE wave per SIMD, up to 512 VGPRs) owns the slab [128 co] x [one ky: 3 kx x 128 ci]
-//    for a partition of the observations: wave w holds 128 co x 96 columns = 8 x 6 tiles of 16x16 (192
-//    accumulator registers).  LDS bytes per MFMA stay at 29 % of the LDS peak; a smaller per-wave block would
-//    be LDS-bound.
+//  * A workgroup (512 threads = 8 waves, two per SIMD) owns one of TWO column slabs [128 co] x [576 of the 1152
+//    (tap, ci) columns] for a partition of the observations; wave w holds 64 co x 144 columns = 4 x 9 tiles of 16x16
+//    (144 accumulator registers).  Three narrower slabs at one wave per SIMD (the first version) pull the same 25 KB
+//    per observation into 1.5x as many CUs -- the kernel is bound by that L2 -> CU stream, not by MFMA or LDS.
+//  * The MFMA is inline asm with the destination TIED to the accumulator: hipcc does not tie the builtin's, and a loop
+//    that carries its accumulators then needs register-shuffle space (v_accvgpr_mov storms at one wave per SIMD,
+//    hundreds of spills at 256 registers).  asm is opaque to hipcc's hazard padding: operands come from LDS reads (the
+//    wait-count pass still sees the registers), and two s_nop 15 precede the epilogue's accumulator reads.
 //  * Both operands need K (= position) along the fragment's register axis while memory has channels contiguous:
 //    ds_read_b64_tr_b16 (hardware transpose read) delivers a [4 positions x 16 channels] block column-major.  Rows
 //    are 288 B apart (256 + 32) so that the 8 consecutive rows a half-wave reads fall in distinct banks.
@@ -22,7 +26,7 @@
 //  * One observation (64 K rows = 2 k-steps, 96 MFMAs per wave) per step through a ring of three LDS buffers: while
 //    observation i is multiplied, i+1 is already resident (its first fragments are prefetched during i's last k-step,
 //    so the hand-over exposes nothing but the barrier) and i+2 travels HBM -> registers -> the third buffer.
-//  * The three ky-slabs of one observation partition run on the same XCD (ids i, i+8, i+16 share an L2), so the
+//  * The two slabs of one observation partition run on the same XCD (ids i, i+8 share an L2), so the
 //    operands come from HBM once.
 //  * Output: per-partition partial sums fp32 [P][128][3][3][128]; the caller adds the P slabs (deterministic).
 #include <hip/hip_runtime.h>
@@ -43,12 +47,14 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 template <int V>
 using I = std::integral_constant<int, V>;
 
-#ifndef MAPF_WGRAD_SETS  // register sets of the HBM -> LDS staging: 1 = prefetch distance 2 observations, 2 = distance 3
-#define MAPF_WGRAD_SETS 1
-#endif
 #ifndef MAPF_WGRAD_ABLATE  // diagnostic builds only (tools/micro/wgrad_ablate.py): 1 = no staging, 2 = no fragment reads, 4 = no barrier
 #define MAPF_WGRAD_ABLATE 0
 #endif
+constexpr int SLABS = MAPF_ENC_WGRAD_SLABS;   // column slabs of the 128 x 1152 output: one workgroup each per partition (2)
+constexpr int NTHR = 512;                    // 8 waves = 2 co halves x 4 column quarters of the slab
+constexpr int CT = 4;                        // 16-row co tiles per wave (64 co)
+constexpr int NTN = 1152 / SLABS / 4 / 16;    // 16-column tiles per wave (9: 144 columns); 144 accumulator registers
+static_assert(NTN * 16 * 4 * SLABS == 1152 && (2 * NTN) % 3 == 0 && NTN >= CT, "");
 constexpr int WROW = 288;                    // LDS bytes per position row
 constexpr int GZ_ROWS = 64;                  // one observation = 64 rows of K (2 k-steps of 32), 49 of them non-zero
 constexpr int IN_ROWS = 64 + 18;             // input image rows reachable through the 9 taps
@@ -72,12 +78,13 @@ __device__ __forceinline__ bf16x8 tr_read2(const unsigned char *p0, const unsign
     return u.v;
 }
 
-__global__ void __launch_bounds__(256, 1) encoder_wgrad_kernel(const uint16_t *__restrict__ gz, const uint16_t *__restrict__ ain,
+__global__ void __launch_bounds__(NTHR, 1) encoder_wgrad_kernel(const uint16_t *__restrict__ gz, const uint16_t *__restrict__ ain,
                                                               long long M, float *__restrict__ ws) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * OBS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-    const int ky = slot % 3, part = (slot / 3) * 8 + xcd;
+    const int slab = slot % SLABS, part = (slot / SLABS) * 8 + xcd;
+    const int chalf = w & 1, nq = w >> 1;  // this wave's 64 output channels / 144 columns of the slab
 
     // observations of this partition
     const long long per = (M + MAPF_ENC_WGRAD_PARTS - 1) / MAPF_ENC_WGRAD_PARTS;
@@ -85,68 +92,61 @@ __global__ void __launch_bounds__(256, 1) encoder_wgrad_kernel(const uint16_t *_
     long long nob = M - ob0;
     nob = nob < 0 ? 0 : (nob > per ? per : nob);
 
-    for (int i = tid; i < NBUF * OBS_BYTES / 16; i += 256) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < NBUF * OBS_BYTES / 16; i += NTHR) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
 
     // ---- staging: an observation is 784 16-byte chunks of gz and 784 of the input (49 positions x 16) ----
-    // loads 0-2 / 4-6: chunk tid + 256 i of gz / of the input (wave-uniform base + tid*16: no per-load address math);
-    // load 3: the last 16 chunks of each tensor (position 48) on threads 0-15 / 16-31, a harmless duplicate elsewhere.
-    // At one wave per SIMD every VALU instruction of the staging code delays an MFMA, hence this shape.
-    int dst[3];  // LDS byte offset of gz chunk tid + 256 i inside an observation buffer; the input chunk sits GZ_BYTES + 9 rows further
+    // per tensor: chunk tid, and chunk 512 + tid on threads 0-271 (a harmless duplicate load elsewhere); wave-uniform
+    // base + tid*16, no per-load address math.
+    int dst[2];  // LDS byte offset of gz chunk tid + 512 i inside an observation buffer; the input chunk sits IN_SHIFT further
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int q = (tid >> 4) + 16 * i, y = q / 7, x = q - 7 * y;
-        dst[i] = (8 * y + x) * WROW + (tid & 15) * 16;
+    for (int i = 0; i < 2; ++i) {
+        const int tt = i == 0 ? tid : (tid < 272 ? tid : 271);
+        const int q = (tt >> 4) + 32 * i, y = q / 7, x = q - 7 * y;
+        dst[i] = (8 * y + x) * WROW + (tt & 15) * 16;
     }
     constexpr int IN_SHIFT = GZ_BYTES + 9 * WROW;
-    const bool tail_in = (tid >> 4) & 1;  // load 3: threads 16-31 carry the input tensor's position 48
-    const int dst3 = (8 * 6 + 6) * WROW + (tid & 15) * 16 + (tail_in ? IN_SHIFT : 0);
-    const int v16 = tid * 16, v16t = (tid & 15) * 16;
-    // (plain structs of seven named registers and compile-time set selection: hipcc puts an ARRAY that is passed to a
-    // lambda or indexed by a lambda parameter into scratch memory or LDS)
+    const int v16 = tid * 16, v16b = (tid < 272 ? tid : 271) * 16;
+    // (a plain struct of named native-vector registers: hipcc puts an ARRAY that is passed to a lambda or indexed by a
+    // lambda parameter into scratch memory or LDS, and HIP's uint4 is a struct with unions)
     struct Stage {
-        u32x4 g0, g1, g2, t3, a0, a1, a2;  // native vectors: first-class SSA values (HIP's uint4 is a struct with unions)
+        u32x4 g0, g1, a0, a1;
     };
     Stage stg0;
-#if MAPF_WGRAD_SETS == 2
-    Stage stg1;  // observation j travels in set j % 2 and is loaded TWO steps before it is written to LDS
-#endif
     auto load_into = [&](Stage &st, long long ob) __attribute__((always_inline)) {
         const char *g = reinterpret_cast<const char *>(gz + ob * 6272), *a = reinterpret_cast<const char *>(ain + ob * 6272);
         st.g0 = *reinterpret_cast<const u32x4 *>(g + v16);
-        st.g1 = *reinterpret_cast<const u32x4 *>(g + 4096 + v16);
-        st.g2 = *reinterpret_cast<const u32x4 *>(g + 8192 + v16);
-        st.t3 = *reinterpret_cast<const u32x4 *>((tail_in ? a : g) + 12288 + v16t);
+        st.g1 = *reinterpret_cast<const u32x4 *>(g + 8192 + v16b);
         st.a0 = *reinterpret_cast<const u32x4 *>(a + v16);
-        st.a1 = *reinterpret_cast<const u32x4 *>(a + 4096 + v16);
-        st.a2 = *reinterpret_cast<const u32x4 *>(a + 8192 + v16);
+        st.a1 = *reinterpret_cast<const u32x4 *>(a + 8192 + v16b);
     };
     auto store_from = [&](const Stage &st, int buf) __attribute__((always_inline)) {
         unsigned char *base = smem + buf * OBS_BYTES;
         *reinterpret_cast<u32x4 *>(base + dst[0]) = st.g0;
-        *reinterpret_cast<u32x4 *>(base + dst[1]) = st.g1;
-        *reinterpret_cast<u32x4 *>(base + dst[2]) = st.g2;
         *reinterpret_cast<u32x4 *>(base + dst[0] + IN_SHIFT) = st.a0;
-        *reinterpret_cast<u32x4 *>(base + dst[1] + IN_SHIFT) = st.a1;
-        *reinterpret_cast<u32x4 *>(base + dst[2] + IN_SHIFT) = st.a2;
-        if (tid < 32) *reinterpret_cast<u32x4 *>(base + dst3) = st.t3;
+        if (tid < 272) {
+            *reinterpret_cast<u32x4 *>(base + dst[1]) = st.g1;
+            *reinterpret_cast<u32x4 *>(base + dst[1] + IN_SHIFT) = st.a1;
+        }
     };
 
     // ---- fragment addresses of this lane (ds_read_b64_tr_b16: lane 4q+p of a 16-lane group supplies row q, columns 4p..) ----
     const int li = lane & 15, lh = lane >> 4, q4 = li >> 2, p4 = li & 3;
     // k-slot (lh, j) of a 32-row k-step: row 4 lh + j for j < 4 (first read), 16 + 4 lh + (j - 4) for the second
-    const int a_base = (4 * lh + q4) * WROW + 8 * p4;
-    int b_base[6];
+    const int a_base = (4 * lh + q4) * WROW + 8 * p4 + (CT * chalf) * 32;
+    // output column = (tap, ci): this wave's tile t covers columns col0(t) .. +16
+    auto col0 = [&](int t) { return (1152 / SLABS) * slab + (16 * NTN) * nq + 16 * t; };
+    int b_base[NTN];
 #pragma unroll
-    for (int t = 0; t < 6; ++t) {
-        const int n0 = 96 * w + 16 * t, kx = n0 >> 7, ci0 = n0 & 127;
-        b_base[t] = GZ_BYTES + (4 * lh + q4 + 8 * ky + kx) * WROW + 8 * p4 + ci0 * 2;
+    for (int t = 0; t < NTN; ++t) {
+        const int c = col0(t), tap = c >> 7, ci0 = c & 127;
+        b_base[t] = GZ_BYTES + (4 * lh + q4 + 8 * (tap / 3) + tap % 3) * WROW + 8 * p4 + ci0 * 2;
     }
 
-    f32x4 acc[8][6];
+    f32x4 acc[CT][NTN];
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int t = 0; t < 6; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NTN; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     __syncthreads();  // zero fill done
     if (nob > 0) {
@@ -157,19 +157,18 @@ __global__ void __launch_bounds__(256, 1) encoder_wgrad_kernel(const uint16_t *_
         load_into(stg0, ob0 + 1);
         store_from(stg0, 1);
     }
-#if MAPF_WGRAD_SETS == 2
-    if (nob > 2) load_into(stg0, ob0 + 2);  // written to buffer 2 at the end of step 0, like every later observation
-#endif  // written to buffer 2 at the end of step 0, like every later observation
     __syncthreads();
 
-    bf16x8 af[2][8], bfr[2][6];
+    // fragments: the CT gz (A) tiles of the current k-step and of the next one; the input (B) tiles pass through a ring of
+    // three (tile t's MFMAs run while tile t+2 is being read)
+    bf16x8 af[2][CT], br[3];
     auto read_a = [&](const unsigned char *sb, int ks, int c) { return tr_read2(sb + a_base + (32 * ks) * WROW + c * 32, sb + a_base + (32 * ks + 16) * WROW + c * 32); };
     auto read_b = [&](const unsigned char *sb, int ks, int t) { return tr_read2(sb + b_base[t] + (32 * ks) * WROW, sb + b_base[t] + (32 * ks + 16) * WROW); };
     if (nob > 0) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) af[0][c] = read_a(smem, 0, c);
-#pragma unroll
-        for (int t = 0; t < 6; ++t) bfr[0][t] = read_b(smem, 0, t);
+        for (int c = 0; c < CT; ++c) af[0][c] = read_a(smem, 0, c);
+        br[0] = read_b(smem, 0, 0);
+        br[1] = read_b(smem, 0, 1);
     }
 
     // One observation (step i): 2 k-steps x 48 MFMAs on buffer `b`; the fragments of its second k-step, then of the
@@ -177,51 +176,35 @@ __global__ void __launch_bounds__(256, 1) encoder_wgrad_kernel(const uint16_t *_
     // Staging: observation i + 2 is loaded HBM -> registers at the start of the step and written to the free buffer
     // b2 after the MFMAs, before the barrier.
     auto one_obs = [&](long long i, auto B, auto B1, auto B2, auto PAR) __attribute__((always_inline)) {
-        constexpr int b = decltype(B)::value, b1 = decltype(B1)::value, b2 = decltype(B2)::value, par = decltype(PAR)::value;
+        constexpr int b = decltype(B)::value, b1 = decltype(B1)::value, b2 = decltype(B2)::value;
         const unsigned char *sb = smem + b * OBS_BYTES, *sb1 = smem + b1 * OBS_BYTES;
-#if MAPF_WGRAD_SETS == 2
-        if (i + 3 < nob && !(MAPF_WGRAD_ABLATE & 1)) {
-            if constexpr (par == 0)
-                load_into(stg1, ob0 + i + 3);
-            else
-                load_into(stg0, ob0 + i + 3);
-        }
-#else
         if (i + 2 < nob && !(MAPF_WGRAD_ABLATE & 1)) load_into(stg0, ob0 + i + 2);  // in flight during this observation's MFMAs
-#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int cur = ks, nxt = ks ^ 1;
+            // the k-step after this one: (this observation, ks 1) or (next observation, ks 0; past the last observation sb1
+            // holds stale but valid LDS: harmless)
+            const unsigned char *nbuf = ks == 0 ? sb : sb1;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-#pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    const int m = c * 6 + t;  // one of the 14 next fragments behind every third MFMA
-                    if (m % 3 == 0 && m / 3 < 14 && !(MAPF_WGRAD_ABLATE & 2)) {
-                        const int f = m / 3;
-                        const unsigned char *src_buf = ks == 0 ? sb : sb1;  // past the last observation sb1 holds stale but valid LDS: harmless
-                        if (f < 8)
-                            af[nxt][f] = read_a(src_buf, nxt, f);
-                        else
-                            bfr[nxt][f - 8] = read_b(src_buf, nxt, f - 8);
-                    }
-                    acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][c], bfr[cur][t], acc[c][t], 0, 0, 0);
-                    if (m % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+            for (int t = 0; t < NTN; ++t) {
+                const int g = ks * NTN + t;  // 2 * NTN tiles per observation, a multiple of 3: ring slots repeat per observation
+                if (!(MAPF_WGRAD_ABLATE & 2)) {
+                    if (t + 2 < NTN)
+                        br[(g + 2) % 3] = read_b(sb, ks, t + 2);
+                    else
+                        br[(g + 2) % 3] = read_b(nbuf, nxt, t + 2 - NTN);
+                    if (t < CT) af[nxt][t] = read_a(nbuf, nxt, t);
                 }
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    // tied destination: hipcc does not tie the builtin's, and shuffles 4 registers per MFMA on the loop back-edge
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[c][t]) : "v"(af[cur][c]), "v"(br[g % 3]));
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-#if MAPF_WGRAD_SETS == 2
-        if (i + 2 < nob && !(MAPF_WGRAD_ABLATE & 1)) {
-            if constexpr (par == 0)
-                store_from(stg0, b2);
-            else
-                store_from(stg1, b2);
-        }
-#else
         if (i + 2 < nob && !(MAPF_WGRAD_ABLATE & 1)) store_from(stg0, b2);
-#endif
         if (!(MAPF_WGRAD_ABLATE & 4)) __syncthreads();
     };
     // Six observations per loop iteration (two turns of the buffer ring): every buffer offset is a constant, and the
@@ -229,32 +212,27 @@ __global__ void __launch_bounds__(256, 1) encoder_wgrad_kernel(const uint16_t *_
     // destination to its source: 192 v_accvgpr_mov per iteration, which HALVED the MFMA rate with one observation per
     // iteration) is paid once per 576 MFMAs.
     long long i = 0;
-    for (; i + 6 <= nob; i += 6) {
+    for (; i + 3 <= nob; i += 3) {
         one_obs(i, I<0>{}, I<1>{}, I<2>{}, I<0>{});
-        one_obs(i + 1, I<1>{}, I<2>{}, I<0>{}, I<1>{});
+        one_obs(i + 1, I<1>{}, I<2>{}, I<0>{}, I<0>{});
         one_obs(i + 2, I<2>{}, I<0>{}, I<1>{}, I<0>{});
-        one_obs(i + 3, I<0>{}, I<1>{}, I<2>{}, I<1>{});
-        one_obs(i + 4, I<1>{}, I<2>{}, I<0>{}, I<0>{});
-        one_obs(i + 5, I<2>{}, I<0>{}, I<1>{}, I<1>{});
     }
-    // tail (i % 6 == 0 here, so the ring and the register sets are in their initial phase)
+    // tail (i % 3 == 0 here, so the ring is in its initial phase)
     if (i < nob) one_obs(i, I<0>{}, I<1>{}, I<2>{}, I<0>{});
-    if (i + 1 < nob) one_obs(i + 1, I<1>{}, I<2>{}, I<0>{}, I<1>{});
-    if (i + 2 < nob) one_obs(i + 2, I<2>{}, I<0>{}, I<1>{}, I<0>{});
-    if (i + 3 < nob) one_obs(i + 3, I<0>{}, I<1>{}, I<2>{}, I<1>{});
-    if (i + 4 < nob) one_obs(i + 4, I<1>{}, I<2>{}, I<0>{}, I<0>{});
+    if (i + 1 < nob) one_obs(i + 1, I<1>{}, I<2>{}, I<0>{}, I<0>{});
 
-    // ---- partial sums of this partition: ws[part][co][ky][kx][ci] ----
+    // ---- partial sums of this partition: ws[part][co][tap = ky*3 + kx][ci] ----
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the asm MFMAs are opaque to hipcc's hazard padding: let the last ones retire
     float *out = ws + (long long)part * (128 * 9 * 128);
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            const int n0 = 96 * w + 16 * t, kx = n0 >> 7, ci = (n0 & 127) + li;
+        for (int t = 0; t < NTN; ++t) {
+            const int cc = col0(t), tap = cc >> 7, ci = (cc & 127) + li;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = 16 * c + 4 * lh + r;
-                out[((co * 3 + ky) * 3 + kx) * 128 + ci] = acc[c][t][r];
+                const int co = 16 * (CT * chalf + c) + 4 * lh + r;
+                out[(co * 9 + tap) * 128 + ci] = acc[c][t][r];
             }
         }
 }
@@ -278,7 +256,7 @@ int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M
         (reinterpret_cast<uintptr_t>(partial_dev) & 15))
         return MAPF_ERR_INVALID_ARG;
     // every partition writes its slab (zeros when it has no observations), so the caller's sum is always defined
-    hipLaunchKernelGGL(encoder_wgrad_kernel, dim3(3 * MAPF_ENC_WGRAD_PARTS), dim3(256), 0, static_cast<hipStream_t>(stream), gz_dev,
+    hipLaunchKernelGGL(encoder_wgrad_kernel, dim3(SLABS * MAPF_ENC_WGRAD_PARTS), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gz_dev,
                        in_dev, (long long)M, partial_dev);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;

@@ -56,7 +56,7 @@ def bias_res_relu(conv_out, bias, res=None):
 ENC_PACKED_ELEMS = 894976
 ENC_BIAS_ELEMS = 912
 ENC_PACKED_BWD_ELEMS = 888832
-ENC_WGRAD_PARTS = 80
+ENC_WGRAD_PARTS = 128
 ENC_OBS_PER_BLOCK = 4
 _ENC_OBS_U8, _ENC_OBS_BF16 = 0, 1
 

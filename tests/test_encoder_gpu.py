@@ -258,7 +258,7 @@ def test_wgrad_kernel_against_fp32(M):
     g = torch.Generator(device="cuda").manual_seed(M)
     gz = (torch.randn((M, 7, 7, 128), device="cuda", generator=g) * (torch.rand((M, 7, 7, 128), device="cuda", generator=g) < 0.5)).to(torch.bfloat16)
     a = torch.relu(torch.randn((M, 7, 7, 128), device="cuda", generator=g)).to(torch.bfloat16)
-    ws = torch.full((80, 128, 3, 3, 128), float("nan"), dtype=torch.float32, device="cuda")
+    ws = torch.full((128, 128, 3, 3, 128), float("nan"), dtype=torch.float32, device="cuda")  # MAPF_ENC_WGRAD_PARTS slabs
     check(lib.mapf_encoder_wgrad(gz.data_ptr(), a.data_ptr(), M, ws.data_ptr(), None), "mapf_encoder_wgrad")
     got = ws.sum(0).permute(0, 3, 1, 2)                                         # [co, ci, ky, kx]
     ref = torch.nn.grad.conv2d_weight(a.float().permute(0, 3, 1, 2), (128, 128, 3, 3), gz.float().permute(0, 3, 1, 2), padding=1)

@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-MODES = [0, 1, 7, 100]  # 100: no ablation, two staging register sets (-DMAPF_WGRAD_SETS=2)
+MODES = [0, 1, 7]
 
 
 def so(mode):
@@ -19,7 +19,7 @@ def so(mode):
 def build():
     for m in MODES:
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-                               "-DMAPF_WGRAD_ABLATE=%d" % (m % 100), "-DMAPF_WGRAD_SETS=%d" % (2 if m >= 100 else 1), os.path.join(ROOT, "mapf_rl_amd", "csrc", "mapf_wgrad.hip"), "-o", so(m)])
+                               "-DMAPF_WGRAD_ABLATE=%d" % m, os.path.join(ROOT, "mapf_rl_amd", "csrc", "mapf_wgrad.hip"), "-o", so(m)])
 
 
 def run():
@@ -28,7 +28,7 @@ def run():
     M = 122880
     gz = (torch.randn((M, 49, 128), device="cuda") * (torch.rand((M, 49, 128), device="cuda") < 0.5)).to(torch.bfloat16)
     a = torch.relu(torch.randn((M, 49, 128), device="cuda")).to(torch.bfloat16)
-    ws = torch.empty((80, 128, 9, 128), dtype=torch.float32, device="cuda")
+    ws = torch.empty((128, 128, 9, 128), dtype=torch.float32, device="cuda")
     for m in MODES:
         lib = ctypes.CDLL(so(m))
         fn = lib.mapf_encoder_wgrad
