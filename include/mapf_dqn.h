@@ -118,6 +118,28 @@ int mapf_recurrent_infer(const uint16_t *gi_dev, const uint16_t *h0_dev, const u
                          uint16_t *agent0_out_dev, void *stream);
 
 /*
+ * Training pair of mapf_recurrent_infer (csrc/mapf_recur.hip, csrc/mapf_recur_bwd.hip): the same forward, additionally
+ * storing what backward-through-time needs, and the backward kernel (one workgroup per environment, steps in reverse).
+ *   save_dev[8] (all bf16, R = T*E*N rows, row = (t*E + e)*N + agent):
+ *     0 hin0 [R][256] state entering the step | 1 g1 [R][4][256] r, z, n, W_hn h + b_hn of the recurrent cell |
+ *     2 hr [2][R][256] state entering round 0/1 | 3 qkv [2][R][384] | 4 ctx [2][R][128] | 5 info [2][R][64] |
+ *     6 g2 [2][R][4][256] gates of the update cell | 7 P [2][T*E][2][48][64] attention weights (zero padded)
+ *   mapf_recurrent_backward: d_agent0_dev bf16 [T][E][256] = gradient w.r.t. agent 0's state after every step;
+ *     weights_t_dev = the TRANSPOSED matrices in fragment order: per gate g (r, z, n) U_ih[g]^T [64][256] | per gate
+ *     U_hh[g]^T [256][256] | per gate W_hh[g]^T [256][256] | W_O^T [128][64] | W_qkv^T [256][384]
+ *     (MAPF_RECUR_WEIGHT_ELEMS bf16);
+ *   out_dev[6] (bf16): 0 d_gi1 [R][768] gradient w.r.t. the GRU input projection gi | 1 d_gh1 [R][768] |
+ *     2 d_gi2 [2][R][768] | 3 d_gh2 [2][R][768] | 4 d_info [2][R][64] | 5 d_qkv [2][R][384]
+ *   -- the gradients of the pre-activations of every linear map; weight gradient = (that)^T (its saved input), bias
+ *   gradient = its column sum, both formed by the caller (six tall GEMMs per update).
+ */
+int mapf_recurrent_forward_save(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev,
+                                const uint16_t *weights_dev, const float *bias_dev, int T, int E, int N,
+                                uint16_t *h_out_dev, uint16_t *agent0_out_dev, uint16_t *const *save_dev, void *stream);
+int mapf_recurrent_backward(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev,
+                            const uint16_t *weights_t_dev, int T, int E, int N, uint16_t *const *out_dev, void *stream);
+
+/*
  * Communication mask of `Network.step` (reference model.py:195-208): mask[e][i][j] = j lies inside i's FOV square
  * (|drow| <= r and |dcol| <= r) AND j is among i's `max_comm` nearest agents by Euclidean distance, i itself
  * included; distance ties go to the LOWEST agent index (the reference's CPU topk leaves ties unspecified).

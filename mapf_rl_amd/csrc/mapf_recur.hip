@@ -135,7 +135,7 @@ template <bool GI_GLOBAL, int KI>
 __device__ __forceinline__ void gru_block(int cblk, const uint16_t *__restrict__ gi_glob, const uint16_t *__restrict__ Wi,
                                           const unsigned char *Xi, int xirow, const uint16_t *__restrict__ Wh, const float *__restrict__ bi,
                                           const float *__restrict__ bh, const unsigned char *Hin, unsigned char *Hout, const int *upd,
-                                          int nagents, int lr, int lh) {
+                                          int nagents, int lr, int lh, uint16_t *__restrict__ gsave = nullptr) {
     f32x4 ar[NT], az[NT], ani[NT], anh[NT];
     const int c0 = 16 * cblk + 4 * lh;  // this lane's 4 channels
     const float4 bir = *reinterpret_cast<const float4 *>(bi + c0), biz = *reinterpret_cast<const float4 *>(bi + 256 + c0),
@@ -167,22 +167,46 @@ __device__ __forceinline__ void gru_block(int cblk, const uint16_t *__restrict__
         const int agent = 16 * n + lr;
         const uint2 hv = *reinterpret_cast<const uint2 *>(Hin + agent * H_ROW + c0 * 2);
         const float h[4] = {bf16_lo(hv.x), bf16_hi(hv.x), bf16_lo(hv.y), bf16_hi(hv.y)};
-        float o[4];
+        float o[4], rg4[4], zg4[4], ng4[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float rg = sigmoidf_(ar[n][r]), zg = sigmoidf_(az[n][r]);
             const float ng = tanhf_(ani[n][r] + rg * anh[n][r]);
             o[r] = (1.f - zg) * ng + zg * h[r];
+            rg4[r] = rg;
+            zg4[r] = zg;
+            ng4[r] = ng;
+        }
+        if (gsave != nullptr && agent < nagents) {  // training forward: r, z, n, W_hn h + b_hn of this cell for the backward pass
+            uint16_t *gs = gsave + (long long)agent * 1024 + c0;
+            *reinterpret_cast<uint2 *>(gs) = make_uint2(pack2_bf16(rg4[0], rg4[1]), pack2_bf16(rg4[2], rg4[3]));
+            *reinterpret_cast<uint2 *>(gs + 256) = make_uint2(pack2_bf16(zg4[0], zg4[1]), pack2_bf16(zg4[2], zg4[3]));
+            *reinterpret_cast<uint2 *>(gs + 512) = make_uint2(pack2_bf16(ng4[0], ng4[1]), pack2_bf16(ng4[2], ng4[3]));
+            *reinterpret_cast<uint2 *>(gs + 768) = make_uint2(pack2_bf16(anh[n][0], anh[n][1]), pack2_bf16(anh[n][2], anh[n][3]));
         }
         const bool keep = upd != nullptr && upd[agent] == 0;
         *reinterpret_cast<uint2 *>(Hout + agent * H_ROW + c0 * 2) = keep ? hv : make_uint2(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]));
     }
 }
 
+// what the training forward stores for the backward kernel (csrc/mapf_recur_bwd.hip); R = T*E*N rows, row = (t*E + e)*N + agent
+struct RecurSave {
+    uint16_t *hin0;  // [R][256]       state entering the step
+    uint16_t *g1;    // [R][4][256]    r, z, n, W_hn h + b_hn of the recurrent cell
+    uint16_t *hr;    // [2][R][256]    state entering communication round 0 / 1
+    uint16_t *qkv;   // [2][R][384]
+    uint16_t *ctx;   // [2][R][128]
+    uint16_t *info;  // [2][R][64]
+    uint16_t *g2;    // [2][R][4][256] gate terms of the update cell
+    uint16_t *P;     // [2][T*E][2][48][64] attention weights (heads x agents x 64 agent slots, zero padded)
+};
+
+template <bool SAVE>
 __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t *__restrict__ gi, const uint16_t *__restrict__ h0,
                                                                   const uint8_t *__restrict__ comm, const uint16_t *__restrict__ W,
                                                                   const float *__restrict__ bias, int T, int E, int N,
-                                                                  uint16_t *__restrict__ h_out, uint16_t *__restrict__ agent0_out) {
+                                                                  uint16_t *__restrict__ h_out, uint16_t *__restrict__ agent0_out,
+                                                                  RecurSave sv) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lh = lane >> 4;
     const int e = blockIdx.x;
@@ -206,7 +230,16 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
     uint32_t *mb = reinterpret_cast<uint32_t *>(smem + OFF_MB);
     const float scale = 0.125f;  // 1 / sqrt(64)
 
+    const long long RTOT = (long long)T * E * N;
+    auto save_hidden = [&](uint16_t *dst_rows, const unsigned char *H) {  // N rows of 256 bf16 from an LDS hidden image
+        for (int i = tid; i < N * 32; i += NTHR) {
+            const int a = i >> 5, ch = i & 31;
+            *reinterpret_cast<uint4 *>(dst_rows + (long long)a * D + ch * 8) = *reinterpret_cast<const uint4 *>(H + a * H_ROW + ch * 16);
+        }
+    };
     for (int t = 0; t < T; ++t) {
+        const long long row0 = ((long long)t * E + e) * N;  // first saved row of this (step, environment)
+        if (SAVE) save_hidden(sv.hin0 + row0 * D, Hc);
         // ---------------- this step's communication mask -> bit rows in LDS (the softmax loops must not touch global memory:
         // 120 dependent byte loads per row made the first version 10x slower than its MFMAs) ----------------
         const uint8_t *comm_t = comm + ((long long)t * E + e) * N * N;
@@ -220,7 +253,8 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
         // ---------------- recurrent GRU cell: Hc -> Hn (the barrier behind it also publishes the mask bits) ----------------
         const uint16_t *gi_t = gi + ((long long)t * E + e) * N * 768;
         for (int c = w; c < 16 && !(MAPF_RECUR_ABLATE & 1); c += NTHR / 64)
-            gru_block<true, 1>((c + rot) & 15, gi_t, nullptr, nullptr, 0, W + W_HH, bias + B_IH, bias + B_HH, Hc, Hn, nullptr, N, lr, lh);
+            gru_block<true, 1>((c + rot) & 15, gi_t, nullptr, nullptr, 0, W + W_HH, bias + B_IH, bias + B_HH, Hc, Hn, nullptr, N, lr, lh,
+                               SAVE ? sv.g1 + row0 * 1024 : nullptr);
         __syncthreads();
         {
             unsigned char *tmp = Hc;
@@ -229,6 +263,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
         }
         // ---------------- two communication rounds (shared weights): Hc -> Hn -> swap ----------------
         for (int round = 0; round < 2; ++round) {
+            if (SAVE) save_hidden(sv.hr + ((long long)round * RTOT + row0) * D, Hc);
             // q | k | v = W_qkv h + b: 24 output tiles of 16
             for (int wq0 = w; wq0 < 8 && !(MAPF_RECUR_ABLATE & 2); wq0 += NTHR / 64) {
                 const int wq = (wq0 + rot) & 7;
@@ -255,6 +290,12 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                     vt[VT_ROW / 2] = (uint16_t)(p01 >> 16);
                     vt[2 * (VT_ROW / 2)] = (uint16_t)(p23 & 0xFFFFu);
                     vt[3 * (VT_ROW / 2)] = (uint16_t)(p23 >> 16);
+                    if (SAVE && agent < N) {
+                        uint16_t *qs = sv.qkv + ((long long)round * RTOT + row0 + agent) * 384 + c0;
+                        *reinterpret_cast<uint2 *>(qs) = make_uint2(pack2_bf16(acc[0][n][0], acc[0][n][1]), pack2_bf16(acc[0][n][2], acc[0][n][3]));
+                        *reinterpret_cast<uint2 *>(qs + 128) = make_uint2(pack2_bf16(acc[1][n][0], acc[1][n][1]), pack2_bf16(acc[1][n][2], acc[1][n][3]));
+                        *reinterpret_cast<uint2 *>(qs + 256) = make_uint2(p01, p23);
+                    }
                 }
             }
             __syncthreads();
@@ -314,6 +355,13 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                 }
             }
             __syncthreads();
+            if (SAVE) {  // P rows (2 heads x 48 agents x 64 slots = 128 B each) -> global
+                uint16_t *pd = sv.P + (((long long)round * T + t) * E + e) * (2 * NA * 64);
+                for (int i = tid; i < 2 * NA * 8; i += NTHR) {
+                    const int rowp = i >> 3, ch = i & 7;
+                    *reinterpret_cast<uint4 *>(pd + rowp * 64 + ch * 8) = *reinterpret_cast<const uint4 *>(smem + OFF_P + rowp * P_ROW + ch * 16);
+                }
+            }
             // ctx^T[d][i] = sum_j vT[d][j] P[i][j]: 2 heads x 4 d-tiles, K = 64 agent slots -> CTX[agent][head*64 + d]
             for (int job = w; job < 8 && !(MAPF_RECUR_ABLATE & 4); job += NTHR / 64) {
                 const int hd = job >> 2, td = job & 3;
@@ -330,9 +378,12 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                     }
                 }
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    *reinterpret_cast<uint2 *>(smem + OFF_CTX + (16 * n + lr) * CTX_ROW + (hd * HD + 16 * td + 4 * lh) * 2) =
-                        make_uint2(pack2_bf16(acc[n][0], acc[n][1]), pack2_bf16(acc[n][2], acc[n][3]));
+                for (int n = 0; n < NT; ++n) {
+                    const uint2 v = make_uint2(pack2_bf16(acc[n][0], acc[n][1]), pack2_bf16(acc[n][2], acc[n][3]));
+                    *reinterpret_cast<uint2 *>(smem + OFF_CTX + (16 * n + lr) * CTX_ROW + (hd * HD + 16 * td + 4 * lh) * 2) = v;
+                    if (SAVE && 16 * n + lr < N)
+                        *reinterpret_cast<uint2 *>(sv.ctx + ((long long)round * RTOT + row0 + 16 * n + lr) * 128 + hd * HD + 16 * td + 4 * lh) = v;
+                }
             }
             __syncthreads();
             // info = W_O ctx (no bias): 4 output tiles, K = 128
@@ -342,14 +393,17 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                 for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
                 gemm16<4>(acc, W + W_O, ot, smem + OFF_CTX, CTX_ROW, lane);
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    *reinterpret_cast<uint2 *>(smem + OFF_INFO + (16 * n + lr) * INFO_ROW + (16 * ot + 4 * lh) * 2) =
-                        make_uint2(pack2_bf16(acc[n][0], acc[n][1]), pack2_bf16(acc[n][2], acc[n][3]));
+                for (int n = 0; n < NT; ++n) {
+                    const uint2 v = make_uint2(pack2_bf16(acc[n][0], acc[n][1]), pack2_bf16(acc[n][2], acc[n][3]));
+                    *reinterpret_cast<uint2 *>(smem + OFF_INFO + (16 * n + lr) * INFO_ROW + (16 * ot + 4 * lh) * 2) = v;
+                    if (SAVE && 16 * n + lr < N) *reinterpret_cast<uint2 *>(sv.info + ((long long)round * RTOT + row0 + 16 * n + lr) * 64 + 16 * ot + 4 * lh) = v;
+                }
             }
             __syncthreads();
             // update cell: Hc -> Hn where the agent has a partner
             for (int c = w; c < 16 && !(MAPF_RECUR_ABLATE & 16); c += NTHR / 64)
-                gru_block<false, 2>((c + rot) & 15, nullptr, W + U_IH, smem + OFF_INFO, INFO_ROW, W + U_HH, bias + UB_IH, bias + UB_HH, Hc, Hn, upd, N, lr, lh);
+                gru_block<false, 2>((c + rot) & 15, nullptr, W + U_IH, smem + OFF_INFO, INFO_ROW, W + U_HH, bias + UB_IH, bias + UB_HH, Hc, Hn, upd, N, lr, lh,
+                                    SAVE ? sv.g2 + ((long long)round * RTOT + row0) * 1024 : nullptr);
             __syncthreads();
             unsigned char *tmp = Hc;
             Hc = Hn;
@@ -385,8 +439,23 @@ int mapf_recurrent_infer(const uint16_t *gi_dev, const uint16_t *h0_dev, const u
         (reinterpret_cast<uintptr_t>(agent0_out_dev) & 15))
         return MAPF_ERR_INVALID_ARG;
     if (E == 0) return MAPF_OK;
-    hipLaunchKernelGGL(recurrent_infer_kernel, dim3(E), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
-                       weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev);
+    hipLaunchKernelGGL(recurrent_infer_kernel<false>, dim3(E), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
+                       weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, RecurSave{});
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+int mapf_recurrent_forward_save(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
+                                const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev,
+                                uint16_t *const *save_dev, void *stream) {
+    if (T < 1 || E < 0 || N < 1 || N > NA || !gi_dev || !comm_dev || !weights_dev || !bias_dev || !h_out_dev || !agent0_out_dev || !save_dev)
+        return MAPF_ERR_INVALID_ARG;
+    for (int i = 0; i < 8; ++i)
+        if (!save_dev[i] || (reinterpret_cast<uintptr_t>(save_dev[i]) & 15)) return MAPF_ERR_INVALID_ARG;
+    if (E == 0) return MAPF_OK;
+    const RecurSave sv{save_dev[0], save_dev[1], save_dev[2], save_dev[3], save_dev[4], save_dev[5], save_dev[6], save_dev[7]};
+    hipLaunchKernelGGL(recurrent_infer_kernel<true>, dim3(E), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
+                       weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, sv);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }

@@ -1,0 +1,450 @@
+// mapf_recur_bwd.hip -- backward through time of the recurrence that csrc/mapf_recur.hip runs forward
+// (reference: autograd through model.py:242-249 `bootstrap`, i.e. GRUCell + 2 x CommBlock round per step, driven by
+// `loss.backward()` at worker.py:316).  One workgroup per environment walks the steps in reverse with DH, the gradient
+// w.r.t. the hidden state, resident in LDS (see include/mapf_dqn.h: mapf_recurrent_backward).
+//
+// Per step, in reverse: for round 1, 0 of the CommBlock
+//   (1) update-cell backward, elementwise on the saved gates:  d = upd ? DH : 0,
+//         dn = d (1-z)(1-n^2),  dz = d (h - n) z (1-z),  dr = dn hn r (1-r);   d_gi = (dr,dz,dn), d_gh = (dr,dz,dn r)
+//       are written to global memory (they are outputs: the caller's weight-gradient GEMMs need them) and DH <- upd ? d z : DH;
+//   (2) DH += U_hh^T d_gh,  d_info = U_ih^T d_gi   (A = transposed weights packed in fragment order, B = the rows just
+//       written, read back from global by the same workgroup);
+//   (3) d_ctx = W_O^T d_info;
+//   (4) attention backward, one head at a time on LDS images of q, k, v, P (saved by the forward): dP = d_ctx v^T,
+//       dS = P (dP - rowsum(dP P)) / 8, dv = P^T d_ctx, dq = dS k, dk = dS^T q.  Every product is an MFMA with both
+//       operands row-major in LDS: an operand whose reduction index is the ROW of its image is read with
+//       ds_read_b64_tr_b16 (blocks at rows 8 lh and 8 lh + 4, so the fragment's k order is that of a plain 16-byte read);
+//   (5) DH += W_qkv^T d_qkv;
+// then the recurrent cell's backward (d_gi of it is the gradient w.r.t. the GRU input projection, an output) and
+// DH += W_hh^T d_gh; agent 0's external gradient of the previous step is added and the loop continues.
+// Weight and bias gradients are NOT formed here: they are six tall GEMMs / column sums over (saved input, d_*) rows that
+// the caller runs once per update.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+
+#include "mapf_dqn.h"
+#include "mapf_env.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+constexpr int NT = 3, NA = 48, D = 256, HD = 64, NTHR = 512;
+constexpr int H_ROW = D * 2 + 32;     // 544
+constexpr int INFO_ROW = 64 * 2 + 32;  // 160
+constexpr int CTX_ROW = 128 * 2 + 32;  // 288
+constexpr int QKV_ROW = 384 * 2 + 32;  // 800
+constexpr int IMG_ROW = 64 * 2 + 32;   // per-head q / k / v / P / dS images: 64 rows x 64 columns
+constexpr int SF_ROW = 52;             // fp32 dP rows
+constexpr int OFF_DH = 0;
+constexpr int OFF_DINFO = OFF_DH + NA * H_ROW;
+constexpr int OFF_DCTX = OFF_DINFO + NA * INFO_ROW;      // 64 rows: rows >= 48 stay zero (K padding of the transposed reads)
+constexpr int OFF_DQKV = OFF_DCTX + 64 * CTX_ROW;
+constexpr int OFF_QI = OFF_DQKV + NA * QKV_ROW;
+constexpr int OFF_KI = OFF_QI + 64 * IMG_ROW;
+constexpr int OFF_VI = OFF_KI + 64 * IMG_ROW;
+constexpr int OFF_PI = OFF_VI + 64 * IMG_ROW;
+constexpr int OFF_DSI = OFF_PI + 64 * IMG_ROW;
+constexpr int OFF_SF = OFF_DSI + 64 * IMG_ROW;
+constexpr int OFF_UPD = OFF_SF + NA * SF_ROW * 4;
+constexpr int LDS_BYTES = OFF_UPD + 64 * 4;
+static_assert(LDS_BYTES <= 160 * 1024 && OFF_SF % 16 == 0 && OFF_UPD % 16 == 0, "LDS budget / alignment");
+
+// transposed-weight buffer (bf16 elements, fragment order [tile][k-step][lane][8], gates outermost for the GRU matrices)
+constexpr int WT_UIH = 0;                         // [3][4][8]   U_ih^T: 64 outputs, K = 768 (3 gates x 256)
+constexpr int WT_UHH = WT_UIH + 3 * 4 * 8 * 512;  // [3][16][8]  U_hh^T: 256 outputs
+constexpr int WT_WHH = WT_UHH + 3 * 16 * 8 * 512; // [3][16][8]  W_hh^T
+constexpr int WT_WO = WT_WHH + 3 * 16 * 8 * 512;  // [8][2]      W_O^T: 128 outputs, K = 64
+constexpr int WT_QKV = WT_WO + 8 * 2 * 512;       // [16][12]    W_qkv^T: 256 outputs, K = 384
+constexpr int WT_TOTAL = WT_QKV + 16 * 12 * 512;
+static_assert(WT_TOTAL == MAPF_RECUR_WEIGHT_ELEMS, "header constant out of date");
+
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+__device__ __forceinline__ void unpack4(const uint2 v, float (&f)[4]) {
+    f[0] = bf16_lo(v.x);
+    f[1] = bf16_hi(v.x);
+    f[2] = bf16_lo(v.y);
+    f[3] = bf16_hi(v.y);
+}
+__device__ __forceinline__ uint2 pack4(const float (&f)[4]) { return make_uint2(pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3])); }
+
+// fragment (16 "columns" col0.. of the image, k = rows row0 .. row0+32) of an operand whose reduction index is the image ROW
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char *img, int row_bytes, int row0, int col0, int lane) {
+    typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+    const int li = lane & 15, lh = lane >> 4, q4 = li >> 2, p4 = li & 3;
+    const unsigned char *p0 = img + (row0 + 8 * lh + q4) * row_bytes + (col0 + 4 * p4) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p0 + 4 * row_bytes));
+    union {
+        s16x4 h[2];
+        bf16x8 v;
+    } u;
+    u.h[0] = lo;
+    u.h[1] = hi;
+    return u.v;
+}
+// fragment of an operand whose reduction index runs along the image row (row = 16 tile + lr, k = k0 + 8 lh .. +8)
+__device__ __forceinline__ bf16x8 row_frag(const unsigned char *img, int row_bytes, int row, int k0, int lane) {
+    return *reinterpret_cast<const bf16x8 *>(img + row * row_bytes + (k0 + 8 * (lane >> 4)) * 2);
+}
+
+// acc[n] += (packed tile `wp`, KS k-steps) * B^T, B rows in GLOBAL memory: row(agent) = B + agent * ldb, columns k0 .. k0 + 32 KS
+template <int KS>
+__device__ __forceinline__ void gemm_gB(f32x4 (&acc)[NT], const bf16x8 *__restrict__ wp, const uint16_t *B, int ldb, int k0, int nagents, int lane) {
+    const int lr = lane & 15, lh = lane >> 4;
+    bf16x8 a[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) a[kk] = wp[kk * 64];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int agent = 16 * n + lr;
+            bf16x8 b = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (agent < nagents) b = *reinterpret_cast<const bf16x8 *>(B + (long long)agent * ldb + k0 + 32 * kk + 8 * lh);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk], b, acc[n], 0, 0, 0);
+        }
+}
+// same with B rows in an LDS image
+template <int KS>
+__device__ __forceinline__ void gemm_lB(f32x4 (&acc)[NT], const bf16x8 *__restrict__ wp, const unsigned char *X, int xrow, int lane) {
+    const int lr = lane & 15, lh = lane >> 4;
+    bf16x8 a[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) a[kk] = wp[kk * 64];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8 *>(X + (16 * n + lr) * xrow + (32 * kk + 8 * lh) * 2);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk], b, acc[n], 0, 0, 0);
+        }
+}
+
+struct BwdArgs {
+    // saved by the forward (see RecurSave in csrc/mapf_recur.hip)
+    const uint16_t *hin0, *g1, *hr, *qkv, *ctx_unused, *info_unused, *g2, *P;
+    const uint8_t *comm;   // [T][E][N][N]
+    const uint16_t *dA0;   // [T][E][256] gradient w.r.t. agent 0's state after every step
+    const uint16_t *WT;    // transposed weights, fragment order
+    // outputs, rows as in the forward's saved tensors
+    uint16_t *d_gi1, *d_gh1;  // [R][768]
+    uint16_t *d_gi2, *d_gh2;  // [2][R][768]
+    uint16_t *d_info;         // [2][R][64]
+    uint16_t *d_qkv;          // [2][R][384]
+    int T, E, N;
+};
+
+// GRU cell backward on this lane's cells (channel blocks cb = w, w + 8; agent tiles n): reads DH (LDS), the saved gates and
+// input state (global), writes d_gi / d_gh rows (global) and DH <- (upd ? d z : DH).
+__device__ __forceinline__ void gru_bwd_elementwise(unsigned char *DH, const uint16_t *__restrict__ gates, const uint16_t *__restrict__ hin,
+                                                    const int *upd, uint16_t *__restrict__ dgi, uint16_t *__restrict__ dgh, int N, int w, int lr,
+                                                    int lh) {
+    for (int cb = w; cb < 16; cb += NTHR / 64) {
+        const int c0 = 16 * cb + 4 * lh;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int agent = 16 * n + lr;
+            if (agent >= N) continue;
+            const uint16_t *g = gates + (long long)agent * 1024 + c0;
+            float r[4], z[4], nn[4], hn[4], h[4], d[4];
+            unpack4(*reinterpret_cast<const uint2 *>(g), r);
+            unpack4(*reinterpret_cast<const uint2 *>(g + 256), z);
+            unpack4(*reinterpret_cast<const uint2 *>(g + 512), nn);
+            unpack4(*reinterpret_cast<const uint2 *>(g + 768), hn);
+            unpack4(*reinterpret_cast<const uint2 *>(hin + (long long)agent * D + c0), h);
+            uint2 *dcell = reinterpret_cast<uint2 *>(DH + agent * H_ROW + c0 * 2);
+            unpack4(*dcell, d);
+            const bool on = upd == nullptr || upd[agent] != 0;
+            float dr[4], dz[4], dn[4], dnr[4], dpass[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dd = on ? d[k] : 0.f;
+                dn[k] = dd * (1.f - z[k]) * (1.f - nn[k] * nn[k]);
+                dz[k] = dd * (h[k] - nn[k]) * z[k] * (1.f - z[k]);
+                dr[k] = dn[k] * hn[k] * r[k] * (1.f - r[k]);
+                dnr[k] = dn[k] * r[k];
+                dpass[k] = on ? dd * z[k] : d[k];
+            }
+            uint16_t *gi = dgi + (long long)agent * 768 + c0, *gh = dgh + (long long)agent * 768 + c0;
+            const uint2 pr = pack4(dr), pz = pack4(dz);
+            *reinterpret_cast<uint2 *>(gi) = pr;
+            *reinterpret_cast<uint2 *>(gi + 256) = pz;
+            *reinterpret_cast<uint2 *>(gi + 512) = pack4(dn);
+            *reinterpret_cast<uint2 *>(gh) = pr;
+            *reinterpret_cast<uint2 *>(gh + 256) = pz;
+            *reinterpret_cast<uint2 *>(gh + 512) = pack4(dnr);
+            *dcell = pack4(dpass);
+        }
+    }
+}
+
+// DH[agent][16 tile + 4 lh ..] += acc  (this lane's own cells)
+__device__ __forceinline__ void add_to_dh(unsigned char *DH, const f32x4 (&acc)[NT], int tile, int lr, int lh) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        uint2 *cell = reinterpret_cast<uint2 *>(DH + (16 * n + lr) * H_ROW + (16 * tile + 4 * lh) * 2);
+        float d[4];
+        unpack4(*cell, d);
+        const float o[4] = {d[0] + acc[n][0], d[1] + acc[n][1], d[2] + acc[n][2], d[3] + acc[n][3]};
+        *cell = pack4(o);
+    }
+}
+
+__global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lh = lane >> 4;
+    const int e = blockIdx.x, T = A.T, E = A.E, N = A.N;
+    const long long RTOT = (long long)T * E * N;
+    unsigned char *DH = smem + OFF_DH;
+    int *upd = reinterpret_cast<int *>(smem + OFF_UPD);
+    float *SF = reinterpret_cast<float *>(smem + OFF_SF);
+    const bf16x8 *WT = reinterpret_cast<const bf16x8 *>(A.WT);
+
+    for (int i = tid; i < LDS_BYTES / 16; i += NTHR) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    for (int t = T - 1; t >= 0; --t) {
+        const long long row0 = ((long long)t * E + e) * N;
+        // ---- external gradient of agent 0's state after step t; partner counts of this step's mask ----
+        if (tid < 64) {
+            const uint2 g = *reinterpret_cast<const uint2 *>(A.dA0 + ((long long)t * E + e) * D + tid * 4);
+            uint2 *cell = reinterpret_cast<uint2 *>(DH + tid * 8);
+            float a[4], b[4];
+            unpack4(*cell, a);
+            unpack4(g, b);
+            const float o[4] = {a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
+            *cell = pack4(o);
+        } else if (tid < 128) {
+            upd[tid - 64] = 0;
+        }
+        __syncthreads();
+        {
+            const uint8_t *cm = A.comm + ((long long)t * E + e) * N * N;
+            for (int idx = tid; idx < N * N; idx += NTHR)
+                if (cm[idx] != 0) atomicAdd(&upd[idx / N], 1);
+        }
+        __syncthreads();
+        if (tid < 64) upd[tid] = upd[tid] > 1 ? 1 : 0;  // model.py:103
+        __syncthreads();
+
+        for (int q = 1; q >= 0; --q) {
+            const long long rq = (long long)q * RTOT + row0;
+            uint16_t *dgi2 = A.d_gi2 + rq * 768, *dgh2 = A.d_gh2 + rq * 768;
+            // (1) update-cell backward
+            gru_bwd_elementwise(DH, A.g2 + rq * 1024, A.hr + rq * D, upd, dgi2, dgh2, N, w, lr, lh);
+            __syncthreads();
+            // (2) DH += U_hh^T d_gh (2 output tiles per wave); d_info = U_ih^T d_gi (waves 0-3, one tile each)
+            {
+                f32x4 acc0[NT], acc1[NT], acci[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc0[n] = acc1[n] = acci[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    gemm_gB<8>(acc0, WT + (WT_UHH / 8) + ((g * 16 + w) * 8) * 64 + lane, dgh2, 768, 256 * g, N, lane);
+                    gemm_gB<8>(acc1, WT + (WT_UHH / 8) + ((g * 16 + w + 8) * 8) * 64 + lane, dgh2, 768, 256 * g, N, lane);
+                    if (w < 4) gemm_gB<8>(acci, WT + (WT_UIH / 8) + ((g * 4 + w) * 8) * 64 + lane, dgi2, 768, 256 * g, N, lane);
+                }
+                add_to_dh(DH, acc0, w, lr, lh);
+                add_to_dh(DH, acc1, w + 8, lr, lh);
+                if (w < 4) {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int agent = 16 * n + lr;
+                        const float o[4] = {acci[n][0], acci[n][1], acci[n][2], acci[n][3]};
+                        const uint2 v = pack4(o);
+                        *reinterpret_cast<uint2 *>(smem + OFF_DINFO + agent * INFO_ROW + (16 * w + 4 * lh) * 2) = v;
+                        if (agent < N) *reinterpret_cast<uint2 *>(A.d_info + (rq + agent) * 64 + 16 * w + 4 * lh) = v;
+                    }
+                }
+            }
+            __syncthreads();
+            // (3) d_ctx = W_O^T d_info: 8 output tiles, K = 64
+            {
+                f32x4 acc[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                gemm_lB<2>(acc, WT + (WT_WO / 8) + (w * 2) * 64 + lane, smem + OFF_DINFO, INFO_ROW, lane);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float o[4] = {acc[n][0], acc[n][1], acc[n][2], acc[n][3]};
+                    *reinterpret_cast<uint2 *>(smem + OFF_DCTX + (16 * n + lr) * CTX_ROW + (16 * w + 4 * lh) * 2) = pack4(o);
+                }
+            }
+            __syncthreads();
+            // (4) attention backward, one head at a time
+            for (int hd = 0; hd < 2; ++hd) {
+                // images: q, k, v rows [agent][64] of this head; P rows [agent i][64 slots j]
+                for (int i = tid; i < N * 8 * 3; i += NTHR) {
+                    const int img = i / (N * 8), rem = i - img * (N * 8), a = rem >> 3, ch = rem & 7;
+                    *reinterpret_cast<uint4 *>(smem + OFF_QI + img * (64 * IMG_ROW) + a * IMG_ROW + ch * 16) =
+                        *reinterpret_cast<const uint4 *>(A.qkv + (rq + a) * 384 + img * 128 + hd * HD + ch * 8);
+                }
+                {
+                    const uint16_t *ps = A.P + ((((long long)q * T + t) * E + e) * 2 + hd) * (NA * 64);
+                    for (int i = tid; i < NA * 8; i += NTHR) {
+                        const int a = i >> 3, ch = i & 7;
+                        *reinterpret_cast<uint4 *>(smem + OFF_PI + a * IMG_ROW + ch * 16) = *reinterpret_cast<const uint4 *>(ps + a * 64 + ch * 8);
+                    }
+                }
+                __syncthreads();
+                // dP[i][j] = sum_d d_ctx[i][d] v[j][d]
+                for (int job = w; job < NT * NT; job += NTHR / 64) {
+                    const int ti = job / NT, tj = job % NT;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(smem + OFF_DCTX, CTX_ROW, 16 * ti + lr, hd * HD + 32 * kk, lane),
+                                                                      row_frag(smem + OFF_VI, IMG_ROW, 16 * tj + lr, 32 * kk, lane), acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) SF[(16 * ti + 4 * lh + r) * SF_ROW + 16 * tj + lr] = acc[r];
+                }
+                __syncthreads();
+                // softmax backward per row i: dS = P (dP - sum_j dP P) / 8
+                if (tid < NA) {
+                    const int i = tid;
+                    const float4 *dp = reinterpret_cast<const float4 *>(SF + i * SF_ROW);
+                    const uint2 *pp = reinterpret_cast<const uint2 *>(smem + OFF_PI + i * IMG_ROW);
+                    float P[NA], dP[NA];
+#pragma unroll
+                    for (int c = 0; c < NA / 4; ++c) {
+                        const float4 x = dp[c];
+                        dP[4 * c] = x.x;
+                        dP[4 * c + 1] = x.y;
+                        dP[4 * c + 2] = x.z;
+                        dP[4 * c + 3] = x.w;
+                        float pv[4];
+                        unpack4(pp[c], pv);
+                        P[4 * c] = pv[0];
+                        P[4 * c + 1] = pv[1];
+                        P[4 * c + 2] = pv[2];
+                        P[4 * c + 3] = pv[3];
+                    }
+                    float dot = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) dot += dP[j] * P[j];
+                    uint32_t *ds = reinterpret_cast<uint32_t *>(smem + OFF_DSI + i * IMG_ROW);
+#pragma unroll
+                    for (int j = 0; j < NA; j += 2) ds[j / 2] = pack2_bf16(P[j] * (dP[j] - dot) * 0.125f, P[j + 1] * (dP[j + 1] - dot) * 0.125f);
+                }
+                __syncthreads();
+                // dv, dq, dk: 3 products x 4 d-tiles x 3 agent tiles, each K = 64 (image rows / slots 48..63 are zero)
+                for (int job = w; job < 3 * 4 * NT; job += NTHR / 64) {
+                    const int prod = job / (4 * NT), td = (job / NT) % 4, ta = job % NT;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        bf16x8 a, b;
+                        if (prod == 0) {  // dv^T[d][j] = sum_i d_ctx[i][d] P[i][j]
+                            a = tr_frag(smem + OFF_DCTX, CTX_ROW, 32 * kk, hd * HD + 16 * td, lane);
+                            b = tr_frag(smem + OFF_PI, IMG_ROW, 32 * kk, 16 * ta, lane);
+                        } else if (prod == 1) {  // dq^T[d][i] = sum_j k[j][d] dS[i][j]
+                            a = tr_frag(smem + OFF_KI, IMG_ROW, 32 * kk, 16 * td, lane);
+                            b = row_frag(smem + OFF_DSI, IMG_ROW, 16 * ta + lr, 32 * kk, lane);
+                        } else {  // dk^T[d][j] = sum_i q[i][d] dS[i][j]
+                            a = tr_frag(smem + OFF_QI, IMG_ROW, 32 * kk, 16 * td, lane);
+                            b = tr_frag(smem + OFF_DSI, IMG_ROW, 32 * kk, 16 * ta, lane);
+                        }
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+                    }
+                    const int colbase = (prod == 0 ? 256 : (prod == 1 ? 0 : 128)) + hd * HD + 16 * td + 4 * lh;
+                    const float o[4] = {acc[0], acc[1], acc[2], acc[3]};
+                    *reinterpret_cast<uint2 *>(smem + OFF_DQKV + (16 * ta + lr) * QKV_ROW + colbase * 2) = pack4(o);
+                }
+                __syncthreads();
+            }
+            // (5) d_qkv rows -> global; DH += W_qkv^T d_qkv (2 output tiles per wave, K = 384)
+            for (int i = tid; i < N * 48; i += NTHR) {
+                const int a = i / 48, ch = i - a * 48;
+                *reinterpret_cast<uint4 *>(A.d_qkv + (rq + a) * 384 + ch * 8) = *reinterpret_cast<const uint4 *>(smem + OFF_DQKV + a * QKV_ROW + ch * 16);
+            }
+            {
+                f32x4 acc0[NT], acc1[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc0[n] = acc1[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                gemm_lB<12>(acc0, WT + (WT_QKV / 8) + (w * 12) * 64 + lane, smem + OFF_DQKV, QKV_ROW, lane);
+                gemm_lB<12>(acc1, WT + (WT_QKV / 8) + ((w + 8) * 12) * 64 + lane, smem + OFF_DQKV, QKV_ROW, lane);
+                add_to_dh(DH, acc0, w, lr, lh);
+                add_to_dh(DH, acc1, w + 8, lr, lh);
+            }
+            __syncthreads();
+        }
+        // ---- recurrent cell backward: d_gi1 is the gradient w.r.t. the GRU input projection ----
+        uint16_t *dgi1 = A.d_gi1 + row0 * 768, *dgh1 = A.d_gh1 + row0 * 768;
+        gru_bwd_elementwise(DH, A.g1 + row0 * 1024, A.hin0 + row0 * D, nullptr, dgi1, dgh1, N, w, lr, lh);
+        __syncthreads();
+        {
+            f32x4 acc0[NT], acc1[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc0[n] = acc1[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                gemm_gB<8>(acc0, WT + (WT_WHH / 8) + ((g * 16 + w) * 8) * 64 + lane, dgh1, 768, 256 * g, N, lane);
+                gemm_gB<8>(acc1, WT + (WT_WHH / 8) + ((g * 16 + w + 8) * 8) * 64 + lane, dgh1, 768, 256 * g, N, lane);
+            }
+            add_to_dh(DH, acc0, w, lr, lh);
+            add_to_dh(DH, acc1, w + 8, lr, lh);
+        }
+        __syncthreads();
+    }
+}
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            std::fprintf(stderr, "mapf_recur_bwd: %s failed: %s\n", #expr, hipGetErrorString(_e)); \
+            return MAPF_ERR_HIP;                                                                 \
+        }                                                                                        \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int mapf_recurrent_backward(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev,
+                            const uint16_t *weights_t_dev, int T, int E, int N, uint16_t *const *out_dev, void *stream) {
+    if (T < 1 || E < 0 || N < 1 || N > NA || !saved_dev || !comm_dev || !d_agent0_dev || !weights_t_dev || !out_dev) return MAPF_ERR_INVALID_ARG;
+    for (int i = 0; i < 8; ++i)
+        if (!saved_dev[i] || (reinterpret_cast<uintptr_t>(saved_dev[i]) & 15)) return MAPF_ERR_INVALID_ARG;
+    for (int i = 0; i < 6; ++i)
+        if (!out_dev[i] || (reinterpret_cast<uintptr_t>(out_dev[i]) & 15)) return MAPF_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(d_agent0_dev) & 15) || (reinterpret_cast<uintptr_t>(weights_t_dev) & 15)) return MAPF_ERR_INVALID_ARG;
+    if (E == 0) return MAPF_OK;
+    BwdArgs a;
+    a.hin0 = saved_dev[0];
+    a.g1 = saved_dev[1];
+    a.hr = saved_dev[2];
+    a.qkv = saved_dev[3];
+    a.ctx_unused = saved_dev[4];
+    a.info_unused = saved_dev[5];
+    a.g2 = saved_dev[6];
+    a.P = saved_dev[7];
+    a.comm = comm_dev;
+    a.dA0 = d_agent0_dev;
+    a.WT = weights_t_dev;
+    a.d_gi1 = out_dev[0];
+    a.d_gh1 = out_dev[1];
+    a.d_gi2 = out_dev[2];
+    a.d_gh2 = out_dev[3];
+    a.d_info = out_dev[4];
+    a.d_qkv = out_dev[5];
+    a.T = T;
+    a.E = E;
+    a.N = N;
+    hipLaunchKernelGGL(recurrent_bwd_kernel, dim3(E), dim3(NTHR), 0, static_cast<hipStream_t>(stream), a);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+}  // extern "C"

@@ -256,3 +256,93 @@ def recurrent_infer(gi, h0, comm, weights, bias, want_agent0=False):
     check(lib.mapf_recurrent_infer(_ptr(gi), _ptr(h0), _ptr(comm), _ptr(weights), _ptr(bias), T, E, N, _ptr(h_out), _ptr(a0),
                                    _stream(gi.device)), "mapf_recurrent_infer")
     return h_out, a0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Training recurrence: forward with saved state + backward through time (mapf_recurrent_forward_save /
+# mapf_recurrent_backward); weight and bias gradients are tall GEMMs / column sums formed here.
+# ---------------------------------------------------------------------------------------------------------
+def _pack_frag(m):
+    """[O, K] -> MFMA A-fragment order [O/16][K/32][lane = 16*((k%32)//8) + o%16][k%8], flattened."""
+    return m.reshape(m.shape[0] // 16, 16, m.shape[1] // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1)
+
+
+def recurrence_params(net):
+    rc, at, uc = net.recurrent, net.comm.self_attn, net.comm.update_cell
+    return [rc.weight_hh, rc.bias_ih, rc.bias_hh, at.W_Q.weight, at.W_K.weight, at.W_V.weight, at.W_Q.bias, at.W_K.bias, at.W_V.bias,
+            at.W_O.weight, uc.weight_ih, uc.weight_hh, uc.bias_ih, uc.bias_hh]
+
+
+def pack_recurrence_transposed(params):
+    """The transposed matrices of the backward kernel in fragment order (see include/mapf_dqn.h)."""
+    w_hh, _, _, wq, wk, wv, _, _, _, w_o, u_ih, u_hh, _, _ = [p.detach() for p in params]
+    parts = [_pack_frag(u_ih[256 * g:256 * (g + 1)].t().contiguous()) for g in range(3)]
+    parts += [_pack_frag(u_hh[256 * g:256 * (g + 1)].t().contiguous()) for g in range(3)]
+    parts += [_pack_frag(w_hh[256 * g:256 * (g + 1)].t().contiguous()) for g in range(3)]
+    parts += [_pack_frag(w_o.t().contiguous()), _pack_frag(torch.cat([wq, wk, wv], dim=0).t().contiguous())]
+    out = torch.cat(parts).to(torch.bfloat16).contiguous()
+    assert out.numel() == 548864
+    return out
+
+
+class _RecurTrain(torch.autograd.Function):
+    """agent-0 states [T, E, 256] of the T-step GRU + CommBlock recurrence from gi = W_ih latent (no bias) [T, E, N, 768]."""
+
+    @staticmethod
+    def forward(ctx, gi, h0, comm, w_pack, b_pack, *params):
+        T, E, N, _ = gi.shape
+        dev, R = gi.device, gi.shape[0] * gi.shape[1] * gi.shape[2]
+        bf = torch.bfloat16
+        saves = [torch.empty((R, 256), dtype=bf, device=dev), torch.empty((R, 1024), dtype=bf, device=dev),
+                 torch.empty((2, R, 256), dtype=bf, device=dev), torch.empty((2, R, 384), dtype=bf, device=dev),
+                 torch.empty((2, R, 128), dtype=bf, device=dev), torch.empty((2, R, 64), dtype=bf, device=dev),
+                 torch.empty((2, R, 1024), dtype=bf, device=dev), torch.empty((2, T * E, 2, 48, 64), dtype=bf, device=dev)]
+        h_out = torch.empty((E, N, 256), dtype=bf, device=dev)
+        a0 = torch.empty((T, E, 256), dtype=bf, device=dev)
+        sp = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in saves])
+        check(lib.mapf_recurrent_forward_save(_ptr(gi), _ptr(h0), _ptr(comm), _ptr(w_pack), _ptr(b_pack), T, E, N, _ptr(h_out), _ptr(a0), sp,
+                                              _stream(dev)), "mapf_recurrent_forward_save")
+        ctx.save_for_backward(comm, *saves, *params)
+        ctx.shape = (T, E, N)
+        return a0
+
+    @staticmethod
+    def backward(ctx, g_a0):
+        from .model import _tall_tn
+
+        T, E, N = ctx.shape
+        comm = ctx.saved_tensors[0]
+        saves = ctx.saved_tensors[1:9]
+        params = ctx.saved_tensors[9:]
+        dev, R, bf = comm.device, T * E * N, torch.bfloat16
+        wt = pack_recurrence_transposed(params)
+        outs = [torch.empty((R, 768), dtype=bf, device=dev), torch.empty((R, 768), dtype=bf, device=dev),
+                torch.empty((2, R, 768), dtype=bf, device=dev), torch.empty((2, R, 768), dtype=bf, device=dev),
+                torch.empty((2, R, 64), dtype=bf, device=dev), torch.empty((2, R, 384), dtype=bf, device=dev)]
+        g_a0 = g_a0.to(bf).contiguous()
+        sp = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in saves])
+        op = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in outs])
+        check(lib.mapf_recurrent_backward(sp, _ptr(comm), _ptr(g_a0), _ptr(wt), T, E, N, op, _stream(dev)), "mapf_recurrent_backward")
+        d_gi1, d_gh1, d_gi2, d_gh2, d_info, d_qkv = outs
+        hin0, _, hr, _, ctxs, info, _, _ = saves
+        f32 = torch.float32
+        d_gi2f, d_gh2f, d_qkvf, hrf = d_gi2.view(2 * R, 768), d_gh2.view(2 * R, 768), d_qkv.view(2 * R, 384), hr.view(2 * R, 256)
+        g_whh = _tall_tn(d_gh1, hin0)
+        g_qkv = _tall_tn(d_qkvf, hrf)
+        b_qkv = d_qkvf.sum(dim=0, dtype=f32)
+        grads = [g_whh, d_gi1.sum(dim=0, dtype=f32), d_gh1.sum(dim=0, dtype=f32), g_qkv[:128], g_qkv[128:256], g_qkv[256:], b_qkv[:128],
+                 b_qkv[128:256], b_qkv[256:], _tall_tn(d_info.view(2 * R, 64), ctxs.view(2 * R, 128)), _tall_tn(d_gi2f, info.view(2 * R, 64)),
+                 _tall_tn(d_gh2f, hrf), d_gi2f.sum(dim=0, dtype=f32), d_gh2f.sum(dim=0, dtype=f32)]
+        grads = [g.to(p.dtype).reshape(p.shape) for g, p in zip(grads, params)]
+        return (d_gi1.view(T, E, N, 768), None, None, None, None, *grads)
+
+
+def recurrent_train(gi, h0, comm, w_pack, b_pack, params):
+    """gi bf16 [T, E, N, 768] (autograd input); h0 bf16 [E, N, 256] or None; comm bool/u8 [T, E, N, N] -> agent-0 states [T, E, 256]."""
+    T, E, N, _ = gi.shape
+    assert gi.dtype == torch.bfloat16 and N <= RECUR_MAX_AGENTS and tuple(comm.shape) == (T, E, N, N)
+    comm = comm.contiguous()
+    comm = comm.view(torch.uint8) if comm.dtype == torch.bool else comm.to(torch.uint8)
+    if h0 is not None:
+        h0 = h0.detach().to(torch.bfloat16).reshape(E, N, 256).contiguous()
+    return _RecurTrain.apply(gi.contiguous(), h0, comm, w_pack, b_pack, *params)

@@ -347,6 +347,7 @@ class Network(nn.Module):
         self.hidden = None
 
     # ------------------------------------------------------------------ learner side
+    FUSED_BPTT = True  # with autograd: the T-step recurrence as a forward-save + a backward-through-time kernel (N <= 48)
     FUSED_RECURRENCE = True  # without autograd: GRU + CommBlock of all steps in one kernel (csrc/mapf_recur.hip), N <= 48
     SDPA = True  # fused scaled-dot-product attention inside _recur_fast
     FAST_RECURRENCE = True  # HIP device: hoisted input projection, fused QKV, deferred weight gradients (see _recur_fast)
@@ -400,6 +401,17 @@ class Network(nn.Module):
         grad = torch.is_grad_enabled()
         if not grad and self.FUSED_RECURRENCE and N <= 48:  # target network: all T steps in one kernel launch
             a0 = self._recur_kernel(latent.transpose(0, 1), hidden, comm_mask.transpose(0, 1), True)[1]
+            return a0.transpose(0, 1)
+        if grad and self.FUSED_BPTT and N <= 48:
+            # online network: forward-with-saved-state and backward-through-time kernels, one workgroup per window
+            from .fused import PackedRecurrence, recurrence_params, recurrent_train
+
+            if self._packed_recur is None:
+                self._packed_recur = PackedRecurrence()
+            w, b = self._packed_recur.get(self)
+            lat_t = latent.transpose(0, 1).reshape(T * B * N, ENC_FEATURES)
+            gi = F.linear(lat_t, self.recurrent.weight_ih.to(lp)).view(T, B, N, 3 * D)   # bias added inside the kernel
+            a0 = recurrent_train(gi, hidden.reshape(B, N, D), comm_mask.transpose(0, 1), w, b, recurrence_params(self))
             return a0.transpose(0, 1)
         sink = _WGradSink() if grad else None
         rc, at, uc = self.recurrent, self.comm.self_attn, self.comm.update_cell

@@ -94,6 +94,7 @@ def test_fast_recurrence_matches_module_path():
     comm[0, :, 1] = torch.eye(N, dtype=torch.bool, device="cuda")[1]   # an agent without partners (no update)
     r = torch.randn((B, 5), device="cuda", generator=g)
     res = {}
+    Network.FUSED_BPTT = False  # this test is about the PyTorch-level fast path; the kernels have their own below
     for fast in (True, False):
         Network.FAST_RECURRENCE = fast
         try:
@@ -106,6 +107,7 @@ def test_fast_recurrence_matches_module_path():
             assert torch.allclose(q_ng, q.detach(), rtol=3e-2, atol=3e-2)
         finally:
             Network.FAST_RECURRENCE = True
+    Network.FUSED_BPTT = True
     assert torch.allclose(res[True][0], res[False][0], rtol=3e-2, atol=3e-2)
     scale = max(float(b.norm()) for b in res[False][1].values())
     for k in res[True][1]:
@@ -151,3 +153,42 @@ def test_fused_recurrence_kernel_matches_module_path(E, N, T):
     for x, y in zip(out[True], out[False]):
         assert x.shape == y.shape
         assert torch.allclose(x, y, rtol=3e-2, atol=3e-2), float((x - y).abs().max())
+
+
+@pytest.mark.parametrize("B,T,N", [(6, 5, 7), (3, 16, 40), (4, 3, 48), (5, 2, 1)])
+def test_bptt_kernels_match_pytorch_recurrence(B, T, N):
+    """mapf_recurrent_forward_save + mapf_recurrent_backward (the whole T-step GRU / CommBlock recurrence forward and
+    backward in two launches) against the PyTorch-level recurrence at the same bf16 precision: Q-values and every
+    parameter gradient of `bootstrap`."""
+    from mapf_rl_amd.model import Network
+
+    torch.manual_seed(B * 10 + N)
+    net = Network().cuda()
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.1, 0.1)
+    g = torch.Generator(device="cuda").manual_seed(N + T)
+    obs = (torch.rand((B, T, N, 6, 9, 9), device="cuda", generator=g) < 0.3).to(torch.bfloat16)
+    steps = torch.randint(1, T + 1, (B,), device="cuda", generator=g)
+    hidden = (torch.randn((B * N, 256), device="cuda", generator=g) * 0.3).to(torch.bfloat16)
+    comm = torch.rand((B, T, N, N), device="cuda", generator=g) < 0.3
+    comm |= torch.eye(N, dtype=torch.bool, device="cuda")
+    if N > 2:
+        comm[0, :, 1] = torch.eye(N, dtype=torch.bool, device="cuda")[1]
+    r = torch.randn((B, 5), device="cuda", generator=g)
+    res = {}
+    for fused in (True, False):
+        Network.FUSED_BPTT = fused
+        try:
+            net.zero_grad()
+            q = net.bootstrap(obs, steps, hidden, comm)
+            (q * r).sum().backward()
+            res[fused] = (q.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+        finally:
+            Network.FUSED_BPTT = True
+    assert torch.allclose(res[True][0], res[False][0], rtol=3e-2, atol=3e-2)
+    scale = max(float(b.norm()) for b in res[False][1].values())
+    for k in res[True][1]:
+        a, b = res[True][1][k], res[False][1][k]
+        assert float((a - b).norm()) <= 8e-2 * float(b.norm()) + 1e-4 * scale, (k, float((a - b).norm()), float(b.norm()))
