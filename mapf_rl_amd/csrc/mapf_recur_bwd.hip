@@ -6,9 +6,10 @@
 // Per step, in reverse: for round 1, 0 of the CommBlock
 //   (1) update-cell backward, elementwise on the saved gates:  d = upd ? DH : 0,
 //         dn = d (1-z)(1-n^2),  dz = d (h - n) z (1-z),  dr = dn hn r (1-r);   d_gi = (dr,dz,dn), d_gh = (dr,dz,dn r)
-//       are written to global memory (they are outputs: the caller's weight-gradient GEMMs need them) and DH <- upd ? d z : DH;
-//   (2) DH += U_hh^T d_gh,  d_info = U_ih^T d_gi   (A = transposed weights packed in fragment order, B = the rows just
-//       written, read back from global by the same workgroup);
+//       are written to global memory (they are outputs: the caller's weight-gradient GEMMs need them) and, as rows
+//       [dr | dz | dn | dn r] of the LDS image G, kept for (2); DH <- upd ? d z : DH;
+//   (2) DH += U_hh^T d_gh,  d_info = U_ih^T d_gi   (A = transposed weights packed in fragment order, B = rows of G: every
+//       wave needs every row, so reading them back from global would cost 16 x the bytes of the weights themselves);
 //   (3) d_ctx = W_O^T d_info;
 //   (4) attention backward, one head at a time on LDS images of q, k, v, P (saved by the forward): dP = d_ctx v^T,
 //       dS = P (dP - rowsum(dP P)) / 8, dv = P^T d_ctx, dq = dS k, dk = dS^T q.  Every product is an MFMA with both
@@ -42,17 +43,20 @@ constexpr int CTX_ROW = 128 * 2 + 32;  // 288
 constexpr int QKV_ROW = 384 * 2 + 32;  // 800
 constexpr int IMG_ROW = 64 * 2 + 32;   // per-head q / k / v / P / dS images: 64 rows x 64 columns
 constexpr int SF_ROW = 52;             // fp32 dP rows
+constexpr int G_ROW = 1024 * 2 + 32;   // [dr | dz | dn | dn r] rows of one GRU-cell backward
 constexpr int OFF_DH = 0;
 constexpr int OFF_DINFO = OFF_DH + NA * H_ROW;
 constexpr int OFF_DCTX = OFF_DINFO + NA * INFO_ROW;      // 64 rows: rows >= 48 stay zero (K padding of the transposed reads)
-constexpr int OFF_DQKV = OFF_DCTX + 64 * CTX_ROW;
+constexpr int OFF_G = OFF_DCTX + 64 * CTX_ROW;           // G and the attention images / d_qkv / dP are never live together
+constexpr int OFF_DQKV = OFF_G;
 constexpr int OFF_QI = OFF_DQKV + NA * QKV_ROW;
 constexpr int OFF_KI = OFF_QI + 64 * IMG_ROW;
 constexpr int OFF_VI = OFF_KI + 64 * IMG_ROW;
 constexpr int OFF_PI = OFF_VI + 64 * IMG_ROW;
 constexpr int OFF_DSI = OFF_PI + 64 * IMG_ROW;
 constexpr int OFF_SF = OFF_DSI + 64 * IMG_ROW;
-constexpr int OFF_UPD = OFF_SF + NA * SF_ROW * 4;
+constexpr int UNION_BYTES = (OFF_SF + NA * SF_ROW * 4 - OFF_G) > NA * G_ROW ? (OFF_SF + NA * SF_ROW * 4 - OFF_G) : NA * G_ROW;
+constexpr int OFF_UPD = OFF_G + UNION_BYTES;
 constexpr int LDS_BYTES = OFF_UPD + 64 * 4;
 static_assert(LDS_BYTES <= 160 * 1024 && OFF_SF % 16 == 0 && OFF_UPD % 16 == 0, "LDS budget / alignment");
 
@@ -98,30 +102,18 @@ __device__ __forceinline__ bf16x8 row_frag(const unsigned char *img, int row_byt
     return *reinterpret_cast<const bf16x8 *>(img + row * row_bytes + (k0 + 8 * (lane >> 4)) * 2);
 }
 
-// acc[n] += (packed tile `wp`, KS k-steps) * B^T, B rows in GLOBAL memory: row(agent) = B + agent * ldb, columns k0 .. k0 + 32 KS
+// acc[n] += (packed tile `wp`, KS k-steps) * B^T, B rows in an LDS image: row(agent) = X + agent * xrow, columns 0 .. 32 KS
 template <int KS>
-__device__ __forceinline__ void gemm_gB(f32x4 (&acc)[NT], const bf16x8 *__restrict__ wp, const uint16_t *B, int ldb, int k0, int nagents, int lane) {
+__device__ __forceinline__ void gemm_lB(f32x4 (&acc)[NT], const unsigned char *__restrict__ wt, int tile_kstep, const unsigned char *X, int xrow,
+                                        int lane) {
     const int lr = lane & 15, lh = lane >> 4;
+    // scalar base + 32-bit lane offset: the load takes its address as (SGPR pair, VGPR offset) instead of a 64-bit VGPR
+    // pair per tile, which the compiler would hoist out of the time loop and spill
+    const unsigned char *wp = wt + (size_t)tile_kstep * 1024;
+    const uint32_t voff = (uint32_t)lane * 16u;
     bf16x8 a[KS];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) a[kk] = wp[kk * 64];
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int agent = 16 * n + lr;
-            bf16x8 b = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (agent < nagents) b = *reinterpret_cast<const bf16x8 *>(B + (long long)agent * ldb + k0 + 32 * kk + 8 * lh);
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk], b, acc[n], 0, 0, 0);
-        }
-}
-// same with B rows in an LDS image
-template <int KS>
-__device__ __forceinline__ void gemm_lB(f32x4 (&acc)[NT], const bf16x8 *__restrict__ wp, const unsigned char *X, int xrow, int lane) {
-    const int lr = lane & 15, lh = lane >> 4;
-    bf16x8 a[KS];
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) a[kk] = wp[kk * 64];
+    for (int kk = 0; kk < KS; ++kk) a[kk] = *reinterpret_cast<const bf16x8 *>(wp + kk * 1024 + voff);
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
@@ -147,15 +139,19 @@ struct BwdArgs {
 
 // GRU cell backward on this lane's cells (channel blocks cb = w, w + 8; agent tiles n): reads DH (LDS), the saved gates and
 // input state (global), writes d_gi / d_gh rows (global) and DH <- (upd ? d z : DH).
-__device__ __forceinline__ void gru_bwd_elementwise(unsigned char *DH, const uint16_t *__restrict__ gates, const uint16_t *__restrict__ hin,
-                                                    const int *upd, uint16_t *__restrict__ dgi, uint16_t *__restrict__ dgh, int N, int w, int lr,
-                                                    int lh) {
+__device__ __forceinline__ void gru_bwd_elementwise(unsigned char *DH, unsigned char *G, const uint16_t *__restrict__ gates,
+                                                    const uint16_t *__restrict__ hin, const int *upd, uint16_t *__restrict__ dgi,
+                                                    uint16_t *__restrict__ dgh, int N, int w, int lr, int lh) {
     for (int cb = w; cb < 16; cb += NTHR / 64) {
         const int c0 = 16 * cb + 4 * lh;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int agent = 16 * n + lr;
-            if (agent >= N) continue;
+            uint2 *grow = reinterpret_cast<uint2 *>(G + agent * G_ROW + c0 * 2);
+            if (agent >= N) {  // G shares its LDS with the attention images: padding rows are re-zeroed every time
+                grow[0] = grow[64] = grow[128] = grow[192] = make_uint2(0, 0);
+                continue;
+            }
             const uint16_t *g = gates + (long long)agent * 1024 + c0;
             float r[4], z[4], nn[4], hn[4], h[4], d[4];
             unpack4(*reinterpret_cast<const uint2 *>(g), r);
@@ -177,13 +173,17 @@ __device__ __forceinline__ void gru_bwd_elementwise(unsigned char *DH, const uin
                 dpass[k] = on ? dd * z[k] : d[k];
             }
             uint16_t *gi = dgi + (long long)agent * 768 + c0, *gh = dgh + (long long)agent * 768 + c0;
-            const uint2 pr = pack4(dr), pz = pack4(dz);
+            const uint2 pr = pack4(dr), pz = pack4(dz), pn = pack4(dn), pnr = pack4(dnr);
             *reinterpret_cast<uint2 *>(gi) = pr;
             *reinterpret_cast<uint2 *>(gi + 256) = pz;
-            *reinterpret_cast<uint2 *>(gi + 512) = pack4(dn);
+            *reinterpret_cast<uint2 *>(gi + 512) = pn;
             *reinterpret_cast<uint2 *>(gh) = pr;
             *reinterpret_cast<uint2 *>(gh + 256) = pz;
-            *reinterpret_cast<uint2 *>(gh + 512) = pack4(dnr);
+            *reinterpret_cast<uint2 *>(gh + 512) = pnr;
+            grow[0] = pr;
+            grow[64] = pz;
+            grow[128] = pn;
+            grow[192] = pnr;
             *dcell = pack4(dpass);
         }
     }
@@ -203,13 +203,14 @@ __device__ __forceinline__ void add_to_dh(unsigned char *DH, const f32x4 (&acc)[
 
 __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lh = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lh = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: weight-tile addresses become scalar base + lane offset
     const int e = blockIdx.x, T = A.T, E = A.E, N = A.N;
     const long long RTOT = (long long)T * E * N;
     unsigned char *DH = smem + OFF_DH;
     int *upd = reinterpret_cast<int *>(smem + OFF_UPD);
     float *SF = reinterpret_cast<float *>(smem + OFF_SF);
-    const bf16x8 *WT = reinterpret_cast<const bf16x8 *>(A.WT);
+    const unsigned char *WTB = reinterpret_cast<const unsigned char *>(A.WT);
 
     for (int i = tid; i < LDS_BYTES / 16; i += NTHR) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -242,7 +243,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
             const long long rq = (long long)q * RTOT + row0;
             uint16_t *dgi2 = A.d_gi2 + rq * 768, *dgh2 = A.d_gh2 + rq * 768;
             // (1) update-cell backward
-            gru_bwd_elementwise(DH, A.g2 + rq * 1024, A.hr + rq * D, upd, dgi2, dgh2, N, w, lr, lh);
+            gru_bwd_elementwise(DH, smem + OFF_G, A.g2 + rq * 1024, A.hr + rq * D, upd, dgi2, dgh2, N, w, lr, lh);
             __syncthreads();
             // (2) DH += U_hh^T d_gh (2 output tiles per wave); d_info = U_ih^T d_gi (waves 0-3, one tile each)
             {
@@ -251,9 +252,10 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
                 for (int n = 0; n < NT; ++n) acc0[n] = acc1[n] = acci[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
-                    gemm_gB<8>(acc0, WT + (WT_UHH / 8) + ((g * 16 + w) * 8) * 64 + lane, dgh2, 768, 256 * g, N, lane);
-                    gemm_gB<8>(acc1, WT + (WT_UHH / 8) + ((g * 16 + w + 8) * 8) * 64 + lane, dgh2, 768, 256 * g, N, lane);
-                    if (w < 4) gemm_gB<8>(acci, WT + (WT_UIH / 8) + ((g * 4 + w) * 8) * 64 + lane, dgi2, 768, 256 * g, N, lane);
+                    const unsigned char *gh = smem + OFF_G + (g == 2 ? 768 : 256 * g) * 2, *gi = smem + OFF_G + 256 * g * 2;
+                    gemm_lB<8>(acc0, WTB, WT_UHH / 512 + ((g * 16 + w) * 8), gh, G_ROW, lane);
+                    gemm_lB<8>(acc1, WTB, WT_UHH / 512 + ((g * 16 + w + 8) * 8), gh, G_ROW, lane);
+                    if (w < 4) gemm_lB<8>(acci, WTB, WT_UIH / 512 + ((g * 4 + w) * 8), gi, G_ROW, lane);
                 }
                 add_to_dh(DH, acc0, w, lr, lh);
                 add_to_dh(DH, acc1, w + 8, lr, lh);
@@ -274,7 +276,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
                 f32x4 acc[NT];
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-                gemm_lB<2>(acc, WT + (WT_WO / 8) + (w * 2) * 64 + lane, smem + OFF_DINFO, INFO_ROW, lane);
+                gemm_lB<2>(acc, WTB, WT_WO / 512 + (w * 2), smem + OFF_DINFO, INFO_ROW, lane);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const float o[4] = {acc[n][0], acc[n][1], acc[n][2], acc[n][3]};
@@ -285,16 +287,19 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
             // (4) attention backward, one head at a time
             for (int hd = 0; hd < 2; ++hd) {
                 // images: q, k, v rows [agent][64] of this head; P rows [agent i][64 slots j]
-                for (int i = tid; i < N * 8 * 3; i += NTHR) {
-                    const int img = i / (N * 8), rem = i - img * (N * 8), a = rem >> 3, ch = rem & 7;
-                    *reinterpret_cast<uint4 *>(smem + OFF_QI + img * (64 * IMG_ROW) + a * IMG_ROW + ch * 16) =
-                        *reinterpret_cast<const uint4 *>(A.qkv + (rq + a) * 384 + img * 128 + hd * HD + ch * 8);
+                for (int i = tid; i < 64 * 8 * 3; i += NTHR) {
+                    const int img = i >> 9, a = (i >> 3) & 63, ch = i & 7;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (a < N) v = *reinterpret_cast<const uint4 *>(A.qkv + (rq + a) * 384 + img * 128 + hd * HD + ch * 8);
+                    *reinterpret_cast<uint4 *>(smem + OFF_QI + img * (64 * IMG_ROW) + a * IMG_ROW + ch * 16) = v;
                 }
                 {
                     const uint16_t *ps = A.P + ((((long long)q * T + t) * E + e) * 2 + hd) * (NA * 64);
-                    for (int i = tid; i < NA * 8; i += NTHR) {
+                    for (int i = tid; i < 64 * 8; i += NTHR) {
                         const int a = i >> 3, ch = i & 7;
-                        *reinterpret_cast<uint4 *>(smem + OFF_PI + a * IMG_ROW + ch * 16) = *reinterpret_cast<const uint4 *>(ps + a * 64 + ch * 8);
+                        uint4 v = make_uint4(0, 0, 0, 0);
+                        if (a < NA) v = *reinterpret_cast<const uint4 *>(ps + a * 64 + ch * 8);
+                        *reinterpret_cast<uint4 *>(smem + OFF_PI + a * IMG_ROW + ch * 16) = v;
                     }
                 }
                 __syncthreads();
@@ -310,14 +315,15 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
                     for (int r = 0; r < 4; ++r) SF[(16 * ti + 4 * lh + r) * SF_ROW + 16 * tj + lr] = acc[r];
                 }
                 __syncthreads();
-                // softmax backward per row i: dS = P (dP - sum_j dP P) / 8
-                if (tid < NA) {
-                    const int i = tid;
-                    const float4 *dp = reinterpret_cast<const float4 *>(SF + i * SF_ROW);
-                    const uint2 *pp = reinterpret_cast<const uint2 *>(smem + OFF_PI + i * IMG_ROW);
-                    float P[NA], dP[NA];
+                // softmax backward per row i, 4 lanes x 12 columns each: dS = P (dP - sum_j dP P) / 8; slots 48..63 and rows 48..63 of
+                // the dS image are zero (K padding)
+                if (tid < 4 * NA) {
+                    const int i = tid >> 2, part = tid & 3;
+                    const float4 *dp = reinterpret_cast<const float4 *>(SF + i * SF_ROW + 12 * part);
+                    const uint2 *pp = reinterpret_cast<const uint2 *>(smem + OFF_PI + i * IMG_ROW + 24 * part);
+                    float P[12], dP[12];
 #pragma unroll
-                    for (int c = 0; c < NA / 4; ++c) {
+                    for (int c = 0; c < 3; ++c) {
                         const float4 x = dp[c];
                         dP[4 * c] = x.x;
                         dP[4 * c + 1] = x.y;
@@ -332,10 +338,24 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
                     }
                     float dot = 0.f;
 #pragma unroll
-                    for (int j = 0; j < NA; ++j) dot += dP[j] * P[j];
-                    uint32_t *ds = reinterpret_cast<uint32_t *>(smem + OFF_DSI + i * IMG_ROW);
+                    for (int j = 0; j < 12; ++j) dot += dP[j] * P[j];
+                    dot += __shfl_xor(dot, 1);
+                    dot += __shfl_xor(dot, 2);
+                    uint2 *ds = reinterpret_cast<uint2 *>(smem + OFF_DSI + i * IMG_ROW + 24 * part);
 #pragma unroll
-                    for (int j = 0; j < NA; j += 2) ds[j / 2] = pack2_bf16(P[j] * (dP[j] - dot) * 0.125f, P[j + 1] * (dP[j + 1] - dot) * 0.125f);
+                    for (int c = 0; c < 3; ++c) {
+                        float o[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = P[4 * c + k] * (dP[4 * c + k] - dot) * 0.125f;
+                        ds[c] = pack4(o);
+                    }
+                    if (part == 0) {
+                        uint4 *pad = reinterpret_cast<uint4 *>(smem + OFF_DSI + i * IMG_ROW + 96);
+                        pad[0] = pad[1] = make_uint4(0, 0, 0, 0);
+                    }
+                } else if (tid < 4 * NA + 16 * 8) {
+                    const int k = tid - 4 * NA;
+                    *reinterpret_cast<uint4 *>(smem + OFF_DSI + (48 + (k >> 3)) * IMG_ROW + (k & 7) * 16) = make_uint4(0, 0, 0, 0);
                 }
                 __syncthreads();
                 // dv, dq, dk: 3 products x 4 d-tiles x 3 agent tiles, each K = 64 (image rows / slots 48..63 are zero)
@@ -372,8 +392,8 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
                 f32x4 acc0[NT], acc1[NT];
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc0[n] = acc1[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-                gemm_lB<12>(acc0, WT + (WT_QKV / 8) + (w * 12) * 64 + lane, smem + OFF_DQKV, QKV_ROW, lane);
-                gemm_lB<12>(acc1, WT + (WT_QKV / 8) + ((w + 8) * 12) * 64 + lane, smem + OFF_DQKV, QKV_ROW, lane);
+                gemm_lB<12>(acc0, WTB, WT_QKV / 512 + (w * 12), smem + OFF_DQKV, QKV_ROW, lane);
+                gemm_lB<12>(acc1, WTB, WT_QKV / 512 + ((w + 8) * 12), smem + OFF_DQKV, QKV_ROW, lane);
                 add_to_dh(DH, acc0, w, lr, lh);
                 add_to_dh(DH, acc1, w + 8, lr, lh);
             }
@@ -381,7 +401,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
         }
         // ---- recurrent cell backward: d_gi1 is the gradient w.r.t. the GRU input projection ----
         uint16_t *dgi1 = A.d_gi1 + row0 * 768, *dgh1 = A.d_gh1 + row0 * 768;
-        gru_bwd_elementwise(DH, A.g1 + row0 * 1024, A.hin0 + row0 * D, nullptr, dgi1, dgh1, N, w, lr, lh);
+        gru_bwd_elementwise(DH, smem + OFF_G, A.g1 + row0 * 1024, A.hin0 + row0 * D, nullptr, dgi1, dgh1, N, w, lr, lh);
         __syncthreads();
         {
             f32x4 acc0[NT], acc1[NT];
@@ -389,8 +409,9 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
             for (int n = 0; n < NT; ++n) acc0[n] = acc1[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                gemm_gB<8>(acc0, WT + (WT_WHH / 8) + ((g * 16 + w) * 8) * 64 + lane, dgh1, 768, 256 * g, N, lane);
-                gemm_gB<8>(acc1, WT + (WT_WHH / 8) + ((g * 16 + w + 8) * 8) * 64 + lane, dgh1, 768, 256 * g, N, lane);
+                const unsigned char *gh = smem + OFF_G + (g == 2 ? 768 : 256 * g) * 2;
+                gemm_lB<8>(acc0, WTB, WT_WHH / 512 + ((g * 16 + w) * 8), gh, G_ROW, lane);
+                gemm_lB<8>(acc1, WTB, WT_WHH / 512 + ((g * 16 + w + 8) * 8), gh, G_ROW, lane);
             }
             add_to_dh(DH, acc0, w, lr, lh);
             add_to_dh(DH, acc1, w + 8, lr, lh);
