@@ -128,16 +128,20 @@ int mapf_recurrent_infer(const uint16_t *gi_dev, const uint16_t *h0_dev, const u
  *     weights_t_dev = the TRANSPOSED matrices in fragment order: per gate g (r, z, n) U_ih[g]^T [64][256] | per gate
  *     U_hh[g]^T [256][256] | per gate W_hh[g]^T [256][256] | W_O^T [128][64] | W_qkv^T [256][384]
  *     (MAPF_RECUR_WEIGHT_ELEMS bf16);
- *   out_dev[6] (bf16): 0 d_gi1 [R][768] gradient w.r.t. the GRU input projection gi | 1 d_gh1 [R][768] |
+ *   out_dev[7]: (bf16) 0 d_gi1 [R][768] gradient w.r.t. the GRU input projection gi | 1 d_gh1 [R][768] |
  *     2 d_gi2 [2][R][768] | 3 d_gh2 [2][R][768] | 4 d_info [2][R][64] | 5 d_qkv [2][R][384]
- *   -- the gradients of the pre-activations of every linear map; weight gradient = (that)^T (its saved input), bias
- *   gradient = its column sum, both formed by the caller (six tall GEMMs per update).
+ *   -- the gradients of the pre-activations of every linear map; weight gradient = (that)^T (its saved input), formed by
+ *   the caller (tall GEMMs, once per update) --, and
+ *     (f32) 6 bsum [E][MAPF_RECUR_BSUM_ELEMS]: per-environment column sums over steps and agents of
+ *     [update cell: dr | dz | dn | dn r] (both rounds) [recurrent cell: dr | dz | dn | dn r] [d_qkv: 384]; summed over E
+ *     they are the bias gradients (b_ih: dr, dz, dn; b_hh: dr, dz, dn r).
  */
+#define MAPF_RECUR_BSUM_ELEMS 2432
 int mapf_recurrent_forward_save(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev,
                                 const uint16_t *weights_dev, const float *bias_dev, int T, int E, int N,
                                 uint16_t *h_out_dev, uint16_t *agent0_out_dev, uint16_t *const *save_dev, void *stream);
 int mapf_recurrent_backward(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev,
-                            const uint16_t *weights_t_dev, int T, int E, int N, uint16_t *const *out_dev, void *stream);
+                            const uint16_t *weights_t_dev, int T, int E, int N, void *const *out_dev, void *stream);
 
 /*
  * Communication mask of `Network.step` (reference model.py:195-208): mask[e][i][j] = j lies inside i's FOV square

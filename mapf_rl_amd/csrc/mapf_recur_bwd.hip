@@ -18,8 +18,9 @@
 //   (5) DH += W_qkv^T d_qkv;
 // then the recurrent cell's backward (d_gi of it is the gradient w.r.t. the GRU input projection, an output) and
 // DH += W_hh^T d_gh; agent 0's external gradient of the previous step is added and the loop continues.
-// Weight and bias gradients are NOT formed here: they are six tall GEMMs / column sums over (saved input, d_*) rows that
-// the caller runs once per update.
+// Weight gradients are NOT formed here: they are tall GEMMs over (saved input, d_*) rows that the caller runs once per
+// update.  Bias gradients are column sums of the d_* rows: accumulated in LDS on the way (fp32) and written as one
+// partial vector per environment, which spares the caller five more passes over 0.2-0.4 GB each.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -57,7 +58,10 @@ constexpr int OFF_DSI = OFF_PI + 64 * IMG_ROW;
 constexpr int OFF_SF = OFF_DSI + 64 * IMG_ROW;
 constexpr int UNION_BYTES = (OFF_SF + NA * SF_ROW * 4 - OFF_G) > NA * G_ROW ? (OFF_SF + NA * SF_ROW * 4 - OFF_G) : NA * G_ROW;
 constexpr int OFF_UPD = OFF_G + UNION_BYTES;
-constexpr int LDS_BYTES = OFF_UPD + 64 * 4;
+constexpr int OFF_BSUM = OFF_UPD + 64 * 4;  // fp32 column sums over (steps, agents): [update cell | recurrent cell][dr|dz|dn|dn r][256], d_qkv[384]
+constexpr int NBSUM = MAPF_RECUR_BSUM_ELEMS;
+static_assert(NBSUM == 2 * 1024 + 384, "header constant out of date");
+constexpr int LDS_BYTES = OFF_BSUM + NBSUM * 4;
 static_assert(LDS_BYTES <= 160 * 1024 && OFF_SF % 16 == 0 && OFF_UPD % 16 == 0, "LDS budget / alignment");
 
 // transposed-weight buffer (bf16 elements, fragment order [tile][k-step][lane][8], gates outermost for the GRU matrices)
@@ -134,6 +138,7 @@ struct BwdArgs {
     uint16_t *d_gi2, *d_gh2;  // [2][R][768]
     uint16_t *d_info;         // [2][R][64]
     uint16_t *d_qkv;          // [2][R][384]
+    float *bsum;              // [E][NBSUM] per-environment column sums (bias gradients)
     int T, E, N;
 };
 
@@ -141,9 +146,14 @@ struct BwdArgs {
 // input state (global), writes d_gi / d_gh rows (global) and DH <- (upd ? d z : DH).
 __device__ __forceinline__ void gru_bwd_elementwise(unsigned char *DH, unsigned char *G, const uint16_t *__restrict__ gates,
                                                     const uint16_t *__restrict__ hin, const int *upd, uint16_t *__restrict__ dgi,
-                                                    uint16_t *__restrict__ dgh, int N, int w, int lr, int lh) {
+                                                    uint16_t *__restrict__ dgh, float *bsum, int N, int w, int lr, int lh) {
     for (int cb = w; cb < 16; cb += NTHR / 64) {
         const int c0 = 16 * cb + 4 * lh;
+        float cs[4][4];  // column sums over this lane's agents: [dr|dz|dn|dn r][channel]
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cs[g][k] = 0.f;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int agent = 16 * n + lr;
@@ -171,6 +181,10 @@ __device__ __forceinline__ void gru_bwd_elementwise(unsigned char *DH, unsigned 
                 dr[k] = dn[k] * hn[k] * r[k] * (1.f - r[k]);
                 dnr[k] = dn[k] * r[k];
                 dpass[k] = on ? dd * z[k] : d[k];
+                cs[0][k] += dr[k];
+                cs[1][k] += dz[k];
+                cs[2][k] += dn[k];
+                cs[3][k] += dnr[k];
             }
             uint16_t *gi = dgi + (long long)agent * 768 + c0, *gh = dgh + (long long)agent * 768 + c0;
             const uint2 pr = pack4(dr), pz = pack4(dz), pn = pack4(dn), pnr = pack4(dnr);
@@ -186,6 +200,18 @@ __device__ __forceinline__ void gru_bwd_elementwise(unsigned char *DH, unsigned 
             grow[192] = pnr;
             *dcell = pack4(dpass);
         }
+        // sum over the 16 agents of the lane group; the lr = 0 lane owns columns c0 .. c0 + 3 of every gate
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v = cs[g][k];
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                if (lr == 0) bsum[256 * g + c0 + k] += v;
+            }
     }
 }
 
@@ -243,7 +269,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
             const long long rq = (long long)q * RTOT + row0;
             uint16_t *dgi2 = A.d_gi2 + rq * 768, *dgh2 = A.d_gh2 + rq * 768;
             // (1) update-cell backward
-            gru_bwd_elementwise(DH, smem + OFF_G, A.g2 + rq * 1024, A.hr + rq * D, upd, dgi2, dgh2, N, w, lr, lh);
+            gru_bwd_elementwise(DH, smem + OFF_G, A.g2 + rq * 1024, A.hr + rq * D, upd, dgi2, dgh2, reinterpret_cast<float *>(smem + OFF_BSUM), N, w, lr, lh);
             __syncthreads();
             // (2) DH += U_hh^T d_gh (2 output tiles per wave); d_info = U_ih^T d_gi (waves 0-3, one tile each)
             {
@@ -384,6 +410,11 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
                 __syncthreads();
             }
             // (5) d_qkv rows -> global; DH += W_qkv^T d_qkv (2 output tiles per wave, K = 384)
+            if (tid < 384) {  // column sums of d_qkv (rows >= N are zero)
+                float v = 0.f;
+                for (int a = 0; a < N; ++a) v += bf16_lo(*reinterpret_cast<const uint16_t *>(smem + OFF_DQKV + a * QKV_ROW + tid * 2));
+                reinterpret_cast<float *>(smem + OFF_BSUM)[2048 + tid] += v;
+            }
             for (int i = tid; i < N * 48; i += NTHR) {
                 const int a = i / 48, ch = i - a * 48;
                 *reinterpret_cast<uint4 *>(A.d_qkv + (rq + a) * 384 + ch * 8) = *reinterpret_cast<const uint4 *>(smem + OFF_DQKV + a * QKV_ROW + ch * 16);
@@ -401,7 +432,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
         }
         // ---- recurrent cell backward: d_gi1 is the gradient w.r.t. the GRU input projection ----
         uint16_t *dgi1 = A.d_gi1 + row0 * 768, *dgh1 = A.d_gh1 + row0 * 768;
-        gru_bwd_elementwise(DH, smem + OFF_G, A.g1 + row0 * 1024, A.hin0 + row0 * D, nullptr, dgi1, dgh1, N, w, lr, lh);
+        gru_bwd_elementwise(DH, smem + OFF_G, A.g1 + row0 * 1024, A.hin0 + row0 * D, nullptr, dgi1, dgh1, reinterpret_cast<float *>(smem + OFF_BSUM) + 1024, N, w, lr, lh);
         __syncthreads();
         {
             f32x4 acc0[NT], acc1[NT];
@@ -418,6 +449,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
         }
         __syncthreads();
     }
+    for (int i = tid; i < NBSUM; i += NTHR) A.bsum[(long long)e * NBSUM + i] = reinterpret_cast<const float *>(smem + OFF_BSUM)[i];
 }
 
 #define HIP_TRY(expr)                                                                            \
@@ -434,11 +466,11 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
 extern "C" {
 
 int mapf_recurrent_backward(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev,
-                            const uint16_t *weights_t_dev, int T, int E, int N, uint16_t *const *out_dev, void *stream) {
+                            const uint16_t *weights_t_dev, int T, int E, int N, void *const *out_dev, void *stream) {
     if (T < 1 || E < 0 || N < 1 || N > NA || !saved_dev || !comm_dev || !d_agent0_dev || !weights_t_dev || !out_dev) return MAPF_ERR_INVALID_ARG;
     for (int i = 0; i < 8; ++i)
         if (!saved_dev[i] || (reinterpret_cast<uintptr_t>(saved_dev[i]) & 15)) return MAPF_ERR_INVALID_ARG;
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 7; ++i)
         if (!out_dev[i] || (reinterpret_cast<uintptr_t>(out_dev[i]) & 15)) return MAPF_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(d_agent0_dev) & 15) || (reinterpret_cast<uintptr_t>(weights_t_dev) & 15)) return MAPF_ERR_INVALID_ARG;
     if (E == 0) return MAPF_OK;
@@ -454,12 +486,13 @@ int mapf_recurrent_backward(const uint16_t *const *saved_dev, const uint8_t *com
     a.comm = comm_dev;
     a.dA0 = d_agent0_dev;
     a.WT = weights_t_dev;
-    a.d_gi1 = out_dev[0];
-    a.d_gh1 = out_dev[1];
-    a.d_gi2 = out_dev[2];
-    a.d_gh2 = out_dev[3];
-    a.d_info = out_dev[4];
-    a.d_qkv = out_dev[5];
+    a.d_gi1 = static_cast<uint16_t *>(out_dev[0]);
+    a.d_gh1 = static_cast<uint16_t *>(out_dev[1]);
+    a.d_gi2 = static_cast<uint16_t *>(out_dev[2]);
+    a.d_gh2 = static_cast<uint16_t *>(out_dev[3]);
+    a.d_info = static_cast<uint16_t *>(out_dev[4]);
+    a.d_qkv = static_cast<uint16_t *>(out_dev[5]);
+    a.bsum = static_cast<float *>(out_dev[6]);
     a.T = T;
     a.E = E;
     a.N = N;

@@ -318,21 +318,22 @@ class _RecurTrain(torch.autograd.Function):
         wt = pack_recurrence_transposed(params)
         outs = [torch.empty((R, 768), dtype=bf, device=dev), torch.empty((R, 768), dtype=bf, device=dev),
                 torch.empty((2, R, 768), dtype=bf, device=dev), torch.empty((2, R, 768), dtype=bf, device=dev),
-                torch.empty((2, R, 64), dtype=bf, device=dev), torch.empty((2, R, 384), dtype=bf, device=dev)]
+                torch.empty((2, R, 64), dtype=bf, device=dev), torch.empty((2, R, 384), dtype=bf, device=dev),
+                torch.empty((E, 2432), dtype=torch.float32, device=dev)]
         g_a0 = g_a0.to(bf).contiguous()
         sp = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in saves])
-        op = (ctypes.c_void_p * 6)(*[t.data_ptr() for t in outs])
+        op = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in outs])
         check(lib.mapf_recurrent_backward(sp, _ptr(comm), _ptr(g_a0), _ptr(wt), T, E, N, op, _stream(dev)), "mapf_recurrent_backward")
-        d_gi1, d_gh1, d_gi2, d_gh2, d_info, d_qkv = outs
+        d_gi1, d_gh1, d_gi2, d_gh2, d_info, d_qkv, bsum = outs
         hin0, _, hr, _, ctxs, info, _, _ = saves
-        f32 = torch.float32
         d_gi2f, d_gh2f, d_qkvf, hrf = d_gi2.view(2 * R, 768), d_gh2.view(2 * R, 768), d_qkv.view(2 * R, 384), hr.view(2 * R, 256)
         g_whh = _tall_tn(d_gh1, hin0)
         g_qkv = _tall_tn(d_qkvf, hrf)
-        b_qkv = d_qkvf.sum(dim=0, dtype=f32)
-        grads = [g_whh, d_gi1.sum(dim=0, dtype=f32), d_gh1.sum(dim=0, dtype=f32), g_qkv[:128], g_qkv[128:256], g_qkv[256:], b_qkv[:128],
+        bs = bsum.sum(dim=0)  # bias gradients: the kernel's per-environment column sums
+        u, r, b_qkv = bs[:1024], bs[1024:2048], bs[2048:]
+        grads = [g_whh, r[:768], torch.cat([r[:512], r[768:]]), g_qkv[:128], g_qkv[128:256], g_qkv[256:], b_qkv[:128],
                  b_qkv[128:256], b_qkv[256:], _tall_tn(d_info.view(2 * R, 64), ctxs.view(2 * R, 128)), _tall_tn(d_gi2f, info.view(2 * R, 64)),
-                 _tall_tn(d_gh2f, hrf), d_gi2f.sum(dim=0, dtype=f32), d_gh2f.sum(dim=0, dtype=f32)]
+                 _tall_tn(d_gh2f, hrf), u[:768], torch.cat([u[:512], u[768:]])]
         grads = [g.to(p.dtype).reshape(p.shape) for g, p in zip(grads, params)]
         return (d_gi1.view(T, E, N, 768), None, None, None, None, *grads)
 

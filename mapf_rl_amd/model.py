@@ -154,6 +154,29 @@ def _accumulate(p, g):
         p.grad.add_(g.reshape(p.shape))
 
 
+class _InputProj(torch.autograd.Function):
+    """y = x W^T (+ b) for the GRU input projection over all T*B*N rows, with the backward GEMMs in the forms that run well at
+    this shape (tools/micro/proj_gemm.py, R = 122,880 rows x 784 -> 768): d_x through a transposed copy of W (TN, 0.21 ms; the
+    NN GEMM autograd would issue takes 0.33 ms) and d_W split along K (0.25 ms; as one GEMM its 6 x 7 output tiles occupy a
+    sixth of the chip for 0.64 ms)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        w_lp = w.detach().to(x.dtype)
+        ctx.save_for_backward(x, w_lp)
+        ctx.has_bias = b is not None
+        return F.linear(x, w_lp, None if b is None else b.detach().to(x.dtype))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_lp = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = F.linear(dy, w_lp.t().contiguous()) if ctx.needs_input_grad[0] else None
+        dw = _tall_tn(dy, x, rows=4096)
+        db = dy.sum(dim=0, dtype=torch.float32) if ctx.has_bias else None
+        return dx, dw, db
+
+
 class _TimeLinear(torch.autograd.Function):
     """y = x W^T (+ b) for one time step of the recurrence; dx in backward, dW/db deferred to `sink`."""
 
@@ -358,11 +381,15 @@ class Network(nn.Module):
         hidden [B*N, 256]; comm_mask bool [B, T, N, N].  Returns q [B, 5] (float32)."""
         B, T, N = obs.shape[:3]
         with self._autocast(obs.device):
-            latent = self.encode(obs.reshape(B * T * N, *OBS_SHAPE)).view(B, T, N, ENC_FEATURES)
-            hidden = hidden.to(latent.dtype)
-            if self.FAST_RECURRENCE and latent.is_cuda and latent.dtype == torch.bfloat16:
-                agent0 = self._recur_fast(latent, hidden, comm_mask)
+            if self.FAST_RECURRENCE and obs.is_cuda and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+                # time-major from the start: transposing the raw observation bytes is 3x cheaper than transposing the latent
+                # (and its gradient, on the way back), and the encoder does not care about row order
+                obs_t = obs.transpose(0, 1).contiguous()
+                latent_t = self.encode(obs_t.view(T * B * N, *OBS_SHAPE)).view(T, B, N, ENC_FEATURES)
+                agent0 = self._recur_fast(latent_t, hidden.to(latent_t.dtype), comm_mask)
             else:
+                latent = self.encode(obs.reshape(B * T * N, *OBS_SHAPE)).view(B, T, N, ENC_FEATURES)
+                hidden = hidden.to(latent.dtype)
                 agent0 = []
                 for t in range(T):
                     hidden = self.recurrent(latent[:, t].reshape(B * N, ENC_FEATURES), hidden)
@@ -387,20 +414,20 @@ class Network(nn.Module):
         h0 = None if hidden is None else hidden.reshape(E, N, self.latent_dim)
         return recurrent_infer(gi, h0, comm_t, w, b, want_agent0)
 
-    def _recur_fast(self, latent, hidden, comm_mask):
+    def _recur_fast(self, latent_t, hidden, comm_mask):
         """The T-step GRU + CommBlock recurrence of `bootstrap` (model.py:242-249), same math as the module path,
         arranged for the GPU:
           * the GRU's input projection W_ih x_t does not depend on the recurrence -> ONE GEMM over all T steps;
           * W_Q, W_K, W_V share their input -> one [384, 256] GEMM per communication round;
           * every weight is cast to bf16 once per call (not once per step);
           * with autograd, the per-step weight gradients are deferred to one GEMM per weight (_WGradSink).
-        latent bf16 [B, T, N, 784]; hidden bf16 [B*N, 256]; comm_mask bool [B, T, N, N] -> agent-0 states [B, T, 256]."""
-        B, T, N, _ = latent.shape
+        latent_t bf16 [T, B, N, 784] (time-major); hidden bf16 [B*N, 256]; comm_mask bool [B, T, N, N] -> agent-0 states [B, T, 256]."""
+        T, B, N, _ = latent_t.shape
         D, H, A = self.latent_dim, NUM_COMM_HEADS, self.comm.output_dim
         lp = torch.bfloat16
         grad = torch.is_grad_enabled()
         if not grad and self.FUSED_RECURRENCE and N <= 48:  # target network: all T steps in one kernel launch
-            a0 = self._recur_kernel(latent.transpose(0, 1), hidden, comm_mask.transpose(0, 1), True)[1]
+            a0 = self._recur_kernel(latent_t, hidden, comm_mask.transpose(0, 1), True)[1]
             return a0.transpose(0, 1)
         if grad and self.FUSED_BPTT and N <= 48:
             # online network: forward-with-saved-state and backward-through-time kernels, one workgroup per window
@@ -409,8 +436,7 @@ class Network(nn.Module):
             if self._packed_recur is None:
                 self._packed_recur = PackedRecurrence()
             w, b = self._packed_recur.get(self)
-            lat_t = latent.transpose(0, 1).reshape(T * B * N, ENC_FEATURES)
-            gi = F.linear(lat_t, self.recurrent.weight_ih.to(lp)).view(T, B, N, 3 * D)   # bias added inside the kernel
+            gi = _InputProj.apply(latent_t.view(T * B * N, ENC_FEATURES), self.recurrent.weight_ih, None).view(T, B, N, 3 * D)  # bias: in the kernel
             a0 = recurrent_train(gi, hidden.reshape(B, N, D), comm_mask.transpose(0, 1), w, b, recurrence_params(self))
             return a0.transpose(0, 1)
         sink = _WGradSink() if grad else None
@@ -437,11 +463,12 @@ class Network(nn.Module):
             return F.linear(x, w, b)
 
         # all T input projections at once, time-major so that step t is a contiguous [B*N, 768] slab
-        lat_t = latent.transpose(0, 1).reshape(T, B * N, ENC_FEATURES)
+        lat_t = latent_t.view(T, B * N, ENC_FEATURES)
         # biases are added by the linears (the GRU cell gets none): with autograd their gradients are then ONE deferred
         # column sum per bias instead of a reduction per (step, cell) inside the fused cell's backward (96 launches)
         b_hh, ub_ih, ub_hh = cast(rc.bias_hh), cast(uc.bias_ih), cast(uc.bias_hh)
-        gi_all = F.linear(lat_t, rc.weight_ih.to(lp), rc.bias_ih.to(lp)) if grad else F.linear(lat_t, cast(rc.weight_ih), cast(rc.bias_ih))
+        gi_all = _InputProj.apply(lat_t.view(T * B * N, ENC_FEATURES), rc.weight_ih, rc.bias_ih).view(T, B * N, 3 * D) if grad else \
+            F.linear(lat_t, cast(rc.weight_ih), cast(rc.bias_ih))
         blocked = (~comm_mask).unsqueeze(2)                              # [B, T, 1, N, N]
         allowed = comm_mask.unsqueeze(2)
         update = (comm_mask.sum(dim=-1) > 1).unsqueeze(-1)               # [B, T, N, 1]  (model.py:103)

@@ -48,6 +48,14 @@ def main():
     print("| category | ms | launches |\n|---|---|---|")
     for k, v in sorted(cat.items(), key=lambda kv: -kv[1][0])[:top]:
         print("| %s | %.3f | %d |" % (k, v[0] / 1e6, v[1]))
+    if len(sys.argv) > 4:  # the largest single launches outside the named hand-written kernels, in launch order
+        n = int(sys.argv[4])
+        big = sorted(range(len(sel)), key=lambda i: int(sel[i]["Start_Timestamp"]) - int(sel[i]["End_Timestamp"]))[:n]
+        print("\n| # in iteration | us | grid | kernel |\n|---|---|---|---|")
+        for i in sorted(big):
+            r = sel[i]
+            print("| %d | %.1f | %s | %s |" % (i, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Grid_Size", "?"),
+                                             r["Kernel_Name"][:110]))
 
 
 if __name__ == "__main__":
