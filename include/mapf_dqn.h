@@ -80,6 +80,16 @@ int mapf_encoder_pack_bwd(const float *const *w_dev, uint16_t *packed_bwd_dev, v
 int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint32_t *relu_bits_dev,
                                const uint16_t *packed_bwd_dev, uint16_t *gz_dev, float *gbias_partial_dev,
                                void *stream);
+/*
+ * The same chain, starting one step earlier: `g_latent_dev` is the gradient w.r.t. the encoder's OUTPUT (bf16 [M][784],
+ * the forward's flattened NCHW order: channel * 49 + position) and `latent_dev` that output; the kernel applies the 1x1
+ * layer's ReLU mask itself while staging (three elementwise passes and a reduction less for the caller) and also writes
+ * the masked gradient position-major, gz7_dev bf16 [M][49][16] (operand of the caller's 1x1 weight-gradient GEMM), and
+ * gb7_partial_dev f32 [4 * ceil(M/4)][16], per-wave partial bias gradients of the 1x1 layer (the caller adds the rows).
+ */
+int mapf_encoder_backward(const uint16_t *g_latent_dev, const uint16_t *latent_dev, int64_t M, const uint32_t *relu_bits_dev,
+                          const uint16_t *packed_bwd_dev, uint16_t *gz_dev, float *gbias_partial_dev, uint16_t *gz7_dev,
+                          float *gb7_partial_dev, void *stream);
 
 /*
  * Weight gradient of one 3x3 128->128 convolution of the encoder (csrc/mapf_wgrad.hip):

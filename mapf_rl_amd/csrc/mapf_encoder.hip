@@ -421,10 +421,16 @@ __device__ __forceinline__ void store_bias_partial(float (&bs)[2][4], float *__r
         }
 }
 
+// HEAD = true: the ReLU mask of the 1x1 layer is applied here as well -- `gz7` is then the gradient w.r.t. the encoder's
+// OUTPUT, bf16 [M][784] in the forward's flattened NCHW order (channel * 49 + position), `latent` that output; the masked
+// gradient is transposed into position-major order while it is staged, and also written to `gz7_out` [M][49][16] (the
+// caller's weight-gradient GEMM wants it) together with this workgroup's partial bias gradient `gb7_part` [blocks][16].
+template <bool HEAD>
 __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t *__restrict__ gz7, long long M,
                                                                   const uint32_t *__restrict__ relu_bits,
                                                                   const uint16_t *__restrict__ wpt, uint16_t *__restrict__ gz,
-                                                                  float *__restrict__ gb_part) {
+                                                                  float *__restrict__ gb_part, const uint16_t *__restrict__ latent,
+                                                                  uint16_t *__restrict__ gz7_out, float *__restrict__ gb7_part) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[ACT_BYTES + GZ7_BYTES];
     unsigned char *const act = smem;
     const unsigned char *const raw = smem + ACT_BYTES;
@@ -436,7 +442,34 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
     const int nobs = left < G ? (int)left : G;
 
     for (int i = tid; i < ACT_BYTES / 16; i += NTHREADS) reinterpret_cast<uint4 *>(act)[i] = make_uint4(0, 0, 0, 0);
-    {   // gz7 rows of this block: contiguous, 32 B per position
+    if (HEAD) {  // mask with (latent > 0) and transpose [obs][c][p] -> [obs][p][c] on the way into LDS
+        // (16-byte loads of both tensors issued together; one observation is 98 chunks, so a chunk is all-valid or all-padding)
+        const uint4 *gsrc = reinterpret_cast<const uint4 *>(gz7 + obs0 * 784), *lsrc = reinterpret_cast<const uint4 *>(latent + obs0 * 784);
+        uint16_t *dst = reinterpret_cast<uint16_t *>(smem + ACT_BYTES);
+        const int have = nobs * 98;
+        uint4 gv[2], lv[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int ch = tid + r * NTHREADS;
+            gv[r] = lv[r] = make_uint4(0, 0, 0, 0);
+            if (ch < have) {
+                gv[r] = gsrc[ch];
+                lv[r] = lsrc[ch];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int ch = tid + r * NTHREADS;
+            if (ch >= G * 98) break;
+            const uint32_t gw[4] = {gv[r].x, gv[r].y, gv[r].z, gv[r].w}, lw[4] = {lv[r].x, lv[r].y, lv[r].z, lv[r].w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = ch * 8 + k, o = i / 784, rem = i - 784 * o, c = rem / 49, p = rem - 49 * c;
+                const uint32_t y = (lw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, gq = (gw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                dst[(o * 49 + p) * 16 + c] = (uint16_t)(((y & 0x7FFFu) != 0u && !(y & 0x8000u)) ? gq : 0u);
+            }
+        }
+    } else {  // gz7 rows of this block: contiguous, 32 B per position
         const uint4 *src = reinterpret_cast<const uint4 *>(gz7 + obs0 * (49 * 16));
         uint4 *dst = reinterpret_cast<uint4 *>(smem + ACT_BYTES);
         const int have = nobs * 49 * 2;
@@ -453,6 +486,21 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
         vmask |= (v ? 1u : 0u) << n;
     }
     __syncthreads();
+    if (HEAD) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(smem + ACT_BYTES);
+        uint4 *dst = reinterpret_cast<uint4 *>(gz7_out + obs0 * (49 * 16));
+        for (int i = tid; i < nobs * 49 * 2; i += NTHREADS) dst[i] = src[i];
+        {   // bias gradient of the 1x1 layer: wave cb sums the 49 rows of observation cb (padding rows are zero), 4 rows at a time
+            const uint16_t *rows = reinterpret_cast<const uint16_t *>(smem + ACT_BYTES) + (49 * cb) * 16 + lr;
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < 13; ++j)
+                if (lh + 4 * j < 49) v += bf16_bits_to_f32(rows[(lh + 4 * j) * 16]);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 16) gb7_part[((long long)blockIdx.x * 4 + cb) * 16 + lane] = v;
+        }
+    }
 
     const int co_lane = cb * 32 + 4 * lh;
     // this lane's element (a, n) of a saved activation / gz tensor of layer k: 4 channels = 8 bytes
@@ -653,8 +701,27 @@ int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint32_
     if (M == 0) return MAPF_OK;
     const long long blocks = (M + G - 1) / G;
     if (blocks > 0x7FFFFFFFLL) return MAPF_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(encoder_bwd_kernel, dim3((unsigned)blocks), dim3(NTHREADS), 0, static_cast<hipStream_t>(stream), gz7_dev,
-                       (long long)M, relu_bits_dev, packed_bwd_dev, gz_dev, gbias_partial_dev);
+    hipLaunchKernelGGL(encoder_bwd_kernel<false>, dim3((unsigned)blocks), dim3(NTHREADS), 0, static_cast<hipStream_t>(stream), gz7_dev,
+                       (long long)M, relu_bits_dev, packed_bwd_dev, gz_dev, gbias_partial_dev, nullptr, nullptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+int mapf_encoder_backward(const uint16_t *g_latent_dev, const uint16_t *latent_dev, int64_t M, const uint32_t *relu_bits_dev,
+                          const uint16_t *packed_bwd_dev, uint16_t *gz_dev, float *gbias_partial_dev, uint16_t *gz7_dev,
+                          float *gb7_partial_dev, void *stream) {
+    if (M < 0 || !packed_bwd_dev ||
+        (M > 0 && (!g_latent_dev || !latent_dev || !relu_bits_dev || !gz_dev || !gbias_partial_dev || !gz7_dev || !gb7_partial_dev)))
+        return MAPF_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(g_latent_dev) & 15) || (reinterpret_cast<uintptr_t>(latent_dev) & 15) ||
+        (reinterpret_cast<uintptr_t>(relu_bits_dev) & 15) || (reinterpret_cast<uintptr_t>(packed_bwd_dev) & 15) ||
+        (reinterpret_cast<uintptr_t>(gz_dev) & 15) || (reinterpret_cast<uintptr_t>(gz7_dev) & 15))
+        return MAPF_ERR_INVALID_ARG;
+    if (M == 0) return MAPF_OK;
+    const long long blocks = (M + G - 1) / G;
+    if (blocks > 0x7FFFFFFFLL) return MAPF_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(encoder_bwd_kernel<true>, dim3((unsigned)blocks), dim3(NTHREADS), 0, static_cast<hipStream_t>(stream), g_latent_dev,
+                       (long long)M, relu_bits_dev, packed_bwd_dev, gz_dev, gbias_partial_dev, latent_dev, gz7_dev, gb7_partial_dev);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }

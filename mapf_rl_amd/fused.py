@@ -160,22 +160,21 @@ class _EncoderTrain(torch.autograd.Function):
         dev = obs.device
         M = obs.shape[0]
         gws = [None] * 8
-        gb7 = torch.zeros(16, dtype=torch.float32, device=dev)
-        # 1x1 layer: ReLU mask + bias gradient in one pass; [M,16,7,7] channels_last == memory [M][49][16]
-        o4 = out.view(M, 16, 7, 7).contiguous(memory_format=cl)
-        g4 = g.to(torch.bfloat16).reshape(M, 16, 7, 7).contiguous(memory_format=cl)
-        gz7 = _mask_bias(g4, o4, gb7)
-        gb7 = gz7.sum(dim=(0, 2, 3), dtype=torch.float32)  # (the mask kernel's own bias sum uses float atomics: not repeatable)
-        # the whole backward-data chain: one kernel, masked pre-activation gradients of all 7 layers out
+        # the whole backward-data chain in one kernel: ReLU mask of the 1x1 layer on the incoming gradient, then the masked
+        # pre-activation gradients of all 7 layers below it and per-workgroup bias-gradient partials
         w32 = [params[2 * i].detach().to(torch.float32).contiguous() for i in range(8)]
         wpt = torch.empty(ENC_PACKED_BWD_ELEMS, dtype=torch.bfloat16, device=dev)
         check(lib.mapf_encoder_pack_bwd((ctypes.c_void_p * 8)(*[w.data_ptr() for w in w32]), _ptr(wpt), _stream(dev)),
               "mapf_encoder_pack_bwd")
+        g = g.to(torch.bfloat16).contiguous()
+        nblk = -(-M // ENC_OBS_PER_BLOCK)
         gz = torch.empty_like(acts)
-        gb_part = torch.empty((7, -(-M // ENC_OBS_PER_BLOCK), 128), dtype=torch.float32, device=dev)
-        check(lib.mapf_encoder_backward_data(_ptr(gz7), M, _ptr(bits), _ptr(wpt), _ptr(gz), _ptr(gb_part), _stream(dev)),
-              "mapf_encoder_backward_data")
-        gbs = list(gb_part.sum(dim=1).unbind(0)) + [gb7]  # per-workgroup partial bias gradients -> [7][128]
+        gz7 = torch.empty((M * 49, 16), dtype=torch.bfloat16, device=dev)
+        gb_part = torch.empty((7, nblk, 128), dtype=torch.float32, device=dev)
+        gb7_part = torch.empty((4 * nblk, 16), dtype=torch.float32, device=dev)
+        check(lib.mapf_encoder_backward(_ptr(g), _ptr(out), M, _ptr(bits), _ptr(wpt), _ptr(gz), _ptr(gb_part), _ptr(gz7), _ptr(gb7_part),
+                                        _stream(dev)), "mapf_encoder_backward")
+        gbs = list(gb_part.sum(dim=1).unbind(0)) + [gb7_part.sum(dim=0)]
         # weight gradients of the six 3x3 128->128 layers: one streaming MFMA kernel per layer (mapf_encoder_wgrad),
         # partial sums per observation partition, added here
         ws = torch.empty((ENC_WGRAD_PARTS, 128, 3, 3, 128), dtype=torch.float32, device=dev)
@@ -189,7 +188,7 @@ class _EncoderTrain(torch.autograd.Function):
         from .model import _tall_tn  # split-K GEMM for [K, m]^T [K, n] with huge K
 
         gws[0] = _tall_tn(gz[0].reshape(M * 49, 128), cols).view(128, 6, 3, 3)
-        gws[7] = _tall_tn(gz7.permute(0, 2, 3, 1).reshape(M * 49, 16), acts[6].reshape(M * 49, 128)).view(16, 128, 1, 1)
+        gws[7] = _tall_tn(gz7, acts[6].reshape(M * 49, 128)).view(16, 128, 1, 1)
         grads = []
         for i in range(8):
             grads += [gws[i].to(params[2 * i].dtype), gbs[i].to(params[2 * i + 1].dtype)]
