@@ -20,12 +20,19 @@
 //  * Both operands need K (= position) along the fragment's register axis while memory has channels contiguous:
 //    ds_read_b64_tr_b16 (hardware transpose read) delivers a [4 positions x 16 channels] block column-major.  Rows
 //    are 288 B apart (256 + 32) so that the 8 consecutive rows a half-wave reads fall in distinct banks.
-//  * Positions live in the same zero-bordered 8-wide image as the forward kernel (row 64*obs + 8*y + x for gz,
-//    +9 for a), so the input row of tap (ky,kx) is a constant offset 8*ky + kx from the gz row; border rows are zero
-//    in gz, which makes the padded K positions contribute nothing.
-//  * One observation (64 K rows = 2 k-steps, 96 MFMAs per wave) per step through a ring of three LDS buffers: while
-//    observation i is multiplied, i+1 is already resident (its first fragments are prefetched during i's last k-step,
-//    so the hand-over exposes nothing but the barrier) and i+2 travels HBM -> registers -> the third buffer.
+//  * K slot k = 8*y + x of an observation (64 slots = 2 k-steps, 49 of them real).  The INPUT lives in the same
+//    zero-bordered 8-wide image as in the forward kernel (row 9 + 8*y + x), so the row of tap (ky,kx) is a constant
+//    offset 8*ky + kx from the slot; gz is stored dense (row 7*y + x) and every lane points the slots that are
+//    padding (x = 7, y = 7) at one all-zero row -- the transposed read takes a row address per lane anyway.
+//  * One observation (72 MFMAs per wave) per step through a ring of FOUR LDS buffers filled by global_load_lds_dwordx4
+//    (HBM -> LDS without passing through registers; lane i of a wave writes LDS bytes [16 i, 16 i + 16) of a 1-KiB
+//    chunk from ANY global address, masked lanes write nothing -- tools/micro/lds_direct_load.hip): while observation i
+//    is multiplied, i+1 and i+2 are resident and i+3 is in flight for two whole steps (~2.5 us, the HBM latency under
+//    this load).  The first version staged through 16 registers per lane and a third buffer: the data of i+2 had one
+//    step to arrive and the kernel sat at 1.53 ms per layer against 0.99 ms for its MFMAs alone.  The loads are inline
+//    asm: hipcc's wait-count pass would make every later LDS read wait for a builtin LDS-DMA load it cannot disambiguate.
+//    Every wave issues exactly 4 chunk loads per observation, so `s_waitcnt vmcnt(4)` at the end of a step means "all but
+//    the newest observation have landed".
 //  * The two slabs of one observation partition run on the same XCD (ids i, i+8 share an L2), so the
 //    operands come from HBM once.
 //  * Output: per-partition partial sums fp32 [P][128][3][3][128]; the caller adds the P slabs (deterministic).
@@ -56,12 +63,15 @@ constexpr int CT = 4;                        // 16-row co tiles per wave (64 co)
 constexpr int NTN = 1152 / SLABS / 4 / 16;    // 16-column tiles per wave (9: 144 columns); 144 accumulator registers
 static_assert(NTN * 16 * 4 * SLABS == 1152 && (2 * NTN) % 3 == 0 && NTN >= CT, "");
 constexpr int WROW = 288;                    // LDS bytes per position row
-constexpr int GZ_ROWS = 64;                  // one observation = 64 rows of K (2 k-steps of 32), 49 of them non-zero
+constexpr int GZ_ZERO_ROW = 49;              // dense gz rows 0..48 = positions 7*y + x; row 49 stays zero (padding K slots)
 constexpr int IN_ROWS = 64 + 18;             // input image rows reachable through the 9 taps
-constexpr int GZ_BYTES = GZ_ROWS * WROW;
-constexpr int OBS_BYTES = (GZ_ROWS + IN_ROWS) * WROW;  // 42,048
-constexpr int NBUF = 3;                      // ring: computing obs i, obs i+1 resident, obs i+2 being written
-static_assert(NBUF * OBS_BYTES <= 160 * 1024, "LDS budget");
+constexpr int GZ_BYTES = 15 * 1024;          // 50 rows of 288 B, rounded up to whole 1-KiB load chunks
+constexpr int OBS_BYTES = GZ_BYTES + IN_ROWS * WROW;  // 38,976
+constexpr int NBUF = 4;                      // ring: computing obs i, obs i+1 and i+2 resident, obs i+3 in flight
+static_assert(NBUF * OBS_BYTES <= 160 * 1024 && (GZ_ZERO_ROW + 1) * WROW <= GZ_BYTES, "LDS budget");
+// direct-to-LDS chunks per observation: gz rows 0..48 = bytes [0, 14112) -> chunks 0..13; input rows 9..63 (the interior)
+// = bytes [2592, 18432) of the input region -> its chunks 2..17; 30 chunks + 2 harmless repeats = 8 waves x 4
+constexpr int LPW = 4;
 static_assert(MAPF_ENC_WGRAD_PARTS % 8 == 0, "");
 
 __device__ __forceinline__ bf16x8 tr_read2(const unsigned char *p0, const unsigned char *p1) {
@@ -81,7 +91,8 @@ __device__ __forceinline__ bf16x8 tr_read2(const unsigned char *p0, const unsign
 __global__ void __launch_bounds__(NTHR, 1) encoder_wgrad_kernel(const uint16_t *__restrict__ gz, const uint16_t *__restrict__ ain,
                                                               long long M, float *__restrict__ ws) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * OBS_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
     const int slab = slot % SLABS, part = (slot / SLABS) * 8 + xcd;
     const int chalf = w & 1, nq = w >> 1;  // this wave's 64 output channels / 144 columns of the slab
@@ -94,45 +105,55 @@ __global__ void __launch_bounds__(NTHR, 1) encoder_wgrad_kernel(const uint16_t *
 
     for (int i = tid; i < NBUF * OBS_BYTES / 16; i += NTHR) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
 
-    // ---- staging: an observation is 784 16-byte chunks of gz and 784 of the input (49 positions x 16) ----
-    // per tensor: chunk tid, and chunk 512 + tid on threads 0-271 (a harmless duplicate load elsewhere); wave-uniform
-    // base + tid*16, no per-load address math.
-    int dst[2];  // LDS byte offset of gz chunk tid + 512 i inside an observation buffer; the input chunk sits IN_SHIFT further
+    // ---- staging: wave w issues chunk-loads j = w, w + 8, w + 16, w + 24 of every observation ----
+    // per lane and load: the global byte offset inside the observation (of gz for j < 14 and the two repeats, of the input
+    // otherwise) of the 16 bytes this lane's LDS slot holds, or -1 where the slot is row padding / a border row
+    int soff[LPW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int tt = i == 0 ? tid : (tid < 272 ? tid : 271);
-        const int q = (tt >> 4) + 32 * i, y = q / 7, x = q - 7 * y;
-        dst[i] = (8 * y + x) * WROW + (tt & 15) * 16;
+    for (int k = 0; k < LPW; ++k) {
+        const int jj = w + 8 * k;
+        const bool isg = jj < 14 || jj >= 30;
+        const int chunk = jj < 14 ? jj : (jj >= 30 ? jj - 30 : jj - 12);  // chunk index inside its region
+        const int L = 1024 * chunk + 16 * lane, row = L / WROW, col = L - row * WROW;
+        int off = -1;
+        if (col < 256) {
+            if (isg) {
+                if (row < 49) off = row * 256 + col;
+            } else {
+                const int r = row - 9;
+                if (r >= 0 && r < 56 && (r & 7) != 7) off = (7 * (r >> 3) + (r & 7)) * 256 + col;
+            }
+        }
+        soff[k] = off;
     }
-    constexpr int IN_SHIFT = GZ_BYTES + 9 * WROW;
-    const int v16 = tid * 16, v16b = (tid < 272 ? tid : 271) * 16;
-    // (a plain struct of named native-vector registers: hipcc puts an ARRAY that is passed to a lambda or indexed by a
-    // lambda parameter into scratch memory or LDS, and HIP's uint4 is a struct with unions)
-    struct Stage {
-        u32x4 g0, g1, a0, a1;
-    };
-    Stage stg0;
-    auto load_into = [&](Stage &st, long long ob) __attribute__((always_inline)) {
-        const char *g = reinterpret_cast<const char *>(gz + ob * 6272), *a = reinterpret_cast<const char *>(ain + ob * 6272);
-        st.g0 = *reinterpret_cast<const u32x4 *>(g + v16);
-        st.g1 = *reinterpret_cast<const u32x4 *>(g + 8192 + v16b);
-        st.a0 = *reinterpret_cast<const u32x4 *>(a + v16);
-        st.a1 = *reinterpret_cast<const u32x4 *>(a + 8192 + v16b);
-    };
-    auto store_from = [&](const Stage &st, int buf) __attribute__((always_inline)) {
-        unsigned char *base = smem + buf * OBS_BYTES;
-        *reinterpret_cast<u32x4 *>(base + dst[0]) = st.g0;
-        *reinterpret_cast<u32x4 *>(base + dst[0] + IN_SHIFT) = st.a0;
-        if (tid < 272) {
-            *reinterpret_cast<u32x4 *>(base + dst[1]) = st.g1;
-            *reinterpret_cast<u32x4 *>(base + dst[1] + IN_SHIFT) = st.a1;
+    typedef __attribute__((address_space(3))) unsigned char *lds_byte_ptr;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte_ptr)smem;
+    auto issue_loads = [&](long long ob, int buf) __attribute__((always_inline)) {
+        const uint16_t *gsrc = gz + ob * 6272, *asrc = ain + ob * 6272;
+#pragma unroll
+        for (int k = 0; k < LPW; ++k) {
+            const int jj = w + 8 * k;
+            const bool isg = jj < 14 || jj >= 30;
+            const int chunk = jj < 14 ? jj : (jj >= 30 ? jj - 30 : jj - 12);
+            const uint32_t dst = lds0 + buf * OBS_BYTES + (isg ? 0 : GZ_BYTES) + 1024 * chunk;
+            const uint16_t *src = isg ? gsrc : asrc;
+            if (soff[k] >= 0)
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(soff[k]), "s"(src) : "memory");
         }
     };
 
     // ---- fragment addresses of this lane (ds_read_b64_tr_b16: lane 4q+p of a 16-lane group supplies row q, columns 4p..) ----
     const int li = lane & 15, lh = lane >> 4, q4 = li >> 2, p4 = li & 3;
-    // k-slot (lh, j) of a 32-row k-step: row 4 lh + j for j < 4 (first read), 16 + 4 lh + (j - 4) for the second
-    const int a_base = (4 * lh + q4) * WROW + 8 * p4 + (CT * chalf) * 32;
+    // k-slot (lh, j) of a 32-slot k-step: slot 4 lh + j for j < 4 (first read), 16 + 4 lh + (j - 4) for the second;
+    // gz row of slot 8 y + x: 7 y + x, or the zero row for the padding slots
+    int a_row[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int slot = 32 * ks + 16 * blk + 4 * lh + q4, y = slot >> 3, x = slot & 7;
+            a_row[ks][blk] = ((x < 7 && y < 7) ? 7 * y + x : GZ_ZERO_ROW) * WROW + 8 * p4 + (CT * chalf) * 32;
+        }
     // output column = (tap, ci): this wave's tile t covers columns col0(t) .. +16
     auto col0 = [&](int t) { return (1152 / SLABS) * slab + (16 * NTN) * nq + 16 * t; };
     int b_base[NTN];
@@ -149,20 +170,22 @@ __global__ void __launch_bounds__(NTHR, 1) encoder_wgrad_kernel(const uint16_t *
         for (int t = 0; t < NTN; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     __syncthreads();  // zero fill done
-    if (nob > 0) {
-        load_into(stg0, ob0);
-        store_from(stg0, 0);
-    }
-    if (nob > 1) {
-        load_into(stg0, ob0 + 1);
-        store_from(stg0, 1);
+    if (!(MAPF_WGRAD_ABLATE & 1)) {
+        if (nob > 0) issue_loads(ob0, 0);
+        if (nob > 1) issue_loads(ob0 + 1, 1);
+        if (nob > 2) {
+            issue_loads(ob0 + 2, 2);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // observations 0 and 1 have landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
     __syncthreads();
 
     // fragments: the CT gz (A) tiles of the current k-step and of the next one; the input (B) tiles pass through a ring of
     // three (tile t's MFMAs run while tile t+2 is being read)
     bf16x8 af[2][CT], br[3];
-    auto read_a = [&](const unsigned char *sb, int ks, int c) { return tr_read2(sb + a_base + (32 * ks) * WROW + c * 32, sb + a_base + (32 * ks + 16) * WROW + c * 32); };
+    auto read_a = [&](const unsigned char *sb, int ks, int c) { return tr_read2(sb + a_row[ks][0] + c * 32, sb + a_row[ks][1] + c * 32); };
     auto read_b = [&](const unsigned char *sb, int ks, int t) { return tr_read2(sb + b_base[t] + (32 * ks) * WROW, sb + b_base[t] + (32 * ks + 16) * WROW); };
     if (nob > 0) {
 #pragma unroll
@@ -173,12 +196,13 @@ __global__ void __launch_bounds__(NTHR, 1) encoder_wgrad_kernel(const uint16_t *
 
     // One observation (step i): 2 k-steps x 48 MFMAs on buffer `b`; the fragments of its second k-step, then of the
     // next observation's first k-step (buffer b1, complete since the last barrier), are read behind the MFMAs.
-    // Staging: observation i + 2 is loaded HBM -> registers at the start of the step and written to the free buffer
-    // b2 after the MFMAs, before the barrier.
-    auto one_obs = [&](long long i, auto B, auto B1, auto B2, auto PAR) __attribute__((always_inline)) {
-        constexpr int b = decltype(B)::value, b1 = decltype(B1)::value, b2 = decltype(B2)::value;
+    // Staging: the loads of observation i + 3 are issued at the start of the step into the buffer that step i - 1 read
+    // (free since its barrier); the step ends by waiting for observation i + 2 (issued one step earlier) and a barrier.
+    auto one_obs = [&](long long i, auto B, auto B1, auto B3) __attribute__((always_inline)) {
+        constexpr int b = decltype(B)::value, b1 = decltype(B1)::value, b3 = decltype(B3)::value;
         const unsigned char *sb = smem + b * OBS_BYTES, *sb1 = smem + b1 * OBS_BYTES;
-        if (i + 2 < nob && !(MAPF_WGRAD_ABLATE & 1)) load_into(stg0, ob0 + i + 2);  // in flight during this observation's MFMAs
+        const bool more = i + 3 < nob && !(MAPF_WGRAD_ABLATE & 1);
+        if (more) issue_loads(ob0 + i + 3, b3);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -204,22 +228,27 @@ __global__ void __launch_bounds__(NTHR, 1) encoder_wgrad_kernel(const uint16_t *
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (i + 2 < nob && !(MAPF_WGRAD_ABLATE & 1)) store_from(stg0, b2);
+        if (more)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // everything but the 4 loads just issued
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(MAPF_WGRAD_ABLATE & 4)) __syncthreads();
     };
-    // Six observations per loop iteration (two turns of the buffer ring): every buffer offset is a constant, and the
-    // accumulator shuffle hipcc emits on the loop back-edge (it does not tie an MFMA's
-    // destination to its source: 192 v_accvgpr_mov per iteration, which HALVED the MFMA rate with one observation per
-    // iteration) is paid once per 576 MFMAs.
+    // Four observations per loop iteration (one turn of the buffer ring): every buffer offset is a constant, and the
+    // accumulator shuffle hipcc emits on the loop back-edge (it does not tie an MFMA's destination to its source:
+    // 192 v_accvgpr_mov per iteration, which HALVED the MFMA rate with one observation per iteration) is paid once
+    // per 288 MFMAs.
     long long i = 0;
-    for (; i + 3 <= nob; i += 3) {
-        one_obs(i, I<0>{}, I<1>{}, I<2>{}, I<0>{});
-        one_obs(i + 1, I<1>{}, I<2>{}, I<0>{}, I<0>{});
-        one_obs(i + 2, I<2>{}, I<0>{}, I<1>{}, I<0>{});
+    for (; i + 4 <= nob; i += 4) {
+        one_obs(i, I<0>{}, I<1>{}, I<3>{});
+        one_obs(i + 1, I<1>{}, I<2>{}, I<0>{});
+        one_obs(i + 2, I<2>{}, I<3>{}, I<1>{});
+        one_obs(i + 3, I<3>{}, I<0>{}, I<2>{});
     }
-    // tail (i % 3 == 0 here, so the ring is in its initial phase)
-    if (i < nob) one_obs(i, I<0>{}, I<1>{}, I<2>{}, I<0>{});
-    if (i + 1 < nob) one_obs(i + 1, I<1>{}, I<2>{}, I<0>{}, I<0>{});
+    // tail (i % 4 == 0 here, so the ring is in its initial phase)
+    if (i < nob) one_obs(i, I<0>{}, I<1>{}, I<3>{});
+    if (i + 1 < nob) one_obs(i + 1, I<1>{}, I<2>{}, I<0>{});
+    if (i + 2 < nob) one_obs(i + 2, I<2>{}, I<3>{}, I<1>{});
 
     // ---- partial sums of this partition: ws[part][co][tap = ky*3 + kx][ci] ----
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the asm MFMAs are opaque to hipcc's hazard padding: let the last ones retire
