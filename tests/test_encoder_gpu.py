@@ -298,3 +298,68 @@ def test_encoder_argument_checks():
     assert lib.mapf_encoder_forward(o.data_ptr() + 1, 0, 1, w.data_ptr(), b.data_ptr(), out.data_ptr(), None) == ERR_INVALID_ARG
     assert lib.mapf_encoder_forward(o.data_ptr(), 0, 0, w.data_ptr(), b.data_ptr(), out.data_ptr(), None) == 0
     assert lib.mapf_encoder_forward(o.data_ptr(), 0, -1, w.data_ptr(), b.data_ptr(), out.data_ptr(), None) == ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("M", [1, 5, 162, 1001])
+def test_backward_with_head_equals_backward_data(M):
+    """mapf_encoder_backward (ReLU mask of the 1x1 layer, NCHW -> position-major transposition and the layer's bias partials
+    done while the kernel stages its input) against the separate steps feeding mapf_encoder_backward_data: the masked
+    gradient gz7 and all seven gz layers bit for bit, bias partial sums to fp32 summation order."""
+    from mapf_rl_amd._lib import check, lib
+    from mapf_rl_amd.fused import ENC_PACKED_BWD_ELEMS, PackedEncoder
+
+    net = _net(M + 7)
+    g = torch.Generator(device="cuda").manual_seed(M)
+    obs = (torch.rand((M, 6, 9, 9), device="cuda", generator=g) < 0.35).to(torch.uint8)
+    wp, bp = PackedEncoder().get(net.obs_encoder)
+    lat = torch.empty((M, 784), dtype=torch.bfloat16, device="cuda")
+    acts = torch.empty((7, M, 49, 128), dtype=torch.bfloat16, device="cuda")
+    bits = torch.empty((7, M, 49, 4), dtype=torch.int32, device="cuda")
+    check(lib.mapf_encoder_forward_save(obs.data_ptr(), 0, M, wp.data_ptr(), bp.data_ptr(), lat.data_ptr(), acts.data_ptr(),
+                                        bits.data_ptr(), None), "mapf_encoder_forward_save")
+    glat = torch.randn((M, 784), device="cuda", generator=g).to(torch.bfloat16)
+    w32 = [c.weight.detach().float().contiguous() for c in _convs(net)]
+    import ctypes
+    wpt = torch.empty(ENC_PACKED_BWD_ELEMS, dtype=torch.bfloat16, device="cuda")
+    check(lib.mapf_encoder_pack_bwd((ctypes.c_void_p * 8)(*[w.data_ptr() for w in w32]), wpt.data_ptr(), None), "mapf_encoder_pack_bwd")
+    nblk = -(-M // 4)
+    # reference chain: mask + transpose in PyTorch, then the kernel without the head
+    gz7_ref = torch.where(lat.view(M, 16, 49) > 0, glat.view(M, 16, 49), torch.zeros((), dtype=torch.bfloat16, device="cuda"))
+    gz7_ref = gz7_ref.transpose(1, 2).contiguous()                                   # [M][49][16]
+    gz_a = torch.full((7, M, 49, 128), float("nan"), dtype=torch.bfloat16, device="cuda")
+    gb_a = torch.empty((7, nblk, 128), dtype=torch.float32, device="cuda")
+    check(lib.mapf_encoder_backward_data(gz7_ref.data_ptr(), M, bits.data_ptr(), wpt.data_ptr(), gz_a.data_ptr(), gb_a.data_ptr(), None),
+          "mapf_encoder_backward_data")
+    gz_b = torch.full((7, M, 49, 128), float("nan"), dtype=torch.bfloat16, device="cuda")
+    gb_b = torch.empty((7, nblk, 128), dtype=torch.float32, device="cuda")
+    gz7 = torch.full((M, 49, 16), float("nan"), dtype=torch.bfloat16, device="cuda")
+    gb7 = torch.full((4 * nblk, 16), float("nan"), dtype=torch.float32, device="cuda")
+    check(lib.mapf_encoder_backward(glat.data_ptr(), lat.data_ptr(), M, bits.data_ptr(), wpt.data_ptr(), gz_b.data_ptr(), gb_b.data_ptr(),
+                                    gz7.data_ptr(), gb7.data_ptr(), None), "mapf_encoder_backward")
+    assert torch.equal(gz7.view(torch.int16), gz7_ref.view(torch.int16))
+    assert torch.equal(gz_a.view(torch.int16), gz_b.view(torch.int16))
+    assert torch.equal(gb_a, gb_b)
+    ref7 = gz7_ref.float().sum(dim=(0, 1))
+    assert torch.isfinite(gb7).all()
+    assert float((gb7.sum(0) - ref7).abs().max()) <= 1e-4 * max(1.0, float(ref7.abs().max()))
+
+
+def test_backward_argument_checks():
+    from mapf_rl_amd._lib import ERR_INVALID_ARG, lib
+
+    t = torch.zeros(4096, dtype=torch.bfloat16, device="cuda")
+    p = t.data_ptr()
+    assert lib.mapf_encoder_backward(None, None, 4, None, None, None, None, None, None, None) == ERR_INVALID_ARG
+    assert lib.mapf_encoder_backward(p, p, 4, p, p, p, p, None, p, None) == ERR_INVALID_ARG      # gz7 output missing
+    assert lib.mapf_encoder_backward(p + 2, p, 4, p, p, p, p, p, p, None) == ERR_INVALID_ARG     # misaligned gradient
+    assert lib.mapf_encoder_backward(p, p, -1, p, p, p, p, p, p, None) == ERR_INVALID_ARG
+    assert lib.mapf_encoder_backward(p, p, 0, p, p, p, p, p, p, None) == 0
+    import ctypes
+    sv = (ctypes.c_void_p * 8)(*[p] * 8)
+    out = (ctypes.c_void_p * 7)(*[p] * 7)
+    assert lib.mapf_recurrent_backward(sv, p, p, p, 0, 1, 4, out, None) == ERR_INVALID_ARG        # T < 1
+    assert lib.mapf_recurrent_backward(sv, p, p, p, 2, 1, 49, out, None) == ERR_INVALID_ARG       # more than 48 agents
+    assert lib.mapf_recurrent_backward(sv, p, p, p, 2, 0, 4, out, None) == 0                      # no environments: nothing to do
+    bad = (ctypes.c_void_p * 7)(*([p] * 6 + [None]))
+    assert lib.mapf_recurrent_backward(sv, p, p, p, 2, 1, 4, bad, None) == ERR_INVALID_ARG
+    assert lib.mapf_recurrent_forward_save(p, None, p, p, p, 2, 1, 49, p, p, sv, None) == ERR_INVALID_ARG
