@@ -81,6 +81,16 @@ int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint32_
                                const uint16_t *packed_bwd_dev, uint16_t *gz_dev, float *gbias_partial_dev,
                                void *stream);
 /*
+ * Weight gradient of conv0 (6 -> 128, 3x3 valid on the 9x9 observation; csrc/mapf_wgrad0.hip):
+ *   partial_dev f32 [MAPF_ENC_WGRAD0_PARTS][128][64]: per-partition partial sums of
+ *   dW0[co][j = ci*9 + ky*3 + kx] = sum_{m,y,x} gz0[m][y][x][co] * obs[m][ci][y+ky][x+kx]   (columns 54..63 are zero);
+ *   gz0_dev bf16 [M][49][128] = layer 0 of mapf_encoder_backward's gz; obs_dev / obs_dtype as in mapf_encoder_forward.
+ * The caller adds the partitions (deterministic) and keeps the first 54 columns = the weight's own [co][ci][ky][kx] order.
+ */
+#define MAPF_ENC_WGRAD0_PARTS 512
+int mapf_encoder_wgrad0(const uint16_t *gz0_dev, const void *obs_dev, int obs_dtype, int64_t M, float *partial_dev, void *stream);
+
+/*
  * The same chain, starting one step earlier: `g_latent_dev` is the gradient w.r.t. the encoder's OUTPUT (bf16 [M][784],
  * the forward's flattened NCHW order: channel * 49 + position) and `latent_dev` that output; the kernel applies the 1x1
  * layer's ReLU mask itself while staging (three elementwise passes and a reduction less for the caller) and also writes

@@ -56,6 +56,7 @@ def bias_res_relu(conv_out, bias, res=None):
 ENC_PACKED_ELEMS = 894976
 ENC_BIAS_ELEMS = 912
 ENC_PACKED_BWD_ELEMS = 888832
+ENC_WGRAD0_PARTS = 512
 ENC_WGRAD_PARTS = 128
 ENC_OBS_PER_BLOCK = 4
 _ENC_OBS_U8, _ENC_OBS_BF16 = 0, 1
@@ -181,13 +182,14 @@ class _EncoderTrain(torch.autograd.Function):
         for k in range(1, 7):
             check(lib.mapf_encoder_wgrad(_ptr(gz[k]), _ptr(acts[k - 1]), M, _ptr(ws), _stream(dev)), "mapf_encoder_wgrad")
             gws[k] = ws.sum(dim=0).permute(0, 3, 1, 2)  # [co][ky][kx][ci] memory == channels_last [co, ci, 3, 3]
-        # conv0 (K = 54) and the 1x1 layer (16 output channels) are 1 % of the work: plain GEMMs over all positions
-        # (im2col of the 9x9 observation for conv0) -- no MIOpen anywhere in this path
-        # (a strided window view, not F.unfold: its bf16 im2col kernel takes 0.5 s at this shape)
-        cols = obs.to(torch.bfloat16).unfold(2, 3, 1).unfold(3, 3, 1).permute(0, 2, 3, 1, 4, 5).reshape(M * 49, 54)  # [position, ci*9 + ky*3 + kx]
+        # conv0 (6 -> 128 on the raw 9x9 observation): its own streaming kernel (csrc/mapf_wgrad0.hip) -- the im2col matrix a
+        # library GEMM would need is 0.65 GB at the learner's shape; the 1x1 layer (16 outputs) is a plain split-K GEMM
+        ws0 = torch.empty((ENC_WGRAD0_PARTS, 128, 64), dtype=torch.float32, device=dev)
+        kind = _ENC_OBS_U8 if obs.dtype == torch.uint8 else _ENC_OBS_BF16
+        check(lib.mapf_encoder_wgrad0(_ptr(gz[0]), _ptr(obs), kind, M, _ptr(ws0), _stream(dev)), "mapf_encoder_wgrad0")
+        gws[0] = ws0.sum(dim=0)[:, :54].reshape(128, 6, 3, 3)
         from .model import _tall_tn  # split-K GEMM for [K, m]^T [K, n] with huge K
 
-        gws[0] = _tall_tn(gz[0].reshape(M * 49, 128), cols).view(128, 6, 3, 3)
         gws[7] = _tall_tn(gz7, acts[6].reshape(M * 49, 128)).view(16, 128, 1, 1)
         grads = []
         for i in range(8):

@@ -363,3 +363,28 @@ def test_backward_argument_checks():
     bad = (ctypes.c_void_p * 7)(*([p] * 6 + [None]))
     assert lib.mapf_recurrent_backward(sv, p, p, p, 2, 1, 4, bad, None) == ERR_INVALID_ARG
     assert lib.mapf_recurrent_forward_save(p, None, p, p, p, 2, 1, 49, p, p, sv, None) == ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("M,dtype", [(1, "u8"), (2, "u8"), (3, "bf16"), (255, "u8"), (257, "bf16"), (1500, "u8")])
+def test_wgrad0_kernel_against_fp32(M, dtype):
+    """mapf_encoder_wgrad0 (conv0's weight gradient straight from the raw observations) against the fp32 weight gradient
+    of a valid 3x3 convolution; the products are exact in fp32, only the summation order differs."""
+    from mapf_rl_amd._lib import ERR_INVALID_ARG, check, lib
+
+    g = torch.Generator(device="cuda").manual_seed(M)
+    if dtype == "u8":
+        obs = (torch.rand((M, 6, 9, 9), device="cuda", generator=g) * 4).to(torch.uint8)   # not only 0/1: any byte is legal
+        kind = 0
+    else:
+        obs = torch.randn((M, 6, 9, 9), device="cuda", generator=g).to(torch.bfloat16)
+        kind = 1
+    gz = (torch.randn((M, 7, 7, 128), device="cuda", generator=g) * (torch.rand((M, 7, 7, 128), device="cuda", generator=g) < 0.5)).to(torch.bfloat16)
+    ws = torch.full((512, 128, 64), float("nan"), dtype=torch.float32, device="cuda")
+    check(lib.mapf_encoder_wgrad0(gz.data_ptr(), obs.data_ptr(), kind, M, ws.data_ptr(), None), "mapf_encoder_wgrad0")
+    tot = ws.sum(0)
+    assert torch.isfinite(tot).all() and float(tot[:, 54:].abs().max()) == 0.0
+    got = tot[:, :54].reshape(128, 6, 3, 3)
+    ref = torch.nn.grad.conv2d_weight(obs.float(), (128, 6, 3, 3), gz.float().permute(0, 3, 1, 2))
+    assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), float((got - ref).abs().max())
+    assert lib.mapf_encoder_wgrad0(gz.data_ptr(), obs.data_ptr(), 5, M, ws.data_ptr(), None) == ERR_INVALID_ARG
+    assert lib.mapf_encoder_wgrad0(None, obs.data_ptr(), kind, M, ws.data_ptr(), None) == ERR_INVALID_ARG
