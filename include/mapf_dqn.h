@@ -57,8 +57,10 @@ int mapf_encoder_forward(const void *obs_dev, int obs_dtype, int64_t M, const ui
 /* Training forward: the same kernel, additionally storing what the backward pass needs:
  *   acts_dev bf16 [7][M][7][7][128] (NHWC) the 7 post-ReLU layer outputs, in order conv0, res1.block1, res1,
  *            res2.block1, res2, res3.block1, res3 -- the inputs of the weight gradients (16-byte aligned);
- *   relu_bits_dev uint32 [7][M][49][4] their sign bits: bit c % 32 of word c / 32 is set iff channel c of that
- *            position is > 0 -- the ReLU masks of the backward-data chain (16 bytes per position instead of 256). */
+ *   relu_bits_dev uint32 [7][M][49][4] their sign bits -- the ReLU masks of the backward-data chain (16 bytes per
+ *            position instead of 256): channel c = 32 w + 16 a + 4 h + r (w < 4, a < 2, h < 4, r < 4) of a position is > 0
+ *            iff bit 8 h + 4 a + r of its word w is set, i.e. byte h of the word belongs to the lane group that holds
+ *            those channels in both kernels' MFMA accumulators (each lane stores / loads one byte, no cross-lane traffic). */
 int mapf_encoder_forward_save(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev,
                               const float *bias_dev, uint16_t *latent_dev, uint16_t *acts_dev,
                               uint32_t *relu_bits_dev, void *stream);

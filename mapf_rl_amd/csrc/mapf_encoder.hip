@@ -38,6 +38,9 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+#ifndef MAPF_ENC_ABLATE  // diagnostic builds only (tools/micro/enc_ablate.py): 1 = no saved-activation copies, 2 = no ReLU sign words
+#define MAPF_ENC_ABLATE 0
+#endif
 constexpr int G = MAPF_ENC_OBS_PER_BLOCK;  // observations per workgroup
 constexpr int ROWB = 272;                  // bytes per activation row (128 bf16 + 16 B pad)
 constexpr int ACT_ROWS = 64 * G + 9;
@@ -85,22 +88,22 @@ __device__ __forceinline__ uint2 pack_relu(const f32x4 &a, const float4 &b) {
 
 // bit r of the result: the r-th of the 4 bf16 values in `y` (a ReLU output) is > 0
 __device__ __forceinline__ uint32_t positive4(const uint2 y) {
-    auto pos = [](uint32_t h) -> uint32_t { return ((h & 0x7FFFu) != 0u && !(h & 0x8000u)) ? 1u : 0u; };
-    return pos(y.x & 0xFFFFu) | (pos(y.x >> 16) << 1) | (pos(y.y & 0xFFFFu) << 2) | (pos(y.y >> 16) << 3);
+    // y holds max(., 0) results: the sign bit can only belong to a -0, so "> 0" is "magnitude bits non-zero"
+    return ((y.x & 0x7FFFu) ? 1u : 0u) | ((y.x & 0x7FFF0000u) ? 2u : 0u) | ((y.y & 0x7FFFu) ? 4u : 0u) | ((y.y & 0x7FFF0000u) ? 8u : 0u);
 }
 
-// Training forward: ReLU sign bits of a layer output, one uint32 per (position, 32-channel block): this lane's two
-// nibbles (tiles a = 0, 1; 4 channels each at bit 16 a + 4 lh) are ORed with those of the three lanes that hold the
-// other channels of the same position (lane ^ 16, lane ^ 32); the lh = 0 lane stores the word.  The backward kernel
-// reads these 16 bytes per position instead of the 256-byte activation rows.
+// Training forward: ReLU sign bits of a layer output, one uint32 per (position, 32-channel block cb = wave), of which every
+// lane owns one BYTE: byte lh holds the lane's two nibbles (tile a = 0 in bits 0-3, a = 1 in bits 4-7), i.e. channel
+// 32 cb + 16 a + 4 lh + r is bit 8 lh + 4 a + r of the word.  The backward kernel has the same lane <-> channel mapping, so a
+// lane stores and later loads just its own byte: no cross-lane traffic (the first version ORed the four lanes' nibbles into
+// one word with two shuffles per tile -- ds_bpermute, i.e. LDS-pipe instructions in a kernel the LDS pipe co-limits --
+// and cost the training forward 1.0 ms of its 9.0).  16 bytes per position instead of the 256-byte activation row.
 __device__ __forceinline__ void store_relu_bits(uint32_t nib[NT], uint32_t vmask, uint32_t *__restrict__ dst, int cb, int lr, int lh) {
+    if (MAPF_ENC_ABLATE & 2) return;
+    uint8_t *d8 = reinterpret_cast<uint8_t *>(dst) + cb * 4 + lh;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        uint32_t wbits = nib[n];
-        wbits |= (uint32_t)__shfl_xor((int)wbits, 16);
-        wbits |= (uint32_t)__shfl_xor((int)wbits, 32);
-        if (lh == 0 && ((vmask >> n) & 1u)) dst[(n * 16 + lr) * 4 + cb] = wbits;
-    }
+    for (int n = 0; n < NT; ++n)
+        if ((vmask >> n) & 1u) d8[(n * 16 + lr) * 16] = (uint8_t)nib[n];
 }
 
 // One 3x3 pad-1 128->128 convolution over the LDS-resident activations: acc[a][n] += W(a) * act(n).
@@ -147,6 +150,7 @@ __device__ __forceinline__ void conv3x3(const unsigned char *act, const bf16x8 *
 // Training forward: copy the layer output that is now resident in LDS (valid rows only) to its saved-activation
 // tensor [M][49][128] (NHWC) -- 49*nobs rows of 256 B, contiguous in global memory for the block's observations.
 __device__ __forceinline__ void save_rows(const unsigned char *act, uint16_t *__restrict__ dst, int nobs, int tid) {
+    if (MAPF_ENC_ABLATE & 1) return;
     const int total = nobs * 49 * 16;  // 16-byte chunks
     for (int c = tid; c < total; c += NTHREADS) {
         const int rowi = c >> 4, ch = c & 15;
@@ -252,7 +256,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const uint2 v = pack_relu(acc[a][n], b4);
-                if (SAVE) nib[n] = (a ? nib[n] : 0u) | (((vmask >> n) & 1u) ? positive4(v) << (16 * a + 4 * lh) : 0u);
+                if (SAVE) nib[n] = (a ? nib[n] : 0u) | (positive4(v) << (4 * a));
                 if ((vmask >> n) & 1u) *reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2) = v;
             }
         }
@@ -282,7 +286,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
                 uint2 *cell = reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2);
                 xres[a][n] = *cell;  // this lane's skip input (lanes without a position read row 9 and drop it)
                 const uint2 v = pack_relu(acc[a][n], b4);
-                if (SAVE) nib[n] = (a ? nib[n] : 0u) | (((vmask >> n) & 1u) ? positive4(v) << (16 * a + 4 * lh) : 0u);
+                if (SAVE) nib[n] = (a ? nib[n] : 0u) | (positive4(v) << (4 * a));
                 if ((vmask >> n) & 1u) *cell = v;
             }
         }
@@ -304,7 +308,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const uint2 v = pack_relu(acc[a][n], b4);
-                if (SAVE) nib[n] = (a ? nib[n] : 0u) | (((vmask >> n) & 1u) ? positive4(v) << (16 * a + 4 * lh) : 0u);
+                if (SAVE) nib[n] = (a ? nib[n] : 0u) | (positive4(v) << (4 * a));
                 if ((vmask >> n) & 1u) *reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2) = v;
             }
         }
@@ -510,13 +514,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
     // bias-gradient partials: gb_part[layer][block][128]
     auto gb_dst = [&](int layer) -> float * { return gb_part + ((long long)layer * gridDim.x + blockIdx.x) * 128; };
 
-    // ReLU sign words of the layer whose mask comes next (one uint32 per tile: this wave's 32 channels of the lane's
-    // position); loaded one convolution ahead, so the 16-byte-per-position reads are long finished when needed
+    // ReLU sign bits of the layer whose mask comes next: this lane's own byte per tile (see store_relu_bits: nibble a in
+    // bits 4 a .. 4 a + 3); loaded one convolution ahead, so the reads are long finished when needed
     uint32_t mk[NT];
     auto load_masks = [&](int layer) {
-        const uint32_t *src = relu_bits + ((long long)layer * M + obs0) * 196 + cb;
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(relu_bits + ((long long)layer * M + obs0) * 196) + cb * 4 + lh;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) mk[n] = ((vmask >> n) & 1u) ? src[(n * 16 + lr) * 4] : 0u;
+        for (int n = 0; n < NT; ++n) mk[n] = ((vmask >> n) & 1u) ? (uint32_t)src[(n * 16 + lr) * 16] : 0u;
     };
     load_masks(6);
 
@@ -545,7 +549,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
             for (int n = 0; n < NT; ++n)
                 if ((vmask >> n) & 1u)
                     *reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2) =
-                        pack_masked(acc[a][n], (mk[n] >> (16 * a + 4 * lh)) & 0xFu, bs[a]);
+                        pack_masked(acc[a][n], (mk[n] >> (4 * a)) & 0xFu, bs[a]);
         store_bias_partial(bs, gb_dst(2 + 2 * blk), co_lane, lr);
         load_masks(1 + 2 * blk);
         __syncthreads();
@@ -565,7 +569,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
             for (int n = 0; n < NT; ++n) {
                 uint2 *cell = reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2);
                 skip[a][n] = *cell;
-                if ((vmask >> n) & 1u) *cell = pack_masked(acc[a][n], (mk[n] >> (16 * a + 4 * lh)) & 0xFu, bs[a]);
+                if ((vmask >> n) & 1u) *cell = pack_masked(acc[a][n], (mk[n] >> (4 * a)) & 0xFu, bs[a]);
             }
         store_bias_partial(bs, gb_dst(1 + 2 * blk), co_lane, lr);
         load_masks(2 * blk);  // y of the previous block, or conv0's output for blk = 0
@@ -589,7 +593,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
 #pragma unroll
             for (int n = 0; n < NT; ++n)
                 if ((vmask >> n) & 1u)
-                    *reinterpret_cast<uint2 *>(g0 + cell_off(a, n)) = pack_masked(acc[a][n], (mk[n] >> (16 * a + 4 * lh)) & 0xFu, bs[a]);
+                    *reinterpret_cast<uint2 *>(g0 + cell_off(a, n)) = pack_masked(acc[a][n], (mk[n] >> (4 * a)) & 0xFu, bs[a]);
         store_bias_partial(bs, gb_dst(0), co_lane, lr);
     }
 }

@@ -230,9 +230,11 @@ def test_forward_save_outputs(M):
                                         bits.data_ptr(), None), "mapf_encoder_forward_save")
     assert torch.equal(lat, encoder_forward(obs, wp, bp))
     assert torch.isfinite(acts.float()).all() and float(acts.float().min()) >= 0
-    # sign bits: bit c % 32 of word c / 32
+    # sign bits (include/mapf_dqn.h): channel 32 w + 16 a + 4 h + r <-> bit 8 h + 4 a + r of word w
     pos = (acts.float() > 0).view(7, M, 49, 4, 32).to(torch.int64)
-    words = (pos << torch.arange(32, device="cuda")).sum(-1)
+    c = torch.arange(32, device="cuda")
+    bitpos = 8 * ((c >> 2) & 3) + 4 * (c >> 4) + (c & 3)
+    words = (pos << bitpos).sum(-1)
     words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
     assert torch.equal(bits, words)
     # the layer outputs against the fp32 network, layer by layer (bf16 tolerance)
