@@ -120,9 +120,17 @@ __device__ __forceinline__ int tap_off(int s) {
     return (8 * (tap / 3) + (tap % 3)) * ROWB + chunk * 64;
 }
 
+//
+// COPY: the layer the convolution READS is also a tensor the training path saves ([M][49][128], valid rows only).  Its LDS ->
+// global copy (13 16-byte chunks per thread) rides inside the MFMA stream, one chunk per 36 tile-steps: the LDS read at
+// step 4, the store at step 22 of each group.  As a separate pass between the barrier and the convolution the same copy
+// cost 3.3 us per layer and workgroup (1.3 of the training forward's 8.5 ms).
+template <bool COPY = false>
 __device__ __forceinline__ void conv3x3(const unsigned char *act, const bf16x8 *__restrict__ wv, const int (&addr)[NT],
-                                        f32x4 (&acc)[2][NT]) {
+                                        f32x4 (&acc)[2][NT], uint16_t *__restrict__ cdst = nullptr, int ctotal = 0, int tid = 0) {
     bf16x8 ar[RA][2], br[RB];
+    uint4 cv = make_uint4(0, 0, 0, 0);
+    int cc = 0;
 #pragma unroll
     for (int s = 0; s < PA; ++s) {
         ar[s][0] = wv[(s * 8 + 0) * 64];
@@ -140,6 +148,18 @@ __device__ __forceinline__ void conv3x3(const unsigned char *act, const bf16x8 *
                 ar[(s + PA) % RA][0] = wv[((s + PA) * 8 + 0) * 64];
                 ar[(s + PA) % RA][1] = wv[((s + PA) * 8 + 1) * 64];
             }
+            // (branch-free: a chunk index past the end is clamped to the last chunk, which is then written twice with the same
+            // bytes -- a branch here splits the pinned basic block and the register allocator spills 50-150 registers;
+            // laundered: otherwise the 13 chunk addresses, which depend on nothing but tid, are all computed before the loop)
+            if (COPY && !(MAPF_ENC_ABLATE & 1) && t % 36 == 4) {
+                cc = tid;
+                asm volatile("" : "+v"(cc));
+                cc = min(cc + NTHREADS * (t / 36), ctotal - 1);
+                const int rowi = cc >> 4, ch = cc & 15;
+                const int o = rowi / 49, q = rowi - 49 * o, y = q / 7, x = q - 7 * y;
+                cv = *reinterpret_cast<const uint4 *>(act + (64 * o + 8 * y + x + 9) * ROWB + ch * 16);
+            }
+            if (COPY && !(MAPF_ENC_ABLATE & 1) && t % 36 == 22) reinterpret_cast<uint4 *>(cdst)[cc] = cv;
             acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[s % RA][0], br[t % RB], acc[0][n], 0, 0, 0);
             acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[s % RA][1], br[t % RB], acc[1][n], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -263,8 +283,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
         if (SAVE) store_relu_bits(nib, vmask, relu_bits + obs0 * 196, cb, lr, lh);
         bl += 128;
         __syncthreads();
-        if (SAVE) save_rows(act, save + obs0 * 6272, nobs, tid);
     }
+    const int ctotal = nobs * 49 * 16;  // 16-byte chunks of one saved layer of this block
 
     // =========================== 3 residual blocks ===========================
     for (int blk = 0; blk < 3; ++blk) {
@@ -275,7 +295,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        conv3x3(act, wv1, addr, acc);
+        // x (conv0's output or the previous block's) is saved layer 2 blk: copied out while this convolution reads it
+        conv3x3<SAVE>(act, wv1, addr, acc, save + ((2 * blk) * M + obs0) * 6272, ctotal, tid);
         __syncthreads();  // every wave has finished reading x
         uint2 xres[2][NT];
 #pragma unroll
@@ -292,7 +313,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
         }
         if (SAVE) store_relu_bits(nib, vmask, relu_bits + ((1 + 2 * blk) * M + obs0) * 196, cb, lr, lh);
         __syncthreads();
-        if (SAVE) save_rows(act, save + ((1 + 2 * blk) * M + obs0) * 6272, nobs, tid);
         // ---- block2: x' = relu(conv(t) + b2 + x): the skip input is the initial accumulator ----
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -300,7 +320,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
             for (int n = 0; n < NT; ++n)
                 acc[a][n] = f32x4{bf16_bits_to_f32(xres[a][n].x & 0xFFFFu), bf16_bits_to_f32(xres[a][n].x >> 16),
                                   bf16_bits_to_f32(xres[a][n].y & 0xFFFFu), bf16_bits_to_f32(xres[a][n].y >> 16)};
-        conv3x3(act, wv2, addr, acc);
+        conv3x3<SAVE>(act, wv2, addr, acc, save + ((1 + 2 * blk) * M + obs0) * 6272, ctotal, tid);  // t = saved layer 1 + 2 blk
         __syncthreads();
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -315,8 +335,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
         if (SAVE) store_relu_bits(nib, vmask, relu_bits + ((2 + 2 * blk) * M + obs0) * 196, cb, lr, lh);
         bl += 256;
         __syncthreads();
-        if (SAVE) save_rows(act, save + ((2 + 2 * blk) * M + obs0) * 6272, nobs, tid);
     }
+    if (SAVE) save_rows(act, save + (6 * M + obs0) * 6272, nobs, tid);  // the last block's output: no convolution left to hide in
 
     // =========================== conv 1x1: 128 -> 16, ReLU, NCHW flatten ===========================
     {
@@ -553,13 +573,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
         store_bias_partial(bs, gb_dst(2 + 2 * blk), co_lane, lr);
         load_masks(1 + 2 * blk);
         __syncthreads();
-        save_rows(act, gz + (2 + 2 * blk) * LSTRIDE + obs0 * 6272, nobs, tid);
         // ---- g_t = conv2^T(gz2) ----
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        conv3x3(act, wv2, addr, acc);
+        conv3x3<true>(act, wv2, addr, acc, gz + (2 + 2 * blk) * LSTRIDE + obs0 * 6272, nobs * 49 * 16, tid);  // gz2 out while it is read
         __syncthreads();
         // ---- gz1 = g_t * (t > 0) -> LDS; the gz2 it overwrites is the skip term of g_x ----
         uint2 skip[2][NT];
@@ -574,7 +593,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
         store_bias_partial(bs, gb_dst(1 + 2 * blk), co_lane, lr);
         load_masks(2 * blk);  // y of the previous block, or conv0's output for blk = 0
         __syncthreads();
-        save_rows(act, gz + (1 + 2 * blk) * LSTRIDE + obs0 * 6272, nobs, tid);
         // ---- g_x = conv1^T(gz1) + gz2 ----
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -582,7 +600,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
             for (int n = 0; n < NT; ++n)
                 acc[a][n] = f32x4{bf16_bits_to_f32(skip[a][n].x & 0xFFFFu), bf16_bits_to_f32(skip[a][n].x >> 16),
                                   bf16_bits_to_f32(skip[a][n].y & 0xFFFFu), bf16_bits_to_f32(skip[a][n].y >> 16)};
-        conv3x3(act, wv1, addr, acc);
+        conv3x3<true>(act, wv1, addr, acc, gz + (1 + 2 * blk) * LSTRIDE + obs0 * 6272, nobs * 49 * 16, tid);
         __syncthreads();
     }
     // ---- gz0 = g_y0 * (y0 > 0): straight to global memory (conv0 has no data gradient) ----

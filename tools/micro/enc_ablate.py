@@ -18,7 +18,7 @@ def so(mode):
 
 def build():
     for m in MODES:
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-mllvm", "-pragma-unroll-threshold=262144", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
                                "-DMAPF_ENC_ABLATE=%d" % m, os.path.join(ROOT, "mapf_rl_amd", "csrc", "mapf_encoder.hip"), "-o", so(m)])
 
 
