@@ -428,6 +428,18 @@ __device__ __forceinline__ uint2 pack_masked(const f32x4 &a, uint32_t m, float (
     bs[3] += v3;
     return make_uint2(pack2_bf16(v0, v1), pack2_bf16(v2, v3));
 }
+// Sum over the 16 lanes of a DPP row (every lane ends up with the total): row rotations by 8 and 4, then the two quad
+// permutations.  VALU-only: __shfl_xor compiles to ds_bpermute_b32, an LDS-pipe instruction with LDS latency.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v = dpp_add<0x128>(v);  // row_ror:8
+    v = dpp_add<0x124>(v);  // row_ror:4
+    v = dpp_add<0x4E>(v);   // quad_perm:[2,3,0,1]
+    return dpp_add<0xB1>(v);  // quad_perm:[1,0,3,2]
+}
 // Sum the per-lane bias shares over the 16 lanes that hold the same channels (different positions) and store this
 // workgroup's partial bias gradient of one layer: dst[co] for co = co_lane + 16 a + r (each written by one lane).
 __device__ __forceinline__ void store_bias_partial(float (&bs)[2][4], float *__restrict__ dst, int co_lane, int lr) {
@@ -435,11 +447,7 @@ __device__ __forceinline__ void store_bias_partial(float (&bs)[2][4], float *__r
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float v = bs[a][r];
-            v += __shfl_xor(v, 1);
-            v += __shfl_xor(v, 2);
-            v += __shfl_xor(v, 4);
-            v += __shfl_xor(v, 8);
+            const float v = row_sum16(bs[a][r]);
             if (lr == 0) dst[co_lane + 16 * a + r] = v;
             bs[a][r] = 0.f;
         }

@@ -86,6 +86,18 @@ __device__ __forceinline__ void unpack4(const uint2 v, float (&f)[4]) {
 }
 __device__ __forceinline__ uint2 pack4(const float (&f)[4]) { return make_uint2(pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3])); }
 
+// Sum over the 16 lanes of a DPP row (every lane ends up with the total): row rotations by 8 and 4, then the two quad
+// permutations.  VALU-only: __shfl_xor compiles to ds_bpermute_b32, an LDS-pipe instruction with LDS latency.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v = dpp_add<0x128>(v);  // row_ror:8
+    v = dpp_add<0x124>(v);  // row_ror:4
+    v = dpp_add<0x4E>(v);   // quad_perm:[2,3,0,1]
+    return dpp_add<0xB1>(v);  // quad_perm:[1,0,3,2]
+}
 // fragment (16 "columns" col0.. of the image, k = rows row0 .. row0+32) of an operand whose reduction index is the image ROW
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char *img, int row_bytes, int row0, int col0, int lane) {
     typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
@@ -205,11 +217,7 @@ __device__ __forceinline__ void gru_bwd_elementwise(unsigned char *DH, unsigned 
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float v = cs[g][k];
-                v += __shfl_xor(v, 1);
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 8);
+                const float v = row_sum16(cs[g][k]);
                 if (lr == 0) bsum[256 * g + c0 + k] += v;
             }
     }
@@ -365,8 +373,8 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
                     float dot = 0.f;
 #pragma unroll
                     for (int j = 0; j < 12; ++j) dot += dP[j] * P[j];
-                    dot += __shfl_xor(dot, 1);
-                    dot += __shfl_xor(dot, 2);
+                    dot = dpp_add<0x4E>(dot);  // the 4 lanes of a row are one quad
+                    dot = dpp_add<0xB1>(dot);
                     uint2 *ds = reinterpret_cast<uint2 *>(smem + OFF_DSI + i * IMG_ROW + 24 * part);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
