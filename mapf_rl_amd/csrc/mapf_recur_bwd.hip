@@ -37,6 +37,9 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
+#ifndef MAPF_RBWD_ABLATE  // diagnostic builds only (tools/micro/recur_bwd_ablate.py): 1 update-cell elementwise, 2 its GEMMs, 4 W_O + attention,
+#define MAPF_RBWD_ABLATE 0  // 8 W_qkv GEMM, 16 recurrent cell; results are wrong, only the time matters
+#endif
 constexpr int NT = 3, NA = 48, D = 256, HD = 64, NTHR = 512;
 constexpr int H_ROW = D * 2 + 32;     // 544
 constexpr int INFO_ROW = 64 * 2 + 32;  // 160
@@ -139,6 +142,30 @@ __device__ __forceinline__ void gemm_lB(f32x4 (&acc)[NT], const unsigned char *_
         }
 }
 
+// two output tiles at once: both tiles' A fragments (2 KS KiB per wave) are requested before the first MFMA -- the kernel is
+// bound by the L2 -> CU weight stream, i.e. by the bytes it keeps in flight -- and every B fragment is read from LDS once
+template <int KS>
+__device__ __forceinline__ void gemm2_lB(f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], const unsigned char *__restrict__ wt, int tk0, int tk1,
+                                         const unsigned char *X, int xrow, int lane) {
+    const int lr = lane & 15, lh = lane >> 4;
+    const unsigned char *w0 = wt + (size_t)tk0 * 1024, *w1 = wt + (size_t)tk1 * 1024;
+    const uint32_t voff = (uint32_t)lane * 16u;
+    bf16x8 a0[KS], a1[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        a0[kk] = *reinterpret_cast<const bf16x8 *>(w0 + kk * 1024 + voff);
+        a1[kk] = *reinterpret_cast<const bf16x8 *>(w1 + kk * 1024 + voff);
+    }
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8 *>(X + (16 * n + lr) * xrow + (32 * kk + 8 * lh) * 2);
+            acc0[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[kk], b, acc0[n], 0, 0, 0);
+            acc1[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[kk], b, acc1[n], 0, 0, 0);
+        }
+}
+
 struct BwdArgs {
     // saved by the forward (see RecurSave in csrc/mapf_recur.hip)
     const uint16_t *hin0, *g1, *hr, *qkv, *ctx_unused, *info_unused, *g2, *P;
@@ -154,73 +181,84 @@ struct BwdArgs {
     int T, E, N;
 };
 
-// GRU cell backward on this lane's cells (channel blocks cb = w, w + 8; agent tiles n): reads DH (LDS), the saved gates and
-// input state (global), writes d_gi / d_gh rows (global) and DH <- (upd ? d z : DH).
+__device__ __forceinline__ void unpack8(const uint4 v, float (&f)[8]) {
+    f[0] = bf16_lo(v.x);
+    f[1] = bf16_hi(v.x);
+    f[2] = bf16_lo(v.y);
+    f[3] = bf16_hi(v.y);
+    f[4] = bf16_lo(v.z);
+    f[5] = bf16_hi(v.z);
+    f[6] = bf16_lo(v.w);
+    f[7] = bf16_hi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    return make_uint4(pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3]), pack2_bf16(f[4], f[5]), pack2_bf16(f[6], f[7]));
+}
+
+// GRU cell backward, elementwise.  Nothing here needs the MFMA lane layout (DH and G are LDS images), so the work is cut
+// into (agent, 8 consecutive channels) tasks: every global access is a 16-byte piece of a fully used 512-byte row segment.
+// (In the accumulator layout -- 4 channels of 16 different agents per load -- this phase was 45 % of the kernel.)
+// Reads DH (LDS), the saved gates and input state (global); writes the d_gi / d_gh rows (global), rows [dr|dz|dn|dn r] of
+// G (LDS; zero for agents >= N: G shares its LDS with the attention images) and DH <- (upd ? d z : DH).
 __device__ __forceinline__ void gru_bwd_elementwise(unsigned char *DH, unsigned char *G, const uint16_t *__restrict__ gates,
                                                     const uint16_t *__restrict__ hin, const int *upd, uint16_t *__restrict__ dgi,
-                                                    uint16_t *__restrict__ dgh, float *bsum, int N, int w, int lr, int lh) {
-    for (int cb = w; cb < 16; cb += NTHR / 64) {
-        const int c0 = 16 * cb + 4 * lh;
-        float cs[4][4];  // column sums over this lane's agents: [dr|dz|dn|dn r][channel]
+                                                    uint16_t *__restrict__ dgh, int N, int tid) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) cs[g][k] = 0.f;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int agent = 16 * n + lr;
-            uint2 *grow = reinterpret_cast<uint2 *>(G + agent * G_ROW + c0 * 2);
-            if (agent >= N) {  // G shares its LDS with the attention images: padding rows are re-zeroed every time
-                grow[0] = grow[64] = grow[128] = grow[192] = make_uint2(0, 0);
-                continue;
-            }
-            const uint16_t *g = gates + (long long)agent * 1024 + c0;
-            float r[4], z[4], nn[4], hn[4], h[4], d[4];
-            unpack4(*reinterpret_cast<const uint2 *>(g), r);
-            unpack4(*reinterpret_cast<const uint2 *>(g + 256), z);
-            unpack4(*reinterpret_cast<const uint2 *>(g + 512), nn);
-            unpack4(*reinterpret_cast<const uint2 *>(g + 768), hn);
-            unpack4(*reinterpret_cast<const uint2 *>(hin + (long long)agent * D + c0), h);
-            uint2 *dcell = reinterpret_cast<uint2 *>(DH + agent * H_ROW + c0 * 2);
-            unpack4(*dcell, d);
-            const bool on = upd == nullptr || upd[agent] != 0;
-            float dr[4], dz[4], dn[4], dnr[4], dpass[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float dd = on ? d[k] : 0.f;
-                dn[k] = dd * (1.f - z[k]) * (1.f - nn[k] * nn[k]);
-                dz[k] = dd * (h[k] - nn[k]) * z[k] * (1.f - z[k]);
-                dr[k] = dn[k] * hn[k] * r[k] * (1.f - r[k]);
-                dnr[k] = dn[k] * r[k];
-                dpass[k] = on ? dd * z[k] : d[k];
-                cs[0][k] += dr[k];
-                cs[1][k] += dz[k];
-                cs[2][k] += dn[k];
-                cs[3][k] += dnr[k];
-            }
-            uint16_t *gi = dgi + (long long)agent * 768 + c0, *gh = dgh + (long long)agent * 768 + c0;
-            const uint2 pr = pack4(dr), pz = pack4(dz), pn = pack4(dn), pnr = pack4(dnr);
-            *reinterpret_cast<uint2 *>(gi) = pr;
-            *reinterpret_cast<uint2 *>(gi + 256) = pz;
-            *reinterpret_cast<uint2 *>(gi + 512) = pn;
-            *reinterpret_cast<uint2 *>(gh) = pr;
-            *reinterpret_cast<uint2 *>(gh + 256) = pz;
-            *reinterpret_cast<uint2 *>(gh + 512) = pnr;
-            grow[0] = pr;
-            grow[64] = pz;
-            grow[128] = pn;
-            grow[192] = pnr;
-            *dcell = pack4(dpass);
+    for (int it = 0; it < NA * 32 / NTHR; ++it) {
+        const int task = tid + it * NTHR, agent = task >> 5, c0 = 8 * (task & 31);
+        uint4 *grow = reinterpret_cast<uint4 *>(G + agent * G_ROW + c0 * 2);  // gate g at + 32 g (512 bytes apart)
+        if (agent >= N) {
+            grow[0] = grow[32] = grow[64] = grow[96] = make_uint4(0, 0, 0, 0);
+            continue;
         }
-        // sum over the 16 agents of the lane group; the lr = 0 lane owns columns c0 .. c0 + 3 of every gate
+        const uint16_t *g = gates + (long long)agent * 1024 + c0;
+        float r[8], z[8], nn[8], hn[8], h[8], d[8];
+        unpack8(*reinterpret_cast<const uint4 *>(g), r);
+        unpack8(*reinterpret_cast<const uint4 *>(g + 256), z);
+        unpack8(*reinterpret_cast<const uint4 *>(g + 512), nn);
+        unpack8(*reinterpret_cast<const uint4 *>(g + 768), hn);
+        unpack8(*reinterpret_cast<const uint4 *>(hin + (long long)agent * D + c0), h);
+        uint4 *dcell = reinterpret_cast<uint4 *>(DH + agent * H_ROW + c0 * 2);
+        unpack8(*dcell, d);
+        const bool on = upd == nullptr || upd[agent] != 0;
+        float dr[8], dz[8], dn[8], dnr[8], dpass[8];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float v = row_sum16(cs[g][k]);
-                if (lr == 0) bsum[256 * g + c0 + k] += v;
-            }
+        for (int k = 0; k < 8; ++k) {
+            const float dd = on ? d[k] : 0.f;
+            dn[k] = dd * (1.f - z[k]) * (1.f - nn[k] * nn[k]);
+            dz[k] = dd * (h[k] - nn[k]) * z[k] * (1.f - z[k]);
+            dr[k] = dn[k] * hn[k] * r[k] * (1.f - r[k]);
+            dnr[k] = dn[k] * r[k];
+            dpass[k] = on ? dd * z[k] : d[k];
+        }
+        uint16_t *gi = dgi + (long long)agent * 768 + c0, *gh = dgh + (long long)agent * 768 + c0;
+        const uint4 pr = pack8(dr), pz = pack8(dz), pn = pack8(dn), pnr = pack8(dnr);
+        *reinterpret_cast<uint4 *>(gi) = pr;
+        *reinterpret_cast<uint4 *>(gi + 256) = pz;
+        *reinterpret_cast<uint4 *>(gi + 512) = pn;
+        *reinterpret_cast<uint4 *>(gh) = pr;
+        *reinterpret_cast<uint4 *>(gh + 256) = pz;
+        *reinterpret_cast<uint4 *>(gh + 512) = pnr;
+        grow[0] = pr;
+        grow[32] = pz;
+        grow[64] = pn;
+        grow[96] = pnr;
+        *dcell = pack8(dpass);
     }
+}
+
+// bias gradients: column sums of G over the agents (rows >= N are zero), two columns per thread, fixed order -> repeatable;
+// runs in the GEMM phase that only reads G
+__device__ __forceinline__ void bias_colsum(const unsigned char *G, float *bsum, int tid) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+    for (int a = 0; a < NA; ++a) {
+        const uint32_t wv = *reinterpret_cast<const uint32_t *>(G + a * G_ROW + tid * 4);
+        s0 += bf16_lo(wv);
+        s1 += bf16_hi(wv);
+    }
+    bsum[2 * tid] += s0;
+    bsum[2 * tid + 1] += s1;
 }
 
 // DH[agent][16 tile + 4 lh ..] += acc  (this lane's own cells)
@@ -277,18 +315,18 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
             const long long rq = (long long)q * RTOT + row0;
             uint16_t *dgi2 = A.d_gi2 + rq * 768, *dgh2 = A.d_gh2 + rq * 768;
             // (1) update-cell backward
-            gru_bwd_elementwise(DH, smem + OFF_G, A.g2 + rq * 1024, A.hr + rq * D, upd, dgi2, dgh2, reinterpret_cast<float *>(smem + OFF_BSUM), N, w, lr, lh);
+            if (!(MAPF_RBWD_ABLATE & 1)) gru_bwd_elementwise(DH, smem + OFF_G, A.g2 + rq * 1024, A.hr + rq * D, upd, dgi2, dgh2, N, tid);
             __syncthreads();
             // (2) DH += U_hh^T d_gh (2 output tiles per wave); d_info = U_ih^T d_gi (waves 0-3, one tile each)
-            {
+            if (!(MAPF_RBWD_ABLATE & 1)) bias_colsum(smem + OFF_G, reinterpret_cast<float *>(smem + OFF_BSUM), tid);
+            if (!(MAPF_RBWD_ABLATE & 2)) {
                 f32x4 acc0[NT], acc1[NT], acci[NT];
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc0[n] = acc1[n] = acci[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
                     const unsigned char *gh = smem + OFF_G + (g == 2 ? 768 : 256 * g) * 2, *gi = smem + OFF_G + 256 * g * 2;
-                    gemm_lB<8>(acc0, WTB, WT_UHH / 512 + ((g * 16 + w) * 8), gh, G_ROW, lane);
-                    gemm_lB<8>(acc1, WTB, WT_UHH / 512 + ((g * 16 + w + 8) * 8), gh, G_ROW, lane);
+                    gemm2_lB<8>(acc0, acc1, WTB, WT_UHH / 512 + ((g * 16 + w) * 8), WT_UHH / 512 + ((g * 16 + w + 8) * 8), gh, G_ROW, lane);
                     if (w < 4) gemm_lB<8>(acci, WTB, WT_UIH / 512 + ((g * 4 + w) * 8), gi, G_ROW, lane);
                 }
                 add_to_dh(DH, acc0, w, lr, lh);
@@ -306,7 +344,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
             }
             __syncthreads();
             // (3) d_ctx = W_O^T d_info: 8 output tiles, K = 64
-            {
+            if (!(MAPF_RBWD_ABLATE & 4)) {
                 f32x4 acc[NT];
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -319,7 +357,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
             }
             __syncthreads();
             // (4) attention backward, one head at a time
-            for (int hd = 0; hd < 2; ++hd) {
+            for (int hd = 0; hd < 2 && !(MAPF_RBWD_ABLATE & 4); ++hd) {
                 // images: q, k, v rows [agent][64] of this head; P rows [agent i][64 slots j]
                 for (int i = tid; i < 64 * 8 * 3; i += NTHR) {
                     const int img = i >> 9, a = (i >> 3) & 63, ch = i & 7;
@@ -427,12 +465,11 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
                 const int a = i / 48, ch = i - a * 48;
                 *reinterpret_cast<uint4 *>(A.d_qkv + (rq + a) * 384 + ch * 8) = *reinterpret_cast<const uint4 *>(smem + OFF_DQKV + a * QKV_ROW + ch * 16);
             }
-            {
+            if (!(MAPF_RBWD_ABLATE & 8)) {
                 f32x4 acc0[NT], acc1[NT];
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc0[n] = acc1[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-                gemm_lB<12>(acc0, WTB, WT_QKV / 512 + (w * 12), smem + OFF_DQKV, QKV_ROW, lane);
-                gemm_lB<12>(acc1, WTB, WT_QKV / 512 + ((w + 8) * 12), smem + OFF_DQKV, QKV_ROW, lane);
+                gemm2_lB<12>(acc0, acc1, WTB, WT_QKV / 512 + (w * 12), WT_QKV / 512 + ((w + 8) * 12), smem + OFF_DQKV, QKV_ROW, lane);
                 add_to_dh(DH, acc0, w, lr, lh);
                 add_to_dh(DH, acc1, w + 8, lr, lh);
             }
@@ -440,17 +477,17 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
         }
         // ---- recurrent cell backward: d_gi1 is the gradient w.r.t. the GRU input projection ----
         uint16_t *dgi1 = A.d_gi1 + row0 * 768, *dgh1 = A.d_gh1 + row0 * 768;
-        gru_bwd_elementwise(DH, smem + OFF_G, A.g1 + row0 * 1024, A.hin0 + row0 * D, nullptr, dgi1, dgh1, reinterpret_cast<float *>(smem + OFF_BSUM) + 1024, N, w, lr, lh);
+        if (!(MAPF_RBWD_ABLATE & 16)) gru_bwd_elementwise(DH, smem + OFF_G, A.g1 + row0 * 1024, A.hin0 + row0 * D, nullptr, dgi1, dgh1, N, tid);
         __syncthreads();
-        {
+        if (!(MAPF_RBWD_ABLATE & 16)) {
+            bias_colsum(smem + OFF_G, reinterpret_cast<float *>(smem + OFF_BSUM) + 1024, tid);
             f32x4 acc0[NT], acc1[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc0[n] = acc1[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 const unsigned char *gh = smem + OFF_G + (g == 2 ? 768 : 256 * g) * 2;
-                gemm_lB<8>(acc0, WTB, WT_WHH / 512 + ((g * 16 + w) * 8), gh, G_ROW, lane);
-                gemm_lB<8>(acc1, WTB, WT_WHH / 512 + ((g * 16 + w + 8) * 8), gh, G_ROW, lane);
+                gemm2_lB<8>(acc0, acc1, WTB, WT_WHH / 512 + ((g * 16 + w) * 8), WT_WHH / 512 + ((g * 16 + w + 8) * 8), gh, G_ROW, lane);
             }
             add_to_dh(DH, acc0, w, lr, lh);
             add_to_dh(DH, acc1, w + 8, lr, lh);
