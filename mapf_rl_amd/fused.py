@@ -128,18 +128,10 @@ def comm_mask(pos, obs_radius=4, max_comm=3, packed_words=0):
 
 # ---------------------------------------------------------------------------------------------------------
 # Training forward of the encoder through the fused kernel (it also stores the 7 layer outputs); the backward-data
-# chain is one more kernel of the same structure (mapf_encoder_backward_data) that emits the ReLU-masked
-# pre-activation gradient of every layer; the weight gradients of the 3x3 128->128 layers are a third kernel
-# (mapf_encoder_wgrad) on (layer input, that gradient).
+# chain is one more kernel of the same structure (mapf_encoder_backward) that starts from the gradient of the latent and
+# emits the ReLU-masked pre-activation gradient of every layer; the weight gradients are a third kernel
+# (mapf_encoder_wgrad, per 3x3 128->128 layer, on (layer input, that gradient)) and a fourth for conv0 (mapf_encoder_wgrad0).
 # ---------------------------------------------------------------------------------------------------------
-def _mask_bias(g, y, gb):
-    """gx = g where y > 0 else 0 (bf16 NHWC); gb += per-channel sum of gx (f32)."""
-    gx = torch.empty_like(y)
-    check(lib.mapf_bias_res_relu_bwd(_ptr(g), _ptr(y), _ptr(gx), _ptr(gb), y.numel(), y.shape[1], _stream(y.device)),
-          "mapf_bias_res_relu_bwd")
-    return gx
-
-
 class _EncoderTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, obs, packed_w, packed_b, *params):
