@@ -78,6 +78,12 @@ __device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 2.f / (1.f + __expf(-2.f * x)) - 1.f; }
 
+// value of another lane of the same DPP quad (0x4E: lanes 2,3,0,1; 0xB1: lanes 1,0,3,2) -- VALU only, no LDS-pipe shuffle
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
 // acc[n] += (tile `t` of 16 rows of W) * X^T for the NT agent tiles; W packed [tile][k-step][lane][8] (see gemm3x16),
 // X an LDS image with `xrow` bytes per agent row.  All KS A fragments are loaded before the first MFMA.
 template <int KS>
@@ -313,17 +319,18 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                 for (int r = 0; r < 4; ++r) S[(hd * NA + 16 * ti + 4 * lh + r) * S_ROW + 16 * tj + lr] = acc[r] * scale;
             }
             __syncthreads();
-            // masked softmax per (head, agent i) row -> P bf16 (zero for j >= N and for rows i >= N); update flags
-            if (tid < 2 * NA && !(MAPF_RECUR_ABLATE & 4)) {
-                const int hd = tid / NA, i = tid % NA;
-                uint16_t *prow = reinterpret_cast<uint16_t *>(smem + OFF_P + (hd * NA + i) * P_ROW);
+            // masked softmax per (head, agent i) row -> P bf16 (zero for j >= N and for rows i >= N); update flags.
+            // Four lanes (one DPP quad) per row, 12 columns each: row maximum and sum through quad permutations
+            // (one thread per row left 416 of the 512 threads idle behind a 48-element serial chain)
+            if (tid < 8 * NA && !(MAPF_RECUR_ABLATE & 4)) {
+                const int rowid = tid >> 2, part = tid & 3, hd = rowid / NA, i = rowid - NA * hd;
                 if (i < N) {
                     const uint64_t bits = (uint64_t)mb[2 * i] | ((uint64_t)mb[2 * i + 1] << 32);  // bits >= N are 0
-                    const float4 *srow = reinterpret_cast<const float4 *>(S + (hd * NA + i) * S_ROW);
-                    // the whole row in registers (12 x 16-byte LDS reads; a scalar loop over j waits ~100 cycles per element)
-                    float v[NA];
+                    const uint32_t mybits = (uint32_t)(bits >> (12 * part)) & 0xFFFu;
+                    const float4 *srow = reinterpret_cast<const float4 *>(S + (hd * NA + i) * S_ROW + 12 * part);
+                    float v[12];
 #pragma unroll
-                    for (int q = 0; q < NA / 4; ++q) {
+                    for (int q = 0; q < 3; ++q) {
                         const float4 x = srow[q];
                         v[4 * q] = x.x;
                         v[4 * q + 1] = x.y;
@@ -332,25 +339,29 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                     }
                     float mx = -3.0e38f;
 #pragma unroll
-                    for (int j = 0; j < NA; ++j) {
+                    for (int j = 0; j < 12; ++j) {
                         // model.py:77 masked_fill(-1e9), columns >= N likewise (weight 0 below); as a bit select, not a
-                        // predicate: 48 compile-time lane masks would live in scalar registers and spill
-                        const uint32_t m = 0u - (uint32_t)((bits >> j) & 1ull);
+                        // predicate: compile-time lane masks would live in scalar registers and spill
+                        const uint32_t m = 0u - ((mybits >> j) & 1u);
                         v[j] = __uint_as_float((__float_as_uint(v[j]) & m) | (__float_as_uint(-1e9f) & ~m));
                         mx = fmaxf(mx, v[j]);
                     }
+                    mx = fmaxf(mx, quad_perm<0x4E>(mx));
+                    mx = fmaxf(mx, quad_perm<0xB1>(mx));
                     float sum = 0.f;
 #pragma unroll
-                    for (int j = 0; j < NA; ++j) {
+                    for (int j = 0; j < 12; ++j) {
                         v[j] = __expf(v[j] - mx);  // masked and padded columns: exp(-1e9 - mx) == 0 (a row always holds its own agent)
                         sum += v[j];
                     }
+                    sum += quad_perm<0x4E>(sum);
+                    sum += quad_perm<0xB1>(sum);
                     const float inv = 1.f / sum;
-                    uint32_t *p32 = reinterpret_cast<uint32_t *>(prow);
+                    uint32_t *p32 = reinterpret_cast<uint32_t *>(smem + OFF_P + (hd * NA + i) * P_ROW + 24 * part);
 #pragma unroll
-                    for (int j = 0; j < NA; j += 2) p32[j / 2] = pack2_bf16(v[j] * inv, v[j + 1] * inv);
-                    if (hd == 0) upd[i] = __popcll(bits) > 1 ? 1 : 0;  // model.py:103
-                } else if (hd == 0) {
+                    for (int j = 0; j < 12; j += 2) p32[j / 2] = pack2_bf16(v[j] * inv, v[j + 1] * inv);
+                    if (hd == 0 && part == 0) upd[i] = __popcll(bits) > 1 ? 1 : 0;  // model.py:103
+                } else if (hd == 0 && part == 0) {
                     upd[i] = 0;
                 }
             }
