@@ -77,7 +77,7 @@ class FlatGradBucket:
 
 class Learner:
     def __init__(self, buffer=None, device=None, batch_size=192, lr=1e-4, milestones=(100000, 300000), save_path="./models",
-                 model=None):
+                 model=None, prefetch=True):
         self.device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
         self.model = (model if model is not None else Network()).to(self.device)
         self.tar_model = deepcopy(self.model)
@@ -90,34 +90,65 @@ class Learner:
         self.counter = self.last_counter = 0
         self.loss = 0.0
         self.done = False
+        # Pipelining across updates (the reference prepares batches ahead too, in a background thread: worker.py:47-58): as soon
+        # as update k has written its priorities, batch k + 1 is sampled and its TARGET-network forward -- which depends on
+        # nothing update k still has to do -- is launched on a second HIP stream, where it fills the chip while update k's
+        # backward runs its low-occupancy tail (192-workgroup recurrence kernels, split-K GEMMs, reductions, optimizer).
+        # Same numbers as the sequential order: priorities are written before the sample, and the step that syncs the target
+        # network does not prefetch.
+        self.prefetch = bool(prefetch) and buffer is not None and self.device.type == "cuda"
+        self._side = torch.cuda.Stream(device=self.device) if self.prefetch else None
+        self._pre = None
 
     # ------------------------------------------------------------------ one update
-    def compute_td(self, batch):
-        """worker.py:296-306 on an 11-tuple from GlobalBuffer.sample_batch. Returns (td_error [B,1], q [B,1], q_next [B,1])."""
-        b_obs, b_action, b_reward, b_done, b_steps, b_bt_steps, b_hidden, b_comm_mask = batch[:8]
+    def target_q(self, batch):
+        """(1 - done) max_a Q_target(s_{t+steps}) [B,1] (worker.py:300-303): the part of an update that needs no gradient."""
+        b_obs, _, _, b_done, b_steps, b_bt_steps, b_hidden, b_comm_mask = batch[:8]
         b_next_bt_steps = b_bt_steps + b_steps.view(-1).to(b_bt_steps.dtype)
         with torch.no_grad():
-            q_next = (1 - b_done) * self.tar_model.bootstrap(b_obs, b_next_bt_steps, b_hidden, b_comm_mask).max(1, keepdim=True)[0]
+            return (1 - b_done) * self.tar_model.bootstrap(b_obs, b_next_bt_steps, b_hidden, b_comm_mask).max(1, keepdim=True)[0]
+
+    def compute_td(self, batch, q_next=None):
+        """worker.py:296-306 on an 11-tuple from GlobalBuffer.sample_batch. Returns (td_error [B,1], q [B,1], q_next [B,1])."""
+        b_obs, b_action, b_reward, b_done, b_steps, b_bt_steps, b_hidden, b_comm_mask = batch[:8]
+        if q_next is None:
+            q_next = self.target_q(batch)
         q = self.model.bootstrap(b_obs[:, :-FORWARD_STEPS], b_bt_steps, b_hidden, b_comm_mask[:, :-FORWARD_STEPS]).gather(1, b_action)
         td = q - (b_reward + (GAMMA ** b_steps) * q_next)
         return td, q, q_next
 
     def update(self, batch=None):
         """One Learner.train iteration (worker.py:287-338).  `batch` defaults to a fresh prioritized sample."""
-        if batch is None:
+        own_batch = batch is None
+        q_next = None
+        if own_batch and self._pre is not None:
+            batch, q_next, ready = self._pre
+            self._pre = None
+            torch.cuda.current_stream(self.device).wait_event(ready)
+        elif own_batch:
             batch = self.buffer.sample_batch(self.batch_size)
         idxes, weights, old_ptr = batch[8], batch[9], batch[10]
-        td, q, q_next = self.compute_td(batch)
+        td, q, q_next = self.compute_td(batch, q_next)
         priorities = td.detach().view(-1).abs().clamp(1e-6)                                      # worker.py:308
         loss = (weights * huber_loss(td)).mean()                                                 # worker.py:310
+        if self.buffer is not None and idxes is not None:
+            self.buffer.update_priorities(idxes, priorities, old_ptr)                            # worker.py:331 (values known here)
+        if self.prefetch and own_batch and (self.counter + 1) % TARGET_SYNC != 0:
+            cur = torch.cuda.current_stream(self.device)
+            nxt = self.buffer.sample_batch(self.batch_size)
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                qn = self.target_q(nxt)
+                ready = torch.cuda.Event()
+                ready.record(self._side)
+            qn.record_stream(cur)  # allocated on the side stream, consumed on this one
+            self._pre = (nxt, qn, ready)
         self.bucket.zero()
         loss.backward()
         self.bucket.all_reduce_mean()                                                            # the only collective
         grad_norm = nn.utils.clip_grad_norm_(self.model.parameters(), GRAD_CLIP)                 # worker.py:319
         self.optimizer.step()
         self.scheduler.step()
-        if self.buffer is not None and idxes is not None:
-            self.buffer.update_priorities(idxes, priorities, old_ptr)                            # worker.py:331
         self.counter += 1
         self._last = (loss.detach(), grad_norm.detach())
         if self.counter % TARGET_SYNC == 0:                                                      # worker.py:336-338

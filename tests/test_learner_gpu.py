@@ -43,3 +43,40 @@ def test_device_pipeline_sample_update_priorities():
     assert not torch.equal(before, after)            # priorities were written back
     leaves = after[-buf.priority_tree.capacity:]
     assert abs(float(after[0]) - float(leaves.sum())) < 1e-6 * float(after[0])   # root == sum of leaves (buffer.py:30)
+
+
+def test_pipelined_target_forward_equals_sequential_order():
+    """Learner(prefetch=True) samples batch k+1 and runs its target-network forward on a second stream while update k's backward
+    is still in flight; the numbers must be those of the sequential order (same samples: the priorities of update k are
+    written before batch k+1 is drawn; same target: nothing the backward does touches the target network)."""
+    from mapf_rl_amd.learner import Learner
+    from mapf_rl_amd.model import Network
+    from mapf_rl_amd.replay import GlobalBuffer
+
+    def run(prefetch):
+        torch.manual_seed(0)
+        rng = np.random.RandomState(1)
+        A = 5
+        buf = GlobalBuffer(8, max_agents=A)
+        for k in range(8):
+            size = int(rng.randint(30, 70))
+            td = np.zeros(256)
+            td[:size] = rng.random_sample(size) + 0.1
+            buf.add_episode(A, rng.random_sample((size + 1, A, 6, 9, 9)) < 0.3, rng.randint(0, 5, size).astype(np.uint8),
+                            rng.choice([-0.075, -0.5, 3.0], size).astype(np.float16), (rng.standard_normal((size, 256)) * 0.3).astype(np.float16),
+                            td, bool(k % 2), size, rng.random_sample((size + 1, A, A)) < 0.5)
+        torch.manual_seed(7)
+        torch.cuda.manual_seed(7)
+        lr = Learner(buf, device="cuda", batch_size=24, model=Network(), prefetch=prefetch)
+        assert lr.prefetch == prefetch
+        outs = [lr.update() for _ in range(4)]
+        torch.cuda.synchronize()
+        return outs, [p.detach().clone() for p in lr.model.parameters()], buf.priority_tree.tree().clone()
+
+    (o_seq, p_seq, t_seq), (o_pre, p_pre, t_pre) = run(False), run(True)
+    for a, b in zip(o_seq, o_pre):
+        assert torch.equal(a["q_next"], b["q_next"]) and torch.equal(a["td"], b["td"])
+        assert float(a["loss"]) == float(b["loss"])
+    for a, b in zip(p_seq, p_pre):
+        assert torch.equal(a, b)
+    assert torch.equal(t_seq, t_pre)
