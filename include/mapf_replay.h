@@ -75,8 +75,9 @@ int mapf_replay_add(mapf_replay_t *r, int num_agents, int size, int done, const 
 /*
  * GlobalBuffer.sample_batch (worker.py:106-184) minus the IS weights (a reduction the caller does on
  * pri_dev): tree sample + window gather.  Outputs (device):
- *   idx int64 [n], pri f64 [n], obs bf16 [n][18][A][6][9][9], comm u8 [n][18][A][A], hidden f16 [n*A][256],
- *   action int64 [n], reward f32 [n], done f32 [n], steps f32 [n], bt_steps int64 [n].
+ *   idx int64 [n], pri f64 [n], obs bf16 [18][n][A][6][9][9], comm u8 [18][n][A][A] (TIME-major: the consumer is a
+ *   recurrence over the 18 window steps; the host wrapper hands them out as [n][18]... views, the reference's shape),
+ *   hidden f16 [n*A][256], action int64 [n], reward f32 [n], done f32 [n], steps f32 [n], bt_steps int64 [n].
  */
 int mapf_replay_sample(mapf_replay_t *r, const double *uniforms_dev, int n, int64_t *idx_dev, double *pri_dev,
                        uint16_t *obs_dev, uint8_t *comm_dev, uint16_t *hidden_dev, int64_t *action_dev,

@@ -113,8 +113,8 @@ struct GatherParams {
     const int32_t *size_buf;    // [cap]
     const int32_t *nag_buf;     // [cap]
     const int64_t *idx;         // [n]
-    uint16_t *obs;              // [n][18][A][486] bf16
-    uint8_t *comm;              // [n][18][A][A]
+    uint16_t *obs;              // [18][n][A][486] bf16
+    uint8_t *comm;              // [18][n][A][A]
     uint16_t *hidden;           // [n*A][256] f16
     int64_t *action;
     float *reward, *done, *steps;
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherParams p) {
     const int A = p.A;
     // observation bits -> bf16 (0x3F80 = 1.0)
     const int nbits = A * kObsBitsPerAgent;
-    uint16_t *out = p.obs + ((size_t)b * kWindow + t) * nbits;
+    uint16_t *out = p.obs + ((size_t)t * p.n + b) * nbits;  // time-major: the recurrence walks steps, see mapf_replay.h
     const uint32_t *src = p.obs_bits + (size_t)row * p.RD;
     for (int q = tid; q < (nbits >> 3); q += blockDim.x) {  // 8 bits -> 8 bf16 (16 bytes)
         uint32_t bits = 0;
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherParams p) {
         out[q] = bit ? 0x3F80u : 0u;
     }
     // comm mask row
-    uint8_t *cm = p.comm + ((size_t)b * kWindow + t) * A * A;
+    uint8_t *cm = p.comm + ((size_t)t * p.n + b) * A * A;
     const uint32_t *cs = p.comm_bits + (size_t)row * A * p.CW;
     for (int q = tid; q < A * A; q += blockDim.x) {
         const int a = q / A, j = q - a * A;

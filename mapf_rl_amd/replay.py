@@ -169,8 +169,10 @@ class GlobalBuffer:
             u = self.priority_tree._uniforms(B, uniforms)
             idx = torch.empty(B, dtype=torch.int64, device=d)
             pri = torch.empty(B, dtype=torch.float64, device=d)
-            obs = torch.empty((B, 18, A, 6, 9, 9), dtype=torch.bfloat16, device=d)
-            comm = torch.empty((B, 18, A, A), dtype=torch.uint8, device=d)
+            # time-major in memory (the learner's recurrence wants [T, B, ...] and would otherwise transpose 130 MB per network);
+            # handed out as [B, 18, ...] views: the reference's shape
+            obs = torch.empty((18, B, A, 6, 9, 9), dtype=torch.bfloat16, device=d)
+            comm = torch.empty((18, B, A, A), dtype=torch.uint8, device=d)
             hidden = torch.empty((B * A, 256), dtype=torch.float16, device=d)
             action = torch.empty(B, dtype=torch.int64, device=d)
             reward = torch.empty(B, dtype=torch.float32, device=d)
@@ -182,8 +184,8 @@ class GlobalBuffer:
                   "mapf_replay_sample")
             old_ptr = self.ptr
         weights = torch.pow(pri / pri.min(), -self.beta).to(torch.float32)  # worker.py:165-166
-        return (obs, action.unsqueeze(1), reward.unsqueeze(1), done.unsqueeze(1), steps.unsqueeze(1), bt, hidden,
-                comm.bool(), idx, weights.unsqueeze(1), old_ptr)
+        return (obs.transpose(0, 1), action.unsqueeze(1), reward.unsqueeze(1), done.unsqueeze(1), steps.unsqueeze(1), bt, hidden,
+                comm.bool().transpose(0, 1), idx, weights.unsqueeze(1), old_ptr)
 
     def update_priorities(self, idxes, priorities, old_ptr):
         """worker.py:186-203; idxes / priorities: device tensors (or array-likes)."""
