@@ -132,7 +132,11 @@ __device__ __forceinline__ void gemm_lB(f32x4 (&acc)[NT], const unsigned char *_
     const uint32_t voff = (uint32_t)lane * 16u;
     bf16x8 a[KS];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) a[kk] = *reinterpret_cast<const bf16x8 *>(wp + kk * 1024 + voff);
+    for (int kk = 0; kk < KS; ++kk) {
+        const unsigned char *pk = wp + kk * 1024;
+        asm volatile("" : "+s"(pk));
+        a[kk] = *reinterpret_cast<const bf16x8 *>(pk + voff);
+    }
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
@@ -153,8 +157,12 @@ __device__ __forceinline__ void gemm2_lB(f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], c
     bf16x8 a0[KS], a1[KS];
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
-        a0[kk] = *reinterpret_cast<const bf16x8 *>(w0 + kk * 1024 + voff);
-        a1[kk] = *reinterpret_cast<const bf16x8 *>(w1 + kk * 1024 + voff);
+        // (laundered scalar bases: otherwise hipcc folds the lane offset into one 64-bit VGPR address per tile, hoists all of
+        // them out of the time loop and spills them)
+        const unsigned char *p0 = w0 + kk * 1024, *p1 = w1 + kk * 1024;
+        asm volatile("" : "+s"(p0), "+s"(p1));
+        a0[kk] = *reinterpret_cast<const bf16x8 *>(p0 + voff);
+        a1[kk] = *reinterpret_cast<const bf16x8 *>(p1 + voff);
     }
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk)
