@@ -211,21 +211,36 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
 __device__ __forceinline__ void gru_bwd_elementwise(unsigned char *DH, unsigned char *G, const uint16_t *__restrict__ gates,
                                                     const uint16_t *__restrict__ hin, const int *upd, uint16_t *__restrict__ dgi,
                                                     uint16_t *__restrict__ dgh, int N, int tid) {
+    constexpr int NTASK = NA * 32 / NTHR;  // 3
+    // all 15 global loads of the thread's three tasks are issued before any of them is used (the phase sits between two
+    // barriers with nothing to overlap: one exposed HBM latency instead of three); agents >= N read agent 0's rows and are
+    // zeroed afterwards, so that the loads carry no control dependence
+    uint4 vr[NTASK], vz[NTASK], vn[NTASK], vh[NTASK], vx[NTASK];
 #pragma unroll
-    for (int it = 0; it < NA * 32 / NTHR; ++it) {
+    for (int it = 0; it < NTASK; ++it) {
+        const int task = tid + it * NTHR, agent = task >> 5, c0 = 8 * (task & 31);
+        const int src = agent < N ? agent : 0;
+        const uint16_t *g = gates + (long long)src * 1024 + c0;
+        vr[it] = *reinterpret_cast<const uint4 *>(g);
+        vz[it] = *reinterpret_cast<const uint4 *>(g + 256);
+        vn[it] = *reinterpret_cast<const uint4 *>(g + 512);
+        vh[it] = *reinterpret_cast<const uint4 *>(g + 768);
+        vx[it] = *reinterpret_cast<const uint4 *>(hin + (long long)src * D + c0);
+    }
+#pragma unroll
+    for (int it = 0; it < NTASK; ++it) {
         const int task = tid + it * NTHR, agent = task >> 5, c0 = 8 * (task & 31);
         uint4 *grow = reinterpret_cast<uint4 *>(G + agent * G_ROW + c0 * 2);  // gate g at + 32 g (512 bytes apart)
         if (agent >= N) {
             grow[0] = grow[32] = grow[64] = grow[96] = make_uint4(0, 0, 0, 0);
             continue;
         }
-        const uint16_t *g = gates + (long long)agent * 1024 + c0;
         float r[8], z[8], nn[8], hn[8], h[8], d[8];
-        unpack8(*reinterpret_cast<const uint4 *>(g), r);
-        unpack8(*reinterpret_cast<const uint4 *>(g + 256), z);
-        unpack8(*reinterpret_cast<const uint4 *>(g + 512), nn);
-        unpack8(*reinterpret_cast<const uint4 *>(g + 768), hn);
-        unpack8(*reinterpret_cast<const uint4 *>(hin + (long long)agent * D + c0), h);
+        unpack8(vr[it], r);
+        unpack8(vz[it], z);
+        unpack8(vn[it], nn);
+        unpack8(vh[it], hn);
+        unpack8(vx[it], h);
         uint4 *dcell = reinterpret_cast<uint4 *>(DH + agent * H_ROW + c0 * 2);
         unpack8(*dcell, d);
         const bool on = upd == nullptr || upd[agent] != 0;
