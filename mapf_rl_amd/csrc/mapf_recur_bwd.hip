@@ -381,21 +381,24 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
             __syncthreads();
             // (4) attention backward, one head at a time
             for (int hd = 0; hd < 2 && !(MAPF_RBWD_ABLATE & 4); ++hd) {
-                // images: q, k, v rows [agent][64] of this head; P rows [agent i][64 slots j]
-                for (int i = tid; i < 64 * 8 * 3; i += NTHR) {
-                    const int img = i >> 9, a = (i >> 3) & 63, ch = i & 7;
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (a < N) v = *reinterpret_cast<const uint4 *>(A.qkv + (rq + a) * 384 + img * 128 + hd * HD + ch * 8);
-                    *reinterpret_cast<uint4 *>(smem + OFF_QI + img * (64 * IMG_ROW) + a * IMG_ROW + ch * 16) = v;
-                }
+                // images: q, k, v rows [agent][64] of this head (zero rows for agents >= N); P rows [agent i][64 slots j] (zero rows
+                // 48..63).  The four 16-byte loads of a thread are issued together, then stored: one exposed latency per head.
                 {
                     const uint16_t *ps = A.P + ((((long long)q * T + t) * E + e) * 2 + hd) * (NA * 64);
-                    for (int i = tid; i < 64 * 8; i += NTHR) {
-                        const int a = i >> 3, ch = i & 7;
-                        uint4 v = make_uint4(0, 0, 0, 0);
-                        if (a < NA) v = *reinterpret_cast<const uint4 *>(ps + a * 64 + ch * 8);
-                        *reinterpret_cast<uint4 *>(smem + OFF_PI + a * IMG_ROW + ch * 16) = v;
+                    const int a = (tid >> 3) & 63, ch = tid & 7;  // every thread: row a, chunk ch of q, of k, of v and of P
+                    uint4 vq = make_uint4(0, 0, 0, 0), vk = vq, vv = vq, vp = vq;
+                    if (a < N) {
+                        const uint16_t *row = A.qkv + (rq + a) * 384 + hd * HD + ch * 8;
+                        vq = *reinterpret_cast<const uint4 *>(row);
+                        vk = *reinterpret_cast<const uint4 *>(row + 128);
+                        vv = *reinterpret_cast<const uint4 *>(row + 256);
                     }
+                    if (a < NA) vp = *reinterpret_cast<const uint4 *>(ps + a * 64 + ch * 8);
+                    unsigned char *dst = smem + a * IMG_ROW + ch * 16;
+                    *reinterpret_cast<uint4 *>(dst + OFF_QI) = vq;
+                    *reinterpret_cast<uint4 *>(dst + OFF_KI) = vk;
+                    *reinterpret_cast<uint4 *>(dst + OFF_VI) = vv;
+                    *reinterpret_cast<uint4 *>(dst + OFF_PI) = vp;
                 }
                 __syncthreads();
                 // dP[i][j] = sum_d d_ctx[i][d] v[j][d]
