@@ -10,19 +10,24 @@ uniform); inputs are resident in HBM before the timed region.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Multi-GPU: environments are independent, so rank g owns its own 4096 envs (weak scaling); there is no
-data-path collective, only the timing barrier / max-over-ranks.
+data-path collective in the env step, only the timing barrier / max-over-ranks; the learner's gradient
+all-reduce (RCCL) is exercised by the secondary `learner_updates_per_sec` rate.  Started WITHOUT a
+launcher (`WORLD_SIZE` unset) and with `--gpus N > 1`, this process starts the N ranks itself -- before it
+touches the GPU -- as fresh child processes (one per LOCAL_RANK, backend nccl = RCCL), forwards rank 0's
+JSON line and exits non-zero if any rank failed.
 
 Prints ONE JSON line on rank 0 (see the driver contract), including `roofline` for the dominant kernel
-(env_step_kernel, HBM-bound) and `cpu_baseline` (the CPU oracle timed on the host cores of this box).
+(env_step_kernel, HBM-bound), `cpu_baseline` (the CPU oracle timed on the host cores of this box) and the
+system rates of the same pipeline (`learner_updates_per_sec`, `actor_loop_env_steps_per_sec`,
+`train_loop_*`) as top-level keys.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -35,18 +40,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def heuristic_actions(obs, gen, p_follow=0.8):
-    """80 % follow a navi flag of the own cell (obs[:, :, 2:6, 4, 4]), 20 % uniform (SURVEY.md 8(d))."""
-    E, N = obs.shape[:2]
-    flags = obs[:, :, 2:6, 4, 4] != 0
-    score = torch.rand((E, N, 4), device=obs.device, generator=gen) * flags
-    follow = torch.where(flags.any(-1), 1 + score.argmax(-1), torch.zeros((), dtype=torch.long, device=obs.device))
-    uni = torch.randint(0, 5, (E, N), device=obs.device, generator=gen)
-    pick = torch.rand((E, N), device=obs.device, generator=gen) < p_follow
-    return torch.where(pick, follow, uni).to(torch.int8).contiguous()
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -62,7 +56,98 @@ def main():
                     "exercise the multi-rank code path on a single GPU (set MAPF_BENCH_SHARE_GPU=1)")
     ap.add_argument("--dqn-updates", type=int, default=5)
     ap.add_argument("--dqn-actor-iters", type=int, default=3)
-    args = ap.parse_args()
+    ap.add_argument("--train-iters", type=int, default=4, help="interleaved actor-step + learner-update iterations")
+    return ap.parse_args(argv)
+
+
+# --------------------------------------------------------------------------------------------------------
+# rank launcher (parent process; never touches the GPU)
+# --------------------------------------------------------------------------------------------------------
+def launch_ranks(n, argv):
+    """Starts `n` ranks of this script as child processes and forwards rank 0's stdout.  The parent makes no HIP call
+    (counting devices does not initialise the runtime on this image), so nothing GPU-initialised is ever re-executed."""
+    import torch
+
+    share = os.environ.get("MAPF_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not share:
+        log("bench.py: --gpus %d requested but only %d HIP device(s) visible" % (n, have))
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, cwd=os.getcwd()))
+    out0 = procs[0].stdout.read().decode()
+    rcs = []
+    deadline = time.time() + 1800
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(-9)
+    if any(rc != 0 for rc in rcs):
+        log("bench.py: rank exit codes %s" % rcs)
+        sys.stdout.write(out0)
+        return 1
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return 0
+
+
+def heuristic_actions(obs, gen, p_follow=0.8):
+    """80 % follow a navi flag of the own cell (obs[:, :, 2:6, 4, 4]), 20 % uniform (SURVEY.md 8(d))."""
+    import torch
+
+    E, N = obs.shape[:2]
+    flags = obs[:, :, 2:6, 4, 4] != 0
+    score = torch.rand((E, N, 4), device=obs.device, generator=gen) * flags
+    follow = torch.where(flags.any(-1), 1 + score.argmax(-1), torch.zeros((), dtype=torch.long, device=obs.device))
+    uni = torch.randint(0, 5, (E, N), device=obs.device, generator=gen)
+    pick = torch.rand((E, N), device=obs.device, generator=gen) < p_follow
+    return torch.where(pick, follow, uni).to(torch.int8).contiguous()
+
+
+def cpu_baseline(args, maps, agents, goals, tape, final_pos, E, T):
+    """The oracle (C restatement with the reference's sequential semantics), in child processes without torch and without
+    the GPU: one single-threaded, pinned process per usable host core (oracle/cpu_bench.py)."""
+    import tempfile
+
+    import numpy as np
+
+    ncpu = len(os.sched_getaffinity(0))
+    S = min(E, max(256, 4 * ncpu))
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "sample.npz")
+        np.savez(f, maps=maps[:S], agents=agents[:S], goals=goals[:S], tape=tape[:, :S].cpu().numpy())
+        out = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", f, str(args.cpu_seconds)],
+                             cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    cb = json.loads(out.stdout.strip().splitlines()[-1])
+    # trajectories must be identical to the GPU's before any number is reported
+    assert np.array_equal(np.array(cb["final_agents"], np.int16), final_pos[:S].cpu().numpy()), "CPU/GPU trajectories differ"
+    return {
+        "value": cb["env_steps_per_sec"], "unit": "env-steps/s", "cores": cb["workers"], "kind": "port",
+        "sample": "first %d envs x %d tape steps, step+observe, repeated for %.1f s by %d single-threaded oracle processes, each pinned "
+                  "to one CPU (%s); trajectories verified identical to the GPU run" % (S, T, cb["seconds"], cb["workers"], cb["how"]),
+        "cpu_model": cb["cpu_model"], "logical_cpus": cb["logical_cpus"], "physical_cores": cb["physical_cores"],
+        "cpu_quota_cores": cb["cpu_quota_cores"], "worker_scan": cb["scan"],
+    }
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    import numpy as np
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -81,6 +166,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.dist_backend)
+        assert dist.get_world_size() == world
 
     import mapf_rl_amd as M
 
@@ -137,6 +223,7 @@ def main():
     alg_bytes = alg_bytes_per_env * E
     achieved = alg_bytes / kern_avg_s / 1e9
 
+    backend = "none" if world == 1 else ("%s, dist.get_world_size()=%d" % (dist.get_backend(), dist.get_world_size()))
     result = {
         "metric": "env_steps_per_sec",
         "value": world * E * K / elapsed,
@@ -151,46 +238,29 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {"workload": "mapf env step+observe, %dx%d grid, %d agents, rho=%.2f, %d envs/GPU" % (L, L, N, args.density, E),
-                   "map": L, "agents": N, "envs_per_gpu": E, "obs_radius": 4, "parallelism": "env-sharded x%d" % world},
+                   "map": L, "agents": N, "envs_per_gpu": E, "obs_radius": 4,
+                   "parallelism": "env-sharded x%d (%s)" % (world, backend)},
         "roofline": {"bound": "hbm", "kernel": "env_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                      "alg_bytes_per_launch": alg_bytes, "kernel_avg_us": kern_avg_s * 1e6},
     }
     tr = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tr) and (E, L, N) == (4096, 32, 40):  # the committed PMC pass was taken on this workload
+    if os.path.exists(tr) and (E, L, N) == (4096, 32, 40):  # the committed PMC passes were taken on this workload
         try:
-            result["roofline"]["traffic"] = json.load(open(tr)).get("env_step_kernel_bytes_per_launch")
+            tj = json.load(open(tr))
+            result["roofline"]["traffic"] = tj.get("env_step_kernel_bytes_per_launch")
+            # NOT measured in this run: PMC counters need rocprofv3 around the process (separate --pmc passes)
+            result["roofline"]["traffic_source"] = "profiles/traffic.json (%s)" % tj.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")
         except Exception:
             pass
 
-    # ---- CPU baseline: the oracle (C restatement with the reference's sequential semantics), in a child
-    # process without torch (its OpenMP runtime serialises the oracle's parallel loop) and without the GPU ----
     if rank == 0 and not args.no_cpu_baseline:
-        import subprocess
-        import tempfile
+        result["cpu_baseline"] = cpu_baseline(args, maps, agents, goals, tape, final_pos_first_pass, E, T)
 
-        nthreads = len(os.sched_getaffinity(0))
-        S = min(E, max(256, 4 * nthreads))
-        with tempfile.TemporaryDirectory() as td:
-            f = os.path.join(td, "sample.npz")
-            np.savez(f, maps=maps[:S], agents=agents[:S], goals=goals[:S], tape=tape[:, :S].cpu().numpy())
-            out = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", f, str(nthreads), str(args.cpu_seconds)],
-                                 cwd=ROOT, capture_output=True, text=True, timeout=600)
-        assert out.returncode == 0, out.stderr[-2000:]
-        cb = json.loads(out.stdout.strip().splitlines()[-1])
-        # trajectories must be identical to the GPU's before any number is reported
-        assert np.array_equal(np.array(cb["final_agents"], np.int16), final_pos_first_pass[:S].cpu().numpy()), \
-            "CPU/GPU trajectories differ"
-        result["cpu_baseline"] = {
-            "value": cb["env_steps_per_sec"], "unit": "env-steps/s", "cores": cb["threads"], "kind": "port",
-            "sample": "first %d envs x %d tape steps x %d repeats (%.1f s), step+observe, OpenMP one env per thread; %d threads = "
-                      "fastest of a scan up to the %d logical CPUs of the box; trajectories verified identical to the GPU run" % (
-                          S, T, cb["reps"], cb["seconds"], cb["threads"], nthreads),
-            "thread_scan": cb.get("scan"),
-        }
-    # ---- secondary rates of the same pipeline (BASELINE metric: "env steps/sec + learner updates/sec") ----
+    # ---- system rates of the same pipeline (BASELINE metric: "env steps/sec + learner updates/sec") ----
     # learner: Learner.update on 192 x 18 x 40 windows sampled from the device replay (bf16, incl. the flat
-    # gradient all-reduce over RCCL when world > 1); actor loop: policy inference + env step + recording.
+    # gradient all-reduce over RCCL when world > 1); actor loop: policy inference + env step + recording;
+    # train loop: one actor iteration + one learner update, interleaved (what train.py runs once learning started).
     if not args.no_dqn:
         try:
             from mapf_rl_amd.actor import VecActor
@@ -232,7 +302,25 @@ def main():
                 actor.step()
             torch.cuda.synchronize()
             dt_act = (time.perf_counter() - t1) / args.dqn_actor_iters
+            # interleaved: the loop train.py runs (one update per actor iteration)
+            actor.step()
+            learner.update()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.train_iters):
+                actor.step()
+                learner.update()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            dt_train = (time.perf_counter() - t1) / args.train_iters
             env.check_status()
+            if world > 1:
+                tt = torch.tensor([dt_upd, dt_act, dt_train], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt_upd, dt_act, dt_train = [float(v) for v in tt.tolist()]
             # the dominant kernel of the actor loop: the fused inference encoder (MFMA-bound), timed alone on the
             # actor's batch with HIP events on the launch stream
             obs_flat = actor.obs.reshape(E * N, 6, 9, 9)
@@ -246,19 +334,22 @@ def main():
             torch.cuda.synchronize()
             enc_s = e0.elapsed_time(e1) * 1e-3 / 5
             enc_flop = 2.0 * (49 * 128 * 54 + 6 * 49 * 128 * 1152 + 49 * 16 * 128) * E * N  # 87.6 MFLOP per observation
-            result["extra"] = {
-                "encoder_roofline": {"bound": "mfma", "kernel": "encoder_fwd_kernel", "achieved": enc_flop / enc_s / 1e12,
-                                     "peak": 2500.0, "unit": "TFLOP/s", "frac": enc_flop / enc_s / 1e12 / 2500.0,
-                                     "flop_per_launch": enc_flop, "kernel_avg_ms": enc_s * 1e3,
-                                     "observations": E * N},
+            result.update({
                 "learner_updates_per_sec": 1.0 / dt_upd, "learner_ms_per_update": dt_upd * 1e3,
-                "learner_config": "B=192 x T=18 x A=%d windows from the device replay, bf16 autocast, Adam, %s" % (
-                    N, "flat-bucket RCCL all-reduce x%d (same update rate on every rank)" % world if world > 1 else "1 GPU"),
+                "learner_config": "B=192 x T=18 x A=%d windows per rank from the device replay, bf16 autocast, Adam, %s" % (
+                    N, "flat-bucket RCCL all-reduce x%d (synchronous data parallel: this is the job's update rate, global batch %d)" % (
+                        world, 192 * world) if world > 1 else "1 GPU"),
                 "actor_loop_env_steps_per_sec": world * E / dt_act, "actor_loop_ms_per_iter": dt_act * 1e3,
                 "actor_loop_config": "Network.step_batch (bf16) + mapf_step + local-buffer recording, %d envs x %d agents per GPU" % (E, N),
-            }
+                "train_loop_updates_per_sec": 1.0 / dt_train, "train_loop_env_steps_per_sec": world * E / dt_train,
+                "train_loop_ms_per_iter": dt_train * 1e3,
+                "train_loop_config": "one actor iteration (%d envs/GPU) + one learner update per iteration, same stream order as train.py" % E,
+                "encoder_roofline": {"bound": "mfma", "kernel": "encoder_fwd_kernel", "achieved": enc_flop / enc_s / 1e12,
+                                     "peak": 2500.0, "unit": "TFLOP/s", "frac": enc_flop / enc_s / 1e12 / 2500.0,
+                                     "flop_per_launch": enc_flop, "kernel_avg_ms": enc_s * 1e3, "observations": E * N},
+            })
         except Exception as ex:  # the primary metric must still be reported
-            result["extra"] = {"error": repr(ex)[:300]}
+            result["dqn_error"] = repr(ex)[:300]
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

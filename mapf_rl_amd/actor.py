@@ -152,12 +152,7 @@ class VecActor:
                 self.buffer.add_episode_device(self.N, size, is_done, self.lb_obs[e], self.lb_comm[e], self.lb_act[e],
                                                self.lb_rew[e], self.lb_hid[e], td[k].contiguous())
                 if self.actor_ids[e] >= 10:  # curriculum statistics (worker.py:74-82)
-                    key = (self.N, self.env.map_length)
-                    if key in self.buffer.stat_dict:
-                        lst = self.buffer.stat_dict[key]
-                        if len(lst) >= 200:
-                            lst.pop(0)
-                        lst.append(is_done)
+                    self.buffer.levels.record((self.N, self.env.map_length), is_done)
             if self.keep_flushed:
                 self.flushed.append(dict(env=e, size=size, done=is_done, obs=self.lb_obs[e, :size + 1].clone(),
                                          comm=self.lb_comm[e, :size + 1].clone(), act=self.lb_act[e, :size].clone(),

@@ -87,7 +87,7 @@ class GlobalBuffer:
     """reference worker.py:21-250 (the Ray plumbing `run/prepare_data/get_data` is replaced by same-device calls)."""
 
     def __init__(self, capacity, max_agents=6, alpha=ALPHA, beta=BETA, device=None, init_set=(1, 10),
-                 max_map_length=40, pass_rate=0.9):
+                 max_map_length=40, pass_rate=0.9, fixed_level=False):
         if not torch.cuda.is_available():
             raise RuntimeError("mapf_rl_amd.GlobalBuffer needs a HIP device (no CPU fallback)")
         assert abs(alpha - ALPHA) < 1e-12, "the priority exponent 0.6 is compiled into the add/update kernels"
@@ -101,9 +101,10 @@ class GlobalBuffer:
         self.priority_tree = SumTree(self._h, capacity * MAX_STEPS, self.device)
         self.lock = threading.Lock()
         # curriculum statistics (worker.py:32,74-82,205-250)
+        from .curriculum import LevelTable
+
         self.init_set, self.max_map_length, self.pass_rate = tuple(init_set), max_map_length, pass_rate
-        self.stat_dict = {self.init_set: []}
-        self.level = [self.init_set]
+        self.levels = LevelTable(init_set, max_agents, max_map_length, pass_rate, fixed=fixed_level)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -151,11 +152,7 @@ class GlobalBuffer:
         (actor_id, num_agents, map_len, obs, act, rew, hid, td_errors, done, size, comm_mask)."""
         for b in buffer_list:
             if b[0] >= 10:  # curriculum statistics only from actors with id >= 10 (worker.py:74)
-                key = (b[1], b[2])
-                if key in self.stat_dict:
-                    if len(self.stat_dict[key]) >= 200:
-                        self.stat_dict[key].pop(0)
-                    self.stat_dict[key].append(b[8])
+                self.levels.record((b[1], b[2]), b[8])
         for b in buffer_list:
             self.add_episode(b[1], b[3], b[4], b[5], b[6], b[7], b[8], b[9], b[10])
 
@@ -197,34 +194,23 @@ class GlobalBuffer:
         self._keep = (idx, pri)  # keep the (possibly temporary) tensors alive until the next call
 
     # ------------------------------------------------------------------ curriculum / stats (worker.py:205-250)
-    def stats(self, interval):
+    # The schedule itself lives in curriculum.LevelTable; these are the reference's names for it.
+    stat_dict = property(lambda self: self.levels.windows, lambda self, v: setattr(self.levels, "windows", {tuple(k): list(w) for k, w in v.items()}))
+    level = property(lambda self: self.levels.levels)
+
+    def stats(self, interval, pooled=None, world=1):
+        """Prints the reference's lines (worker.py:206-210) and advances the curriculum; `pooled` = LevelTable.pooled_counts()
+        in a multi-rank run (every rank must then call this with the same counts)."""
         print("buffer update speed: {}/s".format(int(lib.mapf_replay_counter(self._h, 1)) / interval))
         print("buffer size: {}".format(len(self)))
-        for key, val in self.stat_dict.copy().items():
-            print("{}: {}/{}".format(key, sum(val), len(val)))
-            if len(val) == 200 and sum(val) >= 200 * self.pass_rate:
-                add_agent_key = (key[0] + 1, key[1])
-                if add_agent_key[0] <= self.max_agents and add_agent_key not in self.stat_dict:
-                    self.stat_dict[add_agent_key] = []
-                if key[1] < self.max_map_length:
-                    add_map_key = (key[0], key[1] + 5)
-                    if add_map_key not in self.stat_dict:
-                        self.stat_dict[add_map_key] = []
-                    del self.stat_dict[key]
-        self.level = list(self.stat_dict.keys())
+        for line in self.levels.advance(pooled, self.levels.WINDOW * world):
+            print(line)
 
     def ready(self, learning_starts=50000):
         return len(self) >= learning_starts
 
     def get_level(self):
-        return self.level
+        return self.levels.levels
 
-    def check_done(self):
-        for i in range(self.max_agents):
-            key = (i + 1, self.max_map_length)
-            if key not in self.stat_dict:
-                return False
-            l = self.stat_dict[key]
-            if len(l) < 200 or sum(l) < 200 * self.pass_rate:
-                return False
-        return True
+    def check_done(self, pooled=None, world=1):
+        return self.levels.done(pooled, self.levels.WINDOW * world)

@@ -82,3 +82,38 @@ def test_train_entry_point_runs(tmp_path):
     assert os.path.exists(str(tmp_path / "models" / "6.pth"))
     sd = torch.load(str(tmp_path / "models" / "6.pth"), map_location="cpu")
     assert "obs_encoder.0.weight" in sd and "comm.self_attn.W_Q.weight" in sd and len(sd) == 35
+
+
+def test_train_default_is_the_curriculum(tmp_path):
+    """`python train.py` without a level = the reference's adaptive schedule from config.init_set (worker.py:362)."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "train.py"), "--envs", "64", "--learning-starts", "1500", "--batch-size", "16",
+           "--max-updates", "4", "--interval", "1"]
+    out = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "start training" in out.stdout and "(1, 10): " in out.stdout
+    assert os.path.exists(str(tmp_path / "models" / "4.pth"))
+
+
+def test_train_two_ranks_stop_together(tmp_path):
+    """Two ranks (gloo, sharing GPU 0) with different scenarios per rank: start, statistics and the --minutes stop are
+    collective decisions, so both ranks run the same number of all-reducing updates and exit cleanly."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, PYTHONPATH=ROOT, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MAPF_TRAIN_SHARE_GPU="1")
+        cmd = [sys.executable, os.path.join(ROOT, "train.py"), "--envs", "48" if r == 0 else "32", "--agents", "2", "--map", "10",
+               "--capacity", "256", "--learning-starts", "1500", "--batch-size", "16", "--minutes", "0.2", "--interval", "2",
+               "--dist-backend", "gloo"]
+        procs.append(subprocess.Popen(cmd, cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], (outs[0][1][-1500:], outs[1][1][-1500:])
+    assert "start training" in outs[0][0] and "number of updates" in outs[0][0] and "(2, 10): " in outs[0][0]
+    assert outs[1][0].strip() == ""  # only rank 0 prints
+    assert len(os.listdir(str(tmp_path / "models"))) >= 1

@@ -1,0 +1,9 @@
+# round 2, first GPU call: GPU tests as they stand + the env-step shape sweep under rocprofv3 (kernel trace)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rm -rf $R/gpurun_out/r02_sweep
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r02_sweep -- python3 $R/tools/shape_sweep.py > $R/gpurun_out/r02_sweep.log 2> $R/gpurun_out/r02_sweep.err; echo sweep=$?
+cd $R
+python3 tools/shape_sweep.py --summarize gpurun_out/r02_sweep gpurun_out/r02_sweep.log > gpurun_out/r02_sweep.md 2>> gpurun_out/r02_sweep.err
+find gpurun_out/r02_sweep -name "*.csv" -size +1M -delete
+cat gpurun_out/r02_sweep.log; cat gpurun_out/r02_sweep.md

@@ -1,31 +1,109 @@
 #!/usr/bin/env python3
-"""env_step_kernel time at the other BASELINE shapes (parity-test configs; not bench lines)."""
-import os, sys
-import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-import mapf_rl_amd as M
-from bench import heuristic_actions
-for (E, L, N) in [(4096, 32, 40), (4096, 64, 40), (2048, 64, 128), (4096, 40, 16), (4096, 16, 40), (8192, 20, 6)]:
-    env = M.VecEnvironment(E, L, N)
-    env.reset_envs(None, 0.3, seed=1)
-    env.check_status()
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record(); env.reset_envs(None, 0.3, seed=2); e.record(); torch.cuda.synchronize()
-    t_reset = s.elapsed_time(e) * 1e3
-    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
-    T = 60
-    tape = torch.empty((T, E, N), dtype=torch.int8, device="cuda")
-    obs, pos = env.observe()
-    for t in range(T):
-        tape[t] = heuristic_actions(obs, gen); obs, pos, *_ = env.step(tape[t])
-    start = env.agents_pos().clone()
-    ts = []
-    for rnd in range(3):
+"""env_step_kernel time at the BASELINE shapes and the small curriculum shapes (parity-test configs; not bench lines).
+
+    python3 tools/shape_sweep.py                       # HIP-event timing, one line per shape
+    rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 tools/shape_sweep.py
+    python3 tools/shape_sweep.py --summarize DIR       # per-shape kernel averages from the trace (markdown)
+
+Shapes are (E, L, N); E = 16384 at 32x32/40 puts the working set (navi 336 MB + observations 318 MB) beyond the 256 MiB
+Infinity Cache, so FETCH/WRITE there are HBM traffic proper."""
+import csv
+import glob
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SHAPES = [(4096, 32, 40), (16384, 32, 40), (4096, 64, 40), (2048, 64, 128), (4096, 40, 16), (4096, 16, 40),
+          (8192, 20, 6), (65536, 20, 6), (16384, 10, 1), (262144, 10, 1), (65536, 15, 3)]
+T = 40
+
+
+def alg_bytes(E, L, N):
+    return (L * L + 821 * N + 1) * E
+
+
+def run():
+    import numpy as np
+    import torch
+
+    import mapf_rl_amd as M
+    from bench import heuristic_actions
+
+    shapes = SHAPES
+    if len(sys.argv) > 1:
+        shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+    for (E, L, N) in shapes:
+        env = M.VecEnvironment(E, L, N)
+        env.reset_envs(None, 0.3, seed=1)
+        env.check_status()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        for t in range(T): env.step(tape[t])
-        e.record(); torch.cuda.synchronize(); ts.append(s.elapsed_time(e) * 1e3 / T)
-    alg = (L * L + 821 * N + 1) * E
-    us = float(np.median(ts))
-    print("E=%5d L=%2d N=%3d  step %.2f us  %.0f GB/s alg (frac %.3f)  %.1f M env-steps/s   on-device reset of all envs %.0f us" % (
-        E, L, N, us, alg / us / 1e3, alg / us / 8e6, E / us, t_reset), flush=True)
+        env.reset_envs(None, 0.3, seed=2)
+        e.record()
+        torch.cuda.synchronize()
+        t_reset = s.elapsed_time(e) * 1e3
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(1)
+        tape = torch.empty((T, E, N), dtype=torch.int8, device="cuda")
+        obs, pos = env.observe()
+        for t in range(T):
+            tape[t] = heuristic_actions(obs, gen)
+            obs, pos, *_ = env.step(tape[t])
+        ts = []
+        for rnd in range(3):
+            s.record()
+            for t in range(T):
+                env.step(tape[t])
+            e.record()
+            torch.cuda.synchronize()
+            ts.append(s.elapsed_time(e) * 1e3 / T)
+        env.check_status()
+        alg = alg_bytes(E, L, N)
+        us = float(np.median(ts))
+        print("SHAPE E=%d L=%d N=%d  step %.2f us  %.0f GB/s alg (frac %.3f)  %.1f M env-steps/s   on-device reset of all envs %.0f us" % (
+            E, L, N, us, alg / us / 1e3, alg / us / 8e6, E / us, t_reset), flush=True)
+        del env, tape, obs, pos
+        torch.cuda.empty_cache()
+
+
+def summarize(d, log=None):
+    """Groups the env_step_kernel<..., DO_STEP=true, ...> dispatches of a kernel trace by (instantiation, grid) = shape."""
+    files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    assert files, "no *kernel_trace.csv under " + d
+    groups = {}
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"]
+            if "env_step_kernel" not in name:
+                continue
+            m = re.search(r"env_step_kernel<([^>]*)>", name)
+            targs = [a.strip() for a in m.group(1).split(",")]
+            if targs[2] != "true" or targs[3] != "true":  # step + observe launches only
+                continue
+            key = (m.group(1), int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"]), int(r["LDS_Block_Size"]))
+            groups.setdefault(key, []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    shape_of = {}
+    if log and os.path.exists(log):
+        for line in open(log):
+            m = re.match(r"SHAPE E=(\d+) L=(\d+) N=(\d+)\s+step ([\d.]+) us", line)
+            if m:
+                shape_of[int(m.group(1))] = shape_of.get(int(m.group(1)), []) + [(int(m.group(2)), int(m.group(3)), float(m.group(4)))]
+    print("| instantiation `<W, R, step, obs, VEC, ITERS, NT>` | envs | LDS B | launches | avg us (rocprofv3) | min us | shape(s) with this E in the log: (L, N, HIP-event us) |")
+    print("|---|---|---|---|---|---|---|")
+    for (targs, grid, wg, lds), v in sorted(groups.items(), key=lambda kv: min(x[0] for x in kv[1])):
+        v.sort()
+        timed = [d for _, d in v[T + 1:]] or [d for _, d in v]  # drop the recording pass (interleaved with the policy kernels)
+        E = grid // wg
+        print("| `%s` | %d | %d | %d | %.2f | %.2f | %s |" % (targs, E, lds, len(timed), sum(timed) / len(timed) / 1e3, min(timed) / 1e3,
+                                                          shape_of.get(E, "")))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--summarize":
+        summarize(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
+    else:
+        run()

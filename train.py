@@ -2,13 +2,29 @@
 training of the communicating DQN, with the 16 CPU actors + replay actor + GPU learner of the reference
 replaced by one process per GPU that owns its vectorised environments, device replay and learner.
 
-    python3 train.py                                   # 1 GPU
+    python3 train.py                                   # 1 GPU, the reference's adaptive schedule
     python3 -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py   # 8 GPUs, RCCL grad all-reduce
+    python3 train.py --agents 40 --map 32 --envs 4096  # one fixed level (BASELINE config 2), no promotion
+
+Schedule.  Like the reference (`Environment(adaptive=True)`, worker.py:362; config.init_set, pass_rate), the default
+run starts at level (1 agent, 10x10), opens (agents+1, map) and (agents, map+5) when a level's last 200 episodes
+reach 90 % success, and stops when every agent count has passed on the 40x40 map (worker.py:237-250).  `--envs` is
+the number of lock-step environments PER ACTIVE LEVEL; the replay capacity defaults to what the active levels can
+flush at once (see `--capacity`).  Passing `--agents` and/or `--map` trains ONE fixed level instead (a declared
+deviation, for throughput runs): outcomes are still printed per level, but no level is promoted or retired.
+
+Several ranks.  Every `learner.update()` contains the gradient all-reduce, so all ranks must run the same number of
+updates: whether training has started (every rank's replay holds `--learning-starts` transitions), whether it is
+time to print statistics / advance the curriculum (rank 0's clock), and whether to stop (`--minutes` on any rank,
+or the curriculum's stop criterion on the POOLED level statistics) are decided once per iteration from one small
+all-reduced flag vector, identically on every rank.
 
 Printed statistics keep the reference's wording (worker.py:206-210,348-350): buffer update speed (= env steps/s
 summed over this rank's environments), buffer size, per-level success, number of updates, update speed, loss.
 """
 import argparse
+import contextlib
+import io
 import os
 import random
 import time
@@ -23,95 +39,116 @@ np.random.seed(0)
 random.seed(0)
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--envs", type=int, default=1024, help="lock-step environments per GPU")
-    ap.add_argument("--agents", type=int, default=config.num_agents)
-    ap.add_argument("--map", type=int, default=config.map_length)
-    ap.add_argument("--capacity", type=int, default=2048, help="replay capacity in episodes (train.py:21)")
+    ap.add_argument("--envs", type=int, default=1024, help="lock-step environments per GPU (per active level with the curriculum)")
+    ap.add_argument("--agents", type=int, default=None, help="fixed level: number of agents (implies no curriculum)")
+    ap.add_argument("--map", type=int, default=None, help="fixed level: map side length (implies no curriculum)")
+    ap.add_argument("--curriculum", action="store_true", help="(default) the reference's adaptive schedule; kept for compatibility")
+    ap.add_argument("--capacity", type=int, default=0, help="replay capacity in episodes; 0 = max(2048 (train.py:21), "
+                    "2 x the episodes the active levels can flush in one iteration) so that the stale-priority filter of "
+                    "update_priorities (worker.py:190-199) keeps working")
     ap.add_argument("--updates-per-iter", type=float, default=1.0, help="learner updates per actor iteration once training started")
     ap.add_argument("--max-updates", type=int, default=config.training_times)
-    ap.add_argument("--minutes", type=float, default=0.0, help="stop after this many minutes (0 = until --max-updates)")
+    ap.add_argument("--minutes", type=float, default=0.0, help="stop after this many minutes (0 = until --max-updates / curriculum done)")
     ap.add_argument("--interval", type=float, default=30.0, help="statistics interval in seconds (train.py:39)")
     ap.add_argument("--learning-starts", type=int, default=config.learning_starts)
     ap.add_argument("--batch-size", type=int, default=config.batch_size)
-    ap.add_argument("--curriculum", action="store_true", help="reference schedule: start at config.init_set and promote levels "
-                    "at config.pass_rate (worker.py:205-250); --envs is then the number of environments PER LEVEL")
-    a = ap.parse_args()
+    ap.add_argument("--dist-backend", default="nccl", help="nccl = RCCL; gloo only for the CPU-side multi-rank tests")
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args(argv)
+    fixed = a.agents is not None or a.map is not None
+    n_agents = a.agents if a.agents is not None else config.num_agents
+    map_len = a.map if a.map is not None else config.map_length
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MAPF_TRAIN_SHARE_GPU") == "1":
+        local_rank = 0  # test mode: every rank on GPU 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.dist_backend)
+    flag_dev = dev if (dist is None or a.dist_backend == "nccl") else torch.device("cpu")
 
     import mapf_rl_amd as M
     from mapf_rl_amd.actor import VecActor
     from mapf_rl_amd.learner import Learner
     from mapf_rl_amd.replay import GlobalBuffer
 
-    if a.curriculum:
+    seed = a.seed * 1000 + rank
+    if fixed:
+        capacity = a.capacity or max(2048, 2 * a.envs)
+        env = M.VecEnvironment(a.envs, map_len, n_agents, config.obs_radius, config.reward_fn, device=dev)
+        maps, agents, goals, _ = M.generate_scenarios(a.envs, map_len, n_agents, -1.0, seed=seed)
+        env.load(maps, agents, goals)
+        buffer = GlobalBuffer(capacity, max_agents=max(n_agents, config.max_num_agetns), device=dev, init_set=(n_agents, map_len),
+                              max_map_length=config.max_map_lenght, pass_rate=config.pass_rate, fixed_level=True)
+    else:
         from mapf_rl_amd.curriculum import CurriculumActors
 
-        buffer = GlobalBuffer(a.capacity, max_agents=config.max_num_agetns, device=dev, init_set=config.init_set,
+        # at most max_num_agetns + (max_map - init_map)/5 levels are active together (one per anti-diagonal step)
+        max_levels = config.max_num_agetns + (config.max_map_lenght - config.init_set[1]) // 5
+        capacity = a.capacity or max(2048, 2 * a.envs * max_levels)
+        buffer = GlobalBuffer(capacity, max_agents=config.max_num_agetns, device=dev, init_set=config.init_set,
                               max_map_length=config.max_map_lenght, pass_rate=config.pass_rate)
-    else:
-        env = M.VecEnvironment(a.envs, a.map, a.agents, config.obs_radius, config.reward_fn, device=dev)
-        maps, agents, goals, _ = M.generate_scenarios(a.envs, a.map, a.agents, -1.0, seed=rank)
-        env.load(maps, agents, goals)
-        buffer = GlobalBuffer(a.capacity, max_agents=max(a.agents, config.max_num_agetns), device=dev,
-                              init_set=(a.agents, a.map), max_map_length=config.max_map_lenght, pass_rate=config.pass_rate)
     learner = Learner(buffer, device=dev, batch_size=a.batch_size, save_path=config.save_path)
     if world > 1:  # identical initial weights on every rank
         for p in learner.model.parameters():
             dist.broadcast(p.data, src=0)
         learner.sync_target()
-    if a.curriculum:
-        actor = CurriculumActors(learner.model, buffer, envs_per_level=a.envs, device=dev, seed=rank, reward_fn=config.reward_fn)
+    if fixed:
+        actor = VecActor(env, learner.model, buffer, seed=seed)
     else:
-        actor = VecActor(env, learner.model, buffer, seed=rank)
+        actor = CurriculumActors(learner.model, buffer, envs_per_level=a.envs, device=dev, seed=seed, reward_fn=config.reward_fn)
 
     t_start = t_last = time.time()
     debt = 0.0
     started = False
-    while learner.counter < a.max_updates:
+    stop = False
+    while learner.counter < a.max_updates and not stop:
         actor.step()
-        if not started and len(buffer) >= a.learning_starts:
+        now = time.time()
+        # ---- decisions every rank must take identically (see module docstring): one MAX all-reduce of 3 flags ----
+        not_ready = int(len(buffer) < a.learning_starts)
+        time_up = int(a.minutes > 0 and (now - t_start) > a.minutes * 60)
+        stats_now = int(rank == 0 and now - t_last >= a.interval)
+        if dist is not None:
+            flags = torch.tensor([not_ready, time_up, stats_now], dtype=torch.int32, device=flag_dev)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+            not_ready, time_up, stats_now = flags.tolist()
+        if not started and not not_ready:
             started = True
             if rank == 0:
                 print("start training")
         if started:
             debt += a.updates_per_iter
-            while debt >= 1.0:
+            while debt >= 1.0 and learner.counter < a.max_updates:
                 learner.update()
                 debt -= 1.0
-        now = time.time()
-        if now - t_last >= a.interval:
-            if rank == 0:
+        if stats_now:
+            pooled = buffer.levels.pooled_counts(flag_dev) if dist is not None else None
+            with contextlib.nullcontext() if rank == 0 else contextlib.redirect_stdout(io.StringIO()):
+                # per-rank buffers keep their own counters; only rank 0 prints (its own speed, the pooled level statistics)
                 learner.stats(now - t_last)
-                buffer.stats(now - t_last)
+                buffer.stats(now - t_last, pooled, world)
                 print()
-            else:  # per-rank buffers keep their own counters and levels; only rank 0 prints
-                import contextlib
-                import io
-
-                with contextlib.redirect_stdout(io.StringIO()):
-                    buffer.stats(now - t_last)
-            if a.curriculum:
+            if not fixed:
                 actor.sync_levels()
-                if buffer.check_done():  # worker.py:237-250, train.py:41-43
-                    break
+                stop = buffer.check_done(pooled, world)  # worker.py:237-250, train.py:41-43
             t_last = now
-        if a.minutes > 0 and (now - t_start) > a.minutes * 60:
-            break
+        stop = stop or bool(time_up)
     if rank == 0:
         learner.save()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
