@@ -124,39 +124,50 @@ __device__ __forceinline__ int block_and(int pred) {
     else return __syncthreads_and(pred);
 }
 
-template <typename W, int R, bool DO_STEP, bool DO_OBS, int VEC, int ITERS, int NT>
+// G > 1 (few agents per environment, L <= 32): one workgroup steps G CONSECUTIVE environments.  Every per-agent array of the
+// handle is contiguous over environments ([E][N]...), so the block simply sees G * N "virtual agents" -- agent a belongs to
+// environment a / N of the block -- and ONE observation bit string / byte block of G * N * 486 cells; only the maps, the
+// occupancy rows, the id grids and the all-on-goal flag exist once per environment.  What it buys: the fixed instruction stream
+// of a block (load rounds, LDS init, barriers, the unrolled field loop) is paid once per G environments, and the observation
+// block is a multiple of 16 bytes whenever G * N is a multiple of 8 (with 6 agents a lone environment's 2,916 bytes are not even
+// 16-byte aligned: 4-byte stores; with 1 agent byte stores).
+template <typename W, int R, bool DO_STEP, bool DO_OBS, int VEC, int ITERS, int NT, int G>
 __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
     constexpr int WW = 2 * R + 1;
     constexpr int SPAN = WW + 1;
-    const int e = blockIdx.x, t = threadIdx.x;
+    const int e = blockIdx.x * G, t = threadIdx.x;  // first environment of the block
     constexpr int nt = NT;
-    const int L = p.L, N = p.N;
+    const int L = p.L, N1 = p.N;
+    const int N = G * N1;  // (virtual) agents of the block
     const int LP = L + 2 * R;
     const int GP = L + 2;  // id grid pitch (1-cell border)
     const int NP = (N + 7) & ~7;
-    const int grid_q = (GP * GP + 15) >> 4;          // uint4 count of the id grid
+    const int grid_q = (GP * GP + 15) >> 4;          // uint4 count of one id grid
     const int bits_q = ((N * 6 * WW * WW + 31) / 32 + 1 + 3) >> 2;  // uint4 count of the bit string (+1 spill dword)
 
     extern __shared__ __align__(16) unsigned char smem[];
-    W *s_obst = reinterpret_cast<W *>(smem);                             // [LP]
-    W *s_agent = s_obst + LP;                                            // [LP]
-    unsigned char *base = smem + (((size_t)2 * LP * sizeof(W) + 15) & ~(size_t)15);
-    unsigned char *s_id = base;                                          // [grid_q*16]  0xFF = empty
-    unsigned *s_bits = reinterpret_cast<unsigned *>(s_id + (size_t)grid_q * 16);  // [bits_q*4]
+    W *s_obst = reinterpret_cast<W *>(smem);                             // [G][LP]
+    W *s_agent = s_obst + G * LP;                                        // [G][LP]
+    unsigned char *base = smem + (((size_t)2 * G * LP * sizeof(W) + 15) & ~(size_t)15);
+    unsigned char *s_id = base;                                          // [G][grid_q*16]  0xFF = empty
+    unsigned *s_bits = reinterpret_cast<unsigned *>(s_id + (size_t)G * grid_q * 16);  // [bits_q*4]
     unsigned short *s_cur = reinterpret_cast<unsigned short *>(s_bits + (size_t)bits_q * 4);  // [NP]
     unsigned short *s_next = s_cur + NP;                                 // [NP]
     unsigned short *s_mov = s_next + NP;                                 // [NP]
+    int *s_flag = reinterpret_cast<int *>(s_mov + NP);                   // [G]  G > 1: some agent of the environment is off its goal
 
 #define STAMP(k)                                                                       \
     if (p.dbg && t == 0) {                                                             \
         unsigned long long _ts;                                                        \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_ts)::"memory");   \
-        p.dbg[(size_t)e * 8 + (k)] = _ts;                                              \
+        p.dbg[(size_t)blockIdx.x * 8 + (k)] = _ts;                                     \
     }
     STAMP(0)
     // ---- round 1: every small load, unconditional (clamped indices) so that they all go out back to back ----
     const bool agent = t < N;
-    const size_t own = (size_t)e * N + (agent ? t : N - 1);
+    const size_t own = (size_t)e * N1 + (agent ? t : N - 1);
+    const int ge = (G > 1 && agent) ? t / N1 : 0;  // this lane's environment within the block
+    const int ge_rows = ge * LP, ge_grid = ge * grid_q * 16;
     const short2 cpos = *reinterpret_cast<const short2 *>(p.agents + own * 2);
     short2 gpos = make_short2(0, 0);
     int act = 0;
@@ -165,13 +176,15 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
         act = p.actions[own];
     }
     const W *map_rows = reinterpret_cast<const W *>(p.map_rows) + (size_t)e * L;
-    constexpr int ROW_ITERS = (64 + 2 * R + NT - 1) / NT;  // covers LP <= 64 + 2R
+    constexpr int ROW_ITERS = G == 1 ? (64 + 2 * R + NT - 1) / NT : (G * (32 + 2 * R) + NT - 1) / NT;  // covers G * LP rows
     W mrow[ROW_ITERS];
 #pragma unroll
     for (int q = 0; q < ROW_ITERS; ++q) {
-        int rr = t + q * nt - R;
+        const int r = t + q * nt;
+        const int g = G == 1 ? 0 : min(r / LP, G - 1);
+        int rr = r - g * LP - R;
         rr = rr < 0 ? 0 : (rr >= L ? L - 1 : rr);
-        mrow[q] = map_rows[rr];
+        mrow[q] = map_rows[g * L + rr];
     }
     int px[ITERS], pdx[ITERS];
     if constexpr (DO_OBS) {
@@ -179,7 +192,7 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
         for (int it = 0; it < ITERS; ++it) {
             int k = t + it * nt;
             k = k < N * SPAN ? k : N * SPAN - 1;
-            const size_t o = (size_t)e * N + k / SPAN;
+            const size_t o = (size_t)e * N1 + k / SPAN;
             px[it] = p.agents[o * 2];
             pdx[it] = 0;
             if constexpr (DO_STEP) pdx[it] = p.actions[o];
@@ -190,7 +203,7 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
     int rrow[ITERS];
     if constexpr (DO_OBS) {
         const unsigned navi_mul = (p.ablate & 1) ? 0u : 1u;  // tuning: 0 = every lane reads record 0 (no traffic)
-        const NaviRec<W> *navi = reinterpret_cast<const NaviRec<W> *>(p.navi) + (size_t)e * N * L * navi_mul;
+        const NaviRec<W> *navi = reinterpret_cast<const NaviRec<W> *>(p.navi) + (size_t)e * N1 * L * navi_mul;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int k = t + it * nt;
@@ -209,15 +222,16 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
 #pragma unroll
     for (int q = 0; q < ROW_ITERS; ++q) {
         const int r = t + q * nt;
-        if (r < LP) {
-            const int rr = r - R;
+        if (r < G * LP) {
+            const int rr = (G == 1 ? r : r % LP) - R;
             s_obst[r] = (rr >= 0 && rr < L) ? mrow[q] : (W)0;
             s_agent[r] = (W)0;
         }
     }
     if constexpr (DO_STEP) {
         const uint4 ff = make_uint4(~0u, ~0u, ~0u, ~0u);
-        for (int k = t; k < grid_q; k += nt) reinterpret_cast<uint4 *>(s_id)[k] = ff;
+        for (int k = t; k < G * grid_q; k += nt) reinterpret_cast<uint4 *>(s_id)[k] = ff;
+        if (G > 1 && t < G) s_flag[t] = 0;
     }
     if constexpr (DO_OBS) {
         const uint4 zz = make_uint4(0u, 0u, 0u, 0u);
@@ -245,7 +259,7 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
             // S1 (environment.py:320-332)
             if (mover) {
                 bool blocked = nx < 0 || ny < 0 || nx >= L || ny >= L;
-                if (!blocked) blocked = (s_obst[nx + R] >> ny) & 1;
+                if (!blocked) blocked = (s_obst[ge_rows + nx + R] >> ny) & 1;
                 if (blocked) {
                     mover = false;
                     rc = MAPF_RC_COLLISION;
@@ -253,7 +267,7 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
                     ny = cy;
                 }
             }
-            s_id[(cx + 1) * GP + cy + 1] = (unsigned char)t;
+            s_id[ge_grid + (cx + 1) * GP + cy + 1] = (unsigned char)t;
             s_next[t] = (unsigned short)((nx << 8) | ny);
             s_mov[t] = mover;
         }
@@ -265,7 +279,7 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
         int occ = 0xFF;
         bool swap = false;
         if (mover) {
-            occ = s_id[(nx + 1) * GP + ny + 1];
+            occ = s_id[ge_grid + (nx + 1) * GP + ny + 1];
             if (occ != 0xFF) swap = s_mov[occ] && s_next[occ] == my_cur;
         }
         block_sync<NT>();
@@ -283,7 +297,7 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
         // only stand on the 4 neighbours of the target cell.
         bool lose = false;
         if (mover) {
-            const int c = (nx + 1) * GP + ny + 1;
+            const int c = ge_grid + (nx + 1) * GP + ny + 1;
             const int nb[4] = {c - GP, c + GP, c - 1, c + 1};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -292,7 +306,7 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
             }
         }
         // rule (a) + cascade: target cell held by an agent that is (now) settled
-        for (int round = 0; round <= N; ++round) {
+        for (int round = 0; round <= N1; ++round) {
             bool revert = mover && (lose || (occ != 0xFF && !s_mov[occ]));
             int any = block_or<NT>(revert);
             if (revert) {
@@ -307,14 +321,20 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
         }
 
         // S4 (environment.py:410-430); the result stores are issued at the very end of the kernel
-        all_done = block_and<NT>(!agent || (nx == gx && ny == gy));
+        if constexpr (G == 1) {
+            all_done = block_and<NT>(!agent || (nx == gx && ny == gy));
+        } else {  // per environment of the block
+            if (agent && !(nx == gx && ny == gy)) s_flag[ge] = 1;
+            block_sync<NT>();
+            all_done = !s_flag[ge];
+        }
         if (all_done) rc = MAPF_RC_FINISH;
     }
 
     // ---- agent occupancy rows after the step (+ the overlap invariant, environment.py:424-428) ----
     if (agent) {
         W bit = (W)1 << ny;
-        W old = lds_or(&s_agent[nx + R], bit);
+        W old = lds_or(&s_agent[ge_rows + nx + R], bit);
         if (DO_STEP && (old & bit)) atomicOr(p.status, kStatusOverlap);
         s_cur[t] = (unsigned short)((nx << 8) | ny);
     }
@@ -332,9 +352,10 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
                 const int x = key >> 8, y = key & 255;
                 const int dy = rrow[it] - (x - R);
                 if (dy >= 0 && dy < WW) {
-                    unsigned f_ag = window_bits<W, R>(s_agent[x + dy], y);
+                    const int gr = G == 1 ? 0 : (i / N1) * LP;  // rows of the agent's environment
+                    unsigned f_ag = window_bits<W, R>(s_agent[gr + x + dy], y);
                     if (dy == R) f_ag &= ~(1u << R);  // centre of channel 0 forced to 0 (environment.py:461)
-                    const unsigned f_ob = window_bits<W, R>(s_obst[x + dy], y);
+                    const unsigned f_ob = window_bits<W, R>(s_obst[gr + x + dy], y);
                     const unsigned off = (unsigned)((i * 6 * WW + dy) * WW);
                     deposit_field<WW>(s_bits, off, f_ag);
                     deposit_field<WW>(s_bits, off + WW * WW, f_ob);
@@ -352,11 +373,27 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
         // ---- optional: the bit string itself (bit-packed observation row for the replay) ----
         if (p.obs_bits) {
             uint32_t *ob = p.obs_bits + (size_t)e * p.obs_bits_rd;
-            const int nd = (total + 31) >> 5;
-            for (int k = t; k < p.obs_bits_rd; k += nt) ob[k] = k < nd ? s_bits[k] : 0u;
+            if constexpr (G == 1) {
+                const int nd = (total + 31) >> 5;
+                for (int k = t; k < p.obs_bits_rd; k += nt) ob[k] = k < nd ? s_bits[k] : 0u;
+            } else {  // environment g's row = bits [g * total1, (g + 1) * total1) of the block's string
+                const int total1 = N1 * 6 * WW * WW;
+                for (int q = t; q < G * p.obs_bits_rd; q += nt) {
+                    const int g = q / p.obs_bits_rd, k = q - g * p.obs_bits_rd;
+                    const int left = total1 - 32 * k;  // bits of this row still to come
+                    unsigned v = 0u;
+                    if (left > 0) {
+                        const unsigned b0 = (unsigned)(g * total1 + 32 * k), d = b0 >> 5, sh = b0 & 31u;
+                        v = s_bits[d] >> sh;
+                        if (sh) v |= s_bits[d + 1] << (32u - sh);
+                        if (left < 32) v &= (1u << left) - 1u;
+                    }
+                    ob[q] = v;
+                }
+            }
         }
         // ---- expand the bit string: bit b -> byte b of this env's observation block ----
-        uint8_t *out = p.obs + (size_t)e * total;
+        uint8_t *out = p.obs + (size_t)blockIdx.x * total;
         if (p.obs == nullptr) {
             // bit-packed output only
         } else if constexpr (VEC == 16) {
@@ -386,7 +423,7 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
 
     // ---- small result stores last (nothing waits on them) ----
     if (agent) {
-        const size_t o = (size_t)e * N + t;
+        const size_t o = (size_t)e * N1 + t;
         if constexpr (DO_STEP) {
             *reinterpret_cast<short2 *>(p.agents + o * 2) = make_short2((short)nx, (short)ny);
             if (p.rclass) p.rclass[o] = (int8_t)rc;
@@ -395,9 +432,14 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
         if (p.pos_out) *reinterpret_cast<short2 *>(p.pos_out + o * 2) = make_short2((short)nx, (short)ny);
     }
     if constexpr (DO_STEP) {
-        if (t == 0) {
-            if (p.done) p.done[e] = (uint8_t)(all_done != 0);
-            p.steps[e] += 1;
+        if constexpr (G == 1) {
+            if (t == 0) {
+                if (p.done) p.done[e] = (uint8_t)(all_done != 0);
+                p.steps[e] += 1;
+            }
+        } else if (t < G) {
+            if (p.done) p.done[e + t] = (uint8_t)(s_flag[t] == 0);
+            p.steps[e + t] += 1;
         }
     }
     if (p.dbg) {
@@ -739,6 +781,7 @@ struct mapf_env {
     int tune_threads;  // 0 = default; MAPF_STEP_THREADS (tuning experiments only)
     int tune_lds_pad;  // extra dynamic LDS bytes per block to cap residency; MAPF_STEP_LDS_PAD
     int tune_ablate;   // MAPF_STEP_ABLATE (timing-only builds; results are wrong)
+    int tune_group;    // MAPF_STEP_GROUP: cap on environments per workgroup (1 = never pack)
     unsigned long long *dbg;  // phase-stamp buffer (diagnostics)
 };
 
@@ -766,13 +809,27 @@ struct DeviceGuard {
     }
 };
 
-size_t step_smem_bytes(const mapf_env *h) {
+size_t step_smem_bytes(const mapf_env *h, int G) {
     const int WW = 2 * h->R + 1;
-    size_t LP = h->L + 2 * h->R, GP = h->L + 2, NP = (h->N + 7) & ~7;
-    size_t rows = (2 * LP * word_bytes(h) + 15) & ~(size_t)15;
+    size_t LP = h->L + 2 * h->R, GP = h->L + 2, NP = ((size_t)G * h->N + 7) & ~7;
+    size_t rows = (2 * G * LP * word_bytes(h) + 15) & ~(size_t)15;
     size_t grid_q = (GP * GP + 15) >> 4;
-    size_t bits_q = (((size_t)h->N * 6 * WW * WW + 31) / 32 + 1 + 3) >> 2;
-    return rows + grid_q * 16 + bits_q * 16 + 3 * NP * 2;
+    size_t bits_q = (((size_t)G * h->N * 6 * WW * WW + 31) / 32 + 1 + 3) >> 2;
+    return rows + G * grid_q * 16 + bits_q * 16 + 3 * NP * 2 + 16 + 4 * G;
+}
+
+// Environments per workgroup (env_step_kernel's G): with few agents one environment leaves most of a wavefront idle behind a
+// fixed instruction stream, and its observation block is not a multiple of 16 bytes.  Packed blocks are one wavefront, need
+// 32-bit map rows, G * N agents <= 64, E divisible by G and a 16-byte-granular observation block (G * N a multiple of 8).
+// Measured on MI355X (tools/shape_sweep.py, profiles/r02_shape_sweep.md).  MAPF_STEP_GROUP overrides for tuning runs.
+int step_group(const mapf_env *h, const void *obs) {
+    if (h->wide || (reinterpret_cast<uintptr_t>(obs) & 15)) return 1;
+    const int want = h->tune_group > 0 ? h->tune_group : 8;
+    for (int G = 8; G >= 2; G >>= 1) {
+        if (G > want) continue;
+        if (G * h->N <= 64 && h->E % G == 0 && (G * h->N) % 8 == 0 && (G * h->N * 10 + 63) / 64 <= 10) return G;
+    }
+    return 1;
 }
 
 // threads per block (one lane per agent in the step phase), measured on MI355X (tools/shape_sweep.py):
@@ -791,19 +848,38 @@ int launch_step_nt(const mapf_env *h, const StepParams &p, hipStream_t s, size_t
     const int need = (h->N * 10 + NT - 1) / NT;
     dim3 g(h->E), b(NT);
     if constexpr (!DO_OBS) {
-        hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, false, 16, 1, NT>), g, b, smem, s, p);
+        hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, false, 16, 1, NT, 1>), g, b, smem, s, p);
     } else if constexpr (NT == 64) {
         if (need <= 4)
-            hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 4, NT>), g, b, smem, s, p);
+            hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 4, NT, 1>), g, b, smem, s, p);
         else if (need <= 7)
-            hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 7, NT>), g, b, smem, s, p);
+            hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 7, NT, 1>), g, b, smem, s, p);
         else
-            hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 10, NT>), g, b, smem, s, p);
+            hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 10, NT, 1>), g, b, smem, s, p);
     } else {
         if (need <= 4)
-            hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 4, NT>), g, b, smem, s, p);
+            hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 4, NT, 1>), g, b, smem, s, p);
         else
-            hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 10, NT>), g, b, smem, s, p);
+            hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 10, NT, 1>), g, b, smem, s, p);
+    }
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+// G environments per one-wavefront workgroup (32-bit rows, 16-byte stores; see step_group)
+template <bool DO_STEP, bool DO_OBS, int G>
+int launch_step_packed(const mapf_env *h, const StepParams &p, hipStream_t s, size_t smem) {
+    const int need = (G * h->N * 10 + 63) / 64;
+    dim3 g(h->E / G), b(64);
+    if constexpr (!DO_OBS) {
+        hipLaunchKernelGGL((env_step_kernel<uint32_t, 4, DO_STEP, false, 16, 1, 64, G>), g, b, smem, s, p);
+    } else {
+        if (need <= 4)
+            hipLaunchKernelGGL((env_step_kernel<uint32_t, 4, DO_STEP, true, 16, 4, 64, G>), g, b, smem, s, p);
+        else if (need <= 7)
+            hipLaunchKernelGGL((env_step_kernel<uint32_t, 4, DO_STEP, true, 16, 7, 64, G>), g, b, smem, s, p);
+        else
+            hipLaunchKernelGGL((env_step_kernel<uint32_t, 4, DO_STEP, true, 16, 10, 64, G>), g, b, smem, s, p);
     }
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
@@ -822,7 +898,17 @@ int launch_step_vec(const mapf_env *h, const StepParams &p, hipStream_t s) {
     const int threads = step_block_threads(h);
     const bool a16 = (total % 16 == 0) && ((reinterpret_cast<uintptr_t>(p.obs) & 15) == 0);
     const bool a4 = (total % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.obs) & 3) == 0);
-    const size_t smem = step_smem_bytes(h) + (size_t)h->tune_lds_pad;
+    if constexpr (sizeof(W) == 4) {
+        const int G = step_group(h, p.obs);
+        if (G > 1) {
+            const size_t smem_g = step_smem_bytes(h, G) + (size_t)h->tune_lds_pad;
+            const bool obs = p.obs != nullptr || p.obs_bits != nullptr;
+            if (G == 8) return obs ? launch_step_packed<DO_STEP, true, 8>(h, p, s, smem_g) : launch_step_packed<DO_STEP, false, 8>(h, p, s, smem_g);
+            if (G == 4) return obs ? launch_step_packed<DO_STEP, true, 4>(h, p, s, smem_g) : launch_step_packed<DO_STEP, false, 4>(h, p, s, smem_g);
+            return obs ? launch_step_packed<DO_STEP, true, 2>(h, p, s, smem_g) : launch_step_packed<DO_STEP, false, 2>(h, p, s, smem_g);
+        }
+    }
+    const size_t smem = step_smem_bytes(h, 1) + (size_t)h->tune_lds_pad;
     if (p.obs == nullptr && p.obs_bits == nullptr) return launch_step_iters<W, DO_STEP, false, 16>(h, p, s, threads, smem);
     if (p.obs == nullptr) return launch_step_iters<W, DO_STEP, true, 16>(h, p, s, threads, smem);
     if (a16) return launch_step_iters<W, DO_STEP, true, 16>(h, p, s, threads, smem);
@@ -1005,6 +1091,8 @@ int mapf_create(int num_envs, int map_len, int num_agents, int obs_radius, int d
     h->tune_lds_pad = tv ? std::atoi(tv) : 0;
     tv = std::getenv("MAPF_STEP_ABLATE");
     h->tune_ablate = tv ? std::atoi(tv) : 0;
+    tv = std::getenv("MAPF_STEP_GROUP");
+    h->tune_group = tv ? std::atoi(tv) : 0;
     const float def[5] = {-0.075f, 0.0f, -0.075f, -0.5f, 3.0f};
     std::memcpy(h->rtab, def, sizeof(def));
     DeviceGuard guard(device);

@@ -24,6 +24,7 @@
 
 #include "mapf_dqn.h"
 #include "mapf_env.h"
+#include "mapf_recur_internal.h"
 
 namespace {
 
@@ -194,18 +195,6 @@ __device__ __forceinline__ void gru_block(int cblk, const uint16_t *__restrict__
         *reinterpret_cast<uint2 *>(Hout + agent * H_ROW + c0 * 2) = keep ? hv : make_uint2(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]));
     }
 }
-
-// what the training forward stores for the backward kernel (csrc/mapf_recur_bwd.hip); R = T*E*N rows, row = (t*E + e)*N + agent
-struct RecurSave {
-    uint16_t *hin0;  // [R][256]       state entering the step
-    uint16_t *g1;    // [R][4][256]    r, z, n, W_hn h + b_hn of the recurrent cell
-    uint16_t *hr;    // [2][R][256]    state entering communication round 0 / 1
-    uint16_t *qkv;   // [2][R][384]
-    uint16_t *ctx;   // [2][R][128]
-    uint16_t *info;  // [2][R][64]
-    uint16_t *g2;    // [2][R][4][256] gate terms of the update cell
-    uint16_t *P;     // [2][T*E][2][48][64] attention weights (heads x agents x 64 agent slots, zero padded)
-};
 
 template <bool SAVE>
 __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t *__restrict__ gi, const uint16_t *__restrict__ h0,
@@ -444,12 +433,16 @@ extern "C" {
 
 int mapf_recurrent_infer(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
                          const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev, void *stream) {
-    if (T < 1 || E < 0 || N < 1 || N > NA || !gi_dev || !comm_dev || !weights_dev || !bias_dev || !h_out_dev) return MAPF_ERR_INVALID_ARG;
+    if (T < 1 || E < 0 || N < 1 || N > MAPF_RECUR_MAX_AGENTS || !gi_dev || !comm_dev || !weights_dev || !bias_dev || !h_out_dev)
+        return MAPF_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(gi_dev) & 7) || (reinterpret_cast<uintptr_t>(h0_dev) & 15) || (reinterpret_cast<uintptr_t>(weights_dev) & 15) ||
         (reinterpret_cast<uintptr_t>(bias_dev) & 15) || (reinterpret_cast<uintptr_t>(h_out_dev) & 15) ||
         (reinterpret_cast<uintptr_t>(agent0_out_dev) & 15))
         return MAPF_ERR_INVALID_ARG;
     if (E == 0) return MAPF_OK;
+    if (N > NA)  // 49..128 agents: csrc/mapf_recur_wide.hip
+        return mapf_recur_wide_forward(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, nullptr,
+                                       static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(recurrent_infer_kernel<false>, dim3(E), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
                        weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, RecurSave{});
     HIP_TRY(hipGetLastError());
@@ -459,12 +452,16 @@ int mapf_recurrent_infer(const uint16_t *gi_dev, const uint16_t *h0_dev, const u
 int mapf_recurrent_forward_save(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
                                 const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev,
                                 uint16_t *const *save_dev, void *stream) {
-    if (T < 1 || E < 0 || N < 1 || N > NA || !gi_dev || !comm_dev || !weights_dev || !bias_dev || !h_out_dev || !agent0_out_dev || !save_dev)
+    if (T < 1 || E < 0 || N < 1 || N > MAPF_RECUR_MAX_AGENTS || !gi_dev || !comm_dev || !weights_dev || !bias_dev || !h_out_dev ||
+        !agent0_out_dev || !save_dev)
         return MAPF_ERR_INVALID_ARG;
     for (int i = 0; i < 8; ++i)
         if (!save_dev[i] || (reinterpret_cast<uintptr_t>(save_dev[i]) & 15)) return MAPF_ERR_INVALID_ARG;
     if (E == 0) return MAPF_OK;
     const RecurSave sv{save_dev[0], save_dev[1], save_dev[2], save_dev[3], save_dev[4], save_dev[5], save_dev[6], save_dev[7]};
+    if (N > NA)
+        return mapf_recur_wide_forward(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, &sv,
+                                       static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(recurrent_infer_kernel<true>, dim3(E), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
                        weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, sv);
     HIP_TRY(hipGetLastError());

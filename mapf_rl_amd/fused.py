@@ -208,7 +208,8 @@ def encoder_forward_train(obs, obs_encoder, packed: PackedEncoder):
 # ---------------------------------------------------------------------------------------------------------
 # Inference recurrence behind the encoder (include/mapf_dqn.h: mapf_recurrent_infer)
 # ---------------------------------------------------------------------------------------------------------
-RECUR_MAX_AGENTS = 48
+RECUR_MAX_AGENTS = 128         # include/mapf_dqn.h: the fused recurrence kernels (inference, forward-save, backward)
+RECUR_NARROW_AGENTS = 48       # up to here one workgroup keeps every image in LDS and the forward saves the attention weights P
 
 
 class PackedRecurrence:
@@ -293,7 +294,9 @@ class _RecurTrain(torch.autograd.Function):
         saves = [torch.empty((R, 256), dtype=bf, device=dev), torch.empty((R, 1024), dtype=bf, device=dev),
                  torch.empty((2, R, 256), dtype=bf, device=dev), torch.empty((2, R, 384), dtype=bf, device=dev),
                  torch.empty((2, R, 128), dtype=bf, device=dev), torch.empty((2, R, 64), dtype=bf, device=dev),
-                 torch.empty((2, R, 1024), dtype=bf, device=dev), torch.empty((2, T * E, 2, 48, 64), dtype=bf, device=dev)]
+                 torch.empty((2, R, 1024), dtype=bf, device=dev),
+                 # attention weights: saved for N <= 48; wider environments recompute them in the backward kernel (placeholder)
+                 torch.empty((2, T * E, 2, 48, 64) if N <= RECUR_NARROW_AGENTS else (8,), dtype=bf, device=dev)]
         h_out = torch.empty((E, N, 256), dtype=bf, device=dev)
         a0 = torch.empty((T, E, 256), dtype=bf, device=dev)
         sp = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in saves])

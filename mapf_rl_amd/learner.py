@@ -137,6 +137,9 @@ class Learner:
             cur = torch.cuda.current_stream(self.device)
             nxt = self.buffer.sample_batch(self.batch_size)
             self._side.wait_stream(cur)
+            for t in nxt:  # allocated on this stream, read on the side stream: keep the allocator from reusing them early
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(self._side)
             with torch.cuda.stream(self._side):
                 qn = self.target_q(nxt)
                 ready = torch.cuda.Event()
@@ -157,8 +160,22 @@ class Learner:
         return dict(loss=loss.detach(), td=td.detach(), priorities=priorities, grad_norm=grad_norm.detach(), q=q.detach(),
                     q_next=q_next)
 
+    def _drop_prefetch(self):
+        """A prefetched batch carries Q-values of the target network as it was: void it when that network changes."""
+        if self._pre is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._pre[2])
+            self._pre = None
+
     def sync_target(self):
+        self._drop_prefetch()
         self.tar_model.load_state_dict(self.model.state_dict())
+
+    def load_state_dict(self, state_dict, sync_target=True):
+        """Loads online-network weights (reference key names) and, by default, copies them to the target network."""
+        self._drop_prefetch()
+        self.model.load_state_dict(state_dict)
+        if sync_target:
+            self.tar_model.load_state_dict(self.model.state_dict())
 
     def save(self, path=None):
         """Checkpoint with the reference's key names (worker.py:338); the directory is created if missing."""

@@ -30,6 +30,8 @@ MAX_COMM_AGENTS = 3     # config.py:59
 NUM_COMM_LAYERS = 2     # config.py:62
 NUM_COMM_HEADS = 2      # config.py:63
 ENC_FEATURES = 16 * 7 * 7
+RECUR_MAX_AGENTS = 128  # widest environment of the fused recurrence kernels (include/mapf_dqn.h); beyond it: the PyTorch-level path
+BPTT_MAX_AGENTS = 48
 
 
 class ResBlock(nn.Module):
@@ -64,7 +66,7 @@ class MultiHeadAttention(nn.Module):
         v = self.W_V(x).view(B, N, H, D).transpose(1, 2)
         if Network.SDPA and x.is_cuda and q.dtype == torch.bfloat16:
             # fused kernel, fp32 accumulation of scores / softmax from the bf16 q, k (see Network._recur_fast)
-            ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=(~blocked).unsqueeze(1))
+            ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=_sdpa_mask(~blocked).unsqueeze(1))
             return self.W_O(ctx.transpose(1, 2).reshape(B, N, H * D))
         # scores and softmax in fp32 (model.py:75-78)
         scores = torch.matmul(q.float(), k.float().transpose(-1, -2)) / (D ** 0.5)
@@ -211,6 +213,18 @@ class _Select(torch.autograd.Function):
         return None, g * cond, g * ~cond
 
 
+def _sdpa_mask(allowed):
+    """Boolean SDPA mask for `allowed` [..., N, N].  SDPA fills masked scores with -inf, the reference with -1e9
+    (model.py:77): the same softmax unless a row has NO allowed entry -- zero-padded window rows, padded agents of
+    smaller curriculum levels, the last comm row of finished episodes (buffer.py:124) --, where -inf gives NaN (and
+    0 * NaN in the GRU backward would poison the weight gradients) while -1e9 gives a uniform row.  Such an agent has
+    no partner, so CommBlock discards its output (`update`, model.py:103); letting it attend to itself keeps the
+    row finite without changing any result."""
+    empty = ~allowed.any(dim=-1, keepdim=True)
+    eye = torch.eye(allowed.shape[-1], dtype=torch.bool, device=allowed.device)
+    return allowed | (empty & eye)
+
+
 def comm_mask_from_pos(pos: torch.Tensor, obs_radius: int = OBS_RADIUS, max_comm: int = MAX_COMM_AGENTS) -> torch.Tensor:
     """pos [E, N, 2] (any integer/float dtype) -> bool [E, N, N]: j is within i's FOV square AND among i's
     `max_comm` nearest agents by Euclidean distance, itself included (reference model.py:195-208).
@@ -345,7 +359,7 @@ class Network(nn.Module):
             latent = self.encode(obs.reshape(E * N, *OBS_SHAPE))
             if comm_mask is None:
                 comm_mask = comm_mask_from_pos(pos)
-            if self.FUSED_RECURRENCE and latent.is_cuda and latent.dtype == torch.bfloat16 and N <= 48:
+            if self.FUSED_RECURRENCE and latent.is_cuda and latent.dtype == torch.bfloat16 and N <= RECUR_MAX_AGENTS:
                 # GRU cell + both communication rounds in one kernel, one workgroup per environment (csrc/mapf_recur.hip)
                 hidden = self._recur_kernel(latent.view(1, E, N, ENC_FEATURES), hidden, comm_mask.unsqueeze(0), False)[0]
                 hidden = hidden.view(E * N, self.latent_dim)
@@ -370,8 +384,8 @@ class Network(nn.Module):
         self.hidden = None
 
     # ------------------------------------------------------------------ learner side
-    FUSED_BPTT = True  # with autograd: the T-step recurrence as a forward-save + a backward-through-time kernel (N <= 48)
-    FUSED_RECURRENCE = True  # without autograd: GRU + CommBlock of all steps in one kernel (csrc/mapf_recur.hip), N <= 48
+    FUSED_BPTT = True  # with autograd: the T-step recurrence as a forward-save + a backward-through-time kernel
+    FUSED_RECURRENCE = True  # without autograd: GRU + CommBlock of all steps in one kernel (csrc/mapf_recur.hip, mapf_recur_wide.hip)
     SDPA = True  # fused scaled-dot-product attention inside _recur_fast
     FAST_RECURRENCE = True  # HIP device: hoisted input projection, fused QKV, deferred weight gradients (see _recur_fast)
 
@@ -426,10 +440,10 @@ class Network(nn.Module):
         D, H, A = self.latent_dim, NUM_COMM_HEADS, self.comm.output_dim
         lp = torch.bfloat16
         grad = torch.is_grad_enabled()
-        if not grad and self.FUSED_RECURRENCE and N <= 48:  # target network: all T steps in one kernel launch
+        if not grad and self.FUSED_RECURRENCE and N <= RECUR_MAX_AGENTS:  # target network: all T steps in one kernel launch
             a0 = self._recur_kernel(latent_t, hidden, comm_mask.transpose(0, 1), True)[1]
             return a0.transpose(0, 1)
-        if grad and self.FUSED_BPTT and N <= 48:
+        if grad and self.FUSED_BPTT and N <= BPTT_MAX_AGENTS:
             # online network: forward-with-saved-state and backward-through-time kernels, one workgroup per window
             from .fused import PackedRecurrence, recurrence_params, recurrent_train
 
@@ -470,7 +484,7 @@ class Network(nn.Module):
         gi_all = _InputProj.apply(lat_t.view(T * B * N, ENC_FEATURES), rc.weight_ih, rc.bias_ih).view(T, B * N, 3 * D) if grad else \
             F.linear(lat_t, cast(rc.weight_ih), cast(rc.bias_ih))
         blocked = (~comm_mask).unsqueeze(2)                              # [B, T, 1, N, N]
-        allowed = comm_mask.unsqueeze(2)
+        allowed = _sdpa_mask(comm_mask).unsqueeze(2)                     # rows without any partner attend to themselves
         update = (comm_mask.sum(dim=-1) > 1).unsqueeze(-1)               # [B, T, N, 1]  (model.py:103)
         scale = 1.0 / (A ** 0.5)
         agent0 = []
@@ -482,7 +496,7 @@ class Network(nn.Module):
                 q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2)
                 if self.SDPA:
                     # one fused kernel: scores and softmax accumulate in fp32 from the bf16 q/k (model.py:75-78 keeps them
-                    # in fp32 too); every agent hears itself, so no row is fully masked and -inf == the reference's -1e9
+                    # in fp32 too); no row of `allowed` is fully masked (_sdpa_mask), so -inf == the reference's -1e9
                     ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=allowed[:, t]).transpose(1, 2).reshape(B * N, HA)
                 else:
                     scores = torch.matmul(q.float(), k.float().transpose(-1, -2)) * scale   # fp32 (model.py:75-78)

@@ -91,3 +91,25 @@ def det_state_dict(shapes, seed=1234):
                 bound = 0.05
             out[name] = ((u * 2.0 - 1.0) * bound).astype(np.float32).reshape(shape)
     return out
+
+
+# ---- compact fingerprints of large gradient tensors (goldens hold these instead of 8 MB of raw gradients) ----
+NPROJ = 24
+
+
+def sign_matrix(n, k=NPROJ, seed=99):
+    """k deterministic +-1 vectors of length n (counter-based hash, identical on every box): float32 [k, n]."""
+    with np.errstate(over="ignore"):
+        ctr = np.arange(n * k, dtype=np.uint64) + np.uint64(seed) * np.uint64(1 << 40)
+        bits = (_splitmix64(_splitmix64(ctr)) >> np.uint64(63)).astype(np.float32)
+    return (bits * 2.0 - 1.0).reshape(k, n)
+
+
+def grad_fingerprint(g):
+    """g: float array -> dict(norm, proj [NPROJ] = S g with S = sign_matrix, blocks = norms of up to 3 equal row blocks
+    (the r/z/n gates of a GRU matrix or bias) ), all float64.  For an error e, E|S e| ~ ||e|| per projection."""
+    g = np.asarray(g, np.float64)
+    flat = g.reshape(-1)
+    nb = 3 if (g.shape[0] % 3 == 0 and g.shape[0] >= 3) else 1
+    blocks = np.array([np.linalg.norm(b) for b in np.split(flat, nb)])
+    return dict(norm=np.linalg.norm(flat), proj=sign_matrix(flat.size).astype(np.float64) @ flat, blocks=blocks)

@@ -1,0 +1,79 @@
+"""GPU (bf16 kernels): the product path against REFERENCE goldens at the BASELINE agent counts (tests/golden/dqn_big.npz,
+captured by tests/golden/make_dqn_goldens_big.py from the unmodified reference in fp32): Network.step on the reference's
+64-agent fixture, and one Learner.train body on replay-shaped batches of real observations at A = 40 (config 2), A = 6 (the
+reference's training shape) and A = 128 (config 5) -- Q-values, td error, loss, gradient norm and EVERY parameter's gradient
+(through its fingerprint).  Tolerances: |dQ| <= 2e-2 max(1, |Q|) per bootstrap (td: two bootstraps), and per
+parameter tensor ||g - g_ref|| <= 2e-2 ||g_ref|| (estimated from 24 fixed +-1 projections; exact for small tensors), with
+gradient norms below 1e-3 of the global norm measured against that floor (bf16 rounding noise of the other tensors)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import big_golden as BG
+from tests import helpers as H
+from tests.test_learner_cpu import _models
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.all(np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b)))
+
+
+def test_step_64_agents_fused_kernels_vs_reference():
+    """The reference's own 64-agent fixture (test64_40_0.3.pkl, test.py:82-145) through the fused encoder + the wide
+    recurrence kernel (csrc/mapf_recur_wide.hip)."""
+    from mapf_rl_amd.model import Network
+
+    z = H.load_npz("dqn_big.npz")
+    net = Network().cuda().eval()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in H.det_state_dict(shapes, seed=1234).items()})
+    assert Network.FUSED_RECURRENCE and Network.FUSED_INFERENCE
+    N = 64
+    net.reset()
+    for t in range(z["step64_q"].shape[0]):
+        obs = torch.from_numpy(H.unpack_bits(z["step64_obs_bits"][t], (N, 6, 9, 9))).cuda()
+        cm = np.unpackbits(z["step64_comm_mask"][t], axis=-1, bitorder="little")[:, :N].astype(bool)
+        actions, q, hidden, _ = net.step(obs, torch.from_numpy(z["step64_pos"][t].astype(np.int16)).cuda(), comm_mask=cm)
+        assert _close(q, z["step64_q"][t], 2e-2), (t, np.abs(q - z["step64_q"][t]).max())
+        assert _close(hidden, z["step64_hidden"][t], 2e-2), t
+        gap = np.sort(z["step64_q"][t], axis=1)
+        clear = (gap[:, -1] - gap[:, -2]) > 4e-2
+        assert np.array_equal(np.array(actions)[clear], z["step64_actions"][t][clear])
+
+
+@pytest.mark.parametrize("tag", ["b40", "b6", "b128"])
+def test_update_bf16_kernels_vs_reference(tag):
+    z = H.load_npz("dqn_big.npz")
+    pre = tag + "_"
+    lr = _models("cuda")
+    b = BG.batch(z, tag, "cuda", torch.bfloat16)
+    with torch.no_grad():
+        nxt = b[5] + b[4].view(-1).long()
+        q_tar = lr.tar_model.bootstrap(b[0], nxt, b[6], b[7])
+    assert _close(q_tar.cpu().numpy(), z[pre + "q_target_all"], 2e-2), np.abs(q_tar.cpu().numpy() - z[pre + "q_target_all"]).max()
+    grads = {}
+    orig_clip = torch.nn.utils.clip_grad_norm_
+
+    def grab(params, max_norm):  # gradients as the reference sees them: after backward, before the clip (worker.py:316-319)
+        for k, p in lr.model.named_parameters():
+            grads[k] = p.grad.detach().float().cpu().numpy()
+        return orig_clip(lr.model.parameters(), max_norm)
+
+    torch.nn.utils.clip_grad_norm_ = grab
+    try:
+        out = lr.update(b)
+    finally:
+        torch.nn.utils.clip_grad_norm_ = orig_clip
+    td, ref = out["td"].float().cpu().numpy(), z[pre + "td"]
+    assert np.all(np.isfinite(td))
+    assert _close(td, ref, 4e-2), np.abs(td - ref).max()  # 2 bootstraps: 2 x 2e-2
+    assert abs(float(out["loss"]) - float(z[pre + "loss"])) <= 5e-2 * max(1.0, float(z[pre + "loss"]))
+    assert abs(float(out["grad_norm"]) - float(z[pre + "grad_norm"])) <= 2e-2 * float(z[pre + "grad_norm"])
+    errs = BG.grad_errors(z, tag, grads, floor=1e-3)
+    print(tag, {k: "%.1e/%.1e" % v for k, v in errs.items()})
+    worst = max(errs.items(), key=lambda kv: kv[1][0])
+    assert worst[1][0] <= 2e-2, worst
+    assert max(v[1] for v in errs.values()) <= 2e-2, max(errs.items(), key=lambda kv: kv[1][1])

@@ -117,7 +117,8 @@ def test_fast_recurrence_matches_module_path():
         assert float((a - b).norm()) <= 6e-2 * float(b.norm()) + 1e-4 * scale, (k, float((a - b).norm()), float(b.norm()))
 
 
-@pytest.mark.parametrize("E,N,T", [(5, 7, 1), (3, 40, 4), (2, 48, 2), (4, 1, 3), (3, 17, 2), (2, 64, 2)])  # 64 > 48: PyTorch path on both sides
+@pytest.mark.parametrize("E,N,T", [(5, 7, 1), (3, 40, 4), (2, 48, 2), (4, 1, 3), (3, 17, 2),
+                                   (2, 64, 2), (3, 49, 3), (2, 100, 2), (3, 128, 3), (1, 65, 1)])  # > 48: csrc/mapf_recur_wide.hip
 def test_fused_recurrence_kernel_matches_module_path(E, N, T):
     """mapf_recurrent_infer (GRU cell + two communication rounds per step, all T steps in one launch) against the
     PyTorch module path at the same bf16 precision: actor step (T = 1, with and without an incoming hidden state) and

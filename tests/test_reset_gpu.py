@@ -109,3 +109,17 @@ def test_infeasible_shape_sets_status():
     env.reset_envs(None, 0.3, seed=0)
     with pytest.raises(Exception):
         env.check_status()
+
+
+@pytest.mark.parametrize("N,L,E", [(6, 20, 6000), (40, 32, 4000), (16, 40, 4000)])
+def test_reset_kernel_matches_reference_statistics(N, L, E):
+    """reset_kernel against statistics of the REFERENCE's generator (tests/golden/gen_stats.npz; reference
+    environment.py:21-70,100-138): realised density under triangular(0, 0.33, 0.5), component structure, start-goal BFS /
+    Manhattan distance, share of agents in the largest component.  Two-sample KS <= 0.05 (tests/gen_stats.py)."""
+    import mapf_rl_amd as M
+    from tests import gen_stats as GS
+
+    env = M.VecEnvironment(E, L, N)
+    env.reset_envs(None, -1.0, seed=23)
+    env.check_status()
+    GS.check(N, L, GS.batch_stats(_np(env.maps()), _np(env.agents_pos()), _np(env.goals_pos())))
