@@ -85,7 +85,9 @@ class VecActor:
 
     # ------------------------------------------------------------------ one lock-step iteration
     @torch.no_grad()
-    def step(self):
+    def step(self, actions_override=None):
+        """One lock-step iteration.  `actions_override` (int tensor [E, N], tests only): the joint action to execute instead of
+        the policy's (teacher forcing along a recorded trajectory); the policy's own greedy actions stay in `last_policy_actions`."""
         E, N, d = self.E, self.N, self.device
         if self.pos.dtype == torch.int16 and N <= 128:  # mask + the replay's packed comm row from one kernel
             from .fused import comm_mask
@@ -94,10 +96,13 @@ class VecActor:
         else:
             comm, comm_packed = None, None
         actions, q, hidden, comm = self.model.step_batch(self.obs, self.pos, self.hidden, comm)
+        self.last_policy_actions = actions.clone()
         # worker.py:380-382: only agent 0 of an environment explores
         explore = torch.rand(E, device=d, generator=self.gen, dtype=torch.float64) < self.eps
         rnd = torch.randint(0, 5, (E,), device=d, generator=self.gen)
         actions[:, 0] = torch.where(explore, rnd, actions[:, 0])
+        if actions_override is not None:
+            actions = torch.as_tensor(actions_override).to(d, torch.int64).view(E, N)
         act8 = actions.to(torch.int8).contiguous()
         obs, pos, reward, done, _ = self.env.step(act8, obs_bits_out=self.bits)
         # worker.py:388 -> buffer.py:140-151

@@ -821,26 +821,24 @@ size_t step_smem_bytes(const mapf_env *h, int G) {
 // Environments per workgroup (env_step_kernel's G): with few agents one environment leaves most of a wavefront idle behind a
 // fixed instruction stream, and its observation block is not a multiple of 16 bytes.  Packed blocks are one wavefront, need
 // 32-bit map rows, G * N agents <= 64, E divisible by G and a 16-byte-granular observation block (G * N a multiple of 8).
-// Measured on MI355X (tools/shape_sweep.py, profiles/r02_shape_sweep.md).  MAPF_STEP_GROUP overrides for tuning runs.
+// Measured on MI355X (tools/shape_sweep.py under MAPF_STEP_GROUP caps, profiles/r02_shape_sweep.md), us per launch G = 1 / 2 / 4 / 8:
+//   10x10, 1 agent, 65,536 envs   51.3 /  -   /  -   / 16.0      (byte stores without packing: 486 B per environment)
+//   15x15, 3 agents, 65,536 envs  60.5 /  -   /  -   / 28.9
+//   20x20, 6 agents, 32,768 envs  31.9 / 32.4 / 25.6 / 25.8;  8,192 envs 13.5 / 14.0 / 12.5 / 16.6
+//   16x16, 8 agents, 4,096 envs   10.0 / 10.5 / 14.0 / 17.8;  32,768 envs 34.2 / 33.0 / 34.2 / 32.1
+//   24x24, 12 agents, 4,096 envs  11.5 / 12.4 / 16.4 / 17.2
+// i.e. packing pays below 8 agents (4 environments per block, 8 where the agent count is odd or <= 2: the 16-byte rule) and
+// costs latency from 8 agents on.  MAPF_STEP_GROUP caps G for tuning runs (1 = never pack).
 int step_group(const mapf_env *h, const void *obs) {
-    if (h->wide || (reinterpret_cast<uintptr_t>(obs) & 15)) return 1;
-    const int want = h->tune_group > 0 ? h->tune_group : 8;
-    for (int G = 8; G >= 2; G >>= 1) {
-        if (G > want) continue;
-        if (G * h->N <= 64 && h->E % G == 0 && (G * h->N) % 8 == 0 && (G * h->N * 10 + 63) / 64 <= 10) return G;
+    if (h->wide || h->N >= 8 || (reinterpret_cast<uintptr_t>(obs) & 15)) return 1;
+    const int cap = h->tune_group > 0 ? h->tune_group : 8;
+    const int pref = (h->N <= 2 || (h->N & 1)) ? 8 : 4;
+    for (int G = pref; G >= 2; G >>= 1) {
+        if (G > cap || G * h->N > 64 || h->E % G != 0 || (G * h->N) % 8 != 0) continue;
+        if (h->N > 2 && h->E / G < 1024) continue;  // too few one-wavefront blocks to cover the load latency
+        return G;
     }
     return 1;
-}
-
-// threads per block (one lane per agent in the step phase), measured on MI355X (tools/shape_sweep.py):
-// 32x32 / 40 agents 20.5 us @128 vs 22.0 us @64; 64x64 / 40 agents 23.5 us @64 vs 26.4 us @128; few agents
-// (N <= 24) prefer one wavefront per environment.  MAPF_STEP_THREADS overrides for tuning runs.
-int step_block_threads(const mapf_env *h) {
-    if (h->tune_threads == 64 || h->tune_threads == 128 || h->tune_threads == 256) {
-        if (h->tune_threads >= h->N) return h->tune_threads;
-    }
-    if (h->N <= 64 && (h->N <= 24 || h->L > 32)) return 64;
-    return h->N <= 128 ? 128 : 256;
 }
 
 template <typename W, bool DO_STEP, bool DO_OBS, int VEC, int NT>

@@ -28,6 +28,7 @@
 
 #include "mapf_dqn.h"
 #include "mapf_env.h"
+#include "mapf_recur_internal.h"
 
 namespace {
 
@@ -538,7 +539,8 @@ extern "C" {
 
 int mapf_recurrent_backward(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev,
                             const uint16_t *weights_t_dev, int T, int E, int N, void *const *out_dev, void *stream) {
-    if (T < 1 || E < 0 || N < 1 || N > NA || !saved_dev || !comm_dev || !d_agent0_dev || !weights_t_dev || !out_dev) return MAPF_ERR_INVALID_ARG;
+    if (T < 1 || E < 0 || N < 1 || N > MAPF_RECUR_MAX_AGENTS || !saved_dev || !comm_dev || !d_agent0_dev || !weights_t_dev || !out_dev)
+        return MAPF_ERR_INVALID_ARG;
     for (int i = 0; i < 8; ++i)
         if (!saved_dev[i] || (reinterpret_cast<uintptr_t>(saved_dev[i]) & 15)) return MAPF_ERR_INVALID_ARG;
     for (int i = 0; i < 7; ++i)
@@ -567,6 +569,14 @@ int mapf_recurrent_backward(const uint16_t *const *saved_dev, const uint8_t *com
     a.T = T;
     a.E = E;
     a.N = N;
+    if (N > NA) {  // 49..128 agents: csrc/mapf_recur_wide_bwd.hip
+        RecurBwdArgs b{};
+        b.hin0 = a.hin0, b.g1 = a.g1, b.hr = a.hr, b.qkv = a.qkv, b.ctx_unused = a.ctx_unused, b.info_unused = a.info_unused, b.g2 = a.g2, b.P = a.P;
+        b.comm = a.comm, b.dA0 = a.dA0, b.WT = a.WT;
+        b.d_gi1 = a.d_gi1, b.d_gh1 = a.d_gh1, b.d_gi2 = a.d_gi2, b.d_gh2 = a.d_gh2, b.d_info = a.d_info, b.d_qkv = a.d_qkv, b.bsum = a.bsum;
+        b.T = T, b.E = E, b.N = N;
+        return mapf_recur_wide_backward(b, static_cast<hipStream_t>(stream));
+    }
     hipLaunchKernelGGL(recurrent_bwd_kernel, dim3(E), dim3(NTHR), 0, static_cast<hipStream_t>(stream), a);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;

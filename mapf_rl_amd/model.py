@@ -31,7 +31,7 @@ NUM_COMM_LAYERS = 2     # config.py:62
 NUM_COMM_HEADS = 2      # config.py:63
 ENC_FEATURES = 16 * 7 * 7
 RECUR_MAX_AGENTS = 128  # widest environment of the fused recurrence kernels (include/mapf_dqn.h); beyond it: the PyTorch-level path
-BPTT_MAX_AGENTS = 48
+BPTT_MAX_AGENTS = 128
 
 
 class ResBlock(nn.Module):

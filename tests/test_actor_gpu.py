@@ -110,3 +110,62 @@ def test_full_trajectory_resimulation_single_agent_greedy():
             assert np.array_equal(obs[t + 1], oracle.observe(m, ag, nv)), (e, t)
             assert np.float16(H.REWARD_VALUES[rc[0]]) == ep["rew"].cpu().numpy()[t]
             assert dn == (ep["done"] and t == ep["size"] - 1)
+
+
+def _det_net():
+    from mapf_rl_amd.model import Network
+
+    net = Network().cuda().eval()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in H.det_state_dict(shapes, seed=1234).items()})
+    return net
+
+
+@pytest.mark.parametrize("tag", ["to", "dn"])
+def test_actor_tape_matches_reference(tag):
+    """The reference's actor loop (worker.py:376-407, epsilon = 0, deterministic weights) recorded by its own LocalBuffer
+    (buffer.py:108-179): tests/golden/dqn_actor.npz, episode 'to' (policy actions, ends at the step limit: quirk Q8, the last comm
+    row comes from a model.step on the stale observation) and 'dn' (scripted actions, ends with `done`).  VecActor replays the
+    reference's joint actions (teacher forcing) through the fused bf16 kernels and must record, for agent 0 (quirk Q7):
+    observations, actions, rewards, comm rows, size, done EXACTLY; hidden states, Q-values and the initial priorities (td) within
+    the bf16 tolerance; and its own greedy action must be the reference's wherever the reference's top-2 Q gap exceeds it."""
+    import mapf_rl_amd as M
+    from mapf_rl_amd.actor import VecActor
+    from mapf_rl_amd.replay import GlobalBuffer
+
+    z = H.load_npz("dqn_actor.npz")
+    pre = tag + "_"
+    m, a, g = z[pre + "map"], z[pre + "agents"], z[pre + "goals"]
+    L, N, size, ms = m.shape[0], a.shape[0], int(z[pre + "size"]), int(z[pre + "max_steps"])
+    env = M.VecEnvironment(1, L, N)
+    env.load(m[None], a[None], g[None])
+    buf = GlobalBuffer(4, max_agents=N)
+    actor = VecActor(env, _det_net(), buf, epsilons=0.0, max_steps=ms, seed=0, density=0.2, keep_flushed=True)
+    acts = z[pre + "actions"]
+    TOL = 2e-2
+    for t in range(size):
+        assert not actor.flushed
+        assert np.array_equal(actor.pos[0].cpu().numpy(), z[pre + "pos"][t])
+        actor.step(actions_override=torch.from_numpy(acts[t:t + 1].astype(np.int64)))
+        clear = z[pre + "gap"][t] > 2 * TOL
+        if tag == "to":  # the reference executed its own greedy actions here
+            assert np.array_equal(actor.last_policy_actions[0].cpu().numpy()[clear], acts[t][clear]), t
+    assert len(actor.flushed) == 1
+    ep = actor.flushed[0]
+    assert ep["size"] == size and ep["done"] == bool(z[pre + "done"])
+    ref_obs = H.unpack_bits(z[pre + "obs_bits"], (size + 1, N, 6, 9, 9))
+    assert np.array_equal(_unpack_rows(ep["obs"], N), ref_obs)                                   # every observation row
+    assert np.array_equal(ep["act"].cpu().numpy(), z[pre + "act_buf"])
+    assert np.array_equal(ep["rew"].cpu().numpy().astype(np.float32), z[pre + "rew_buf"])         # f16 values, exact
+    comm = ep["comm"].cpu().numpy().view(np.uint32)                                              # [size + 1, A, CW] bit rows
+    comm_bool = np.unpackbits(comm.view(np.uint8).reshape(size + 1, N, -1), axis=2, bitorder="little")[:, :, :N].astype(bool)
+    assert np.array_equal(comm_bool, z[pre + "comm_buf"])      # incl. the last row: zeros after `done`, the stale-observation mask on time-out
+    close = lambda x, y, tol: np.all(np.abs(np.asarray(x, np.float64) - y) <= tol * np.maximum(1.0, np.abs(y)))
+    assert close(ep["q"].cpu().numpy(), z[pre + "q0"], TOL)
+    assert close(ep["hid"].float().cpu().numpy(), z[pre + "hid_buf0"], TOL)
+    td = ep["td"].cpu().numpy()
+    assert td.shape == (256,) and not td[size:].any()
+    assert close(td[:size], z[pre + "td"][:size], 2 * TOL)     # |r + 0.99 r' + max Q - Q(a)|: two Q-values
+    # and the reference's own numbers through the same formula reproduce its td (the recording logic, fp-exact)
+    ref_td = RO.local_finish(np.concatenate([z[pre + "q0"], np.zeros((1, 5), np.float32)]), z[pre + "act_buf"], z[pre + "rew_buf"].astype(np.float16), size, capacity=ms)
+    assert np.allclose(ref_td[:size], z[pre + "td"][:size], rtol=0, atol=1e-12)

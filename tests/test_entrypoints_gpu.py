@@ -88,7 +88,7 @@ def test_train_default_is_the_curriculum(tmp_path):
     """`python train.py` without a level = the reference's adaptive schedule from config.init_set (worker.py:362)."""
     env = dict(os.environ, PYTHONPATH=ROOT)
     cmd = [sys.executable, os.path.join(ROOT, "train.py"), "--envs", "64", "--learning-starts", "1500", "--batch-size", "16",
-           "--max-updates", "4", "--interval", "1"]
+           "--max-updates", "4", "--interval", "0.05"]
     out = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "start training" in out.stdout and "(1, 10): " in out.stdout
@@ -115,5 +115,5 @@ def test_train_two_ranks_stop_together(tmp_path):
     outs = [p.communicate(timeout=600) for p in procs]
     assert [p.returncode for p in procs] == [0, 0], (outs[0][1][-1500:], outs[1][1][-1500:])
     assert "start training" in outs[0][0] and "number of updates" in outs[0][0] and "(2, 10): " in outs[0][0]
-    assert outs[1][0].strip() == ""  # only rank 0 prints
+    assert "number of updates" not in outs[1][0] and "(2, 10): " not in outs[1][0]  # only rank 0 prints statistics
     assert len(os.listdir(str(tmp_path / "models"))) >= 1

@@ -155,6 +155,54 @@ def test_differential_vs_oracle(M, E, L, N, rho, T):
     assert np.array_equal(_np(env.steps()), np.full(E, T, np.int32))
 
 
+@pytest.mark.parametrize("E,L,N", [(4096, 20, 6), (48, 10, 1), (8192, 15, 3), (24, 12, 2), (4096, 16, 4), (8192, 9, 5), (8, 32, 8), (8192, 10, 7)])
+def test_packed_blocks_equal_one_block_per_environment(M, E, L, N):
+    """Few agents: one workgroup steps G consecutive environments (env_step_kernel<..., G>, csrc/mapf_env.hip).  Same scenario and
+    tape through the packed launch and through one block per environment (MAPF_STEP_GROUP=1): every output of every step is
+    identical -- byte observations, bit-packed observation rows, positions, reward classes, rewards, done (environments finish at
+    different steps), step counters -- and the trajectory equals the sequential oracle's."""
+    import os
+
+    maps, agents, goals, _ = M.generate_scenarios(E, L, N, 0.15, seed=E + L + N)
+    envs = []
+    for cap in ("8", "1"):
+        os.environ["MAPF_STEP_GROUP"] = cap
+        try:
+            env = M.VecEnvironment(E, L, N)
+        finally:
+            del os.environ["MAPF_STEP_GROUP"]
+        env.load(maps, agents, goals)
+        envs.append(env)
+    RD = envs[0].obs_bits_row_dwords
+    bits = [torch.zeros((E, RD), dtype=torch.int32, device="cuda") for _ in envs]
+    rng = np.random.RandomState(E * 7 + N)
+    obs = [env.observe(obs_bits_out=b)[0] for env, b in zip(envs, bits)]
+    assert torch.equal(obs[0], obs[1]) and torch.equal(bits[0], bits[1])
+    T = 3 * L
+    tape = np.zeros((T, E, N), np.int8)
+    any_done = False
+    for t in range(T):
+        tape[t] = _heuristic_tape_step(_np(obs[0]), rng, (0.6, 1.0, 1.0)[t % 3])
+        a = torch.from_numpy(tape[t]).cuda()
+        outs = [env.step(a, obs_bits_out=b) for env, b in zip(envs, bits)]
+        for x, y in zip(outs[0], outs[1]):
+            assert torch.equal(x, y), t
+        assert torch.equal(bits[0], bits[1]), t
+        obs = [o[0] for o in outs]
+        any_done |= bool(outs[0][3].any())
+        # the bit-packed row is the byte observation, bit b of row e = byte b of environment e's block
+        raw = np.unpackbits(_np(bits[0]).view(np.uint32).view(np.uint8).reshape(E, -1), axis=1, bitorder="little")
+        assert np.array_equal(raw[:, :N * 486], _np(obs[0]).reshape(E, -1))
+        assert not raw[:, N * 486:].any()
+    for env in envs:
+        env.check_status()
+    assert any_done  # some environment reached its goals within 3 L greedy-ish steps
+    nv = oracle.navi_batch(maps, goals)
+    ref = oracle.rollout(maps, agents, goals, nv, tape, want_obs_last=True)
+    assert np.array_equal(_np(envs[0].agents_pos()), ref["pos"][-1]) and np.array_equal(_np(obs[0]), ref["obs_last"])
+    assert np.array_equal(_np(envs[0].steps()), np.full(E, T, np.int32))
+
+
 def test_full_size_config2_properties(M):
     """BASELINE config 2 at full size (4096 x 32x32 x 40 agents): size-independent invariants on every
     env (reference environment.py:424-428 uniqueness; obstacles never entered; observation channels

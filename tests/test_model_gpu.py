@@ -156,7 +156,8 @@ def test_fused_recurrence_kernel_matches_module_path(E, N, T):
         assert torch.allclose(x, y, rtol=3e-2, atol=3e-2), float((x - y).abs().max())
 
 
-@pytest.mark.parametrize("B,T,N", [(6, 5, 7), (3, 16, 40), (4, 3, 48), (5, 2, 1)])
+@pytest.mark.parametrize("B,T,N", [(6, 5, 7), (3, 16, 40), (4, 3, 48), (5, 2, 1),
+                                   (3, 4, 64), (2, 3, 100), (2, 5, 128), (3, 2, 49)])  # > 48: csrc/mapf_recur_wide*.hip
 def test_bptt_kernels_match_pytorch_recurrence(B, T, N):
     """mapf_recurrent_forward_save + mapf_recurrent_backward (the whole T-step GRU / CommBlock recurrence forward and
     backward in two launches) against the PyTorch-level recurrence at the same bf16 precision: Q-values and every
