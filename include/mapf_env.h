@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MAPF_ABI_VERSION 1
+#define MAPF_ABI_VERSION 2
 
 /* status codes; the reference's exception each one stands for is in the comment */
 #define MAPF_OK 0

@@ -8,8 +8,9 @@
  * learner's [B, 18, A, 6, 9, 9] bf16 window tensor.
  *
  * Same conventions as mapf_env.h: plain C, int status returns (MAPF_* codes), *_dev = caller-owned device
- * memory, `stream` = hipStream_t as void*.  The ring pointer / size counters are host-side state exactly as
- * in the reference (GlobalBuffer.ptr / .size / .counter).
+ * memory, `stream` = hipStream_t as void*.  The ring pointer / size / counter (GlobalBuffer.ptr / .size / .counter)
+ * live on the DEVICE: a vectorised actor appends the episodes of all environments that finished in a step with
+ * one call (mapf_replay_add_many) and no host round trip; the getters below read them back (and block the host).
  *
  * Storage per slot p (A = max_agents, RD = mapf_replay_row_dwords, CW = (A+31)/32):
  *   obs_bits  uint32 [257][RD]     bit (a*486 + c*81 + cell) of row t = obs[t][a][c][cell]   (worker.py:36)
@@ -41,9 +42,12 @@ int mapf_replay_destroy(mapf_replay_t *r);
 
 int mapf_replay_row_dwords(const mapf_replay_t *r);  /* RD: dwords per bit-packed observation row */
 int mapf_replay_capacity(const mapf_replay_t *r);
+/* Host reads of the device-side ring state; each waits for the stream of the handle's most recent call. */
 int mapf_replay_ptr(const mapf_replay_t *r);         /* GlobalBuffer.ptr */
 int64_t mapf_replay_size(const mapf_replay_t *r);    /* len(GlobalBuffer): stored transitions */
 int64_t mapf_replay_counter(const mapf_replay_t *r, int reset); /* GlobalBuffer.counter (worker.py:92,226) */
+/* out = {ptr, size, counter, episodes added by the last add call}, read behind `stream` (NULL: the most recent one). */
+int mapf_replay_state(mapf_replay_t *r, int64_t out[4], void *stream);
 
 /*
  * SumTree.batch_update (buffer.py:95-105): leaves[idx[i]] = alpha > 0 ? pri[i]^alpha : pri[i], then every
@@ -54,10 +58,13 @@ int mapf_replay_tree_update(mapf_replay_t *r, const int64_t *idx_dev, const doub
                             void *stream);
 /*
  * SumTree.batch_sample (buffer.py:56-78) with the uniform draws supplied by the caller:
- * prefix[k] = k*(sum/n) + uniforms[k] (0 -> 1e-5), descent "left iff prefix <= tree[left]".
+ * prefix[k] = k*(sum/n) + u[k] (0 -> 1e-5), descent "left iff prefix <= tree[left]"; u[k] = uniforms[k] when
+ * unit_uniforms == 0 (draws already scaled to [0, sum/n), as np.random.uniform(0, interval) returns them) and
+ * uniforms[k] * (sum/n) when unit_uniforms != 0 (draws in [0, 1): numpy's own scaling, done on the device so that the
+ * caller needs no copy of the root).  old_ptr_dev (optional int64[1]) receives the ring pointer at sample time.
  */
-int mapf_replay_tree_sample(mapf_replay_t *r, const double *uniforms_dev, int n, int64_t *idx_dev, double *pri_dev,
-                            void *stream);
+int mapf_replay_tree_sample(mapf_replay_t *r, const double *uniforms_dev, int n, int unit_uniforms, int64_t *idx_dev,
+                            double *pri_dev, int64_t *old_ptr_dev, void *stream);
 /* Copies the whole tree (2*leaves-1 doubles, root first, leaves last) to a device buffer. */
 int mapf_replay_tree_read(mapf_replay_t *r, double *tree_dev, void *stream);
 
@@ -73,22 +80,40 @@ int mapf_replay_add(mapf_replay_t *r, int num_agents, int size, int done, const 
                     const uint16_t *hid_dev, const double *td_dev, void *stream);
 
 /*
+ * GlobalBuffer.add for EVERY finished environment of a vectorised actor (worker.py:71-104 per episode, in ascending
+ * environment order) including LocalBuffer.finish's initial priorities (buffer.py:170-177), entirely on the device: three
+ * launches, no host read.  Local buffers of `num_envs` environments with `local_steps` (<= 256) transitions each:
+ *   finished_dev u8 [E] (non-zero = append this environment's episode; NULL = all), sizes_dev int64 [E] episode lengths,
+ *   done_dev u8 [E], obs_bits_dev uint32 [E][local_steps+1][RD], comm_bits_dev uint32 [E][local_steps+1][A][CW],
+ *   act_dev u8 [E][local_steps], rew_dev f16 [E][local_steps], hid_dev f16 [E][local_steps][256] (agent 0's state, quirk Q4),
+ *   q_dev f32 [E][local_steps][5] agent 0's Q-values (priorities |r_t + 0.99 r_{t+1} + max Q(s_t) - Q(s_t, a_t)| in f64).
+ * With more finished episodes than slots the last `capacity` ones survive, as if added one by one.  A call with nothing
+ * finished changes nothing (the kernels return at once).
+ */
+int mapf_replay_add_many(mapf_replay_t *r, int num_envs, int num_agents, int local_steps, const uint8_t *finished_dev,
+                         const int64_t *sizes_dev, const uint8_t *done_dev, const uint32_t *obs_bits_dev,
+                         const uint32_t *comm_bits_dev, const uint8_t *act_dev, const uint16_t *rew_dev,
+                         const uint16_t *hid_dev, const float *q_dev, void *stream);
+
+/*
  * GlobalBuffer.sample_batch (worker.py:106-184) minus the IS weights (a reduction the caller does on
  * pri_dev): tree sample + window gather.  Outputs (device):
  *   idx int64 [n], pri f64 [n], obs bf16 [18][n][A][6][9][9], comm u8 [18][n][A][A] (TIME-major: the consumer is a
  *   recurrence over the 18 window steps; the host wrapper hands them out as [n][18]... views, the reference's shape),
- *   hidden f16 [n*A][256], action int64 [n], reward f32 [n], done f32 [n], steps f32 [n], bt_steps int64 [n].
+ *   hidden f16 [n*A][256], action int64 [n], reward f32 [n], done f32 [n], steps f32 [n], bt_steps int64 [n],
+ *   old_ptr int64 [1] (optional) the ring pointer at sample time (worker.py:182).  unit_uniforms: see _tree_sample.
  */
-int mapf_replay_sample(mapf_replay_t *r, const double *uniforms_dev, int n, int64_t *idx_dev, double *pri_dev,
-                       uint16_t *obs_dev, uint8_t *comm_dev, uint16_t *hidden_dev, int64_t *action_dev,
-                       float *reward_dev, float *done_dev, float *steps_dev, int64_t *bt_steps_dev, void *stream);
+int mapf_replay_sample(mapf_replay_t *r, const double *uniforms_dev, int n, int unit_uniforms, int64_t *idx_dev,
+                       double *pri_dev, uint16_t *obs_dev, uint8_t *comm_dev, uint16_t *hidden_dev, int64_t *action_dev,
+                       float *reward_dev, float *done_dev, float *steps_dev, int64_t *bt_steps_dev, int64_t *old_ptr_dev,
+                       void *stream);
 
 /*
- * GlobalBuffer.update_priorities (worker.py:186-203): entries whose slot was overwritten between `old_ptr`
- * (the ring pointer returned with the sample) and now are dropped, the rest get pri^0.6.
+ * GlobalBuffer.update_priorities (worker.py:186-203): entries whose slot was overwritten between *old_ptr_dev
+ * (the ring pointer written by mapf_replay_sample / _tree_sample) and now are dropped, the rest get pri^0.6.
  */
-int mapf_replay_update_priorities(mapf_replay_t *r, const int64_t *idx_dev, const double *pri_dev, int n, int old_ptr,
-                                  void *stream);
+int mapf_replay_update_priorities(mapf_replay_t *r, const int64_t *idx_dev, const double *pri_dev, int n,
+                                  const int64_t *old_ptr_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -48,11 +48,13 @@ SYMBOLS = [
     ("mapf_replay_size", ctypes.c_int64, [_vp]),
     ("mapf_replay_counter", ctypes.c_int64, [_vp, _i]),
     ("mapf_replay_tree_update", _i, [_vp, _vp, _vp, _i, ctypes.c_double, _vp]),
-    ("mapf_replay_tree_sample", _i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    ("mapf_replay_state", _i, [_vp, ctypes.POINTER(ctypes.c_int64), _vp]),
+    ("mapf_replay_tree_sample", _i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("mapf_replay_tree_read", _i, [_vp, _vp, _vp]),
     ("mapf_replay_add", _i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    ("mapf_replay_sample", _i, [_vp, _vp, _i] + [_vp] * 11),
-    ("mapf_replay_update_priorities", _i, [_vp, _vp, _vp, _i, _i, _vp]),
+    ("mapf_replay_add_many", _i, [_vp, _i, _i, _i] + [_vp] * 10),
+    ("mapf_replay_sample", _i, [_vp, _vp, _i, _i] + [_vp] * 12),
+    ("mapf_replay_update_priorities", _i, [_vp, _vp, _vp, _i, _vp, _vp]),
     # include/mapf_dqn.h
     ("mapf_bias_res_relu_fwd", _i, [_vp, _vp, _vp, ctypes.c_int64, _i, _vp]),
     ("mapf_bias_res_relu_bwd", _i, [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp]),
@@ -91,7 +93,7 @@ def _load():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if L.mapf_abi_version() != 1:
+    if L.mapf_abi_version() != 2:
         raise ImportError("mapf_rl_amd: ABI version mismatch")
     return L
 

@@ -12,7 +12,13 @@ Per iteration (= worker.py:376-414 for every environment at once):
 Quirk Q8 (worker.py:399): on a time-out the reference runs one more model.step on the STALE observation only
 to obtain `comm_mask` for the last buffer row (its q value is never used by the priorities, buffer.py:173).
 The stale positions equal those of the previous step, so the same row is obtained here by repeating the
-previous comm mask -- no extra inference."""
+previous comm mask -- no extra inference.
+
+No host synchronisation in `step()`: which environments finished stays a device mask -- the replay append
+(`GlobalBuffer.add_finished` = mapf_replay_add_many: priorities, ring slots, rows, sum tree), the scenario reset
+(`mapf_reset_envs` takes the mask) and the local-buffer rewind are all launched unconditionally and do nothing for
+environments that are still running.  Episode outcomes for the curriculum go through a small device log that is read
+when statistics are asked for (`drain_outcomes`)."""
 import ctypes
 
 import numpy as np
@@ -71,7 +77,13 @@ class VecActor:
         self.ar = torch.arange(E, device=d)
         self.hidden = None
         self.env_steps = 0
-        self.episodes = 0
+        self._episodes = torch.zeros((), dtype=torch.int64, device=d)
+        self.stat_mask = torch.tensor([a >= 10 for a in self.actor_ids], dtype=torch.bool, device=d)
+        self.stat_log = torch.zeros(self.STAT_LOG + 1, dtype=torch.uint8, device=d)  # + 1: dump slot of the scatter
+        self.stat_n = torch.zeros((), dtype=torch.int64, device=d)
+        self._stat_read = 0
+        if buffer is not None:
+            buffer.register_actor(self)
         self.keep_flushed = keep_flushed
         self.on_device_reset = on_device_reset
         self.flushed = []
@@ -118,13 +130,13 @@ class VecActor:
         self.obs, self.pos = obs, pos
         self.env_steps += E
         finished = (done != 0) | (self.t >= self.max_steps)   # worker.py:390
-        if bool(finished.any()):
-            self._flush(finished.nonzero().view(-1), done)
+        self._flush(finished, done != 0)
         return finished
 
     # ------------------------------------------------------------------ episode end
     def _finish_priorities(self, ids, sizes):
-        """LocalBuffer.finish (buffer.py:170-177) for the listed environments, f64 on the device."""
+        """LocalBuffer.finish (buffer.py:170-177) for the listed environments, f64 on the device, as torch ops: the independent
+        statement of what mapf_replay_add_many computes (tests; `keep_flushed` records)."""
         S = self.max_steps
         q = self.lb_q[ids].double()                                   # [n, S, 5]
         rew = self.lb_rew[ids].double()                               # [n, S] (f16 values)
@@ -140,43 +152,68 @@ class VecActor:
             td = torch.cat([td, torch.zeros((td.shape[0], 256 - S), dtype=td.dtype, device=td.device)], dim=1)
         return td.contiguous()
 
-    def _flush(self, ids, done):
-        ids_h = ids.tolist()
-        sizes = self.t[ids]
-        dn = (done[ids] != 0)
-        td = self._finish_priorities(ids, sizes)
-        sizes_h, dn_h = sizes.tolist(), dn.tolist()
-        for k, e in enumerate(ids_h):
-            size, is_done = sizes_h[k], dn_h[k]
-            # last comm row: zeros when done (np.zeros init, buffer.py:124), the stale-observation mask on time-out (Q8)
-            if is_done:
-                self.lb_comm[e, size].zero_()
-            else:
-                self.lb_comm[e, size] = self.lb_comm[e, size - 1]
-            if self.buffer is not None:
-                self.buffer.add_episode_device(self.N, size, is_done, self.lb_obs[e], self.lb_comm[e], self.lb_act[e],
-                                               self.lb_rew[e], self.lb_hid[e], td[k].contiguous())
-                if self.actor_ids[e] >= 10:  # curriculum statistics (worker.py:74-82)
-                    self.buffer.levels.record((self.N, self.env.map_length), is_done)
-            if self.keep_flushed:
-                self.flushed.append(dict(env=e, size=size, done=is_done, obs=self.lb_obs[e, :size + 1].clone(),
+    def _flush(self, finished, dn):
+        """finished / dn: bool [E] device masks (episode over; all agents on their goals)."""
+        E, N = self.E, self.N
+        sizes = self.t
+        # last comm row of a finished episode: zeros when done (np.zeros init, buffer.py:124), the stale-observation mask on
+        # time-out (Q8); environments still running rewrite their (not yet recorded) row `t` with itself
+        prev = self.lb_comm[self.ar, (sizes - 1).clamp(min=0)]
+        cur = self.lb_comm[self.ar, sizes]
+        last = torch.where(dn.view(E, 1, 1), torch.zeros_like(prev), prev)
+        self.lb_comm[self.ar, sizes] = torch.where(finished.view(E, 1, 1), last, cur)
+        if self.keep_flushed:  # tests: host-side copies of every finished episode (synchronises)
+            ids = finished.nonzero().view(-1)
+            td = self._finish_priorities(ids, sizes[ids])
+            for k, e in enumerate(ids.tolist()):
+                size = int(sizes[e])
+                self.flushed.append(dict(env=e, size=size, done=bool(dn[e]), obs=self.lb_obs[e, :size + 1].clone(),
                                          comm=self.lb_comm[e, :size + 1].clone(), act=self.lb_act[e, :size].clone(),
                                          rew=self.lb_rew[e, :size].clone(), hid=self.lb_hid[e, :size].clone(),
                                          q=self.lb_q[e, :size].clone(), td=td[k].clone()))
-        self.episodes += len(ids_h)
+        if self.buffer is not None:
+            self.buffer.add_finished(N, finished, sizes, dn, self.lb_obs, self.lb_comm, self.lb_act, self.lb_rew, self.lb_hid, self.lb_q)
+            # curriculum statistics (worker.py:74-82: actors with id >= 10): outcomes in episode order into the device log
+            m = finished & self.stat_mask
+            pos = self.stat_n + torch.cumsum(m, 0) - 1
+            self.stat_log.scatter_(0, torch.where(m, pos % self.STAT_LOG, self.STAT_LOG), dn.to(torch.uint8))
+            self.stat_n += m.sum()
+        self._episodes += finished.sum()
         # Actor.reset (worker.py:422-428): fresh scenario, recurrent state cleared
         self.scenario_seed += 1
-        if self.on_device_reset:   # mapf_reset_envs: generation + placement + navi in one launch, no host round trip
-            mask = torch.zeros(self.E, dtype=torch.uint8, device=self.device)
-            mask[ids] = 1
-            self.env.reset_envs(mask, self.density, self.scenario_seed)
-        else:                      # host generator + partial load
-            maps, agents, goals, _ = generate_scenarios(len(ids_h), self.env.map_length, self.N, self.density, self.scenario_seed)
-            self.env.load_envs(ids_h, maps, agents, goals)
+        if self.on_device_reset:   # mapf_reset_envs: generation + placement + navi in one launch, only where the mask is set
+            self.env.reset_envs(finished.to(torch.uint8), self.density, self.scenario_seed)
+        else:                      # host generator + partial load (synchronises)
+            ids_h = finished.nonzero().view(-1).tolist()
+            if ids_h:
+                maps, agents, goals, _ = generate_scenarios(len(ids_h), self.env.map_length, N, self.density, self.scenario_seed)
+                self.env.load_envs(ids_h, maps, agents, goals)
         self.obs, self.pos = self.env.observe(obs_bits_out=self.bits)
-        self.lb_obs[ids, 0, :self.RD] = self.bits[ids]
-        self.t[ids] = 0
-        self.hidden.view(self.E, self.N, 256)[ids] = 0                # model.reset(): GRUCell(x, None) == zero state
+        fin1 = finished.view(E, 1)
+        self.lb_obs[:, 0, :self.RD] = torch.where(fin1, self.bits, self.lb_obs[:, 0, :self.RD])
+        self.t = torch.where(finished, torch.zeros_like(self.t), self.t)
+        self.hidden.view(E, N, 256).mul_((~finished).view(E, 1, 1))      # model.reset(): GRUCell(x, None) == zero state
+
+    STAT_LOG = 4096  # outcomes kept between two reads (a level's window is the last 200)
+
+    def drain_outcomes(self):
+        """Feeds the episode outcomes logged since the last call to the curriculum's level table, in episode order
+        (worker.py:74-82).  Reads the device log: synchronises; called when statistics are asked for."""
+        if self.buffer is None:
+            return 0
+        n = int(self.stat_n)
+        k = min(n - self._stat_read, self.STAT_LOG)
+        if k > 0:
+            log = self.stat_log[:self.STAT_LOG].cpu().numpy()
+            key = (self.N, self.env.map_length)
+            for i in range(n - k, n):
+                self.buffer.levels.record(key, bool(log[i % self.STAT_LOG]))
+        self._stat_read = n
+        return k
+
+    @property
+    def episodes(self):
+        return int(self._episodes)
 
     def run(self, num_iterations):
         for _ in range(num_iterations):

@@ -841,6 +841,17 @@ int step_group(const mapf_env *h, const void *obs) {
     return 1;
 }
 
+// threads per block (one lane per agent in the step phase), measured on MI355X (tools/shape_sweep.py):
+// 32x32 / 40 agents 20.5 us @128 vs 22.0 us @64; 64x64 / 40 agents 23.5 us @64 vs 26.4 us @128; few agents
+// (N <= 24) prefer one wavefront per environment.  MAPF_STEP_THREADS overrides for tuning runs.
+int step_block_threads(const mapf_env *h) {
+    if (h->tune_threads == 64 || h->tune_threads == 128 || h->tune_threads == 256) {
+        if (h->tune_threads >= h->N) return h->tune_threads;
+    }
+    if (h->N <= 64 && (h->N <= 24 || h->L > 32)) return 64;
+    return h->N <= 128 ? 128 : 256;
+}
+
 template <typename W, bool DO_STEP, bool DO_OBS, int VEC, int NT>
 int launch_step_nt(const mapf_env *h, const StepParams &p, hipStream_t s, size_t smem) {
     const int need = (h->N * 10 + NT - 1) / NT;

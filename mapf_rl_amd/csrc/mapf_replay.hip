@@ -43,8 +43,18 @@ struct DeviceGuard {
 // later entry carries the same index (numpy's `tree[idx] = p` keeps the last one).
 __global__ void __launch_bounds__(1024) tree_update_kernel(double *tree, long long capacity, int layers,
                                                            const int64_t *idx, const double *pri, int n, double alpha,
-                                                           int stale_mode, long long lo, long long hi) {
+                                                           const int64_t *state, const int64_t *old_ptr_dev) {
     const int tid = threadIdx.x;
+    // worker.py:190-201: entries whose slot was overwritten between the sample (ring pointer old_ptr) and now (ring pointer ptr)
+    // are dropped.  Both pointers live on the device (the ring advances without the host: mapf_replay_add_many)
+    int stale_mode = 0;
+    long long lo = 0, hi = 0;
+    if (old_ptr_dev != nullptr) {
+        const long long ptr = state[0], old = *old_ptr_dev;
+        lo = old * kMaxSteps;
+        hi = ptr * kMaxSteps;
+        stale_mode = ptr > old ? 1 : (ptr < old ? 2 : 0);
+    }
     for (int base = 0; base < n; base += blockDim.x) {
         const int i = base + tid;
         bool active = i < n;
@@ -80,12 +90,16 @@ __global__ void __launch_bounds__(1024) tree_update_kernel(double *tree, long lo
 }
 
 __global__ void tree_sample_kernel(const double *tree, long long capacity, int layers, const double *uniforms, int n,
-                                   int64_t *idx_out, double *pri_out) {
+                                   int unit_uniforms, int64_t *idx_out, double *pri_out, const int64_t *state, int64_t *old_ptr_out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0 && old_ptr_out != nullptr) *old_ptr_out = state[0];  // worker.py:182: the ring pointer at sample time
     if (k >= n) return;
     const double sum = tree[0];
     const double interval = sum / (double)n;              // buffer.py:58
-    double prefix = (double)k * interval + uniforms[k];   // buffer.py:60 (np.arange(0, sum, interval)[k] = k*interval)
+    // buffer.py:60: np.random.uniform(0, interval) = interval * U(0,1); unit_uniforms: the caller passes U(0,1) and the scaling
+    // happens here (same f64 product), so that it needs neither the tree's root nor a host round trip
+    const double u = unit_uniforms ? uniforms[k] * interval : uniforms[k];
+    double prefix = (double)k * interval + u;             // np.arange(0, sum, interval)[k] = k*interval
     if (k == 0 && prefix == 0.0) prefix = 1e-5;           // buffer.py:61-62
     long long node = 0;
     for (int l = 1; l < layers; ++l) {                    // buffer.py:66-70
@@ -202,26 +216,171 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherParams p) {
     }
 }
 
-__global__ void set_slot_meta_kernel(uint8_t *done_buf, int32_t *size_buf, int32_t *nag_buf, int slot, int done, int size,
-                                     int nag) {
-    done_buf[slot] = (uint8_t)done;
-    size_buf[slot] = size;
-    nag_buf[slot] = nag;
+// ---------------------------------------------------------------------------------------------------------------------
+// GlobalBuffer.add for every finished environment of a vectorised actor, on the device (worker.py:71-104 per episode, in
+// ascending environment order; LocalBuffer.finish priorities buffer.py:170-177 when `td` is not supplied).
+//   flush_scan_kernel   one block: ranks the finished environments, assigns ring slots, advances ptr / size / counter and the
+//                       slots' (size, done, num_agents);
+//   flush_copy_kernel   one block per environment: priorities td^0.6 into the slot's 256 leaves, the episode's rows into the slot,
+//                       and the slot's own sub-tree (8 levels) re-summed;
+//   flush_top_kernel    one block: the tree above the slot roots re-summed (every node = left + right of its final children, so
+//                       the result is bit-identical to the reference's per-episode batch_update, buffer.py:95-105).
+// state: int64 {ptr, size, counter, episodes added by the last flush}.
+// ---------------------------------------------------------------------------------------------------------------------
+struct FlushParams {
+    int E, S, A, RD, CW, capacity, num_agents;  // S = transitions per local buffer (rows = S + 1)
+    const uint8_t *finished;   // [E] non-zero = flush this environment (nullptr: all)
+    const int64_t *sizes;      // [E] episode lengths
+    const uint8_t *done;       // [E]
+    const uint32_t *obs_bits;  // [E][S+1][RD]
+    const uint32_t *comm_bits; // [E][S+1][A][CW]
+    const uint8_t *act;        // [E][S]
+    const uint16_t *rew;       // [E][S] f16
+    const uint16_t *hid;       // [E][S][256] f16
+    const float *q;            // [E][S][5] or nullptr when td is given
+    const double *td;          // [E][256] or nullptr
+    int32_t *slot_of;          // [E] scratch: ring slot or -1
+    int64_t *state;
+    uint32_t *dst_obs, *dst_comm;
+    uint8_t *dst_act, *dst_done;
+    uint16_t *dst_rew, *dst_hid;
+    int32_t *dst_size, *dst_nag;
+    double *tree;
+    long long leaves;
+    int cap_log2;
+};
+
+__global__ void __launch_bounds__(1024) flush_scan_kernel(FlushParams p) {
+    __shared__ int s_cnt[1024];
+    __shared__ long long s_sum[1024];
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int per = (p.E + nth - 1) / nth, e0 = tid * per, e1 = min(p.E, e0 + per);
+    int cnt = 0;
+    for (int e = e0; e < e1; ++e) cnt += (p.finished == nullptr || p.finished[e] != 0) ? 1 : 0;
+    s_cnt[tid] = cnt;
+    __syncthreads();
+    for (int d = 1; d < nth; d <<= 1) {  // inclusive scan
+        const int v = tid >= d ? s_cnt[tid - d] : 0;
+        __syncthreads();
+        s_cnt[tid] += v;
+        __syncthreads();
+    }
+    const int n = s_cnt[nth - 1];
+    int rank = s_cnt[tid] - cnt;
+    const long long ptr = p.state[0];
+    long long dsize = 0, dcount = 0;
+    for (int e = e0; e < e1; ++e) {
+        int slot = -1;
+        if (p.finished == nullptr || p.finished[e] != 0) {
+            const int size = (int)p.sizes[e];
+            dcount += size;
+            if (rank >= n - p.capacity) {  // with more episodes than slots only the last `capacity` survive (later adds overwrite)
+                slot = (int)((ptr + rank) % p.capacity);
+                dsize += size - p.dst_size[slot];      // worker.py:90-91
+                p.dst_size[slot] = size;
+                p.dst_done[slot] = p.done[e] != 0;
+                p.dst_nag[slot] = p.num_agents;
+            }
+            ++rank;
+        }
+        p.slot_of[e] = slot;
+    }
+    s_sum[tid] = dsize;
+    __syncthreads();
+    for (int d = nth >> 1; d > 0; d >>= 1) {
+        if (tid < d) s_sum[tid] += s_sum[tid + d];
+        __syncthreads();
+    }
+    const long long tsize = s_sum[0];
+    __syncthreads();
+    s_sum[tid] = dcount;
+    __syncthreads();
+    for (int d = nth >> 1; d > 0; d >>= 1) {
+        if (tid < d) s_sum[tid] += s_sum[tid + d];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        p.state[0] = (ptr + n) % p.capacity;  // worker.py:104
+        p.state[1] += tsize;
+        p.state[2] += s_sum[0];               // worker.py:92
+        p.state[3] = n;
+    }
 }
 
-__global__ void iota_kernel(int64_t *out, long long start, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = start + i;
+__global__ void __launch_bounds__(256) flush_copy_kernel(FlushParams p) {
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const int slot = p.slot_of[e];
+    if (slot < 0) return;
+    const int size = (int)p.sizes[e], S = p.S;
+    // ---- priorities (buffer.py:170-177 in f64: |r_t + 0.99 r_{t+1} + max_a Q(s_t) - Q(s_t, a_t)|, zeros past the episode end) ----
+    double td = 0.0;
+    if (p.td != nullptr) {
+        td = p.td[(size_t)e * kMaxSteps + tid];
+    } else if (tid < size && tid < S) {
+        const float *q = p.q + ((size_t)e * S + tid) * 5;
+        float qmax = q[0];
+        for (int a = 1; a < 5; ++a) qmax = fmaxf(qmax, q[a]);
+        const double r0 = (double)half_bits_to_float(p.rew[(size_t)e * S + tid]);
+        const double r1 = (tid + 1 < size) ? (double)half_bits_to_float(p.rew[(size_t)e * S + tid + 1]) : 0.0;
+        const double ret = (r0 + 0.99 * r1) + (double)qmax;   // np.convolve(ret, [0.99, 1], 'valid') + q_max
+        td = fabs(ret - (double)q[p.act[(size_t)e * S + tid]]);
+    }
+    const long long leaf0 = p.leaves - 1 + (long long)slot * kMaxSteps;
+    p.tree[leaf0 + tid] = pow(td, kAlpha);  // worker.py:94
+    // ---- the episode's rows (worker.py:96-102) ----
+    const size_t row0 = (size_t)slot * kRows, tr0 = (size_t)slot * kMaxSteps;
+    {
+        const uint32_t *src = p.obs_bits + (size_t)e * (S + 1) * p.RD;
+        uint32_t *dst = p.dst_obs + row0 * p.RD;
+        const int n16 = ((size + 1) * p.RD) >> 2;  // RD is a multiple of 4
+        for (int i = tid; i < n16; i += 256) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+    }
+    {
+        const int rw = p.A * p.CW;
+        const uint32_t *src = p.comm_bits + (size_t)e * (S + 1) * rw;
+        uint32_t *dst = p.dst_comm + row0 * rw;
+        for (int i = tid; i < (size + 1) * rw; i += 256) dst[i] = src[i];
+    }
+    for (int i = tid; i < size; i += 256) {
+        p.dst_act[tr0 + i] = p.act[(size_t)e * S + i];
+        p.dst_rew[tr0 + i] = p.rew[(size_t)e * S + i];
+    }
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.hid + (size_t)e * S * 256);
+        uint4 *dst = reinterpret_cast<uint4 *>(p.dst_hid + tr0 * 256);
+        for (int i = tid; i < size * 32; i += 256) dst[i] = src[i];
+    }
+    // ---- the slot's sub-tree: 256 aligned leaves -> 8 levels up to the slot root ----
+    __syncthreads();
+    for (int k = 1; k <= 8; ++k) {
+        if (tid < (kMaxSteps >> k)) {
+            const long long node = ((leaf0 + 1) >> k) - 1 + tid;
+            p.tree[node] = p.tree[2 * node + 1] + p.tree[2 * node + 2];
+        }
+        __syncthreads();
+    }
 }
+
+__global__ void __launch_bounds__(1024) flush_top_kernel(double *tree, int cap_log2, const int64_t *state) {
+    if (state[3] == 0) return;  // nothing was added
+    for (int lvl = cap_log2 - 1; lvl >= 0; --lvl) {
+        const long long first = (1ll << lvl) - 1, count = 1ll << lvl;
+        for (long long i = threadIdx.x; i < count; i += blockDim.x) {
+            const long long node = first + i;
+            tree[node] = tree[2 * node + 1] + tree[2 * node + 2];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void state_reset_counter_kernel(int64_t *state) { state[2] = 0; }
 
 }  // namespace
 
 struct mapf_replay {
-    int capacity, A, RD, CW, device, layers;
+    int capacity, A, RD, CW, device, layers, cap_log2;
     long long leaves;
-    int ptr;
-    long long size, counter;
-    int32_t *host_sizes;  // mirror of size_buf for the host-side `size` accounting (worker.py:90-91)
+    hipStream_t last_stream;  // stream of the most recent call: the state getters order their read behind it
     uint32_t *obs_bits;
     uint32_t *comm_bits;
     uint8_t *act;
@@ -231,7 +390,12 @@ struct mapf_replay {
     int32_t *size_buf;
     int32_t *nag_buf;
     double *tree;
-    int64_t *slot_idx;  // scratch [256]
+    int64_t *state;     // device: {ptr, size, counter, episodes added by the last flush} (GlobalBuffer.ptr / .size / .counter)
+    int32_t *slot_of;   // scratch [slot_cap]
+    int slot_cap;
+    uint8_t *one;       // device constants for the single-episode add: finished = 1
+    int64_t *tmp_size;  // [1]
+    uint8_t *tmp_done;  // [1]
 };
 
 extern "C" {
@@ -253,10 +417,10 @@ int mapf_replay_create(int capacity_episodes, int max_agents, int device, mapf_r
     r->CW = (max_agents + 31) / 32;
     r->device = device;
     r->layers = layers;
+    r->cap_log2 = layers - 1 - 8;  // capacity_episodes = 2^cap_log2
     r->leaves = leaves;
-    r->ptr = 0;
-    r->size = r->counter = 0;
-    r->host_sizes = new (std::nothrow) int32_t[capacity_episodes]();
+    r->last_stream = nullptr;
+    r->slot_cap = 0;
     DeviceGuard guard(device);
     hipError_t err = guard.ok ? hipSuccess : hipErrorInvalidDevice;
     auto alloc = [&err](void **p, size_t bytes) {
@@ -273,12 +437,18 @@ int mapf_replay_create(int capacity_episodes, int max_agents, int device, mapf_r
     alloc(reinterpret_cast<void **>(&r->size_buf), cap * 4);
     alloc(reinterpret_cast<void **>(&r->nag_buf), cap * 4);
     alloc(reinterpret_cast<void **>(&r->tree), (size_t)(2 * leaves - 1) * 8);
-    alloc(reinterpret_cast<void **>(&r->slot_idx), kMaxSteps * 8);
-    if (err != hipSuccess || !r->host_sizes) {
+    alloc(reinterpret_cast<void **>(&r->state), 4 * 8);
+    alloc(reinterpret_cast<void **>(&r->slot_of), 4);
+    alloc(reinterpret_cast<void **>(&r->one), 16);
+    alloc(reinterpret_cast<void **>(&r->tmp_size), 8);
+    alloc(reinterpret_cast<void **>(&r->tmp_done), 16);
+    if (err == hipSuccess) err = hipMemset(r->one, 1, 1);
+    if (err != hipSuccess) {
         std::fprintf(stderr, "mapf_replay_create: %s\n", hipGetErrorString(err));
         mapf_replay_destroy(r);
         return MAPF_ERR_HIP;
     }
+    r->slot_cap = 1;
     *out = r;
     return MAPF_OK;
 }
@@ -295,29 +465,52 @@ int mapf_replay_destroy(mapf_replay_t *r) {
     (void)hipFree(r->size_buf);
     (void)hipFree(r->nag_buf);
     (void)hipFree(r->tree);
-    (void)hipFree(r->slot_idx);
-    delete[] r->host_sizes;
+    (void)hipFree(r->state);
+    (void)hipFree(r->slot_of);
+    (void)hipFree(r->one);
+    (void)hipFree(r->tmp_size);
+    (void)hipFree(r->tmp_done);
     delete r;
     return MAPF_OK;
 }
 
 int mapf_replay_row_dwords(const mapf_replay_t *r) { return r ? r->RD : MAPF_ERR_INVALID_ARG; }
 int mapf_replay_capacity(const mapf_replay_t *r) { return r ? r->capacity : MAPF_ERR_INVALID_ARG; }
-int mapf_replay_ptr(const mapf_replay_t *r) { return r ? r->ptr : MAPF_ERR_INVALID_ARG; }
-int64_t mapf_replay_size(const mapf_replay_t *r) { return r ? r->size : MAPF_ERR_INVALID_ARG; }
+
+// {ptr, size, counter, last flush count}: a 32-byte read ordered behind the handle's most recent stream (blocks the host)
+int mapf_replay_state(mapf_replay_t *r, int64_t out[4], void *stream) {
+    if (!r || !out) return MAPF_ERR_INVALID_ARG;
+    DeviceGuard guard(r->device);
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : r->last_stream;
+    HIP_TRY(hipMemcpyAsync(out, r->state, 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return MAPF_OK;
+}
+int mapf_replay_ptr(const mapf_replay_t *r) {
+    int64_t st[4];
+    return mapf_replay_state(const_cast<mapf_replay_t *>(r), st, nullptr) == MAPF_OK ? (int)st[0] : MAPF_ERR_INVALID_ARG;
+}
+int64_t mapf_replay_size(const mapf_replay_t *r) {
+    int64_t st[4];
+    return mapf_replay_state(const_cast<mapf_replay_t *>(r), st, nullptr) == MAPF_OK ? st[1] : MAPF_ERR_INVALID_ARG;
+}
 int64_t mapf_replay_counter(const mapf_replay_t *r, int reset) {
-    if (!r) return MAPF_ERR_INVALID_ARG;
-    int64_t c = r->counter;
-    if (reset) const_cast<mapf_replay_t *>(r)->counter = 0;
-    return c;
+    int64_t st[4];
+    mapf_replay_t *rr = const_cast<mapf_replay_t *>(r);
+    if (mapf_replay_state(rr, st, nullptr) != MAPF_OK) return MAPF_ERR_INVALID_ARG;
+    if (reset) {
+        DeviceGuard guard(rr->device);
+        hipLaunchKernelGGL(state_reset_counter_kernel, dim3(1), dim3(1), 0, rr->last_stream, rr->state);
+    }
+    return st[2];
 }
 
-static int tree_update(mapf_replay_t *r, const int64_t *idx, const double *pri, int n, double alpha, int stale_mode,
-                       long long lo, long long hi, hipStream_t s) {
+static int tree_update(mapf_replay_t *r, const int64_t *idx, const double *pri, int n, double alpha, const int64_t *old_ptr_dev,
+                       hipStream_t s) {
     if (n <= 0) return MAPF_OK;
     int threads = n < 64 ? 64 : (n > 1024 ? 1024 : ((n + 63) / 64) * 64);
-    hipLaunchKernelGGL(tree_update_kernel, dim3(1), dim3(threads), 0, s, r->tree, r->leaves, r->layers, idx, pri, n, alpha,
-                       stale_mode, lo, hi);
+    hipLaunchKernelGGL(tree_update_kernel, dim3(1), dim3(threads), 0, s, r->tree, r->leaves, r->layers, idx, pri, n, alpha, r->state,
+                       old_ptr_dev);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }
@@ -326,15 +519,17 @@ int mapf_replay_tree_update(mapf_replay_t *r, const int64_t *idx_dev, const doub
                             void *stream) {
     if (!r || !idx_dev || !pri_dev || n < 0) return MAPF_ERR_INVALID_ARG;
     DeviceGuard guard(r->device);
-    return tree_update(r, idx_dev, pri_dev, n, alpha, 0, 0, 0, static_cast<hipStream_t>(stream));
+    r->last_stream = static_cast<hipStream_t>(stream);
+    return tree_update(r, idx_dev, pri_dev, n, alpha, nullptr, static_cast<hipStream_t>(stream));
 }
 
-int mapf_replay_tree_sample(mapf_replay_t *r, const double *uniforms_dev, int n, int64_t *idx_dev, double *pri_dev,
-                            void *stream) {
+int mapf_replay_tree_sample(mapf_replay_t *r, const double *uniforms_dev, int n, int unit_uniforms, int64_t *idx_dev, double *pri_dev,
+                            int64_t *old_ptr_dev, void *stream) {
     if (!r || !uniforms_dev || !idx_dev || !pri_dev || n < 1) return MAPF_ERR_INVALID_ARG;
     DeviceGuard guard(r->device);
+    r->last_stream = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(tree_sample_kernel, dim3((n + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), r->tree,
-                       r->leaves, r->layers, uniforms_dev, n, idx_dev, pri_dev);
+                       r->leaves, r->layers, uniforms_dev, n, unit_uniforms, idx_dev, pri_dev, r->state, old_ptr_dev);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }
@@ -342,8 +537,42 @@ int mapf_replay_tree_sample(mapf_replay_t *r, const double *uniforms_dev, int n,
 int mapf_replay_tree_read(mapf_replay_t *r, double *tree_dev, void *stream) {
     if (!r || !tree_dev) return MAPF_ERR_INVALID_ARG;
     DeviceGuard guard(r->device);
+    r->last_stream = static_cast<hipStream_t>(stream);
     HIP_TRY(hipMemcpyAsync(tree_dev, r->tree, (size_t)(2 * r->leaves - 1) * 8, hipMemcpyDeviceToDevice,
                            static_cast<hipStream_t>(stream)));
+    return MAPF_OK;
+}
+
+static int flush(mapf_replay_t *r, FlushParams &p, hipStream_t s) {
+    if (p.E > r->slot_cap) {  // scratch grows with the widest actor seen (first call with a new width only)
+        HIP_TRY(hipStreamSynchronize(s));
+        (void)hipFree(r->slot_of);
+        r->slot_of = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&r->slot_of), (size_t)p.E * 4));
+        r->slot_cap = p.E;
+    }
+    p.A = r->A;
+    p.RD = r->RD;
+    p.CW = r->CW;
+    p.capacity = r->capacity;
+    p.slot_of = r->slot_of;
+    p.state = r->state;
+    p.dst_obs = r->obs_bits;
+    p.dst_comm = r->comm_bits;
+    p.dst_act = r->act;
+    p.dst_done = r->done_buf;
+    p.dst_rew = r->rew;
+    p.dst_hid = r->hid;
+    p.dst_size = r->size_buf;
+    p.dst_nag = r->nag_buf;
+    p.tree = r->tree;
+    p.leaves = r->leaves;
+    p.cap_log2 = r->cap_log2;
+    r->last_stream = s;
+    hipLaunchKernelGGL(flush_scan_kernel, dim3(1), dim3(1024), 0, s, p);
+    hipLaunchKernelGGL(flush_copy_kernel, dim3(p.E), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(flush_top_kernel, dim3(1), dim3(1024), 0, s, r->tree, r->cap_log2, r->state);
+    HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }
 
@@ -354,40 +583,61 @@ int mapf_replay_add(mapf_replay_t *r, int num_agents, int size, int done, const 
     if (num_agents < 1 || num_agents > r->A || size < 1 || size > kMaxSteps) return MAPF_ERR_INVALID_ARG;
     DeviceGuard guard(r->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int p = r->ptr;
-    const size_t row0 = (size_t)p * kRows, tr0 = (size_t)p * kMaxSteps;
-    // worker.py:90-92
-    r->size -= r->host_sizes[p];
-    r->size += size;
-    r->counter += size;
-    r->host_sizes[p] = size;
-    // worker.py:94: priorities td^alpha for all 256 leaves of the slot
-    hipLaunchKernelGGL(iota_kernel, dim3(1), dim3(kMaxSteps), 0, s, r->slot_idx, (long long)tr0, kMaxSteps);
-    HIP_TRY(hipGetLastError());
-    int st = tree_update(r, r->slot_idx, td_dev, kMaxSteps, kAlpha, 0, 0, 0, s);
-    if (st != MAPF_OK) return st;
-    // worker.py:96-102
-    HIP_TRY(hipMemcpyAsync(r->obs_bits + row0 * r->RD, obs_bits_dev, (size_t)(size + 1) * r->RD * 4, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(r->comm_bits + row0 * r->A * r->CW, comm_bits_dev, (size_t)(size + 1) * r->A * r->CW * 4,
-                           hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(r->act + tr0, act_dev, (size_t)size, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(r->rew + tr0, rew_dev, (size_t)size * 2, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(r->hid + tr0 * 256, hid_dev, (size_t)size * 256 * 2, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(set_slot_meta_kernel, dim3(1), dim3(1), 0, s, r->done_buf, r->size_buf, r->nag_buf, p, done, size,
-                       num_agents);
-    HIP_TRY(hipGetLastError());
-    r->ptr = (p + 1) % r->capacity;  // worker.py:104
-    return MAPF_OK;
+    const int64_t sz = size;
+    const uint8_t dn = done ? 1 : 0;
+    HIP_TRY(hipMemcpyAsync(r->tmp_size, &sz, 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(r->tmp_done, &dn, 1, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // (pageable host sources)
+    FlushParams p{};
+    p.E = 1;
+    p.S = size;  // the caller's arrays hold exactly size (+ 1) rows
+    p.num_agents = num_agents;
+    p.finished = r->one;
+    p.sizes = r->tmp_size;
+    p.done = r->tmp_done;
+    p.obs_bits = obs_bits_dev;
+    p.comm_bits = comm_bits_dev;
+    p.act = act_dev;
+    p.rew = rew_dev;
+    p.hid = hid_dev;
+    p.q = nullptr;
+    p.td = td_dev;
+    return flush(r, p, s);
 }
 
-int mapf_replay_sample(mapf_replay_t *r, const double *uniforms_dev, int n, int64_t *idx_dev, double *pri_dev,
+int mapf_replay_add_many(mapf_replay_t *r, int num_envs, int num_agents, int local_steps, const uint8_t *finished_dev,
+                         const int64_t *sizes_dev, const uint8_t *done_dev, const uint32_t *obs_bits_dev,
+                         const uint32_t *comm_bits_dev, const uint8_t *act_dev, const uint16_t *rew_dev, const uint16_t *hid_dev,
+                         const float *q_dev, void *stream) {
+    if (!r || !sizes_dev || !done_dev || !obs_bits_dev || !comm_bits_dev || !act_dev || !rew_dev || !hid_dev || !q_dev)
+        return MAPF_ERR_INVALID_ARG;
+    if (num_envs < 1 || num_agents < 1 || num_agents > r->A || local_steps < 1 || local_steps > kMaxSteps) return MAPF_ERR_INVALID_ARG;
+    DeviceGuard guard(r->device);
+    FlushParams p{};
+    p.E = num_envs;
+    p.S = local_steps;
+    p.num_agents = num_agents;
+    p.finished = finished_dev;
+    p.sizes = sizes_dev;
+    p.done = done_dev;
+    p.obs_bits = obs_bits_dev;
+    p.comm_bits = comm_bits_dev;
+    p.act = act_dev;
+    p.rew = rew_dev;
+    p.hid = hid_dev;
+    p.q = q_dev;
+    p.td = nullptr;
+    return flush(r, p, static_cast<hipStream_t>(stream));
+}
+
+int mapf_replay_sample(mapf_replay_t *r, const double *uniforms_dev, int n, int unit_uniforms, int64_t *idx_dev, double *pri_dev,
                        uint16_t *obs_dev, uint8_t *comm_dev, uint16_t *hidden_dev, int64_t *action_dev,
-                       float *reward_dev, float *done_dev, float *steps_dev, int64_t *bt_steps_dev, void *stream) {
+                       float *reward_dev, float *done_dev, float *steps_dev, int64_t *bt_steps_dev, int64_t *old_ptr_dev,
+                       void *stream) {
     if (!r || !uniforms_dev || !idx_dev || !pri_dev || !obs_dev || !comm_dev || !hidden_dev || !action_dev ||
         !reward_dev || !done_dev || !steps_dev || !bt_steps_dev || n < 1)
         return MAPF_ERR_INVALID_ARG;
-    if (r->size <= 0) return MAPF_ERR_NOT_READY;
-    int st = mapf_replay_tree_sample(r, uniforms_dev, n, idx_dev, pri_dev, stream);
+    int st = mapf_replay_tree_sample(r, uniforms_dev, n, unit_uniforms, idx_dev, pri_dev, old_ptr_dev, stream);
     if (st != MAPF_OK) return st;
     DeviceGuard guard(r->device);
     GatherParams g{};
@@ -417,15 +667,12 @@ int mapf_replay_sample(mapf_replay_t *r, const double *uniforms_dev, int n, int6
     return MAPF_OK;
 }
 
-int mapf_replay_update_priorities(mapf_replay_t *r, const int64_t *idx_dev, const double *pri_dev, int n, int old_ptr,
+int mapf_replay_update_priorities(mapf_replay_t *r, const int64_t *idx_dev, const double *pri_dev, int n, const int64_t *old_ptr_dev,
                                   void *stream) {
-    if (!r || !idx_dev || !pri_dev || n < 0 || old_ptr < 0 || old_ptr >= r->capacity) return MAPF_ERR_INVALID_ARG;
+    if (!r || !idx_dev || !pri_dev || n < 0 || !old_ptr_dev) return MAPF_ERR_INVALID_ARG;
     DeviceGuard guard(r->device);
-    int mode = 0;
-    long long lo = (long long)old_ptr * kMaxSteps, hi = (long long)r->ptr * kMaxSteps;
-    if (r->ptr > old_ptr) mode = 1;       // worker.py:192-196
-    else if (r->ptr < old_ptr) mode = 2;  // worker.py:197-201
-    return tree_update(r, idx_dev, pri_dev, n, kAlpha, mode, lo, hi, static_cast<hipStream_t>(stream));
+    r->last_stream = static_cast<hipStream_t>(stream);
+    return tree_update(r, idx_dev, pri_dev, n, kAlpha, old_ptr_dev, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

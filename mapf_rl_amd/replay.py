@@ -2,7 +2,8 @@
 (reference worker.py:21-250) and `SumTree` (reference buffer.py:16-105) on top of include/mapf_replay.h.
 
 All episode data and the f64 sum tree live in HBM; `sample_batch` is a tree descent plus one gather kernel.
-The ring pointer / size / counter and the curriculum statistics stay on the host like in the reference.
+The ring pointer / size / counter live on the device too (a vectorised actor appends finished episodes without a host
+round trip, `add_finished`); the curriculum statistics stay on the host like in the reference.
 PyTorch is used for device memory and streams only."""
 import ctypes
 import threading
@@ -61,18 +62,19 @@ class SumTree:
         torch.cuda.current_stream(self.device).synchronize()
 
     def batch_sample(self, batch_size, uniforms=None):
-        u = self._uniforms(batch_size, uniforms)
+        u, unit = self._uniforms(batch_size, uniforms)
         idx = torch.empty(batch_size, dtype=torch.int64, device=self.device)
         pri = torch.empty(batch_size, dtype=torch.float64, device=self.device)
-        check(lib.mapf_replay_tree_sample(self._h, _ptr(u), batch_size, _ptr(idx), _ptr(pri), _stream(self.device)),
+        check(lib.mapf_replay_tree_sample(self._h, _ptr(u), batch_size, unit, _ptr(idx), _ptr(pri), None, _stream(self.device)),
               "mapf_replay_tree_sample")
         return idx, pri
 
     def _uniforms(self, batch_size, uniforms):
+        """(draws, unit flag): caller-supplied draws are already scaled to [0, sum/n) like np.random.uniform(0, interval)
+        (buffer.py:60); own draws are U(0,1) and the kernel scales them by sum/n -- no copy of the root, no host round trip."""
         if uniforms is not None:
-            return torch.as_tensor(uniforms, dtype=torch.float64).to(self.device).contiguous()
-        # buffer.py:60: U(0, interval) per stratum; interval = sum / batch_size
-        return torch.rand(batch_size, dtype=torch.float64, device=self.device) * (self.sum() / batch_size)
+            return torch.as_tensor(uniforms, dtype=torch.float64).to(self.device).contiguous(), 0
+        return torch.rand(batch_size, dtype=torch.float64, device=self.device), 1
 
     def tree(self):
         out = torch.empty(2 * self.capacity - 1, dtype=torch.float64, device=self.device)
@@ -80,7 +82,7 @@ class SumTree:
         return out
 
     def sum(self):
-        return float(self.tree()[0].item())
+        return float(self.tree()[0].item())  # diagnostic / tests only: copies the tree
 
 
 class GlobalBuffer:
@@ -105,6 +107,7 @@ class GlobalBuffer:
 
         self.init_set, self.max_map_length, self.pass_rate = tuple(init_set), max_map_length, pass_rate
         self.levels = LevelTable(init_set, max_agents, max_map_length, pass_rate, fixed=fixed_level)
+        self._actors = []  # weak references to the vectorised actors recording into this buffer (their outcome logs)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -112,15 +115,19 @@ class GlobalBuffer:
             lib.mapf_replay_destroy(h)
             self._h = ctypes.c_void_p()
 
+    def state(self):
+        """(ptr, size, counter, episodes added by the last add): the ring state lives on the device (the actor appends finished
+        episodes without the host, `add_finished`); reading it waits for the current stream."""
+        out = (ctypes.c_int64 * 4)()
+        check(lib.mapf_replay_state(self._h, out, _stream(self.device)), "mapf_replay_state")
+        return tuple(int(v) for v in out)
+
     def __len__(self):
-        return int(lib.mapf_replay_size(self._h))
+        return self.state()[1]
 
     size = property(lambda self: len(self))
-    ptr = property(lambda self: int(lib.mapf_replay_ptr(self._h)))
-
-    @property
-    def counter(self):
-        return int(lib.mapf_replay_counter(self._h, 0))
+    ptr = property(lambda self: self.state()[0])
+    counter = property(lambda self: self.state()[2])
 
     # ------------------------------------------------------------------ add
     def add_episode_device(self, num_agents, size, done, obs_bits, comm_bits, act, rew, hid, td):
@@ -147,6 +154,21 @@ class GlobalBuffer:
         self.add_episode_device(num_agents, size, done, t["obs"], t["comm"], t["act"], t["rew"], t["hid"], t["td"])
         torch.cuda.current_stream(d).synchronize()  # the staging tensors above are temporaries
 
+    def add_finished(self, num_agents, finished, sizes, done, obs_bits, comm_bits, act, rew, hid, q):
+        """GlobalBuffer.add (worker.py:71-104) + LocalBuffer.finish (buffer.py:153-179) for every environment flagged in
+        `finished` (bool/u8 [E]) of a vectorised actor, in environment order, without any host read: see
+        include/mapf_replay.h mapf_replay_add_many.  Local buffers: obs_bits int32 [E, S+1, RD], comm_bits int32 [E, S+1, A, CW],
+        act u8 [E, S], rew f16 [E, S], hid f16 [E, S, 256], q f32 [E, S, 5]; sizes int64 [E]; done u8/bool [E]."""
+        E, S = act.shape
+        assert obs_bits.shape == (E, S + 1, self.row_dwords) and comm_bits.shape[:2] == (E, S + 1) and q.shape == (E, S, 5)
+        assert sizes.dtype == torch.int64 and hid.shape == (E, S, 256)
+        fin = finished.view(torch.uint8) if finished.dtype == torch.bool else finished
+        dn = done.view(torch.uint8) if done.dtype == torch.bool else done
+        assert fin.dtype == torch.uint8 and dn.dtype == torch.uint8
+        with self.lock:
+            check(lib.mapf_replay_add_many(self._h, E, int(num_agents), S, _ptr(fin), _ptr(sizes), _ptr(dn), _ptr(obs_bits), _ptr(comm_bits),
+                                           _ptr(act), _ptr(rew), _ptr(hid), _ptr(q), _stream(self.device)), "mapf_replay_add_many")
+
     def add(self, buffer_list):
         """reference signature (worker.py:71): list of LocalBuffer.finish() tuples
         (actor_id, num_agents, map_len, obs, act, rew, hid, td_errors, done, size, comm_mask)."""
@@ -160,10 +182,12 @@ class GlobalBuffer:
     def sample_batch(self, batch_size, uniforms=None):
         """Returns the reference's 11-tuple (worker.py:168-182) as device tensors:
         (obs bf16 [B,18,A,6,9,9], action i64 [B,1], reward f32 [B,1], done f32 [B,1], steps f32 [B,1],
-         bt_steps i64 [B], hidden f16 [B*A,256], comm_mask bool [B,18,A,A], idxes i64 [B], weights f32 [B,1], old_ptr)."""
+         bt_steps i64 [B], hidden f16 [B*A,256], comm_mask bool [B,18,A,A], idxes i64 [B], weights f32 [B,1],
+         old_ptr 0-dim i64 device tensor)."""
         d, A, B = self.device, self.max_agents, batch_size
         with self.lock:
-            u = self.priority_tree._uniforms(B, uniforms)
+            u, unit = self.priority_tree._uniforms(B, uniforms)
+            old_ptr = torch.empty(1, dtype=torch.int64, device=d)
             idx = torch.empty(B, dtype=torch.int64, device=d)
             pri = torch.empty(B, dtype=torch.float64, device=d)
             # time-major in memory (the learner's recurrence wants [T, B, ...] and would otherwise transpose 130 MB per network);
@@ -176,10 +200,10 @@ class GlobalBuffer:
             done = torch.empty(B, dtype=torch.float32, device=d)
             steps = torch.empty(B, dtype=torch.float32, device=d)
             bt = torch.empty(B, dtype=torch.int64, device=d)
-            check(lib.mapf_replay_sample(self._h, _ptr(u), B, _ptr(idx), _ptr(pri), _ptr(obs), _ptr(comm), _ptr(hidden),
-                                         _ptr(action), _ptr(reward), _ptr(done), _ptr(steps), _ptr(bt), _stream(d)),
+            check(lib.mapf_replay_sample(self._h, _ptr(u), B, unit, _ptr(idx), _ptr(pri), _ptr(obs), _ptr(comm), _ptr(hidden),
+                                         _ptr(action), _ptr(reward), _ptr(done), _ptr(steps), _ptr(bt), _ptr(old_ptr), _stream(d)),
                   "mapf_replay_sample")
-            old_ptr = self.ptr
+            old_ptr = old_ptr[0]  # 0-dim device tensor: the ring pointer at sample time (worker.py:182); int(old_ptr) reads it
         weights = torch.pow(pri / pri.min(), -self.beta).to(torch.float32)  # worker.py:165-166
         return (obs.transpose(0, 1), action.unsqueeze(1), reward.unsqueeze(1), done.unsqueeze(1), steps.unsqueeze(1), bt, hidden,
                 comm.bool().transpose(0, 1), idx, weights.unsqueeze(1), old_ptr)
@@ -188,19 +212,37 @@ class GlobalBuffer:
         """worker.py:186-203; idxes / priorities: device tensors (or array-likes)."""
         idx = torch.as_tensor(idxes, dtype=torch.int64).to(self.device).contiguous()
         pri = torch.as_tensor(priorities).to(self.device, torch.float64).contiguous()
+        old = torch.as_tensor(old_ptr, dtype=torch.int64).to(self.device).reshape(1).contiguous()  # int or the sample's tensor
         with self.lock:
-            check(lib.mapf_replay_update_priorities(self._h, _ptr(idx), _ptr(pri), idx.numel(), int(old_ptr), _stream(self.device)),
+            check(lib.mapf_replay_update_priorities(self._h, _ptr(idx), _ptr(pri), idx.numel(), _ptr(old), _stream(self.device)),
                   "mapf_replay_update_priorities")
-        self._keep = (idx, pri)  # keep the (possibly temporary) tensors alive until the next call
+        self._keep = (idx, pri, old)  # keep the (possibly temporary) tensors alive until the next call
 
     # ------------------------------------------------------------------ curriculum / stats (worker.py:205-250)
     # The schedule itself lives in curriculum.LevelTable; these are the reference's names for it.
     stat_dict = property(lambda self: self.levels.windows, lambda self, v: setattr(self.levels, "windows", {tuple(k): list(w) for k, w in v.items()}))
     level = property(lambda self: self.levels.levels)
 
+    def register_actor(self, actor):
+        import weakref
+
+        self._actors.append(weakref.ref(actor))
+
+    def drain_outcomes(self):
+        """Episode outcomes the actors logged on the device -> the level table's windows (actor.VecActor.drain_outcomes)."""
+        self._actors = [a for a in self._actors if a() is not None]
+        for a in self._actors:
+            a().drain_outcomes()
+
+    def pooled_counts(self, device, group=None):
+        """Multi-rank: every rank's per-level (successes, episodes), summed (curriculum.LevelTable.pooled_counts)."""
+        self.drain_outcomes()
+        return self.levels.pooled_counts(device, group)
+
     def stats(self, interval, pooled=None, world=1):
-        """Prints the reference's lines (worker.py:206-210) and advances the curriculum; `pooled` = LevelTable.pooled_counts()
+        """Prints the reference's lines (worker.py:206-210) and advances the curriculum; `pooled` = self.pooled_counts()
         in a multi-rank run (every rank must then call this with the same counts)."""
+        self.drain_outcomes()
         print("buffer update speed: {}/s".format(int(lib.mapf_replay_counter(self._h, 1)) / interval))
         print("buffer size: {}".format(len(self)))
         for line in self.levels.advance(pooled, self.levels.WINDOW * world):
@@ -213,4 +255,6 @@ class GlobalBuffer:
         return self.levels.levels
 
     def check_done(self, pooled=None, world=1):
+        if pooled is None:
+            self.drain_outcomes()
         return self.levels.done(pooled, self.levels.WINDOW * world)

@@ -35,7 +35,13 @@ def check_sample(z, tag, out, A=6):
     assert int(out["old_ptr"]) == int(z[tag + "old_ptr"])
 
 
-def run(z, buf):
+def _exact(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def run(z, buf, leaves_equal=_exact, root_equal=_exact):
+    """`leaves_equal` / `root_equal`: how sum-tree leaves (td ** 0.6) and the root are compared -- exactly for a numpy
+    implementation, within an explicit relative bound for the device (its f64 pow() is <= 2 ulp from numpy's)."""
     stale = None
     for k, ep in episodes(z):
         buf.add(ep)
@@ -44,11 +50,11 @@ def run(z, buf):
             out = buf.sample(z[tag + "u"])
             check_sample(z, tag, out)
             assert buf.size == int(z[tag + "size"])
-            assert abs(buf.tree_root() - float(z[tag + "tree_root"])) == 0.0
+            assert root_equal(buf.tree_root(), float(z[tag + "tree_root"]))
             if k == 3:
                 buf.update_priorities(np.asarray(out["idxes"]).copy(), z[tag + "newp"].copy(), int(out["old_ptr"]))
-                assert np.array_equal(buf.leaves(), z[tag + "leaves_after"])
+                assert leaves_equal(buf.leaves(), z[tag + "leaves_after"])
                 stale = (np.asarray(out["idxes"]).copy(), int(out["old_ptr"]))
     buf.update_priorities(stale[0], z["gb_stale_newp"].copy(), stale[1])
-    assert np.array_equal(buf.leaves(), z["gb_stale_leaves_after"])
+    assert leaves_equal(buf.leaves(), z["gb_stale_leaves_after"])
     assert buf.ptr == int(z["gb_final_ptr"])

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_abi_version_and_strerror():
     from mapf_rl_amd._lib import lib
 
-    assert lib.mapf_abi_version() == 1
+    assert lib.mapf_abi_version() == 2
     assert lib.mapf_strerror(0) == b"ok"
     assert b"action" in lib.mapf_strerror(-2)
     assert b"unique" in lib.mapf_strerror(-3)

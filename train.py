@@ -39,6 +39,11 @@ np.random.seed(0)
 random.seed(0)
 
 
+def _pow2(n):
+    """capacity * 256 leaves must be a power of two (buffer.py:23)."""
+    return 1 << (int(n) - 1).bit_length()
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=1024, help="lock-step environments per GPU (per active level with the curriculum)")
@@ -86,7 +91,7 @@ def main(argv=None):
 
     seed = a.seed * 1000 + rank
     if fixed:
-        capacity = a.capacity or max(2048, 2 * a.envs)
+        capacity = a.capacity or _pow2(max(2048, 2 * a.envs))
         env = M.VecEnvironment(a.envs, map_len, n_agents, config.obs_radius, config.reward_fn, device=dev)
         maps, agents, goals, _ = M.generate_scenarios(a.envs, map_len, n_agents, -1.0, seed=seed)
         env.load(maps, agents, goals)
@@ -97,7 +102,7 @@ def main(argv=None):
 
         # at most max_num_agetns + (max_map - init_map)/5 levels are active together (one per anti-diagonal step)
         max_levels = config.max_num_agetns + (config.max_map_lenght - config.init_set[1]) // 5
-        capacity = a.capacity or max(2048, 2 * a.envs * max_levels)
+        capacity = a.capacity or _pow2(max(2048, 2 * a.envs * max_levels))
         buffer = GlobalBuffer(capacity, max_agents=config.max_num_agetns, device=dev, init_set=config.init_set,
                               max_map_length=config.max_map_lenght, pass_rate=config.pass_rate)
     learner = Learner(buffer, device=dev, batch_size=a.batch_size, save_path=config.save_path)
@@ -118,7 +123,7 @@ def main(argv=None):
         actor.step()
         now = time.time()
         # ---- decisions every rank must take identically (see module docstring): one MAX all-reduce of 3 flags ----
-        not_ready = int(len(buffer) < a.learning_starts)
+        not_ready = 0 if started else int(len(buffer) < a.learning_starts)  # (reads the device-side ring state)
         time_up = int(a.minutes > 0 and (now - t_start) > a.minutes * 60)
         stats_now = int(rank == 0 and now - t_last >= a.interval)
         if dist is not None:
@@ -135,7 +140,7 @@ def main(argv=None):
                 learner.update()
                 debt -= 1.0
         if stats_now:
-            pooled = buffer.levels.pooled_counts(flag_dev) if dist is not None else None
+            pooled = buffer.pooled_counts(flag_dev) if dist is not None else None
             with contextlib.nullcontext() if rank == 0 else contextlib.redirect_stdout(io.StringIO()):
                 # per-rank buffers keep their own counters; only rank 0 prints (its own speed, the pooled level statistics)
                 learner.stats(now - t_last)
