@@ -38,7 +38,7 @@ _TRAINING = {
     "grad_norm_dqn": 40,        # dead in the reference (40 is hard-coded in worker.py:319)
     "prioritized_replay_alpha": 0.6,
     "prioritized_replay_beta": 0.4,
-    "double_q": False,          # dead in the reference: double-Q is not implemented there (nor here)
+    "double_q": False,          # dead in the reference (worker.py:300-303 always takes max Q_target); here: opt-in double-DQN target (learner.py)
     "forward_steps": 2,
 }
 

@@ -1,6 +1,18 @@
-"""Autograd wrappers of the fused conv epilogues (include/mapf_dqn.h): y = relu(conv_out + bias (+ residual))
-in one in-place pass over a bf16 NHWC activation, with a one-pass backward (masked gradient + bias-gradient
-reduction).  Used by `Network.encode` on a HIP device under bf16 autocast."""
+"""Python side of the hand-written DQN kernels (C ABI: include/mapf_dqn.h; kernels: csrc/mapf_encoder.hip, mapf_wgrad.hip,
+mapf_wgrad0.hip, mapf_recur.hip, mapf_recur_bwd.hip, mapf_recur_wide.hip, mapf_recur_wide_bwd.hip, mapf_dqn.hip), used by
+`mapf_rl_amd.model.Network` on a HIP device under bf16 autocast:
+
+  * `PackedEncoder`, `encoder_forward`            the 8-layer observation encoder as ONE inference kernel (actor, target network);
+  * `encoder_forward_train` / `_EncoderTrain`     the same forward saving layer outputs + sign bits, the backward-data chain in one
+                                                  kernel, the weight-gradient kernels (3x3 layers, conv0) and the bias partials;
+  * `comm_mask`                                   reference model.py:195-208 (FOV square AND 3 nearest) + the replay's packed row;
+  * `PackedRecurrence`, `recurrent_infer`         GRU cell + 2 communication rounds for T steps in one launch, N <= 128 agents
+                                                  (<= 48: everything of an environment in LDS; 49..128: the wide kernels);
+  * `recurrent_train` / `_RecurTrain`             forward-with-saved-state + backward-through-time kernels with the tall
+                                                  weight-gradient GEMMs and bias column sums formed here;
+  * `bias_res_relu` / `_BiasResReLU`              fused bias + residual + ReLU epilogue of the layer-by-layer path (kept for
+                                                  fp32 / FUSED_TRAINING = False runs and as the comparison path of the tests).
+Nothing here falls back to a CPU implementation: without the HIP library the import of `._lib` fails."""
 import ctypes
 
 import torch

@@ -3,7 +3,7 @@ an optional data-parallel gradient all-reduce across the GPUs of a node.
 
 One `update()` = worker.py:287-338: sample a prioritized batch of [B, 18, A] windows from the device replay,
 target = r + 0.99^steps * (1 - done) * max_a Q_target(window, bt+steps)  (1-step reward even when steps = 2:
-quirk Q2; no double-Q: quirk Q6), Huber(kappa=1) loss weighted by the IS weights, Adam(1e-4) with
+quirk Q2; no double-Q: quirk Q6 -- `Learner(double_q=True)` is an opt-in, see __init__), Huber(kappa=1) loss weighted by the IS weights, Adam(1e-4) with
 MultiStepLR(100k, 300k, x0.5), global grad-norm clip 40, new priorities |td| back into the sum tree, target
 sync + checkpoint every 2500 updates.
 
@@ -77,7 +77,7 @@ class FlatGradBucket:
 
 class Learner:
     def __init__(self, buffer=None, device=None, batch_size=192, lr=1e-4, milestones=(100000, 300000), save_path="./models",
-                 model=None, prefetch=True):
+                 model=None, prefetch=True, double_q=False):
         self.device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
         self.model = (model if model is not None else Network()).to(self.device)
         self.tar_model = deepcopy(self.model)
@@ -87,6 +87,10 @@ class Learner:
         self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=list(milestones), gamma=0.5)  # :261
         self.bucket = FlatGradBucket(self.model.parameters())
         self.buffer, self.batch_size, self.save_path = buffer, batch_size, save_path
+        # config.double_q (config.py:46) is dead in the reference (quirk Q6: worker.py:300-303 always takes max_a Q_target).
+        # Opt-in here for BASELINE config 5 ("prioritized replay + double-DQN"): the ONLINE network picks the action, the
+        # TARGET network values it (van Hasselt et al.); off by default = the reference's update.
+        self.double_q = bool(double_q)
         self.counter = self.last_counter = 0
         self.loss = 0.0
         self.done = False
@@ -106,7 +110,11 @@ class Learner:
         b_obs, _, _, b_done, b_steps, b_bt_steps, b_hidden, b_comm_mask = batch[:8]
         b_next_bt_steps = b_bt_steps + b_steps.view(-1).to(b_bt_steps.dtype)
         with torch.no_grad():
-            return (1 - b_done) * self.tar_model.bootstrap(b_obs, b_next_bt_steps, b_hidden, b_comm_mask).max(1, keepdim=True)[0]
+            q_tar = self.tar_model.bootstrap(b_obs, b_next_bt_steps, b_hidden, b_comm_mask)
+            if self.double_q:
+                pick = self.model.bootstrap(b_obs, b_next_bt_steps, b_hidden, b_comm_mask).argmax(1, keepdim=True)
+                return (1 - b_done) * q_tar.gather(1, pick)
+            return (1 - b_done) * q_tar.max(1, keepdim=True)[0]
 
     def compute_td(self, batch, q_next=None):
         """worker.py:296-306 on an 11-tuple from GlobalBuffer.sample_batch. Returns (td_error [B,1], q [B,1], q_next [B,1])."""

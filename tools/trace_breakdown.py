@@ -12,8 +12,9 @@ from collections import defaultdict
 def category(n):
     if "igemm" in n or "SubTensorOp" in n or "naive_conv" in n or "kernel_grouped_conv" in n or "batched_gemm_xdlops_bwd_weight" in n:
         return "miopen conv"
-    for k in ("bias_res_relu", "encoder_fwd_kernel", "encoder_bwd_kernel", "encoder_pack", "env_step_kernel", "comm_mask_kernel",
-              "gather_kernel", "tree_", "reset_kernel", "navi_bfs"):
+    for k in ("bias_res_relu", "encoder_fwd_kernel", "encoder_bwd_kernel", "encoder_wgrad_kernel", "conv0_wgrad_kernel", "encoder_pack",
+              "env_step_kernel", "comm_mask_kernel", "gather_kernel", "tree_", "reset_kernel", "navi_bfs", "recurrent_wide_bwd_kernel",
+              "recurrent_wide_kernel", "recurrent_bwd_kernel", "recurrent_infer_kernel", "flush_"):
         if k in n:
             return "hip: " + k
     if "Cijk" in n:

@@ -60,6 +60,8 @@ def main(argv=None):
     ap.add_argument("--learning-starts", type=int, default=config.learning_starts)
     ap.add_argument("--batch-size", type=int, default=config.batch_size)
     ap.add_argument("--dist-backend", default="nccl", help="nccl = RCCL; gloo only for the CPU-side multi-rank tests")
+    ap.add_argument("--double-q", action="store_true", default=bool(getattr(config, "double_q", False)),
+                    help="double-DQN target (online argmax, target value); config.double_q is dead in the reference (worker.py:300-303)")
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args(argv)
     fixed = a.agents is not None or a.map is not None
@@ -105,7 +107,7 @@ def main(argv=None):
         capacity = a.capacity or _pow2(max(2048, 2 * a.envs * max_levels))
         buffer = GlobalBuffer(capacity, max_agents=config.max_num_agetns, device=dev, init_set=config.init_set,
                               max_map_length=config.max_map_lenght, pass_rate=config.pass_rate)
-    learner = Learner(buffer, device=dev, batch_size=a.batch_size, save_path=config.save_path)
+    learner = Learner(buffer, device=dev, batch_size=a.batch_size, save_path=config.save_path, double_q=a.double_q)
     if world > 1:  # identical initial weights on every rank
         for p in learner.model.parameters():
             dist.broadcast(p.data, src=0)
