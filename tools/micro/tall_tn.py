@@ -27,3 +27,14 @@ for K in (122880, 245760, 393216, 786432):
             err = float((out - ref).abs().max() / ref.abs().max())
             line += "  rows %5d: %.3f ms (%.0f TF, d %.1e)" % (rows, dt * 1e3, 2.0 * K * m * n / dt / 1e12, err)
         print(line, flush=True)
+import torch.nn.functional as F
+for R in (122880, 393216):
+    dy = torch.randn((R, 768), device="cuda", dtype=torch.bfloat16) * 0.1
+    x = torch.randn((R, 784), device="cuda", dtype=torch.bfloat16) * 0.1
+    w = torch.randn((768, 784), device="cuda", dtype=torch.bfloat16) * 0.1
+    wt = w.t().contiguous()
+    for name, fn in (("fwd  x W^T          ", lambda: F.linear(x, w)), ("dx   dy (W^T)^T [TN]", lambda: F.linear(dy, wt)), ("dx   dy W      [NN]", lambda: torch.mm(dy, w))):
+        fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5): fn()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+        print("R=%d %s %.3f ms (%.0f TF)" % (R, name, dt * 1e3, 2.0 * R * 768 * 784 / dt / 1e12), flush=True)

@@ -19,6 +19,14 @@ maps, agents, goals, _ = M.generate_scenarios(E, 32, N, 0.3, seed=1)
 env = M.VecEnvironment(E, 32, N)
 env.load(maps, agents, goals)
 actor = VecActor(env, model, None, seed=0, density=0.3)
-for _ in range(int(os.environ.get("TACT", 6))):
-    actor.step()
+import time
+n = int(os.environ.get("TACT", 6))
+actor.step()
 torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+    actor.step()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("actor loop: %.3f ms per iteration (host enqueue %.3f ms per iteration), %d iterations" % ((t2 - t0) / n * 1e3, (t1 - t0) / n * 1e3, n))
