@@ -96,6 +96,32 @@ int mapf_replay_add_many(mapf_replay_t *r, int num_envs, int num_agents, int loc
                          const uint16_t *hid_dev, const float *q_dev, void *stream);
 
 /*
+ * Per-step bookkeeping of a vectorised actor (reference worker.py:376-414 for E lock-step environments; csrc/mapf_actor.hip).
+ * Local buffers as in mapf_replay_add_many (S = local_steps transitions per environment, A = max_agents, CW = (A+31)/32,
+ * RDA = row_dwords of the replay, RD = env_row_dwords of the environment handle, RD <= RDA).
+ *
+ * mapf_actor_record = LocalBuffer.add (buffer.py:140-151; agent 0's q / action / reward / hidden: quirk Q7) at row t_dev[e], then
+ *   t_dev[e] += 1, finished[e] = done[e] | (t_dev[e] >= S) (worker.py:390), and for finished environments the comm row behind
+ *   the last transition: zeros after `done`, this step's mask on a time-out (quirk Q8, worker.py:399).
+ *   q f32 [E][N][5], actions int64 [E][N], reward f32 [E][N], hidden bf16 [E][N][256], comm int32 [E][N][CW] (packed, as
+ *   mapf_comm_mask writes it with cw = CW), obs_bits int32 [E][RD] (observation after the step), done u8 [E].
+ * mapf_actor_rewind = Actor.reset's local part (worker.py:422-428) for finished environments, called behind the replay append, the
+ *   scenario reset and the observation of the fresh scenario: row 0 <- that observation, t <- 0, hidden rows <- 0.
+ * mapf_actor_log: counters_dev int64 {episodes, logged}: episodes += finished; the `done` flags of finished environments with
+ *   stat_mask[e] != 0 (actor id >= 10, worker.py:74) are appended in environment order to the ring log_dev[log_size].
+ */
+int mapf_actor_record(int num_envs, int num_agents, int local_steps, int env_row_dwords, int row_dwords, int max_agents,
+                      const float *q_dev, const int64_t *actions_dev, const float *reward_dev, const uint16_t *hidden_dev,
+                      const int32_t *comm_dev, const int32_t *obs_bits_dev, const uint8_t *done_dev, int64_t *t_dev,
+                      float *lb_q_dev, uint8_t *lb_act_dev, uint16_t *lb_rew_dev, uint16_t *lb_hid_dev, int32_t *lb_comm_dev,
+                      int32_t *lb_obs_dev, uint8_t *finished_dev, void *stream);
+int mapf_actor_rewind(int num_envs, int num_agents, int local_steps, int env_row_dwords, int row_dwords,
+                      const uint8_t *finished_dev, const int32_t *obs_bits_dev, int64_t *t_dev, int32_t *lb_obs_dev,
+                      uint16_t *hidden_dev, void *stream);
+int mapf_actor_log(int num_envs, const uint8_t *finished_dev, const uint8_t *done_dev, const uint8_t *stat_mask_dev,
+                   uint8_t *log_dev, int log_size, int64_t *counters_dev, void *stream);
+
+/*
  * GlobalBuffer.sample_batch (worker.py:106-184) minus the IS weights (a reduction the caller does on
  * pri_dev): tree sample + window gather.  Outputs (device):
  *   idx int64 [n], pri f64 [n], obs bf16 [18][n][A][6][9][9], comm u8 [18][n][A][A] (TIME-major: the consumer is a

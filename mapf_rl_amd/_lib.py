@@ -53,6 +53,9 @@ SYMBOLS = [
     ("mapf_replay_tree_read", _i, [_vp, _vp, _vp]),
     ("mapf_replay_add", _i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_replay_add_many", _i, [_vp, _i, _i, _i] + [_vp] * 10),
+    ("mapf_actor_record", _i, [_i] * 6 + [_vp] * 16),
+    ("mapf_actor_rewind", _i, [_i] * 5 + [_vp] * 6),
+    ("mapf_actor_log", _i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     ("mapf_replay_sample", _i, [_vp, _vp, _i, _i] + [_vp] * 12),
     ("mapf_replay_update_priorities", _i, [_vp, _vp, _vp, _i, _vp, _vp]),
     # include/mapf_dqn.h

@@ -25,7 +25,16 @@ import numpy as np
 import torch
 
 from . import environment as _envmod
+from ._lib import check, lib
 from .environment import VecEnvironment, generate_scenarios
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 MAX_STEPS = 256      # config.max_steps
 FORWARD_GAMMA = 0.99
@@ -77,10 +86,10 @@ class VecActor:
         self.ar = torch.arange(E, device=d)
         self.hidden = None
         self.env_steps = 0
-        self._episodes = torch.zeros((), dtype=torch.int64, device=d)
-        self.stat_mask = torch.tensor([a >= 10 for a in self.actor_ids], dtype=torch.bool, device=d)
-        self.stat_log = torch.zeros(self.STAT_LOG + 1, dtype=torch.uint8, device=d)  # + 1: dump slot of the scatter
-        self.stat_n = torch.zeros((), dtype=torch.int64, device=d)
+        self.finished = torch.zeros(E, dtype=torch.uint8, device=d)
+        self.counters = torch.zeros(2, dtype=torch.int64, device=d)  # {episodes finished, outcomes logged}
+        self.stat_mask = torch.tensor([a >= 10 for a in self.actor_ids], dtype=torch.uint8, device=d)
+        self.stat_log = torch.zeros(self.STAT_LOG, dtype=torch.uint8, device=d)
         self._stat_read = 0
         if buffer is not None:
             buffer.register_actor(self)
@@ -117,20 +126,21 @@ class VecActor:
             actions = torch.as_tensor(actions_override).to(d, torch.int64).view(E, N)
         act8 = actions.to(torch.int8).contiguous()
         obs, pos, reward, done, _ = self.env.step(act8, obs_bits_out=self.bits)
-        # worker.py:388 -> buffer.py:140-151
-        t = self.t
-        self.lb_q[self.ar, t] = q[:, 0]
-        self.lb_act[self.ar, t] = actions[:, 0].to(torch.uint8)
-        self.lb_rew[self.ar, t] = reward[:, 0].to(torch.float16)
-        self.lb_hid[self.ar, t] = hidden.view(E, N, 256)[:, 0].to(torch.float16)
-        self.lb_comm[self.ar, t, :N] = comm_packed if comm_packed is not None else pack_comm_device(comm, self.CW)
-        self.lb_obs[self.ar, t + 1, :self.RD] = self.bits
-        self.t = t + 1
+        if comm_packed is None:
+            comm_packed = pack_comm_device(comm, self.CW)
+        assert hidden.dtype == torch.bfloat16 and hidden.is_contiguous() and q.is_contiguous() and q.dtype == torch.float32
+        actions = actions.contiguous()
+        # worker.py:388 -> buffer.py:140-151, the episode-end test (worker.py:390) and the last comm row of finished episodes
+        # (Q8): one launch (csrc/mapf_actor.hip); self.t becomes the episode length so far, self.finished the end-of-episode mask
+        st = _stream(d)
+        check(lib.mapf_actor_record(E, N, self.max_steps, self.RD, self.RDA, self.A, _ptr(q), _ptr(actions), _ptr(reward), _ptr(hidden),
+                                    _ptr(comm_packed), _ptr(self.bits), _ptr(done), _ptr(self.t), _ptr(self.lb_q), _ptr(self.lb_act),
+                                    _ptr(self.lb_rew), _ptr(self.lb_hid), _ptr(self.lb_comm), _ptr(self.lb_obs), _ptr(self.finished), st),
+              "mapf_actor_record")
         self.hidden = hidden
-        self.obs, self.pos = obs, pos
         self.env_steps += E
-        finished = (done != 0) | (self.t >= self.max_steps)   # worker.py:390
-        self._flush(finished, done != 0)
+        finished = self.finished.bool()
+        self._flush(finished, done)
         return finished
 
     # ------------------------------------------------------------------ episode end
@@ -152,47 +162,38 @@ class VecActor:
             td = torch.cat([td, torch.zeros((td.shape[0], 256 - S), dtype=td.dtype, device=td.device)], dim=1)
         return td.contiguous()
 
-    def _flush(self, finished, dn):
-        """finished / dn: bool [E] device masks (episode over; all agents on their goals)."""
-        E, N = self.E, self.N
+    def _flush(self, finished, done):
+        """finished: bool [E] device mask (episode over); done: u8 [E] (all agents on their goals).  Nothing here reads the
+        device: every launch is unconditional and returns at once for environments that are still running."""
+        E, N, d = self.E, self.N, self.device
         sizes = self.t
-        # last comm row of a finished episode: zeros when done (np.zeros init, buffer.py:124), the stale-observation mask on
-        # time-out (Q8); environments still running rewrite their (not yet recorded) row `t` with itself
-        prev = self.lb_comm[self.ar, (sizes - 1).clamp(min=0)]
-        cur = self.lb_comm[self.ar, sizes]
-        last = torch.where(dn.view(E, 1, 1), torch.zeros_like(prev), prev)
-        self.lb_comm[self.ar, sizes] = torch.where(finished.view(E, 1, 1), last, cur)
+        st = _stream(d)
         if self.keep_flushed:  # tests: host-side copies of every finished episode (synchronises)
             ids = finished.nonzero().view(-1)
             td = self._finish_priorities(ids, sizes[ids])
             for k, e in enumerate(ids.tolist()):
                 size = int(sizes[e])
-                self.flushed.append(dict(env=e, size=size, done=bool(dn[e]), obs=self.lb_obs[e, :size + 1].clone(),
+                self.flushed.append(dict(env=e, size=size, done=bool(done[e]), obs=self.lb_obs[e, :size + 1].clone(),
                                          comm=self.lb_comm[e, :size + 1].clone(), act=self.lb_act[e, :size].clone(),
                                          rew=self.lb_rew[e, :size].clone(), hid=self.lb_hid[e, :size].clone(),
                                          q=self.lb_q[e, :size].clone(), td=td[k].clone()))
         if self.buffer is not None:
-            self.buffer.add_finished(N, finished, sizes, dn, self.lb_obs, self.lb_comm, self.lb_act, self.lb_rew, self.lb_hid, self.lb_q)
-            # curriculum statistics (worker.py:74-82: actors with id >= 10): outcomes in episode order into the device log
-            m = finished & self.stat_mask
-            pos = self.stat_n + torch.cumsum(m, 0) - 1
-            self.stat_log.scatter_(0, torch.where(m, pos % self.STAT_LOG, self.STAT_LOG), dn.to(torch.uint8))
-            self.stat_n += m.sum()
-        self._episodes += finished.sum()
+            self.buffer.add_finished(N, self.finished, sizes, done, self.lb_obs, self.lb_comm, self.lb_act, self.lb_rew, self.lb_hid, self.lb_q)
+        # episode counter + curriculum outcomes (worker.py:74-82: actors with id >= 10) in episode order into the device log
+        check(lib.mapf_actor_log(E, _ptr(self.finished), _ptr(done), _ptr(self.stat_mask), _ptr(self.stat_log), self.STAT_LOG,
+                                 _ptr(self.counters), st), "mapf_actor_log")
         # Actor.reset (worker.py:422-428): fresh scenario, recurrent state cleared
         self.scenario_seed += 1
         if self.on_device_reset:   # mapf_reset_envs: generation + placement + navi in one launch, only where the mask is set
-            self.env.reset_envs(finished.to(torch.uint8), self.density, self.scenario_seed)
+            self.env.reset_envs(self.finished, self.density, self.scenario_seed)
         else:                      # host generator + partial load (synchronises)
             ids_h = finished.nonzero().view(-1).tolist()
             if ids_h:
                 maps, agents, goals, _ = generate_scenarios(len(ids_h), self.env.map_length, N, self.density, self.scenario_seed)
                 self.env.load_envs(ids_h, maps, agents, goals)
         self.obs, self.pos = self.env.observe(obs_bits_out=self.bits)
-        fin1 = finished.view(E, 1)
-        self.lb_obs[:, 0, :self.RD] = torch.where(fin1, self.bits, self.lb_obs[:, 0, :self.RD])
-        self.t = torch.where(finished, torch.zeros_like(self.t), self.t)
-        self.hidden.view(E, N, 256).mul_((~finished).view(E, 1, 1))      # model.reset(): GRUCell(x, None) == zero state
+        check(lib.mapf_actor_rewind(E, N, self.max_steps, self.RD, self.RDA, _ptr(self.finished), _ptr(self.bits), _ptr(self.t),
+                                    _ptr(self.lb_obs), _ptr(self.hidden), st), "mapf_actor_rewind")
 
     STAT_LOG = 4096  # outcomes kept between two reads (a level's window is the last 200)
 
@@ -201,10 +202,10 @@ class VecActor:
         (worker.py:74-82).  Reads the device log: synchronises; called when statistics are asked for."""
         if self.buffer is None:
             return 0
-        n = int(self.stat_n)
+        n = int(self.counters[1])
         k = min(n - self._stat_read, self.STAT_LOG)
         if k > 0:
-            log = self.stat_log[:self.STAT_LOG].cpu().numpy()
+            log = self.stat_log.cpu().numpy()
             key = (self.N, self.env.map_length)
             for i in range(n - k, n):
                 self.buffer.levels.record(key, bool(log[i % self.STAT_LOG]))
@@ -213,7 +214,7 @@ class VecActor:
 
     @property
     def episodes(self):
-        return int(self._episodes)
+        return int(self.counters[0])
 
     def run(self, num_iterations):
         for _ in range(num_iterations):

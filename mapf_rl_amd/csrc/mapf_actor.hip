@@ -1,0 +1,160 @@
+// mapf_actor.hip -- per-step bookkeeping of the vectorised actor loop (reference worker.py:376-414 for E lock-step environments):
+// LocalBuffer.add (buffer.py:140-151), the episode-end test (worker.py:390), LocalBuffer.finish's last comm row (buffer.py:153-160,
+// quirk Q8) and, behind the replay append + scenario reset, Actor.reset's rewind (worker.py:422-428).  As separate PyTorch
+// index / select operations this was ~25 tiny launches per step (0.5 ms of an 11 ms iteration at config 2, most of the iteration for
+// the curriculum's first levels); here it is two launches, one block per environment.  See include/mapf_replay.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+
+#include "mapf_env.h"
+#include "mapf_replay.h"
+
+namespace {
+
+struct RecordParams {
+    int E, N, S, RD, RDA, A, CW;
+    const float *q;           // [E][N][5]   Q-values of the step (agent 0's row is recorded: quirk Q7)
+    const int64_t *actions;   // [E][N]      executed joint action
+    const float *reward;      // [E][N]
+    const uint16_t *hidden;   // [E][N][256] bf16 post-communication hidden state
+    const int32_t *comm;      // [E][N][CW]  packed comm mask of the step
+    const int32_t *bits;      // [E][RD]     bit-packed observation AFTER the step
+    const uint8_t *done;      // [E]
+    int64_t *t;               // [E] in: transitions recorded so far; out: + 1
+    float *lb_q;              // [E][S][5]
+    uint8_t *lb_act;          // [E][S]
+    uint16_t *lb_rew;         // [E][S] f16
+    uint16_t *lb_hid;         // [E][S][256] f16
+    int32_t *lb_comm;         // [E][S+1][A][CW]
+    int32_t *lb_obs;          // [E][S+1][RDA]
+    uint8_t *finished;        // [E] out
+};
+
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+
+__global__ void __launch_bounds__(256) actor_record_kernel(RecordParams p) {
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const long long t = p.t[e];
+    const size_t tr = (size_t)e * p.S + t;
+    // worker.py:388 -> buffer.py:140-151 (agent 0's q / action / reward / hidden; the joint comm mask; the next observation)
+    p.lb_hid[tr * 256 + tid] = f32_to_f16_bits(bf16_to_f32(p.hidden[(size_t)e * p.N * 256 + tid]));
+    if (tid < 5) p.lb_q[tr * 5 + tid] = p.q[(size_t)e * p.N * 5 + tid];
+    const bool dn = p.done[e] != 0;
+    const bool fin = dn || (t + 1 >= p.S);  // worker.py:390
+    if (tid == 0) {
+        p.lb_act[tr] = (uint8_t)p.actions[(size_t)e * p.N];
+        p.lb_rew[tr] = f32_to_f16_bits(p.reward[(size_t)e * p.N]);
+        p.t[e] = t + 1;
+        p.finished[e] = fin ? 1 : 0;
+    }
+    const int crow = p.A * p.CW;
+    int32_t *c_now = p.lb_comm + ((size_t)e * (p.S + 1) + t) * crow, *c_last = c_now + crow;
+    const int32_t *cs = p.comm + (size_t)e * p.N * p.CW;
+    for (int i = tid; i < p.N * p.CW; i += 256) {
+        const int32_t v = cs[i];
+        c_now[i] = v;
+        // the row behind a finished episode's last transition: zeros after `done` (buffer.py:124), the mask of the stale
+        // observation on a time-out (quirk Q8, worker.py:399: same positions as this step's, hence this row again)
+        if (fin) c_last[i] = dn ? 0 : v;
+    }
+    int32_t *o = p.lb_obs + ((size_t)e * (p.S + 1) + t + 1) * p.RDA;
+    const int32_t *b = p.bits + (size_t)e * p.RD;
+    for (int i = tid; i < p.RD; i += 256) o[i] = b[i];
+}
+
+struct RewindParams {
+    int E, N, S, RD, RDA;
+    const uint8_t *finished;  // [E]
+    const int32_t *bits;      // [E][RD] observation of the freshly reset scenario
+    int64_t *t;               // [E]
+    int32_t *lb_obs;          // [E][S+1][RDA]
+    uint16_t *hidden;         // [E][N][256] bf16
+};
+
+__global__ void __launch_bounds__(256) actor_rewind_kernel(RewindParams p) {
+    const int e = blockIdx.x, tid = threadIdx.x;
+    if (p.finished[e] == 0) return;
+    if (tid == 0) p.t[e] = 0;
+    int32_t *o = p.lb_obs + (size_t)e * (p.S + 1) * p.RDA;
+    const int32_t *b = p.bits + (size_t)e * p.RD;
+    for (int i = tid; i < p.RD; i += 256) o[i] = b[i];
+    uint4 *h = reinterpret_cast<uint4 *>(p.hidden + (size_t)e * p.N * 256);  // model.reset(): GRUCell(x, None) == zero state
+    for (int i = tid; i < p.N * 32; i += 256) h[i] = make_uint4(0, 0, 0, 0);
+}
+
+// episode counter + outcomes of the statistics-bearing environments (actor id >= 10, worker.py:74) in environment order into a
+// ring log of `log_size` entries (+ 1 dump slot); one block
+__global__ void __launch_bounds__(1024) actor_log_kernel(int E, const uint8_t *finished, const uint8_t *done, const uint8_t *stat_mask,
+                                                        uint8_t *log, int log_size, int64_t *counters /* {episodes, logged} */) {
+    __shared__ int s_cnt[1024], s_fin[1024];
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int per = (E + nth - 1) / nth, e0 = tid * per, e1 = min(E, e0 + per);
+    int cnt = 0, fin = 0;
+    for (int e = e0; e < e1; ++e) {
+        fin += finished[e] != 0;
+        cnt += (finished[e] != 0 && stat_mask[e] != 0);
+    }
+    s_cnt[tid] = cnt;
+    s_fin[tid] = fin;
+    __syncthreads();
+    for (int d = 1; d < nth; d <<= 1) {
+        const int v = tid >= d ? s_cnt[tid - d] : 0, f = tid >= d ? s_fin[tid - d] : 0;
+        __syncthreads();
+        s_cnt[tid] += v;
+        s_fin[tid] += f;
+        __syncthreads();
+    }
+    const long long base = counters[1];
+    long long pos = base + s_cnt[tid] - cnt;
+    for (int e = e0; e < e1; ++e)
+        if (finished[e] != 0 && stat_mask[e] != 0) log[(pos++) % log_size] = done[e] != 0;
+    __syncthreads();
+    if (tid == 0) {
+        counters[0] += s_fin[nth - 1];
+        counters[1] = base + s_cnt[nth - 1];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mapf_actor_record(int num_envs, int num_agents, int local_steps, int env_row_dwords, int row_dwords, int max_agents, const float *q_dev,
+                      const int64_t *actions_dev, const float *reward_dev, const uint16_t *hidden_dev, const int32_t *comm_dev,
+                      const int32_t *obs_bits_dev, const uint8_t *done_dev, int64_t *t_dev, float *lb_q_dev, uint8_t *lb_act_dev,
+                      uint16_t *lb_rew_dev, uint16_t *lb_hid_dev, int32_t *lb_comm_dev, int32_t *lb_obs_dev, uint8_t *finished_dev, void *stream) {
+    if (num_envs < 1 || num_agents < 1 || max_agents < num_agents || local_steps < 1 || local_steps > MAPF_REPLAY_MAX_STEPS ||
+        env_row_dwords < 1 || row_dwords < env_row_dwords)
+        return MAPF_ERR_INVALID_ARG;
+    if (!q_dev || !actions_dev || !reward_dev || !hidden_dev || !comm_dev || !obs_bits_dev || !done_dev || !t_dev || !lb_q_dev || !lb_act_dev ||
+        !lb_rew_dev || !lb_hid_dev || !lb_comm_dev || !lb_obs_dev || !finished_dev)
+        return MAPF_ERR_INVALID_ARG;
+    RecordParams p{num_envs, num_agents, local_steps, env_row_dwords, row_dwords, max_agents, (max_agents + 31) / 32, q_dev, actions_dev, reward_dev,
+                   hidden_dev, comm_dev, obs_bits_dev, done_dev, t_dev, lb_q_dev, lb_act_dev, lb_rew_dev, lb_hid_dev, lb_comm_dev, lb_obs_dev,
+                   finished_dev};
+    hipLaunchKernelGGL(actor_record_kernel, dim3(num_envs), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
+}
+
+int mapf_actor_rewind(int num_envs, int num_agents, int local_steps, int env_row_dwords, int row_dwords, const uint8_t *finished_dev,
+                      const int32_t *obs_bits_dev, int64_t *t_dev, int32_t *lb_obs_dev, uint16_t *hidden_dev, void *stream) {
+    if (num_envs < 1 || num_agents < 1 || local_steps < 1 || env_row_dwords < 1 || row_dwords < env_row_dwords || !finished_dev || !obs_bits_dev ||
+        !t_dev || !lb_obs_dev || !hidden_dev || (reinterpret_cast<uintptr_t>(hidden_dev) & 15))
+        return MAPF_ERR_INVALID_ARG;
+    RewindParams p{num_envs, num_agents, local_steps, env_row_dwords, row_dwords, finished_dev, obs_bits_dev, t_dev, lb_obs_dev, hidden_dev};
+    hipLaunchKernelGGL(actor_rewind_kernel, dim3(num_envs), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
+}
+
+int mapf_actor_log(int num_envs, const uint8_t *finished_dev, const uint8_t *done_dev, const uint8_t *stat_mask_dev, uint8_t *log_dev,
+                   int log_size, int64_t *counters_dev, void *stream) {
+    if (num_envs < 1 || log_size < 1 || !finished_dev || !done_dev || !stat_mask_dev || !log_dev || !counters_dev) return MAPF_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(actor_log_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), num_envs, finished_dev, done_dev, stat_mask_dev,
+                       log_dev, log_size, counters_dev);
+    return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
+}
+
+}  // extern "C"
