@@ -192,6 +192,12 @@ def main():
     agents_dev = torch.from_numpy(agents).to(dev)
 
     # ---- timed replay ----
+    # (two untimed passes over the whole tape first: the recording pass above ran interleaved with the policy's own kernels, and a
+    # profile of this command should be dominated by launches in the regime the timed region measures)
+    for _ in range(2):
+        env.set_agents(agents_dev)
+        for t in range(T):
+            env.step(tape[t])
     env.set_agents(agents_dev)
     for t in range(W):
         env.step(tape[t])

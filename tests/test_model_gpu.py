@@ -137,6 +137,7 @@ def test_fused_recurrence_kernel_matches_module_path(E, N, T):
     comm |= torch.eye(N, dtype=torch.bool, device="cuda")
     if N > 2:
         comm[0, :, 1] = torch.eye(N, dtype=torch.bool, device="cuda")[1]   # an agent without partners keeps its state
+    comm[-1, -1] = False   # a zero-padded window row (worker.py:139-142): every mask row all-False, nobody is updated
     hidden = (torch.randn((E * N, 256), device="cuda", generator=g) * 0.3).to(torch.bfloat16)
     steps = torch.randint(1, T + 1, (E,), device="cuda", generator=g)
     pos = torch.zeros((E, N, 2), dtype=torch.int16, device="cuda")
@@ -178,6 +179,10 @@ def test_bptt_kernels_match_pytorch_recurrence(B, T, N):
     comm |= torch.eye(N, dtype=torch.bool, device="cuda")
     if N > 2:
         comm[0, :, 1] = torch.eye(N, dtype=torch.bool, device="cuda")[1]
+    comm[-1, -1] = False   # a zero-padded window row: all-False mask rows must neither produce NaN (SDPA path) nor gradients
+    if N > 3:
+        comm[-1, :, 2] = False   # a padded agent (smaller curriculum level): its mask row is all-False at every step
+    steps[-1] = T
     r = torch.randn((B, 5), device="cuda", generator=g)
     res = {}
     for fused in (True, False):

@@ -55,7 +55,7 @@ def main():
         print("\n| # in iteration | us | grid | kernel |\n|---|---|---|---|")
         for i in sorted(big):
             r = sel[i]
-            print("| %d | %.1f | %s | %s |" % (i, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Grid_Size", "?"),
+            print("| %d | %.1f | %s | %s |" % (i, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, "x".join(r.get(k, "?") for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z")),
                                              r["Kernel_Name"][:110]))
 
 
