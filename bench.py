@@ -83,21 +83,32 @@ def launch_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, cwd=os.getcwd()))
-    out0 = procs[0].stdout.read().decode()
-    rcs = []
+    # rank 0's stdout is collected by a reader thread; the ranks are polled so that one failing rank ends the others
+    # (they would otherwise wait for it at the next collective until the driver's timeout)
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     deadline = time.time() + 1800
-    for p in procs:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(-9)
-    if any(rc != 0 for rc in rcs):
-        log("bench.py: rank exit codes %s" % rcs)
-        sys.stdout.write(out0)
-        return 1
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs) or time.time() > deadline:
+            failed = True
+            time.sleep(2.0)  # let a rank that is already failing print its traceback
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()  # exactly the children started above
+            break
+        time.sleep(0.2)
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    out0 = b"".join(chunks).decode()
     sys.stdout.write(out0)
     sys.stdout.flush()
+    if failed or any(rc != 0 for rc in rcs):
+        log("bench.py: rank exit codes %s" % rcs)
+        return 1
     return 0
 
 

@@ -100,6 +100,9 @@ class Learner:
         # backward runs its low-occupancy tail (192-workgroup recurrence kernels, split-K GEMMs, reductions, optimizer).
         # Same numbers as the sequential order: priorities are written before the sample, and the step that syncs the target
         # network does not prefetch.
+        # (Measured, tools/learner_modes.py: 39.5 ms per update without prefetch, 38.7 with it; sampling one update EARLIER and
+        # running the update on a high-priority stream -- so that the target forward would only fill idle CUs -- gave 39.7: the chip
+        # is saturated by the update's own kernels, the update is ~39.5 ms of work whichever way it is ordered.)
         self.prefetch = bool(prefetch) and buffer is not None and self.device.type == "cuda"
         self._side = torch.cuda.Stream(device=self.device) if self.prefetch else None
         self._pre = None
@@ -127,6 +130,23 @@ class Learner:
 
     def update(self, batch=None):
         """One Learner.train iteration (worker.py:287-338).  `batch` defaults to a fresh prioritized sample."""
+        return self._update(batch)
+
+    def _launch_prefetch(self):
+        cur = torch.cuda.current_stream(self.device)
+        nxt = self.buffer.sample_batch(self.batch_size)
+        self._side.wait_stream(cur)
+        for t in nxt:  # allocated on this stream, read on the side stream: keep the allocator from reusing them early
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(self._side)
+        with torch.cuda.stream(self._side):
+            qn = self.target_q(nxt)
+            ready = torch.cuda.Event()
+            ready.record(self._side)
+        qn.record_stream(cur)  # allocated on the side stream, consumed on this one
+        self._pre = (nxt, qn, ready)
+
+    def _update(self, batch=None):
         own_batch = batch is None
         q_next = None
         if own_batch and self._pre is not None:
@@ -142,18 +162,7 @@ class Learner:
         if self.buffer is not None and idxes is not None:
             self.buffer.update_priorities(idxes, priorities, old_ptr)                            # worker.py:331 (values known here)
         if self.prefetch and own_batch and (self.counter + 1) % TARGET_SYNC != 0:
-            cur = torch.cuda.current_stream(self.device)
-            nxt = self.buffer.sample_batch(self.batch_size)
-            self._side.wait_stream(cur)
-            for t in nxt:  # allocated on this stream, read on the side stream: keep the allocator from reusing them early
-                if torch.is_tensor(t) and t.is_cuda:
-                    t.record_stream(self._side)
-            with torch.cuda.stream(self._side):
-                qn = self.target_q(nxt)
-                ready = torch.cuda.Event()
-                ready.record(self._side)
-            qn.record_stream(cur)  # allocated on the side stream, consumed on this one
-            self._pre = (nxt, qn, ready)
+            self._launch_prefetch()
         self.bucket.zero()
         loss.backward()
         self.bucket.all_reduce_mean()                                                            # the only collective
