@@ -93,16 +93,6 @@ int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint32_
 int mapf_encoder_wgrad0(const uint16_t *gz0_dev, const void *obs_dev, int obs_dtype, int64_t M, float *partial_dev, void *stream);
 
 /*
- * Weight gradient of the 1x1 head convolution (128 -> 16; csrc/mapf_wgrad7.hip):
- *   partial_dev f32 [MAPF_ENC_WGRAD7_PARTS][16][128]: per-workgroup partial sums of
- *   dW7[co][ci] = sum_{m, position} gz7[m][position][co] * in[m][position][ci];
- *   gz7_dev bf16 [M][49][16] = mapf_encoder_backward's gz7 output, in_dev bf16 [M][49][128] = the head's input (layer 6 of
- *   mapf_encoder_forward_save's acts).  The caller adds the partitions (deterministic); [co][ci] is the weight's own order.
- */
-#define MAPF_ENC_WGRAD7_PARTS 1024
-int mapf_encoder_wgrad7(const uint16_t *gz7_dev, const uint16_t *in_dev, int64_t M, float *partial_dev, void *stream);
-
-/*
  * The same chain, starting one step earlier: `g_latent_dev` is the gradient w.r.t. the encoder's OUTPUT (bf16 [M][784],
  * the forward's flattened NCHW order: channel * 49 + position) and `latent_dev` that output; the kernel applies the 1x1
  * layer's ReLU mask itself while staging (three elementwise passes and a reduction less for the caller) and also writes

@@ -70,7 +70,6 @@ ENC_BIAS_ELEMS = 912
 ENC_PACKED_BWD_ELEMS = 888832
 ENC_WGRAD0_PARTS = 512
 ENC_WGRAD_PARTS = 128
-ENC_WGRAD7_PARTS = 1024
 ENC_OBS_PER_BLOCK = 4
 _ENC_OBS_U8, _ENC_OBS_BF16 = 0, 1
 
@@ -197,11 +196,11 @@ class _EncoderTrain(torch.autograd.Function):
         kind = _ENC_OBS_U8 if obs.dtype == torch.uint8 else _ENC_OBS_BF16
         check(lib.mapf_encoder_wgrad0(_ptr(gz[0]), _ptr(obs), kind, M, _ptr(ws0), _stream(dev)), "mapf_encoder_wgrad0")
         gws[0] = ws0.sum(dim=0)[:, :54].reshape(128, 6, 3, 3)
-        # the 1x1 head (16 outputs): a streaming kernel too (csrc/mapf_wgrad7.hip) -- as a library GEMM its 16 x 128 output got a
-        # 256 x 192 macro tile: 5.5 ms of the 38.8 ms update at 40 agents, 24 ms at 128
-        ws7 = torch.empty((ENC_WGRAD7_PARTS, 16, 128), dtype=torch.float32, device=dev)
-        check(lib.mapf_encoder_wgrad7(_ptr(gz7), _ptr(acts[6]), M, _ptr(ws7), _stream(dev)), "mapf_encoder_wgrad7")
-        gws[7] = ws7.sum(dim=0).view(16, 128, 1, 1)
+        from .model import _tall_tn  # split-K GEMM for [K, m]^T [K, n] with huge K
+
+        # the 1x1 head (16 x 128 outputs over 6 M rows): the library's split-K GEMM streams its 1.7 GB of input at 5.3-5.9 TB/s
+        # (0.33 ms at 40 agents); a hand-written vector-ALU streaming kernel tried in round 2 reached 3.2-3.8 TB/s and was dropped
+        gws[7] = _tall_tn(gz7, acts[6].reshape(M * 49, 128)).view(16, 128, 1, 1)
         grads = []
         for i in range(8):
             grads += [gws[i].to(params[2 * i].dtype), gbs[i].to(params[2 * i + 1].dtype)]
