@@ -46,16 +46,18 @@ def test_pkl_round_trip(tmp_path):
         EV.load_tests(bad)
 
 
-def test_vectorised_evaluation_equals_sequential():
+@pytest.mark.parametrize("nag", [16, 64])
+def test_vectorised_evaluation_equals_sequential(nag):
     """test_model's loop (reference test.py:105-143) vectorised over cases == the same loop run case by case
-    through the reference-compatible single-env facade with the same network."""
+    through the reference-compatible single-env facade with the same network; 64 = the reference's largest fixture
+    (test64_40_0.3.pkl), whose recurrence runs through the wide kernels."""
     import mapf_rl_amd as M
     from mapf_rl_amd import evaluate as EV
     from mapf_rl_amd.model import Network
 
     torch.manual_seed(3)
     net = Network().cuda().eval()
-    tests = _tests_from_golden(16)
+    tests = _tests_from_golden(nag)
     f_rate, mean_steps, steps, ok = EV.evaluate(net, tests, max_steps=12, num_cases=3)
     for i in range(3):
         env = M.Environment()
