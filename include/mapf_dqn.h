@@ -112,7 +112,7 @@ int mapf_encoder_backward(const uint16_t *g_latent_dev, const uint16_t *latent_d
  * weight); the weight gradient is their sum over the first axis (deterministic, no atomics).
  */
 #define MAPF_ENC_WGRAD_PARTS 128
-#define MAPF_ENC_WGRAD_SLABS 2 /* internal: column slabs of the output, one workgroup each per partition */
+#define MAPF_ENC_WGRAD_SLABS 2 /* internal: input-channel halves of the output, one workgroup each per partition */
 int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M, float *partial_dev, void *stream);
 
 /*

@@ -9,32 +9,43 @@
 // (mapf_encoder_forward_save), both bf16 [M][49][128].  As a GEMM: 128 (co) x 1152 (tap, ci) outputs, K = all
 // positions of all observations -- tiny output, enormous K, so the output is held in registers and the
 // operands stream through LDS:
-//  * A workgroup (512 threads = 8 waves, two per SIMD) owns one of TWO column slabs [128 co] x [576 of the 1152
-//    (tap, ci) columns] for a partition of the observations; wave w holds 64 co x 144 columns = 4 x 9 tiles of 16x16
-//    (144 accumulator registers).  Three narrower slabs at one wave per SIMD (the first version) pull the same 25 KB
-//    per observation into 1.5x as many CUs -- the kernel is bound by that L2 -> CU stream, not by MFMA or LDS.
-//  * The MFMA is inline asm with the destination TIED to the accumulator: hipcc does not tie the builtin's, and a loop
-//    that carries its accumulators then needs register-shuffle space (v_accvgpr_mov storms at one wave per SIMD,
-//    hundreds of spills at 256 registers).  asm is opaque to hipcc's hazard padding: operands come from LDS reads (the
-//    wait-count pass still sees the registers), and two s_nop 15 precede the epilogue's accumulator reads.
+//  * A workgroup (512 threads = 8 waves, two per SIMD) owns one of TWO slabs of the output -- all 128 co x 9 taps x
+//    64 of the input channels -- for a partition of the observations; wave w holds 64 co x (9 taps x 16 ci) = 4 x 9
+//    tiles of 16x16 (144 accumulator registers).  Splitting by INPUT CHANNEL means a workgroup stages only half of
+//    every input row.
+//  * K IS DENSE: the partition's positions form one stream s = 49 * obs + 7 y + x (exactly the row order of gz in
+//    memory) that is cut into blocks of 64 = two MFMA k-steps, regardless of observation boundaries.  (The first
+//    version gave every observation 64 K slots, 49 of them real: 23 % of the MFMAs and of the LDS fragment reads
+//    multiplied zeros.)
+//  * gz blocks (64 rows of 256 B, contiguous in global memory) go through a ring of four 16-KiB LDS buffers.
+//  * The INPUT needs, for stream position s and tap (ky,kx), the row of the zero-bordered 8-wide image
+//        beta(s) - 9 + 8 ky + kx,      beta = 64 obs + 8 (y+1) + (x+1)
+//    (the same image as in the forward kernel: one image row's right border is the next one's left border, one
+//    observation's bottom border the next one's top border).  These rows live in ONE circular buffer of 448 rows
+//    (7 observations): bordered row rb sits at LDS row rb mod 448, so border rows are always the same LDS rows, zeroed
+//    once and never overwritten with anything but zeros.  Every block tops the buffer up with a window of 16 chunks of 8
+//    rows starting at the chunk that holds the first bordered row its positions need and nobody loaded yet (a block
+//    needs at most 90 new rows; three blocks + a window stay below 448 rows, so nothing that is still needed is
+//    overwritten: tools/micro/wgrad_ring_check.py replays the schedule).
 //  * Both operands need K (= position) along the fragment's register axis while memory has channels contiguous:
-//    ds_read_b64_tr_b16 (hardware transpose read) delivers a [4 positions x 16 channels] block column-major.  Rows
-//    are 288 B apart (256 + 32) so that the 8 consecutive rows a half-wave reads fall in distinct banks.
-//  * K slot k = 8*y + x of an observation (64 slots = 2 k-steps, 49 of them real).  The INPUT lives in the same
-//    zero-bordered 8-wide image as in the forward kernel (row 9 + 8*y + x), so the row of tap (ky,kx) is a constant
-//    offset 8*ky + kx from the slot; gz is stored dense (row 7*y + x) and every lane points the slots that are
-//    padding (x = 7, y = 7) at one all-zero row -- the transposed read takes a row address per lane anyway.
-//  * One observation (72 MFMAs per wave) per step through a ring of FOUR LDS buffers filled by global_load_lds_dwordx4
-//    (HBM -> LDS without passing through registers; lane i of a wave writes LDS bytes [16 i, 16 i + 16) of a 1-KiB
-//    chunk from ANY global address, masked lanes write nothing -- tools/micro/lds_direct_load.hip): while observation i
-//    is multiplied, i+1 and i+2 are resident and i+3 is in flight for two whole steps (~2.5 us, the HBM latency under
-//    this load).  The first version staged through 16 registers per lane and a third buffer: the data of i+2 had one
-//    step to arrive and the kernel sat at 1.53 ms per layer against 0.99 ms for its MFMAs alone.  The loads are inline
-//    asm: hipcc's wait-count pass would make every later LDS read wait for a builtin LDS-DMA load it cannot disambiguate.
-//    Every wave issues exactly 4 chunk loads per observation, so `s_waitcnt vmcnt(4)` at the end of a step means "all but
-//    the newest observation have landed".
-//  * The two slabs of one observation partition run on the same XCD (ids i, i+8 share an L2), so the
-//    operands come from HBM once.
+//    ds_read_b64_tr_b16 (hardware transpose read) delivers a [4 positions x 16 channels] block column-major and takes
+//    a row address per lane -- so a k-step's 32 positions may sit in any rows.  A lane keeps the ring position
+//    (49 * slot + 7 y + x) of its K slots, advances it by 32 per k-step and looks the row addresses up in a small LDS table.
+//  * No row padding: rows are 256 B (gz) / 128 B (input) and bank conflicts are avoided by XOR-swizzling the 32-byte
+//    column groups with the row number -- free on the way in, because an LDS-DMA lane may fetch ANY 16 global bytes
+//    for its fixed LDS slot, and one v_xad_u32 per fragment address on the way out.  A load instruction is then a
+//    whole number of rows, every lane of every load is active (lanes without data of this partition -- border rows,
+//    rows behind the partition's end -- read 16 zero bytes), and all waves issue the same loads per block: 2 gz
+//    chunks + 2 input chunks.  Earlier versions masked lanes and gave waves different numbers of loads; the exec
+//    juggling and the wave-dependent scalar branches around every load cost more issue time than the MFMAs left over.
+//  * Staging is global_load_lds_dwordx4 (HBM -> LDS without passing through registers); while block j is multiplied, j+1
+//    and j+2 are resident and j+3 is in flight.  The loads are inline asm (hipcc's wait-count pass would make every later
+//    LDS read wait for a builtin LDS-DMA load it cannot disambiguate), spread over the block's tile-steps (issued together
+//    behind the barrier they queue up in the CU's one vector-memory pipeline), and counted by hand:
+//    `s_waitcnt vmcnt(4)` at the end of a block means "all but the newest block have landed".
+//  * The MFMA is inline asm with the destination TIED to the accumulator: hipcc does not tie the builtin's, and a loop
+//    that carries its accumulators then needs register-shuffle space (v_accvgpr_mov storms).
+//  * The two slabs of one observation partition run on the same XCD (ids i, i+8 share an L2), so gz comes from HBM once.
 //  * Output: per-partition partial sums fp32 [P][128][3][3][128]; the caller adds the P slabs (deterministic).
 #include <hip/hip_runtime.h>
 
@@ -45,33 +56,43 @@
 #include "mapf_dqn.h"
 #include "mapf_env.h"
 
+__device__ __attribute__((aligned(16))) unsigned int g_wgrad_zero[4];  // what lanes without data of the partition read
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 template <int V>
 using I = std::integral_constant<int, V>;
 
-#ifndef MAPF_WGRAD_ABLATE  // diagnostic builds only (tools/micro/wgrad_ablate.py): 1 = no staging, 2 = no fragment reads, 4 = no barrier
+#ifndef MAPF_WGRAD_ABLATE  // diagnostic builds only (tools/micro/wgrad_ab.py): 1 = no staging, 2 = no fragment reads, 4 = no barrier
 #define MAPF_WGRAD_ABLATE 0
 #endif
-constexpr int SLABS = MAPF_ENC_WGRAD_SLABS;   // column slabs of the 128 x 1152 output: one workgroup each per partition (2)
-constexpr int NTHR = 512;                    // 8 waves = 2 co halves x 4 column quarters of the slab
+constexpr int SLABS = MAPF_ENC_WGRAD_SLABS;  // input-channel halves of the output: one workgroup each per partition (2)
+constexpr int NW = 8;                        // waves = 2 co halves x 4 groups of 16 input channels
 constexpr int CT = 4;                        // 16-row co tiles per wave (64 co)
-constexpr int NTN = 1152 / SLABS / 4 / 16;    // 16-column tiles per wave (9: 144 columns); 144 accumulator registers
-static_assert(NTN * 16 * 4 * SLABS == 1152 && (2 * NTN) % 3 == 0 && NTN >= CT, "");
-constexpr int WROW = 288;                    // LDS bytes per position row
-constexpr int GZ_ZERO_ROW = 49;              // dense gz rows 0..48 = positions 7*y + x; row 49 stays zero (padding K slots)
-constexpr int IN_ROWS = 64 + 18;             // input image rows reachable through the 9 taps
-constexpr int GZ_BYTES = 15 * 1024;          // 50 rows of 288 B, rounded up to whole 1-KiB load chunks
-constexpr int OBS_BYTES = GZ_BYTES + IN_ROWS * WROW;  // 38,976
-constexpr int NBUF = 4;                      // ring: computing obs i, obs i+1 and i+2 resident, obs i+3 in flight
-static_assert(NBUF * OBS_BYTES <= 160 * 1024 && (GZ_ZERO_ROW + 1) * WROW <= GZ_BYTES, "LDS budget");
-// direct-to-LDS chunks per observation: gz rows 0..48 = bytes [0, 14112) -> chunks 0..13; input rows 9..63 (the interior)
-// = bytes [2592, 18432) of the input region -> its chunks 2..17; 30 chunks + 2 harmless repeats = 8 waves x 4
-constexpr int LPW = 4;
+constexpr int NTHR = 64 * NW;
+constexpr int NTAP = 9;                      // 16-column tiles per wave: one per tap
+static_assert(SLABS == 2, "");
+constexpr int RING = 448;                    // input ring: bordered rows (7 observations)
+constexpr int RING_OBS = RING / 64;
+constexpr int CH_ROWS = 8;                   // input load chunk: 8 ring rows of 128 B
+constexpr int RING_CHUNKS = RING / CH_ROWS;  // 56
+constexpr int WIN_CHUNKS = 16;             // input window of a block, in chunks
+constexpr int GZ_CHUNKS = 16;              // 64 rows of 256 B in 1-KiB chunks
+constexpr int NBUF = 4;                      // gz ring: computing block j, j+1 and j+2 resident, j+3 in flight
+constexpr int GZ_BLK = 64 * 256;
+constexpr int IN_BASE = NBUF * GZ_BLK;       // 65,536: gz buffers first, so that their fragment reads fit the 16-bit DS offset
+constexpr int IN_BYTES = (RING + 9) * 128;   // + the 9 rows the taps of the last ring rows reach: a top border, always zero
+constexpr int TAB_BASE = IN_BASE + ((IN_BYTES + 1023) / 1024) * 1024;
+constexpr int TAB_N = RING_OBS * 49;         // u16 [343][4]: swizzled byte offset of the top-left tap row + kx of ring position u, kx = 0..2
+constexpr int LTAB_BASE = TAB_BASE + ((TAB_N * 8 + 63) / 64) * 64;  // u16 [56 chunks][8 rows]: ring position of a ring row (0xFFFF: border)
+constexpr int LDS_BYTES = LTAB_BASE + RING_CHUNKS * CH_ROWS * 2;
+constexpr int RB = 4;                        // ring of input (B) fragments: tile t's MFMAs run while tile t + RB - 1 is being read
+constexpr int LPW = (GZ_CHUNKS + WIN_CHUNKS) / NW, GPW = GZ_CHUNKS / NW;  // loads per wave and block (4); the first GPW (2) are gz
+static_assert(RING % 64 == 0 && (2 * NTAP * NBUF) % RB == 0 && LDS_BYTES <= 160 * 1024 && (RING + 11) * 128 < 65536, "");
 static_assert(MAPF_ENC_WGRAD_PARTS % 8 == 0, "");
 
 __device__ __forceinline__ bf16x8 tr_read2(const unsigned char *p0, const unsigned char *p1) {
@@ -88,167 +109,226 @@ __device__ __forceinline__ bf16x8 tr_read2(const unsigned char *p0, const unsign
     return u.v;
 }
 
-__global__ void __launch_bounds__(NTHR, 1) encoder_wgrad_kernel(const uint16_t *__restrict__ gz, const uint16_t *__restrict__ ain,
-                                                              long long M, float *__restrict__ ws) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * OBS_BYTES];
+// first bordered row that the blocks before block jb have not asked for: beta(64 jb - 1) + 10
+__device__ __forceinline__ int frontier(int jb) {
+    if (jb == 0) return 0;
+    const int s = 64 * jb - 1, o = s / 49, p = s - 49 * o, y = p / 7;
+    return 64 * o + p + y + 19;
+}
+
+__global__ void __launch_bounds__(NTHR) encoder_wgrad_kernel(const uint16_t *__restrict__ gz, const uint16_t *__restrict__ ain, long long M,
+                                                           float *__restrict__ ws) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
     const int slab = slot % SLABS, part = (slot / SLABS) * 8 + xcd;
-    const int chalf = w & 1, nq = w >> 1;  // this wave's 64 output channels / 144 columns of the slab
+    const int chalf = w & 1, nq = w >> 1;  // this wave's 64 output channels / 16 input channels of the slab
 
-    // observations of this partition
+    // observations of this partition -> a stream of S positions in nblk blocks of 64
     const long long per = (M + MAPF_ENC_WGRAD_PARTS - 1) / MAPF_ENC_WGRAD_PARTS;
     const long long ob0 = per * part;
-    long long nob = M - ob0;
-    nob = nob < 0 ? 0 : (nob > per ? per : nob);
+    long long nobl = M - ob0;
+    nobl = nobl < 0 ? 0 : (nobl > per ? per : nobl);
+    const int nob = (int)nobl, S = 49 * nob, nblk = (S + 63) >> 6;
+    const uint16_t *gpart = gz + ob0 * 6272, *apart = ain + ob0 * 6272 + 64 * slab;
 
-    for (int i = tid; i < NBUF * OBS_BYTES / 16; i += NTHR) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
-
-    // ---- staging: wave w issues chunk-loads j = w, w + 8, w + 16, w + 24 of every observation ----
-    // per lane and load: the global byte offset inside the observation (of gz for j < 14 and the two repeats, of the input
-    // otherwise) of the 16 bytes this lane's LDS slot holds, or -1 where the slot is row padding / a border row
-    int soff[LPW];
-#pragma unroll
-    for (int k = 0; k < LPW; ++k) {
-        const int jj = w + 8 * k;
-        const bool isg = jj < 14 || jj >= 30;
-        const int chunk = jj < 14 ? jj : (jj >= 30 ? jj - 30 : jj - 12);  // chunk index inside its region
-        const int L = 1024 * chunk + 16 * lane, row = L / WROW, col = L - row * WROW;
-        int off = -1;
-        if (col < 256) {
-            if (isg) {
-                if (row < 49) off = row * 256 + col;
-            } else {
-                const int r = row - 9;
-                if (r >= 0 && r < 56 && (r & 7) != 7) off = (7 * (r >> 3) + (r & 7)) * 256 + col;
-            }
-        }
-        soff[k] = off;
+    for (int i = tid; i < TAB_BASE / 16; i += NTHR) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < TAB_N * 4; i += NTHR) {  // fragment table: ring position u, kx -> (row * 128) | (swizzle * 32), row = 64 o + 8 y + x + kx
+        const int u = i >> 2, kx = i & 3, o = u / 49, p = u - 49 * o, row = 64 * o + p + p / 7 + kx;
+        reinterpret_cast<uint16_t *>(smem + TAB_BASE)[i] = (uint16_t)(kx < 3 ? row * 128 + ((row >> 1) & 3) * 32 : 0);
     }
+    for (int i = tid; i < RING_CHUNKS * CH_ROWS; i += NTHR) {  // load table: ring row -> ring position 49 * slot + 7 y + x, or 0xFFFF for a border row
+        const int rr = (i & 63) - 9;
+        reinterpret_cast<uint16_t *>(smem + LTAB_BASE)[i] = (uint16_t)((rr >= 0 && rr < 56 && (rr & 7) != 7) ? 49 * (i >> 6) + 7 * (rr >> 3) + (rr & 7) : 0xFFFF);
+    }
+
+    // ---- staging: every wave issues LPW chunk-loads per block: gz chunks w + NW k (k < GPW), then input window chunks w + NW (k - GPW) ----
+    // gz chunk = 4 rows of 256 B: lane l holds 16-byte column (l & 15) ^ (2 * (row & 7)) of row 4 chunk + (l >> 4)
+    int goff[GPW];
+#pragma unroll
+    for (int k = 0; k < GPW; ++k) {
+        const int row = 4 * (w + NW * k) + (lane >> 4);
+        goff[k] = row * 256 + 16 * ((lane & 15) ^ ((row & 7) << 1));
+    }
+    // input chunk = 8 rows of 128 B: lane l holds 16-byte column (l & 7) ^ (2 * ((row >> 1) & 3)) of chunk row l >> 3, and
+    // (row >> 1) & 3 = (l >> 4) & 3 because chunks start at multiples of 8 rows
+    const int in_col = 16 * ((lane & 7) ^ (((lane >> 4) & 3) << 1)), in_row = lane >> 3;
     typedef __attribute__((address_space(3))) unsigned char *lds_byte_ptr;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte_ptr)smem;
-    auto issue_loads = [&](long long ob, int buf) __attribute__((always_inline)) {
-        const uint16_t *gsrc = gz + ob * 6272, *asrc = ain + ob * 6272;
+    const unsigned long long zsrc = (unsigned long long)(uintptr_t)g_wgrad_zero, abase = (unsigned long long)(uintptr_t)apart;
+    struct LoadCtx {  // wave-uniform description of one block's loads
+        const uint16_t *gsrc;
+        int rows_left, c0, posA, thr;
+    };
+    auto load_ctx = [&](int jb) __attribute__((always_inline)) {
+        // input window: 16 chunks of 8 ring rows from the chunk that holds bordered row F.  A ring row's position q (table)
+        // is stream position q + posA, + 343 if its ring slot is before the slot of the window's first row
+        const int F = frontier(jb), Fm = F % RING, c0 = Fm / CH_ROWS, rb0 = F - (Fm - c0 * CH_ROWS), ow = rb0 >> 6, omw = ow % RING_OBS;
+        return LoadCtx{gpart + (long long)jb * (64 * 128), S - 64 * jb, c0, 49 * (ow - omw), 49 * omw};
+    };
+    int qv[LPW - GPW];  // ring positions of this lane's rows in the block's input chunks, read from the table well before the loads need them
+    auto fetch_q = [&](const LoadCtx &c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < LPW; ++k) {
-            const int jj = w + 8 * k;
-            const bool isg = jj < 14 || jj >= 30;
-            const int chunk = jj < 14 ? jj : (jj >= 30 ? jj - 30 : jj - 12);
-            const uint32_t dst = lds0 + buf * OBS_BYTES + (isg ? 0 : GZ_BYTES) + 1024 * chunk;
-            const uint16_t *src = isg ? gsrc : asrc;
-            if (soff[k] >= 0)
-                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(soff[k]), "s"(src) : "memory");
+        for (int k = 0; k < LPW - GPW; ++k) {
+            int ch = c.c0 + w + NW * k;
+            ch = ch >= RING_CHUNKS ? ch - RING_CHUNKS : ch;
+            qv[k] = reinterpret_cast<const uint16_t *>(smem + LTAB_BASE)[ch * CH_ROWS + in_row];
         }
+    };
+    auto issue_one = [&](const LoadCtx &c, int buf, int k) __attribute__((always_inline)) {
+        if (k < GPW) {
+            const uint32_t dst = lds0 + buf * GZ_BLK + 1024 * (w + NW * k);
+            if (c.rows_left >= 64) {
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(goff[k]), "s"(c.gsrc) : "memory");
+            } else {  // last block: rows behind the end of the stream read zeros
+                const int row = 4 * (w + NW * k) + (lane >> 4);
+                const unsigned long long src = row < c.rows_left ? (unsigned long long)(uintptr_t)c.gsrc + (unsigned)goff[k] : zsrc;
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory");
+            }
+        } else {
+            int ch = c.c0 + w + NW * (k - GPW);
+            ch = ch >= RING_CHUNKS ? ch - RING_CHUNKS : ch;
+            const uint32_t dst = lds0 + IN_BASE + 1024 * ch;
+            const int q = qv[k - GPW];
+            const int pos = q + c.posA + (q < c.thr ? TAB_N : 0);
+            // every lane loads: the ones without data of this partition read 16 zero bytes (border rows are zero anyway)
+            const unsigned long long src = (q != 0xFFFF && pos < S) ? abase + (unsigned)(pos * 256 + in_col) : zsrc;
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory");
+        }
+    };
+    auto issue_loads = [&](int jb, int buf) __attribute__((always_inline)) {
+        const LoadCtx c = load_ctx(jb);
+        fetch_q(c);
+#pragma unroll
+        for (int k = 0; k < LPW; ++k) issue_one(c, buf, k);
+    };
+    auto wait_all_but_newest = [&]() __attribute__((always_inline)) {
+        static_assert(LPW == 4, "the count below is the loads per wave and block");
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     };
 
     // ---- fragment addresses of this lane (ds_read_b64_tr_b16: lane 4q+p of a 16-lane group supplies row q, columns 4p..) ----
     const int li = lane & 15, lh = lane >> 4, q4 = li >> 2, p4 = li & 3;
-    // k-slot (lh, j) of a 32-slot k-step: slot 4 lh + j for j < 4 (first read), 16 + 4 lh + (j - 4) for the second;
-    // gz row of slot 8 y + x: 7 y + x, or the zero row for the padding slots
-    int a_row[2][2];
+    // K slot (lh, j) of a 32-slot k-step: slot 4 lh + j for j < 4 (first read, "blk 0"), 16 + 4 lh + (j - 4) for the second
+    // gz: row = slot of the block; the 32 bytes of co tile ct sit in column group ct ^ (row & 7), and row & 7 = (4 lh + q4) & 7
+    int a_addr[CT];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int c = 0; c < CT; ++c) a_addr[c] = (4 * lh + q4) * 256 + (((CT * chalf + c) ^ ((4 * lh + q4) & 7)) << 5) + 8 * p4;
+    // input: ring position u = (49 * observation + 7 y + x) mod 343 of this lane's two slots in the NEXT k-step to be addressed;
+    // table -> (row << 7) | (swizzle << 5) per kx; this lane's 8 bytes of its wave's 16 channels: ^ ((nq << 5) | (p4 << 3)); tap row
+    // ky is the immediate 8 ky * 128 (8 rows further the swizzle is the same)
+    int un[2] = {4 * lh + q4, 16 + 4 * lh + q4};
+    const unsigned b_lane = (unsigned)((nq << 5) | (p4 << 3));
+    unsigned bc[2][3], bn[2][3];  // current / next k-step: [blk][kx]
+    auto next_addresses = [&](unsigned (&dst)[2][3]) __attribute__((always_inline)) {
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
-            const int slot = 32 * ks + 16 * blk + 4 * lh + q4, y = slot >> 3, x = slot & 7;
-            a_row[ks][blk] = ((x < 7 && y < 7) ? 7 * y + x : GZ_ZERO_ROW) * WROW + 8 * p4 + (CT * chalf) * 32;
+            const u32x2 e = *reinterpret_cast<const u32x2 *>(smem + TAB_BASE + 8 * un[blk]);
+            dst[blk][0] = ((e[0] & 0xFFFFu) ^ b_lane) + (unsigned)IN_BASE;
+            dst[blk][1] = ((e[0] >> 16) ^ b_lane) + (unsigned)IN_BASE;
+            dst[blk][2] = (e[1] ^ b_lane) + (unsigned)IN_BASE;
+            const unsigned u = (unsigned)un[blk] + 32u;  // advance by one k-step (32 positions)
+            un[blk] = (int)min(u, u - (unsigned)TAB_N);
         }
-    // output column = (tap, ci): this wave's tile t covers columns col0(t) .. +16
-    auto col0 = [&](int t) { return (1152 / SLABS) * slab + (16 * NTN) * nq + 16 * t; };
-    int b_base[NTN];
-#pragma unroll
-    for (int t = 0; t < NTN; ++t) {
-        const int c = col0(t), tap = c >> 7, ci0 = c & 127;
-        b_base[t] = GZ_BYTES + (4 * lh + q4 + 8 * (tap / 3) + tap % 3) * WROW + 8 * p4 + ci0 * 2;
-    }
+    };
 
-    f32x4 acc[CT][NTN];
+    f32x4 acc[CT][NTAP];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int t = 0; t < NTN; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NTAP; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    __syncthreads();  // zero fill done
+    __syncthreads();  // zero fill and tables done
     if (!(MAPF_WGRAD_ABLATE & 1)) {
-        if (nob > 0) issue_loads(ob0, 0);
-        if (nob > 1) issue_loads(ob0 + 1, 1);
-        if (nob > 2) {
-            issue_loads(ob0 + 2, 2);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // observations 0 and 1 have landed
+        if (nblk > 0) issue_loads(0, 0);
+        if (nblk > 1) issue_loads(1, 1);
+        if (nblk > 2) {
+            issue_loads(2, 2);
+            wait_all_but_newest();  // blocks 0 and 1 have landed
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
     __syncthreads();
 
-    // fragments: the CT gz (A) tiles of the current k-step and of the next one; the input (B) tiles pass through a ring of
-    // three (tile t's MFMAs run while tile t+2 is being read)
-    bf16x8 af[2][CT], br[3];
-    auto read_a = [&](const unsigned char *sb, int ks, int c) { return tr_read2(sb + a_row[ks][0] + c * 32, sb + a_row[ks][1] + c * 32); };
-    auto read_b = [&](const unsigned char *sb, int ks, int t) { return tr_read2(sb + b_base[t] + (32 * ks) * WROW, sb + b_base[t] + (32 * ks + 16) * WROW); };
-    if (nob > 0) {
+    // fragments: the CT gz (A) tiles of the current k-step and of the next one; the input (B) tiles pass through a ring of RB
+    bf16x8 af[2][CT], br[RB];
+    auto read_a = [&](const unsigned char *gbuf, int ks, int c) {
+        return tr_read2(gbuf + a_addr[c] + (32 * ks) * 256, gbuf + a_addr[c] + (32 * ks + 16) * 256);
+    };
+    auto read_b = [&](const unsigned (&q)[2][3], int t) {
+        return tr_read2(smem + q[0][t % 3] + (8 * (t / 3)) * 128, smem + q[1][t % 3] + (8 * (t / 3)) * 128);
+    };
+    next_addresses(bc);
+    if (nblk > 0) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) af[0][c] = read_a(smem, 0, c);
-        br[0] = read_b(smem, 0, 0);
-        br[1] = read_b(smem, 0, 1);
+#pragma unroll
+        for (int t = 0; t < RB - 1; ++t) br[t] = read_b(bc, t);
     }
 
-    // One observation (step i): 2 k-steps x 48 MFMAs on buffer `b`; the fragments of its second k-step, then of the
-    // next observation's first k-step (buffer b1, complete since the last barrier), are read behind the MFMAs.
-    // Staging: the loads of observation i + 3 are issued at the start of the step into the buffer that step i - 1 read
-    // (free since its barrier); the step ends by waiting for observation i + 2 (issued one step earlier) and a barrier.
-    auto one_obs = [&](long long i, auto B, auto B1, auto B3) __attribute__((always_inline)) {
+    // One block (step j): 2 k-steps x NTAP x CT MFMAs on gz buffer `b`; the fragments of its second k-step, then of the next
+    // block's first k-step (buffer b1, complete since the last barrier), are read behind the MFMAs.
+    // Staging: the loads of block j + 3 go into the gz buffer that step j - 1 read (free since its barrier) and into the
+    // input ring; the step ends by waiting for block j + 2 (issued one step earlier) and a barrier.
+    auto one_blk = [&](int j, auto B, auto B1, auto B3) __attribute__((always_inline)) {
         constexpr int b = decltype(B)::value, b1 = decltype(B1)::value, b3 = decltype(B3)::value;
-        const unsigned char *sb = smem + b * OBS_BYTES, *sb1 = smem + b1 * OBS_BYTES;
-        const bool more = i + 3 < nob && !(MAPF_WGRAD_ABLATE & 1);
-        if (more) issue_loads(ob0 + i + 3, b3);
+        const unsigned char *ga = smem + b * GZ_BLK, *ga1 = smem + b1 * GZ_BLK;
+        const bool more = j + 3 < nblk && !(MAPF_WGRAD_ABLATE & 1);
+        LoadCtx lc = {gpart, 64, 0, 0, 0};
+        if (more) {
+            lc = load_ctx(j + 3);
+            fetch_q(lc);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int cur = ks, nxt = ks ^ 1;
-            // the k-step after this one: (this observation, ks 1) or (next observation, ks 0; past the last observation sb1
-            // holds stale but valid LDS: harmless)
-            const unsigned char *nbuf = ks == 0 ? sb : sb1;
+            // the k-step after this one: (this block, ks 1) or (next block, ks 0; past the last block ga1 holds stale
+            // but valid LDS: harmless)
+            const unsigned char *nbuf = ks == 0 ? ga : ga1;
 #pragma unroll
-            for (int t = 0; t < NTN; ++t) {
-                const int g = ks * NTN + t;  // 2 * NTN tiles per observation, a multiple of 3: ring slots repeat per observation
+            for (int t = 0; t < NTAP; ++t) {
+                const int g = ks * NTAP + t, gr = b * 2 * NTAP + g;  // tile-step of the block / of the 4-block turn (72: a multiple of RB)
+                if (t == 1) next_addresses(bn);
+                if (more && g % 4 == 1 && g / 4 < LPW) issue_one(lc, b3, g / 4);  // tile-steps 1, 5, 9, 13
                 if (!(MAPF_WGRAD_ABLATE & 2)) {
-                    if (t + 2 < NTN)
-                        br[(g + 2) % 3] = read_b(sb, ks, t + 2);
+                    if (t + RB - 1 < NTAP)
+                        br[(gr + RB - 1) % RB] = read_b(bc, t + RB - 1);
                     else
-                        br[(g + 2) % 3] = read_b(nbuf, nxt, t + 2 - NTN);
+                        br[(gr + RB - 1) % RB] = read_b(bn, t + RB - 1 - NTAP);
                     if (t < CT) af[nxt][t] = read_a(nbuf, nxt, t);
                 }
 #pragma unroll
                 for (int c = 0; c < CT; ++c)
                     // tied destination: hipcc does not tie the builtin's, and shuffles 4 registers per MFMA on the loop back-edge
-                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[c][t]) : "v"(af[cur][c]), "v"(br[g % 3]));
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[c][t]) : "v"(af[cur][c]), "v"(br[gr % RB]));
                 __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) bc[i / 3][i % 3] = bn[i / 3][i % 3];
         }
         __builtin_amdgcn_sched_barrier(0);
         if (more)
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // everything but the 4 loads just issued
+            wait_all_but_newest();
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(MAPF_WGRAD_ABLATE & 4)) __syncthreads();
     };
-    // Four observations per loop iteration (one turn of the buffer ring): every buffer offset is a constant, and the
-    // accumulator shuffle hipcc emits on the loop back-edge (it does not tie an MFMA's destination to its source:
-    // 192 v_accvgpr_mov per iteration, which HALVED the MFMA rate with one observation per iteration) is paid once
-    // per 288 MFMAs.
-    long long i = 0;
-    for (; i + 4 <= nob; i += 4) {
-        one_obs(i, I<0>{}, I<1>{}, I<3>{});
-        one_obs(i + 1, I<1>{}, I<2>{}, I<0>{});
-        one_obs(i + 2, I<2>{}, I<3>{}, I<1>{});
-        one_obs(i + 3, I<3>{}, I<0>{}, I<2>{});
+    // Four blocks per loop iteration (one turn of the gz ring): every gz buffer offset is a constant, and whatever hipcc
+    // emits on the loop back-edge is paid once per 288 MFMAs.
+    int j = 0;
+    for (; j + 4 <= nblk; j += 4) {
+        one_blk(j, I<0>{}, I<1>{}, I<3>{});
+        one_blk(j + 1, I<1>{}, I<2>{}, I<0>{});
+        one_blk(j + 2, I<2>{}, I<3>{}, I<1>{});
+        one_blk(j + 3, I<3>{}, I<0>{}, I<2>{});
     }
-    // tail (i % 4 == 0 here, so the ring is in its initial phase)
-    if (i < nob) one_obs(i, I<0>{}, I<1>{}, I<3>{});
-    if (i + 1 < nob) one_obs(i + 1, I<1>{}, I<2>{}, I<0>{});
-    if (i + 2 < nob) one_obs(i + 2, I<2>{}, I<3>{}, I<1>{});
+    // tail (j % 4 == 0 here, so the ring is in its initial phase)
+    if (j < nblk) one_blk(j, I<0>{}, I<1>{}, I<3>{});
+    if (j + 1 < nblk) one_blk(j + 1, I<1>{}, I<2>{}, I<0>{});
+    if (j + 2 < nblk) one_blk(j + 2, I<2>{}, I<3>{}, I<1>{});
 
     // ---- partial sums of this partition: ws[part][co][tap = ky*3 + kx][ci] ----
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the asm MFMAs are opaque to hipcc's hazard padding: let the last ones retire
@@ -256,12 +336,12 @@ __global__ void __launch_bounds__(NTHR, 1) encoder_wgrad_kernel(const uint16_t *
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int t = 0; t < NTN; ++t) {
-            const int cc = col0(t), tap = cc >> 7, ci = (cc & 127) + li;
+        for (int t = 0; t < NTAP; ++t) {
+            const int ci = 64 * slab + 16 * nq + li;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = 16 * (CT * chalf + c) + 4 * lh + r;
-                out[(co * 9 + tap) * 128 + ci] = acc[c][t][r];
+                out[(co * 9 + t) * 128 + ci] = acc[c][t][r];
             }
         }
 }
@@ -284,6 +364,7 @@ int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M
     if ((reinterpret_cast<uintptr_t>(gz_dev) & 15) || (reinterpret_cast<uintptr_t>(in_dev) & 15) ||
         (reinterpret_cast<uintptr_t>(partial_dev) & 15))
         return MAPF_ERR_INVALID_ARG;
+    if ((M + MAPF_ENC_WGRAD_PARTS - 1) / MAPF_ENC_WGRAD_PARTS > (1 << 17)) return MAPF_ERR_INVALID_ARG;  // 32-bit byte offsets inside a partition
     // every partition writes its slab (zeros when it has no observations), so the caller's sum is always defined
     hipLaunchKernelGGL(encoder_wgrad_kernel, dim3(SLABS * MAPF_ENC_WGRAD_PARTS), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gz_dev,
                        in_dev, (long long)M, partial_dev);
