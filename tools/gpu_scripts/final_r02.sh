@@ -12,7 +12,7 @@ done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_actor -- python3 $R/tools/profile_actor.py > $R/gpurun_out/prof_actor.log 2>&1; echo actor=$?
 TUPD=6 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_learner -- python3 $R/tools/profile_update.py > $R/gpurun_out/prof_learner.log 2>&1; echo learner=$?
 cd $R
-python tools/summarize_rocprof.py gpurun_out/prof_bench bench > gpurun_out/prof_bench.md
+python tools/summarize_rocprof.py gpurun_out/prof_bench bench env_step_kernel > gpurun_out/prof_bench.md
 python tools/summarize_rocprof.py gpurun_out/prof_actor actor > gpurun_out/prof_actor.md
 python tools/summarize_rocprof.py gpurun_out/prof_learner learner > gpurun_out/prof_learner.md
 python tools/trace_breakdown.py gpurun_out/prof_actor comm_mask_kernel 24 > gpurun_out/prof_actor_iter.md
