@@ -13,36 +13,34 @@
 //    64 of the input channels -- for a partition of the observations; wave w holds 64 co x (9 taps x 16 ci) = 4 x 9
 //    tiles of 16x16 (144 accumulator registers).  Splitting by INPUT CHANNEL means a workgroup stages only half of
 //    every input row.
-//  * K IS DENSE: the partition's positions form one stream s = 49 * obs + 7 y + x (exactly the row order of gz in
-//    memory) that is cut into blocks of 64 = two MFMA k-steps, regardless of observation boundaries.  (The first
-//    version gave every observation 64 K slots, 49 of them real: 23 % of the MFMAs and of the LDS fragment reads
-//    multiplied zeros.)
-//  * gz blocks (64 rows of 256 B, contiguous in global memory) go through a ring of four 16-KiB LDS buffers.
-//  * The INPUT needs, for stream position s and tap (ky,kx), the row of the zero-bordered 8-wide image
-//        beta(s) - 9 + 8 ky + kx,      beta = 64 obs + 8 (y+1) + (x+1)
-//    (the same image as in the forward kernel: one image row's right border is the next one's left border, one
-//    observation's bottom border the next one's top border).  These rows live in ONE circular buffer of 448 rows
-//    (7 observations): bordered row rb sits at LDS row rb mod 448, so border rows are always the same LDS rows, zeroed
-//    once and never overwritten with anything but zeros.  Every block tops the buffer up with a window of 16 chunks of 8
-//    rows starting at the chunk that holds the first bordered row its positions need and nobody loaded yet (a block
-//    needs at most 90 new rows; three blocks + a window stay below 448 rows, so nothing that is still needed is
-//    overwritten: tools/micro/wgrad_ring_check.py replays the schedule).
-//  * Both operands need K (= position) along the fragment's register axis while memory has channels contiguous:
-//    ds_read_b64_tr_b16 (hardware transpose read) delivers a [4 positions x 16 channels] block column-major and takes
-//    a row address per lane -- so a k-step's 32 positions may sit in any rows.  A lane keeps the ring position
-//    (49 * slot + 7 y + x) of its K slots, advances it by 32 per k-step and looks the row addresses up in a small LDS table.
+//  * K RUNS OVER IMAGE ROWS: the partition's 7 * observations image rows form one stream; a K slot is (image row,
+//    x' = 0..7) with x' = 7 a padding slot (its gz row is zero), a block is 8 image rows = 64 slots = two MFMA k-steps,
+//    regardless of observation boundaries: 1/8 of the MFMAs multiply zeros.  (Round 1 gave every observation 64 slots,
+//    49 real: 23 % zeros.  A fully dense position stream was built too, 0 % zeros -- and 38 % of its LDS cycles were
+//    bank conflicts: 8 consecutive positions of a 7-wide image span 9 bordered rows minus a border row that differs
+//    per kx tap, and no row -> bank map separates all three; here a half-wave reads the 8 slots of ONE image row,
+//    8 consecutive rows for every tap.)
+//  * gz blocks (64 slot rows of 256 B; the x' = 7 rows are zeroed once and never written) go through a ring of four
+//    16-KiB LDS buffers.
+//  * The INPUT lives as the zero-bordered 8-wide image of the forward kernel: bordered image row (8 cells of 128 B =
+//    one 1-KiB load chunk, cell 0 the left border) number 8 * obs + y + 1, in a circular buffer of 7 observations = 56
+//    chunks; the top border row of an observation is the bottom border row of the one before, tap (ky,kx) of slot
+//    (row, x') is cell 8 ky + kx further on.  Border cells are zeroed once and never written.  A block needs exactly 8
+//    new image rows (rows 8 j + 1 .. 8 j + 8; its taps reach one row back and one ahead), one per wave.
+//  * Both operands need K along the fragment's register axis while memory has channels contiguous:
+//    ds_read_b64_tr_b16 (hardware transpose read) delivers a [4 slots x 16 channels] block column-major.
 //  * No row padding: rows are 256 B (gz) / 128 B (input) and bank conflicts are avoided by XOR-swizzling the 32-byte
-//    column groups with the row number -- free on the way in, because an LDS-DMA lane may fetch ANY 16 global bytes
-//    for its fixed LDS slot, and one v_xad_u32 per fragment address on the way out.  A load instruction is then a
-//    whole number of rows, every lane of every load is active (lanes without data of this partition -- border rows,
-//    rows behind the partition's end -- read 16 zero bytes), and all waves issue the same loads per block: 2 gz
-//    chunks + 2 input chunks.  Earlier versions masked lanes and gave waves different numbers of loads; the exec
-//    juggling and the wave-dependent scalar branches around every load cost more issue time than the MFMAs left over.
-//  * Staging is global_load_lds_dwordx4 (HBM -> LDS without passing through registers); while block j is multiplied, j+1
-//    and j+2 are resident and j+3 is in flight.  The loads are inline asm (hipcc's wait-count pass would make every later
-//    LDS read wait for a builtin LDS-DMA load it cannot disambiguate), spread over the block's tile-steps (issued together
-//    behind the barrier they queue up in the CU's one vector-memory pipeline), and counted by hand:
-//    `s_waitcnt vmcnt(4)` at the end of a block means "all but the newest block have landed".
+//    column groups with the row number -- free on the way in, because a lane of global_load_lds_dwordx4 (HBM -> LDS
+//    without passing through registers; lane i writes LDS bytes [16 i, 16 i + 16) of a 1-KiB chunk from ANY global
+//    address, masked lanes write nothing: tools/micro/lds_direct_load.hip) simply fetches the 16 bytes that belong in
+//    its slot; on the way out the swizzle of a slot's taps depends only on the lane (x' + kx), so it is folded into
+//    three per-lane constants.  Everything that varies per block (which observation / row an image row is) is
+//    wave-uniform and computed on the scalar unit.
+//  * Every wave issues the same 2 gz + 1 input loads per block, spread over the block's tile-steps (issued together
+//    behind the barrier they queue up in the CU's one vector-memory pipeline).  The loads are inline asm (hipcc's
+//    wait-count pass would make every later LDS read wait for a builtin LDS-DMA load it cannot disambiguate) and counted
+//    by hand: `s_waitcnt vmcnt(3)` at the end of a block means "all but the newest block have landed".  While block j
+//    is multiplied, j+1 and j+2 are resident and j+3 is in flight.
 //  * The MFMA is inline asm with the destination TIED to the accumulator: hipcc does not tie the builtin's, and a loop
 //    that carries its accumulators then needs register-shuffle space (v_accvgpr_mov storms).
 //  * The two slabs of one observation partition run on the same XCD (ids i, i+8 share an L2), so gz comes from HBM once.
@@ -56,14 +54,13 @@
 #include "mapf_dqn.h"
 #include "mapf_env.h"
 
-__device__ __attribute__((aligned(16))) unsigned int g_wgrad_zero[4];  // what lanes without data of the partition read
+__device__ __attribute__((aligned(16))) unsigned int g_wgrad_zero[4];  // what the loads of image rows behind the partition's end read
 
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 template <int V>
 using I = std::integral_constant<int, V>;
 
@@ -76,23 +73,16 @@ constexpr int CT = 4;                        // 16-row co tiles per wave (64 co)
 constexpr int NTHR = 64 * NW;
 constexpr int NTAP = 9;                      // 16-column tiles per wave: one per tap
 static_assert(SLABS == 2, "");
-constexpr int RING = 448;                    // input ring: bordered rows (7 observations)
-constexpr int RING_OBS = RING / 64;
-constexpr int CH_ROWS = 8;                   // input load chunk: 8 ring rows of 128 B
-constexpr int RING_CHUNKS = RING / CH_ROWS;  // 56
-constexpr int WIN_CHUNKS = 16;             // input window of a block, in chunks
-constexpr int GZ_CHUNKS = 16;              // 64 rows of 256 B in 1-KiB chunks
+constexpr int RING_OBS = 7;                  // input ring: observations (8 bordered image rows of 1 KiB each)
+constexpr int RING_CHUNKS = 8 * RING_OBS;    // 56
 constexpr int NBUF = 4;                      // gz ring: computing block j, j+1 and j+2 resident, j+3 in flight
 constexpr int GZ_BLK = 64 * 256;
 constexpr int IN_BASE = NBUF * GZ_BLK;       // 65,536: gz buffers first, so that their fragment reads fit the 16-bit DS offset
-constexpr int IN_BYTES = (RING + 9) * 128;   // + the 9 rows the taps of the last ring rows reach: a top border, always zero
-constexpr int TAB_BASE = IN_BASE + ((IN_BYTES + 1023) / 1024) * 1024;
-constexpr int TAB_N = RING_OBS * 49;         // u16 [343][4]: swizzled byte offset of the top-left tap row + kx of ring position u, kx = 0..2
-constexpr int LTAB_BASE = TAB_BASE + ((TAB_N * 8 + 63) / 64) * 64;  // u16 [56 chunks][8 rows]: ring position of a ring row (0xFFFF: border)
-constexpr int LDS_BYTES = LTAB_BASE + RING_CHUNKS * CH_ROWS * 2;
+constexpr int IN_BYTES = (8 * RING_CHUNKS + 8 + 18) * 128;  // + what the taps of the last ring row reach: border, always zero
+constexpr int LDS_BYTES = IN_BASE + IN_BYTES;
 constexpr int RB = 4;                        // ring of input (B) fragments: tile t's MFMAs run while tile t + RB - 1 is being read
-constexpr int LPW = (GZ_CHUNKS + WIN_CHUNKS) / NW, GPW = GZ_CHUNKS / NW;  // loads per wave and block (4); the first GPW (2) are gz
-static_assert(RING % 64 == 0 && (2 * NTAP * NBUF) % RB == 0 && LDS_BYTES <= 160 * 1024 && (RING + 11) * 128 < 65536, "");
+constexpr int LPW = 3;                       // loads per wave and block: gz chunks w and w + 8, input image row 8 j + 1 + w
+static_assert((2 * NTAP * NBUF) % RB == 0 && LDS_BYTES <= 160 * 1024, "");
 static_assert(MAPF_ENC_WGRAD_PARTS % 8 == 0, "");
 
 __device__ __forceinline__ bf16x8 tr_read2(const unsigned char *p0, const unsigned char *p1) {
@@ -109,13 +99,6 @@ __device__ __forceinline__ bf16x8 tr_read2(const unsigned char *p0, const unsign
     return u.v;
 }
 
-// first bordered row that the blocks before block jb have not asked for: beta(64 jb - 1) + 10
-__device__ __forceinline__ int frontier(int jb) {
-    if (jb == 0) return 0;
-    const int s = 64 * jb - 1, o = s / 49, p = s - 49 * o, y = p / 7;
-    return 64 * o + p + y + 19;
-}
-
 __global__ void __launch_bounds__(NTHR) encoder_wgrad_kernel(const uint16_t *__restrict__ gz, const uint16_t *__restrict__ ain, long long M,
                                                            float *__restrict__ ws) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
@@ -125,113 +108,88 @@ __global__ void __launch_bounds__(NTHR) encoder_wgrad_kernel(const uint16_t *__r
     const int slab = slot % SLABS, part = (slot / SLABS) * 8 + xcd;
     const int chalf = w & 1, nq = w >> 1;  // this wave's 64 output channels / 16 input channels of the slab
 
-    // observations of this partition -> a stream of S positions in nblk blocks of 64
+    // observations of this partition -> a stream of IR image rows in nblk blocks of 8
     const long long per = (M + MAPF_ENC_WGRAD_PARTS - 1) / MAPF_ENC_WGRAD_PARTS;
     const long long ob0 = per * part;
     long long nobl = M - ob0;
     nobl = nobl < 0 ? 0 : (nobl > per ? per : nobl);
-    const int nob = (int)nobl, S = 49 * nob, nblk = (S + 63) >> 6;
+    const int IR = 7 * (int)nobl, nblk = (IR + 7) >> 3;
     const uint16_t *gpart = gz + ob0 * 6272, *apart = ain + ob0 * 6272 + 64 * slab;
 
-    for (int i = tid; i < TAB_BASE / 16; i += NTHR) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
-    for (int i = tid; i < TAB_N * 4; i += NTHR) {  // fragment table: ring position u, kx -> (row * 128) | (swizzle * 32), row = 64 o + 8 y + x + kx
-        const int u = i >> 2, kx = i & 3, o = u / 49, p = u - 49 * o, row = 64 * o + p + p / 7 + kx;
-        reinterpret_cast<uint16_t *>(smem + TAB_BASE)[i] = (uint16_t)(kx < 3 ? row * 128 + ((row >> 1) & 3) * 32 : 0);
-    }
-    for (int i = tid; i < RING_CHUNKS * CH_ROWS; i += NTHR) {  // load table: ring row -> ring position 49 * slot + 7 y + x, or 0xFFFF for a border row
-        const int rr = (i & 63) - 9;
-        reinterpret_cast<uint16_t *>(smem + LTAB_BASE)[i] = (uint16_t)((rr >= 0 && rr < 56 && (rr & 7) != 7) ? 49 * (i >> 6) + 7 * (rr >> 3) + (rr & 7) : 0xFFFF);
-    }
+    for (int i = tid; i < LDS_BYTES / 16; i += NTHR) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
 
-    // ---- staging: every wave issues LPW chunk-loads per block: gz chunks w + NW k (k < GPW), then input window chunks w + NW (k - GPW) ----
-    // gz chunk = 4 rows of 256 B: lane l holds 16-byte column (l & 15) ^ (2 * (row & 7)) of row 4 chunk + (l >> 4)
-    int goff[GPW];
-#pragma unroll
-    for (int k = 0; k < GPW; ++k) {
-        const int row = 4 * (w + NW * k) + (lane >> 4);
-        goff[k] = row * 256 + 16 * ((lane & 15) ^ ((row & 7) << 1));
-    }
-    // input chunk = 8 rows of 128 B: lane l holds 16-byte column (l & 7) ^ (2 * ((row >> 1) & 3)) of chunk row l >> 3, and
-    // (row >> 1) & 3 = (l >> 4) & 3 because chunks start at multiples of 8 rows
-    const int in_col = 16 * ((lane & 7) ^ (((lane >> 4) & 3) << 1)), in_row = lane >> 3;
+    // ---- staging ----
+    // gz chunk c = w + 8 k (k = 0, 1) = slot rows 4 c .. 4 c + 3 of the block = image row c >> 1, x' = 4 (c & 1) + (lane >> 4);
+    // lane l holds 16-byte column (l & 15) ^ (2 x') of its row (x' = row & 7: the bank swizzle); x' = 7 is the padding slot
+    const int g_xp = 4 * (w & 1) + (lane >> 4);
+    const int g_off = g_xp * 256 + 16 * ((lane & 15) ^ (g_xp << 1));
+    // input chunk = one bordered image row, cell Xb = lane >> 3 (0 = border, pixel x = Xb - 1); lane l holds 16-byte column
+    // (l & 7) ^ (2 * ((row >> 1) & 3)) of its cell, and (row >> 1) & 3 = (l >> 4) & 3 because chunks start at multiples of 8 rows
+    const int i_off = ((lane >> 3) - 1) * 256 + 16 * ((lane & 7) ^ (((lane >> 4) & 3) << 1));
     typedef __attribute__((address_space(3))) unsigned char *lds_byte_ptr;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_byte_ptr)smem;
-    const unsigned long long zsrc = (unsigned long long)(uintptr_t)g_wgrad_zero, abase = (unsigned long long)(uintptr_t)apart;
-    struct LoadCtx {  // wave-uniform description of one block's loads
-        const uint16_t *gsrc;
-        int rows_left, c0, posA, thr;
-    };
-    auto load_ctx = [&](int jb) __attribute__((always_inline)) {
-        // input window: 16 chunks of 8 ring rows from the chunk that holds bordered row F.  A ring row's position q (table)
-        // is stream position q + posA, + 343 if its ring slot is before the slot of the window's first row
-        const int F = frontier(jb), Fm = F % RING, c0 = Fm / CH_ROWS, rb0 = F - (Fm - c0 * CH_ROWS), ow = rb0 >> 6, omw = ow % RING_OBS;
-        return LoadCtx{gpart + (long long)jb * (64 * 128), S - 64 * jb, c0, 49 * (ow - omw), 49 * omw};
-    };
-    int qv[LPW - GPW];  // ring positions of this lane's rows in the block's input chunks, read from the table well before the loads need them
-    auto fetch_q = [&](const LoadCtx &c) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < LPW - GPW; ++k) {
-            int ch = c.c0 + w + NW * k;
-            ch = ch >= RING_CHUNKS ? ch - RING_CHUNKS : ch;
-            qv[k] = reinterpret_cast<const uint16_t *>(smem + LTAB_BASE)[ch * CH_ROWS + in_row];
-        }
-    };
-    auto issue_one = [&](const LoadCtx &c, int buf, int k) __attribute__((always_inline)) {
-        if (k < GPW) {
-            const uint32_t dst = lds0 + buf * GZ_BLK + 1024 * (w + NW * k);
-            if (c.rows_left >= 64) {
-                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(goff[k]), "s"(c.gsrc) : "memory");
-            } else {  // last block: rows behind the end of the stream read zeros
-                const int row = 4 * (w + NW * k) + (lane >> 4);
-                const unsigned long long src = row < c.rows_left ? (unsigned long long)(uintptr_t)c.gsrc + (unsigned)goff[k] : zsrc;
-                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory");
+    const unsigned long long zsrc = (unsigned long long)(uintptr_t)g_wgrad_zero;
+    // load k of this wave for block jb: k = 0, 1 gz chunks w, w + 8; k = 2 image row 8 jb + 1 + w of the input (-1: row 0, prologue)
+    auto issue_one = [&](int jb, int buf, int k) __attribute__((always_inline)) {
+        if (k < 2) {
+            const int c = w + 8 * k, Ir = 8 * jb + (c >> 1), o = Ir / 7, y = Ir - 7 * o;  // wave-uniform
+            const uint32_t dst = lds0 + buf * GZ_BLK + 1024 * c;
+            if (Ir < IR) {
+                const uint16_t *src = gpart + (49 * o + 7 * y) * 128;
+                if (g_xp < 7) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(g_off), "s"(src) : "memory");
+            } else {  // behind the end of the stream: zeros (also over the padding rows, which are zero anyway)
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(zsrc) : "memory");
             }
         } else {
-            int ch = c.c0 + w + NW * (k - GPW);
-            ch = ch >= RING_CHUNKS ? ch - RING_CHUNKS : ch;
-            const uint32_t dst = lds0 + IN_BASE + 1024 * ch;
-            const int q = qv[k - GPW];
-            const int pos = q + c.posA + (q < c.thr ? TAB_N : 0);
-            // every lane loads: the ones without data of this partition read 16 zero bytes (border rows are zero anyway)
-            const unsigned long long src = (q != 0xFFFF && pos < S) ? abase + (unsigned)(pos * 256 + in_col) : zsrc;
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory");
+            const int Ir = k == 2 ? 8 * jb + 1 + w : 0, o = Ir / 7, y = Ir - 7 * o;  // wave-uniform
+            const uint32_t dst = lds0 + IN_BASE + 1024 * (8 * (o % RING_OBS) + y + 1);
+            if (Ir < IR) {
+                const uint16_t *src = apart + (49 * o + 7 * y) * 128;
+                if (lane >= 8) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(i_off), "s"(src) : "memory");
+            } else {  // nobody multiplies these rows by anything but zero gz rows; the load keeps every wave's count equal
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(zsrc) : "memory");
+            }
         }
     };
-    auto issue_loads = [&](int jb, int buf) __attribute__((always_inline)) {
-        const LoadCtx c = load_ctx(jb);
-        fetch_q(c);
-#pragma unroll
-        for (int k = 0; k < LPW; ++k) issue_one(c, buf, k);
-    };
     auto wait_all_but_newest = [&]() __attribute__((always_inline)) {
-        static_assert(LPW == 4, "the count below is the loads per wave and block");
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        static_assert(LPW == 3, "the count below is the loads per wave and block");
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     };
 
     // ---- fragment addresses of this lane (ds_read_b64_tr_b16: lane 4q+p of a 16-lane group supplies row q, columns 4p..) ----
     const int li = lane & 15, lh = lane >> 4, q4 = li >> 2, p4 = li & 3;
-    // K slot (lh, j) of a 32-slot k-step: slot 4 lh + j for j < 4 (first read, "blk 0"), 16 + 4 lh + (j - 4) for the second
-    // gz: row = slot of the block; the 32 bytes of co tile ct sit in column group ct ^ (row & 7), and row & 7 = (4 lh + q4) & 7
+    // K slot (lh, j) of a 32-slot k-step: slot 4 lh + j for j < 4 (first read, "blk 0"), 16 + 4 lh + (j - 4) for the second;
+    // slot s of a k-step = image row 4 ks + (s >> 3) of the block, x' = s & 7: this lane has x' = (4 lh + q4) & 7 in both reads
+    // and image rows 4 ks + 2 blk + (lh >> 1)
+    const int xp = (4 * lh + q4) & 7;
+    // gz: row = slot of the block; the 32 bytes of co tile ct sit in column group ct ^ (row & 7), and row & 7 = x'
     int a_addr[CT];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) a_addr[c] = (4 * lh + q4) * 256 + (((CT * chalf + c) ^ ((4 * lh + q4) & 7)) << 5) + 8 * p4;
-    // input: ring position u = (49 * observation + 7 y + x) mod 343 of this lane's two slots in the NEXT k-step to be addressed;
-    // table -> (row << 7) | (swizzle << 5) per kx; this lane's 8 bytes of its wave's 16 channels: ^ ((nq << 5) | (p4 << 3)); tap row
-    // ky is the immediate 8 ky * 128 (8 rows further the swizzle is the same)
-    int un[2] = {4 * lh + q4, 16 + 4 * lh + q4};
-    const unsigned b_lane = (unsigned)((nq << 5) | (p4 << 3));
-    unsigned bc[2][3], bn[2][3];  // current / next k-step: [blk][kx]
-    auto next_addresses = [&](unsigned (&dst)[2][3]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            const u32x2 e = *reinterpret_cast<const u32x2 *>(smem + TAB_BASE + 8 * un[blk]);
-            dst[blk][0] = ((e[0] & 0xFFFFu) ^ b_lane) + (unsigned)IN_BASE;
-            dst[blk][1] = ((e[0] >> 16) ^ b_lane) + (unsigned)IN_BASE;
-            dst[blk][2] = (e[1] ^ b_lane) + (unsigned)IN_BASE;
-            const unsigned u = (unsigned)un[blk] + 32u;  // advance by one k-step (32 positions)
-            un[blk] = (int)min(u, u - (unsigned)TAB_N);
-        }
+    for (int c = 0; c < CT; ++c) a_addr[c] = (4 * lh + q4) * 256 + (((CT * chalf + c) ^ xp) << 5) + 8 * p4;
+    // input: tap (ky,kx) of slot (image row, x') is bordered cell row 8 * (chunk of the row above) + x' + kx + 8 ky; the 32 bytes of
+    // this wave's 16 channels sit in column group nq ^ ((row >> 1) & 3) = nq ^ (((x' + kx) & 7) >> 1): per lane and kx
+    const int b_kx0 = IN_BASE + (xp + 0) * 128 + ((nq ^ (((xp + 0) & 7) >> 1)) << 5) + 8 * p4;
+    const int b_kx1 = IN_BASE + (xp + 1) * 128 + ((nq ^ (((xp + 1) & 7) >> 1)) << 5) + 8 * p4;
+    const int b_kx2 = IN_BASE + (xp + 2) * 128 + ((nq ^ (((xp + 2) & 7) >> 1)) << 5) + 8 * p4;
+    // scalar walk over the image rows: (observation mod 7, y) of the first image row of the NEXT k-step to be addressed
+    int s_om = 0, s_y = 0;
+    struct KAddr {  // byte offsets of the taps' cell rows (ky = 0) of one k-step: blk 0 / 1, kx 0..2 (named members: an array
+        int a0, a1, a2, b0, b1, b2;  // handed through a lambda lands in LDS)
     };
+    const bool upper = (lh >> 1) != 0;
+    auto next_chunk = [&]() __attribute__((always_inline)) {  // chunk (bordered image row) ABOVE the walk's image row: 8 om + y
+        const int c = 8 * s_om + s_y;
+        const bool wrap = s_y == 6;
+        s_y = wrap ? 0 : s_y + 1;
+        s_om = wrap ? (s_om == RING_OBS - 1 ? 0 : s_om + 1) : s_om;
+        return c;
+    };
+    auto next_addresses = [&]() __attribute__((always_inline)) {
+        const int c0 = next_chunk(), c1 = next_chunk(), c2 = next_chunk(), c3 = next_chunk();
+        const int base0 = (upper ? c1 : c0) << 10, base1 = (upper ? c3 : c2) << 10;  // 8 cells of 128 B per chunk
+        return KAddr{base0 + b_kx0, base0 + b_kx1, base0 + b_kx2, base1 + b_kx0, base1 + b_kx1, base1 + b_kx2};
+    };
+    KAddr bc, bn;  // current / next k-step
 
     f32x4 acc[CT][NTAP];
 #pragma unroll
@@ -239,16 +197,15 @@ __global__ void __launch_bounds__(NTHR) encoder_wgrad_kernel(const uint16_t *__r
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    __syncthreads();  // zero fill and tables done
-    if (!(MAPF_WGRAD_ABLATE & 1)) {
-        if (nblk > 0) issue_loads(0, 0);
-        if (nblk > 1) issue_loads(1, 1);
-        if (nblk > 2) {
-            issue_loads(2, 2);
+    __syncthreads();  // zero fill done
+    if (!(MAPF_WGRAD_ABLATE & 1) && nblk > 0) {
+        issue_one(0, 0, 3);  // image row 0 (every wave loads it: same data, equal load counts)
+        for (int jb = 0; jb < 3 && jb < nblk; ++jb)
+            for (int k = 0; k < LPW; ++k) issue_one(jb, jb, k);
+        if (nblk > 2)
             wait_all_but_newest();  // blocks 0 and 1 have landed
-        } else {
+        else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
     }
     __syncthreads();
 
@@ -257,10 +214,11 @@ __global__ void __launch_bounds__(NTHR) encoder_wgrad_kernel(const uint16_t *__r
     auto read_a = [&](const unsigned char *gbuf, int ks, int c) {
         return tr_read2(gbuf + a_addr[c] + (32 * ks) * 256, gbuf + a_addr[c] + (32 * ks + 16) * 256);
     };
-    auto read_b = [&](const unsigned (&q)[2][3], int t) {
-        return tr_read2(smem + q[0][t % 3] + (8 * (t / 3)) * 128, smem + q[1][t % 3] + (8 * (t / 3)) * 128);
+    auto read_b = [&](const KAddr &q, int t) {
+        const int q0 = t % 3 == 0 ? q.a0 : (t % 3 == 1 ? q.a1 : q.a2), q1 = t % 3 == 0 ? q.b0 : (t % 3 == 1 ? q.b1 : q.b2);
+        return tr_read2(smem + q0 + (8 * (t / 3)) * 128, smem + q1 + (8 * (t / 3)) * 128);
     };
-    next_addresses(bc);
+    bc = next_addresses();
     if (nblk > 0) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) af[0][c] = read_a(smem, 0, c);
@@ -271,16 +229,12 @@ __global__ void __launch_bounds__(NTHR) encoder_wgrad_kernel(const uint16_t *__r
     // One block (step j): 2 k-steps x NTAP x CT MFMAs on gz buffer `b`; the fragments of its second k-step, then of the next
     // block's first k-step (buffer b1, complete since the last barrier), are read behind the MFMAs.
     // Staging: the loads of block j + 3 go into the gz buffer that step j - 1 read (free since its barrier) and into the
-    // input ring; the step ends by waiting for block j + 2 (issued one step earlier) and a barrier.
+    // input ring (image rows at least 17 behind the oldest one block j still reads); the step ends by waiting for block
+    // j + 2 (issued one step earlier) and a barrier.
     auto one_blk = [&](int j, auto B, auto B1, auto B3) __attribute__((always_inline)) {
         constexpr int b = decltype(B)::value, b1 = decltype(B1)::value, b3 = decltype(B3)::value;
         const unsigned char *ga = smem + b * GZ_BLK, *ga1 = smem + b1 * GZ_BLK;
         const bool more = j + 3 < nblk && !(MAPF_WGRAD_ABLATE & 1);
-        LoadCtx lc = {gpart, 64, 0, 0, 0};
-        if (more) {
-            lc = load_ctx(j + 3);
-            fetch_q(lc);
-        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -291,8 +245,8 @@ __global__ void __launch_bounds__(NTHR) encoder_wgrad_kernel(const uint16_t *__r
 #pragma unroll
             for (int t = 0; t < NTAP; ++t) {
                 const int g = ks * NTAP + t, gr = b * 2 * NTAP + g;  // tile-step of the block / of the 4-block turn (72: a multiple of RB)
-                if (t == 1) next_addresses(bn);
-                if (more && g % 4 == 1 && g / 4 < LPW) issue_one(lc, b3, g / 4);  // tile-steps 1, 5, 9, 13
+                if (t == 1) bn = next_addresses();
+                if (more && g % 5 == 1 && g / 5 < LPW) issue_one(j + 3, b3, g / 5);  // tile-steps 1, 6, 11
                 if (!(MAPF_WGRAD_ABLATE & 2)) {
                     if (t + RB - 1 < NTAP)
                         br[(gr + RB - 1) % RB] = read_b(bc, t + RB - 1);
@@ -306,8 +260,7 @@ __global__ void __launch_bounds__(NTHR) encoder_wgrad_kernel(const uint16_t *__r
                     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[c][t]) : "v"(af[cur][c]), "v"(br[gr % RB]));
                 __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) bc[i / 3][i % 3] = bn[i / 3][i % 3];
+            bc = bn;
         }
         __builtin_amdgcn_sched_barrier(0);
         if (more)
@@ -364,7 +317,7 @@ int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M
     if ((reinterpret_cast<uintptr_t>(gz_dev) & 15) || (reinterpret_cast<uintptr_t>(in_dev) & 15) ||
         (reinterpret_cast<uintptr_t>(partial_dev) & 15))
         return MAPF_ERR_INVALID_ARG;
-    if ((M + MAPF_ENC_WGRAD_PARTS - 1) / MAPF_ENC_WGRAD_PARTS > (1 << 17)) return MAPF_ERR_INVALID_ARG;  // 32-bit byte offsets inside a partition
+    if ((M + MAPF_ENC_WGRAD_PARTS - 1) / MAPF_ENC_WGRAD_PARTS > (1 << 18)) return MAPF_ERR_INVALID_ARG;  // int element offsets inside a partition
     // every partition writes its slab (zeros when it has no observations), so the caller's sum is always defined
     hipLaunchKernelGGL(encoder_wgrad_kernel, dim3(SLABS * MAPF_ENC_WGRAD_PARTS), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gz_dev,
                        in_dev, (long long)M, partial_dev);
