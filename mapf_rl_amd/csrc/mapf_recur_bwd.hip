@@ -122,6 +122,9 @@ __device__ __forceinline__ bf16x8 row_frag(const unsigned char *img, int row_byt
     return *reinterpret_cast<const bf16x8 *>(img + row * row_bytes + (k0 + 8 * (lane >> 4)) * 2);
 }
 
+// A pointer that went through an opaque `asm volatile("" : "+s"(p))` comes back GENERIC, and hipcc then emits FLAT loads -- which
+// also count on the LDS counter, so every LDS wait waits for the weight stream too.  Back into the global address space:
+#define GLOBAL_FRAG(p) ((const __attribute__((address_space(1))) bf16x8 *)(p))
 // acc[n] += (packed tile `wp`, KS k-steps) * B^T, B rows in an LDS image: row(agent) = X + agent * xrow, columns 0 .. 32 KS
 template <int KS>
 __device__ __forceinline__ void gemm_lB(f32x4 (&acc)[NT], const unsigned char *__restrict__ wt, int tile_kstep, const unsigned char *X, int xrow,
@@ -136,7 +139,7 @@ __device__ __forceinline__ void gemm_lB(f32x4 (&acc)[NT], const unsigned char *_
     for (int kk = 0; kk < KS; ++kk) {
         const unsigned char *pk = wp + kk * 1024;
         asm volatile("" : "+s"(pk));
-        a[kk] = *reinterpret_cast<const bf16x8 *>(pk + voff);
+        a[kk] = *GLOBAL_FRAG(pk + voff);
     }
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk)
@@ -162,8 +165,8 @@ __device__ __forceinline__ void gemm2_lB(f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], c
         // them out of the time loop and spills them)
         const unsigned char *p0 = w0 + kk * 1024, *p1 = w1 + kk * 1024;
         asm volatile("" : "+s"(p0), "+s"(p1));
-        a0[kk] = *reinterpret_cast<const bf16x8 *>(p0 + voff);
-        a1[kk] = *reinterpret_cast<const bf16x8 *>(p1 + voff);
+        a0[kk] = *GLOBAL_FRAG(p0 + voff);
+        a1[kk] = *GLOBAL_FRAG(p1 + voff);
     }
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk)

@@ -26,6 +26,22 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// A pointer that went through an opaque `asm volatile("" : "+s"(p))` (to keep step-invariant loads inside the step loop) comes
+// back GENERIC, and hipcc then emits FLAT loads/stores -- which also count on the LDS counter, so every LDS wait waits for the
+// weight stream too.  GLOBAL_PTR puts it back into the global address space.
+#define GLOBAL_PTR(T, p) ((__attribute__((address_space(1))) T *)(p))
+// (through native vector types: HIP's float4 / uint2 are classes, and copying one takes a generic `this`)
+typedef __attribute__((ext_vector_type(4))) float gf32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int gu32x2;
+__device__ __forceinline__ float4 gload_f4(const void *p) {
+    const gf32x4 v = *GLOBAL_PTR(const gf32x4, p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ uint2 gload_u2(const void *p) {
+    const gu32x2 v = *GLOBAL_PTR(const gu32x2, p);
+    return make_uint2(v[0], v[1]);
+}
+__device__ __forceinline__ void gstore_u2(void *p, uint2 v) { *GLOBAL_PTR(gu32x2, p) = gu32x2{v.x, v.y}; }
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -98,9 +114,9 @@ __device__ __forceinline__ void gemm3(f32x4 (&acc0)[NTH], f32x4 (&acc1)[NTH], f3
         for (int kk = 0; kk < KC; ++kk) {
             const unsigned char *p0 = w0 + (kc + kk) * 1024, *p1 = w1 + (kc + kk) * 1024, *p2 = w2 + (kc + kk) * 1024;
             asm volatile("" : "+s"(p0), "+s"(p1), "+s"(p2));
-            a[kk][0] = *reinterpret_cast<const bf16x8 *>(p0 + voff);
-            a[kk][1] = *reinterpret_cast<const bf16x8 *>(p1 + voff);
-            a[kk][2] = *reinterpret_cast<const bf16x8 *>(p2 + voff);
+            a[kk][0] = *GLOBAL_PTR(const bf16x8, p0 + voff);
+            a[kk][1] = *GLOBAL_PTR(const bf16x8, p1 + voff);
+            a[kk][2] = *GLOBAL_PTR(const bf16x8, p2 + voff);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -132,10 +148,8 @@ __device__ __forceinline__ void gru_job(uint2 (&outv)[NTH], int cblk, int tile0,
     // (opaque scalar bases: the bias values do not depend on the step, and the compiler would otherwise load all of them -- 24
     // registers per job -- once in front of the step loop and keep them in scratch)
     asm volatile("" : "+s"(bi), "+s"(bh), "+s"(gi_glob), "+s"(gsave));
-    const float4 bir = *reinterpret_cast<const float4 *>(bi + c0), biz = *reinterpret_cast<const float4 *>(bi + 256 + c0),
-                 bin = *reinterpret_cast<const float4 *>(bi + 512 + c0);
-    const float4 bhr = *reinterpret_cast<const float4 *>(bh + c0), bhz = *reinterpret_cast<const float4 *>(bh + 256 + c0),
-                 bhn = *reinterpret_cast<const float4 *>(bh + 512 + c0);
+    const float4 bir = gload_f4(bi + c0), biz = gload_f4(bi + 256 + c0), bin = gload_f4(bi + 512 + c0);
+    const float4 bhr = gload_f4(bh + c0), bhz = gload_f4(bh + 256 + c0), bhn = gload_f4(bh + 512 + c0);
 #pragma unroll
     for (int n = 0; n < NTH; ++n) {
         ar[n] = f32x4{bir.x + bhr.x, bir.y + bhr.y, bir.z + bhr.z, bir.w + bhr.w};
@@ -146,8 +160,7 @@ __device__ __forceinline__ void gru_job(uint2 (&outv)[NTH], int cblk, int tile0,
             const int agent = 16 * (tile0 + n) + lr;
             if (agent < nagents) {
                 const unsigned char *g = reinterpret_cast<const unsigned char *>(gi_glob) + (uint32_t)(agent * 768 + c0) * 2u;
-                const uint2 gr = *reinterpret_cast<const uint2 *>(g), gz = *reinterpret_cast<const uint2 *>(g + 512),
-                            gn = *reinterpret_cast<const uint2 *>(g + 1024);
+                const uint2 gr = gload_u2(g), gz = gload_u2(g + 512), gn = gload_u2(g + 1024);
                 ar[n] += f32x4{bf16_lo(gr.x), bf16_hi(gr.x), bf16_lo(gr.y), bf16_hi(gr.y)};
                 az[n] += f32x4{bf16_lo(gz.x), bf16_hi(gz.x), bf16_lo(gz.y), bf16_hi(gz.y)};
                 ani[n] += f32x4{bf16_lo(gn.x), bf16_hi(gn.x), bf16_lo(gn.y), bf16_hi(gn.y)};
@@ -173,10 +186,10 @@ __device__ __forceinline__ void gru_job(uint2 (&outv)[NTH], int cblk, int tile0,
         }
         if (gsave != nullptr && agent < nagents) {
             unsigned char *gs = reinterpret_cast<unsigned char *>(gsave) + (uint32_t)(agent * 1024 + c0) * 2u;
-            *reinterpret_cast<uint2 *>(gs) = pack4(rg4);
-            *reinterpret_cast<uint2 *>(gs + 512) = pack4(zg4);
-            *reinterpret_cast<uint2 *>(gs + 1024) = pack4(ng4);
-            *reinterpret_cast<uint2 *>(gs + 1536) = pack4(anh[n]);
+            gstore_u2(gs, pack4(rg4));
+            gstore_u2(gs + 512, pack4(zg4));
+            gstore_u2(gs + 1024, pack4(ng4));
+            gstore_u2(gs + 1536, pack4(anh[n]));
         }
         const bool keep = upd != nullptr && upd[agent] == 0;
         outv[n] = keep ? hv : pack4(o);
@@ -303,8 +316,8 @@ __device__ __forceinline__ void wo_accumulate(f32x4 (&acc_info)[4], const f32x4 
                 uint2 u[2];
                 bf16x8 v;
             } a;
-            a.u[0] = *reinterpret_cast<const uint2 *>(p);            // k = 4 lh + jj
-            a.u[1] = *reinterpret_cast<const uint2 *>(p + 32 * 16);  // k = 16 + 4 lh + jj
+            a.u[0] = gload_u2(p);            // k = 4 lh + jj
+            a.u[1] = gload_u2(p + 32 * 16);  // k = 16 + 4 lh + jj
             acc_info[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, bc, acc_info[ot], 0, 0, 0);
         }
     }
@@ -387,7 +400,7 @@ __global__ void __launch_bounds__(NTHR) recurrent_wide_kernel(const uint16_t *__
                     asm volatile("" : "+s"(bq));
 #pragma unroll
                     for (int g = 0; g < 3; ++g) {
-                        const float4 b4 = *reinterpret_cast<const float4 *>(bq + 128 * g + 64 * hd + 16 * ct + 4 * lh);
+                        const float4 b4 = gload_f4(bq + 128 * g + 64 * hd + 16 * ct + 4 * lh);
 #pragma unroll
                         for (int n = 0; n < NTH; ++n) acc[g][n] = f32x4{b4.x, b4.y, b4.z, b4.w};
                     }

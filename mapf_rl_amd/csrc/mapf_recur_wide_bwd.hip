@@ -112,7 +112,9 @@ __device__ __forceinline__ bf16x8 row_frag(const unsigned char *img, int row_byt
 __device__ __forceinline__ bf16x8 wfrag(const unsigned char *WTB, int unit, uint32_t voff) {
     const unsigned char *p = WTB + (size_t)unit * 1024;
     asm volatile("" : "+s"(p));
-    return *reinterpret_cast<const bf16x8 *>(p + voff);
+    // (behind the asm the pointer is generic; back to the global address space, or hipcc emits FLAT loads, which also count on the
+    // LDS counter and make every LDS wait wait for the weight stream)
+    return *((const __attribute__((address_space(1))) bf16x8 *)(p + voff));
 }
 
 template <int NT>

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CAND = os.path.join(ROOT, "mapf_rl_amd", "csrc", "mapf_wgrad.hip")
 ABLATE = (1, 2, 3)
-NAMES = ["base", "cand"] + ["cand_a%d" % m for m in ABLATE]
+NAMES = ["base", "cand"] + ["cand_a%d" % m for m in ABLATE] + [n for n in os.environ.get("WGRAD_EXTRA", "").split(",") if n]  # extras: prebuilt wgrad_ab_<name>.so
 
 
 def so(name):
@@ -51,7 +51,7 @@ def run():
         gz = (torch.randn((M, 7, 7, 128), device="cuda", generator=g) * (torch.rand((M, 7, 7, 128), device="cuda", generator=g) < 0.5)).to(torch.bfloat16)
         a = torch.relu(torch.randn((M, 7, 7, 128), device="cuda", generator=g)).to(torch.bfloat16)
         ref = torch.nn.grad.conv2d_weight(a.float().permute(0, 3, 1, 2), (128, 128, 3, 3), gz.float().permute(0, 3, 1, 2), padding=1)
-        for name in ("base", "cand"):
+        for name in [n for n in NAMES if "_a" not in n]:
             ws = torch.full((128, 128, 3, 3, 128), float("nan"), dtype=torch.float32, device="cuda")
             rc = libs[name](gz.data_ptr(), a.data_ptr(), M, ws.data_ptr(), st)
             torch.cuda.synchronize()
