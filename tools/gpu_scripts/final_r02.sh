@@ -25,3 +25,14 @@ find gpurun_out/prof_bench gpurun_out/prof_actor gpurun_out/prof_learner gpurun_
 cat gpurun_out/pmc_FETCH_SIZE.txt gpurun_out/pmc_WRITE_SIZE.txt gpurun_out/pmc_FETCH_SIZE_16k.txt gpurun_out/pmc_WRITE_SIZE_16k.txt
 head -14 gpurun_out/prof_bench.md; head -30 gpurun_out/prof_learner_iter.md; head -16 gpurun_out/prof_actor_iter.md
 tail -c 1200 gpurun_out/prof_bench.json
+# config 5's agent count (128): learner breakdown + rates (64x64 / 128 agents / 2048 envs and 40x40 / 64 agents)
+cd /tmp
+NAGENTS=128 TUPD=4 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_learner128 -- python3 $R/tools/profile_update.py > $R/gpurun_out/prof_learner128.log 2>&1; echo learner128=$?
+cd $R
+python tools/trace_breakdown.py gpurun_out/prof_learner128 encoder_bwd_kernel 30 > gpurun_out/prof_learner128_iter.md
+find gpurun_out/prof_learner128 -name "*.csv" -size +1M -delete
+timeout -k 10 400 python tools/c5_bench.py > gpurun_out/c5_rates.txt 2>&1; echo c5=$?
+timeout -k 10 400 python tools/c5_bench.py --double-q >> gpurun_out/c5_rates.txt 2>&1; echo c5dq=$?
+timeout -k 10 400 python tools/c5_bench.py 64 40 2048 >> gpurun_out/c5_rates.txt 2>&1; echo c5_64=$?
+grep -v amdgpu.ids gpurun_out/c5_rates.txt
+head -14 gpurun_out/prof_learner128_iter.md
