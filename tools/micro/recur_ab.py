@@ -18,7 +18,7 @@ def so(name):
 
 
 def hipcc(src, out):
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-mllvm", "-pragma-unroll-threshold=262144",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3"] + os.environ.get("RECUR_CAND_FLAGS", "").split() * (out.endswith("cand.so")) + [ "--offload-arch=gfx950", "-std=c++17", "-mllvm", "-pragma-unroll-threshold=262144",
                            "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "mapf_rl_amd", "csrc"), src,
                            os.path.join(ROOT, "mapf_rl_amd", "csrc", "mapf_recur_wide.hip"), "-o", out])  # (the wide kernel: the N > 48 entry it forwards to)
 
