@@ -175,6 +175,17 @@ int mapf_recurrent_backward(const uint16_t *const *saved_dev, const uint8_t *com
 int mapf_comm_mask(const int16_t *pos_dev, int E, int N, int obs_radius, int max_comm, uint8_t *mask_dev,
                    int32_t *packed_dev, int cw, void *stream);
 
+/*
+ * Which (step, window, agent) entries of a training batch can influence `Network.bootstrap`'s output at all.  The reference
+ * learns from agent 0's hidden state at step steps[b] - 1 only (model.py:248,255), and within a step an agent's state depends on
+ * another's only through the communication mask (two attention rounds, model.py:116-130: agent i reads the agents j with
+ * comm[b][t][i][j]); encoder, GRU cells and Q head are per agent.  rel = the backward closure of {agent 0 at step steps[b] - 1}:
+ * per step two hops along the mask, carried to the step before through the agent's own recurrent state.  Entries outside it
+ * contribute nothing to q and receive an exactly zero gradient, so the caller need not encode their observations.
+ * comm_dev u8 [B][T][N][N] (non-zero = allowed); steps_dev int64 [B], 1-based; rel_dev u8 [T][B][N] (time-major).  N <= 128.
+ */
+int mapf_window_relevance(const uint8_t *comm_dev, const int64_t *steps_dev, int T, int B, int N, uint8_t *rel_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,7 @@ SYMBOLS = [
     ("mapf_recurrent_forward_save", _i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, ctypes.POINTER(_vp), _vp]),
     ("mapf_recurrent_backward", _i, [ctypes.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(_vp), _vp]),
     ("mapf_comm_mask", _i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    ("mapf_window_relevance", _i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     ("mapf_encoder_pack", _i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp, _vp]),
     ("mapf_encoder_forward", _i, [_vp, _i, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     ("mapf_encoder_pack_bwd", _i, [ctypes.POINTER(_vp), _vp, _vp]),

@@ -150,6 +150,36 @@ int pick_grid(long long nvec, int groups) {
     return (int)(blocks < 1 ? 1 : blocks);
 }
 
+// ---- which entries of a training window can reach its output (see mapf_dqn.h: mapf_window_relevance) ----
+// One workgroup per window, thread j = agent j.  Walks the steps backwards: the set starts as {agent 0} at the window's last
+// step, grows by two hops along the step's communication mask (agent i reads agent j where comm[i][j]), and is carried to the
+// step before through every agent's own recurrent state.  As ~20 PyTorch launches per step this cost more host time than the
+// pruned encoder launches it makes possible.
+__global__ void __launch_bounds__(128) window_relevance_kernel(const uint8_t *__restrict__ comm, const long long *__restrict__ steps, int T, int B,
+                                                               int N, uint8_t *__restrict__ rel) {
+    __shared__ uint8_t r[128];
+    const int b = blockIdx.x, j = threadIdx.x;
+    const long long last = steps[b] - 1;
+    r[j] = 0;
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+        if (t == last && j == 0) r[0] = 1;
+        __syncthreads();
+        if (t <= last) {  // (uniform: before the window's last step the set is empty)
+            const uint8_t *m = comm + ((size_t)b * T + t) * N * N;
+            for (int round = 0; round < 2; ++round) {
+                uint8_t v = j < N ? r[j] : 0;
+                for (int i = 0; i < N; ++i)
+                    if (r[i] && j < N && m[i * N + j]) v = 1;
+                __syncthreads();
+                r[j] = v;
+                __syncthreads();
+            }
+        }
+        if (j < N) rel[((size_t)t * B + b) * N + j] = r[j];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -193,6 +223,16 @@ int mapf_comm_mask(const int16_t *pos_dev, int E, int N, int obs_radius, int max
     const int k = max_comm < N ? max_comm : N;
     hipLaunchKernelGGL(comm_mask_kernel, dim3(E), dim3(128), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const short2 *>(pos_dev), N, obs_radius, k, mask_dev, packed_dev, cw);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+int mapf_window_relevance(const uint8_t *comm_dev, const int64_t *steps_dev, int T, int B, int N, uint8_t *rel_dev, void *stream) {
+    if (T < 1 || B < 0 || N < 1 || N > 128 || !comm_dev || !steps_dev || !rel_dev) return MAPF_ERR_INVALID_ARG;
+    if (reinterpret_cast<uintptr_t>(steps_dev) & 7) return MAPF_ERR_INVALID_ARG;
+    if (B == 0) return MAPF_OK;
+    hipLaunchKernelGGL(window_relevance_kernel, dim3(B), dim3(128), 0, static_cast<hipStream_t>(stream), comm_dev,
+                       reinterpret_cast<const long long *>(steps_dev), T, B, N, rel_dev);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }

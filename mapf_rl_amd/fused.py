@@ -125,6 +125,18 @@ def encoder_forward(obs, packed_weights, packed_bias):
     return out
 
 
+def window_relevance(comm_mask_bt, steps):
+    """comm_mask_bt bool/uint8 [B, T, N, N], steps int64 [B] (1-based) on a HIP device -> bool [T, B, N]:
+    include/mapf_dqn.h mapf_window_relevance (the entries of a training window that can reach agent 0's Q-value)."""
+    assert comm_mask_bt.is_cuda and comm_mask_bt.dim() == 4 and comm_mask_bt.dtype in (torch.bool, torch.uint8)
+    m = comm_mask_bt.contiguous()
+    B, T, N, _ = m.shape
+    st = steps.to(device=m.device, dtype=torch.int64).contiguous()
+    rel = torch.empty((T, B, N), dtype=torch.bool, device=m.device)
+    check(lib.mapf_window_relevance(_ptr(m), _ptr(st), T, B, N, _ptr(rel), _stream(m.device)), "mapf_window_relevance")
+    return rel
+
+
 def comm_mask(pos, obs_radius=4, max_comm=3, packed_words=0):
     """pos int16 [E, N, 2] on a HIP device -> (bool [E, N, N], int32 [E, N, packed_words] or None):
     include/mapf_dqn.h mapf_comm_mask (reference model.py:195-208)."""

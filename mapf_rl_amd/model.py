@@ -225,6 +225,36 @@ def _sdpa_mask(allowed):
     return allowed | (empty & eye)
 
 
+def relevance(comm_mask: torch.Tensor, steps: torch.Tensor) -> torch.Tensor:
+    """Which (step, sample, agent) entries of a training window can influence its output at all.
+
+    `bootstrap` learns from agent 0's hidden state at step `steps - 1` only (model.py:248,255), and within a step an agent's state
+    depends on another's only through the communication mask: CommBlock runs two attention rounds in which agent i reads the
+    agents j with comm_mask[b, t, i, j] (model.py:116-130).  Everything else -- encoder, GRU cells, Q head -- is per agent.
+    So the entries that matter are the backward closure of {agent 0 at step steps - 1}: per step two hops along the mask,
+    carried to the step before through the agent's own recurrent state.  Entries outside it (other agents' observations that never
+    reach agent 0, steps behind the window's end) contribute exactly nothing to q and receive an exactly zero gradient.
+
+    comm_mask bool [B, T, N, N]; steps int64 [B] (1-based) -> bool [T, B, N] (time-major, as `bootstrap` lays out its latents)."""
+    B, T, N, _ = comm_mask.shape
+    if comm_mask.is_cuda and N <= 128:  # one launch (csrc/mapf_dqn.hip) instead of ~20 per step
+        from .fused import window_relevance
+
+        return window_relevance(comm_mask, steps.view(B))
+    m = comm_mask.to(torch.bool)
+    last = steps.to(comm_mask.device).view(B) - 1
+    agent0 = torch.zeros((B, N), dtype=torch.bool, device=comm_mask.device)
+    agent0[:, 0] = True
+    r = torch.zeros((B, N), dtype=torch.bool, device=comm_mask.device)
+    rel = torch.zeros((T, B, N), dtype=torch.bool, device=comm_mask.device)
+    for t in range(T - 1, -1, -1):
+        r = r | (agent0 & (last == t).view(B, 1))
+        for _ in range(2):  # i needed and i reads j  =>  j needed
+            r = r | (r.unsqueeze(2) & m[:, t]).any(dim=1)
+        rel[t] = r
+    return rel
+
+
 def comm_mask_from_pos(pos: torch.Tensor, obs_radius: int = OBS_RADIUS, max_comm: int = MAX_COMM_AGENTS) -> torch.Tensor:
     """pos [E, N, 2] (any integer/float dtype) -> bool [E, N, N]: j is within i's FOV square AND among i's
     `max_comm` nearest agents by Euclidean distance, itself included (reference model.py:195-208).
@@ -387,6 +417,7 @@ class Network(nn.Module):
     FUSED_BPTT = True  # with autograd: the T-step recurrence as a forward-save + a backward-through-time kernel
     FUSED_RECURRENCE = True  # without autograd: GRU + CommBlock of all steps in one kernel (csrc/mapf_recur.hip, mapf_recur_wide.hip)
     SDPA = True  # fused scaled-dot-product attention inside _recur_fast
+    PRUNE_UNREACHABLE = True  # HIP device, `bootstrap`: encode only the observations that can reach agent 0's Q-value (see `relevance`)
     FAST_RECURRENCE = True  # HIP device: hoisted input projection, fused QKV, deferred weight gradients (see _recur_fast)
 
     def bootstrap(self, obs, steps, hidden, comm_mask):
@@ -399,7 +430,17 @@ class Network(nn.Module):
                 # time-major from the start: transposing the raw observation bytes is 3x cheaper than transposing the latent
                 # (and its gradient, on the way back), and the encoder does not care about row order
                 obs_t = obs.transpose(0, 1).contiguous()
-                latent_t = self.encode(obs_t.view(T * B * N, *OBS_SHAPE)).view(T, B, N, ENC_FEATURES)
+                if self.PRUNE_UNREACHABLE:
+                    # only the observations agent 0's Q-value can depend on go through the encoder (see `relevance`): at 40
+                    # agents that is ~1/9 of the window -- the encoder is 80 % of an update -- and the result is the same, not an
+                    # approximation.  The other rows of the latent stay zero: their agents run through the recurrence on
+                    # meaningless states that, by construction, nobody who matters reads.
+                    rows = relevance(comm_mask, steps).view(-1).nonzero().squeeze(1)  # (one host sync: the row count)
+                    lat = self.encode(obs_t.view(T * B * N, *OBS_SHAPE).index_select(0, rows))
+                    latent_t = torch.zeros((T * B * N, ENC_FEATURES), dtype=lat.dtype, device=lat.device).index_copy(0, rows, lat)
+                    latent_t = latent_t.view(T, B, N, ENC_FEATURES)
+                else:
+                    latent_t = self.encode(obs_t.view(T * B * N, *OBS_SHAPE)).view(T, B, N, ENC_FEATURES)
                 agent0 = self._recur_fast(latent_t, hidden.to(latent_t.dtype), comm_mask)
             else:
                 latent = self.encode(obs.reshape(B * T * N, *OBS_SHAPE)).view(B, T, N, ENC_FEATURES)
