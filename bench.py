@@ -284,41 +284,49 @@ def main():
             from mapf_rl_amd.learner import Learner
             from mapf_rl_amd.replay import GlobalBuffer
 
+            from mapf_rl_amd.model import Network, relevance
+
             torch.manual_seed(1234)  # identical initial weights on every rank
-            buf = GlobalBuffer(64, max_agents=N, device=dev)
-            g2 = torch.Generator(device=dev)
-            g2.manual_seed(5 + rank)
-            RD, CW, S = buf.row_dwords, (N + 31) // 32, 96
-            for k in range(64):  # synthetic episodes written straight into the ring (random observation bits)
-                td = torch.zeros(256, dtype=torch.float64, device=dev)
-                td[:S] = torch.rand(S, generator=g2, device=dev, dtype=torch.float64) + 0.05
-                buf.add_episode_device(
-                    N, S, k % 2, torch.randint(-2**31, 2**31 - 1, (S + 1, RD), generator=g2, device=dev, dtype=torch.int32) &
-                    torch.randint(-2**31, 2**31 - 1, (S + 1, RD), generator=g2, device=dev, dtype=torch.int32),
-                    torch.randint(0, 2**20, (S + 1, N, CW), generator=g2, device=dev, dtype=torch.int32),
-                    torch.randint(0, 5, (S,), generator=g2, device=dev, dtype=torch.uint8),
-                    (torch.rand(S, generator=g2, device=dev) - 0.5).half(), (torch.randn((S, 256), generator=g2, device=dev) * 0.3).half(), td)
+            # The replay is filled by the actor loop itself (random-init policy on the bench's scenarios): the learner's windows
+            # then carry REAL communication masks.  That matters: only agent 0's Q-value is learned from, so the update encodes
+            # just the observations that can reach it through the masks (model.relevance) -- with random mask bits everything
+            # would be reachable.  Episodes enter the replay when they end or time out (256 steps), hence the 260 iterations.
+            cap = 1 << (2 * E - 1).bit_length()
+            buf = GlobalBuffer(cap, max_agents=max(N, 6), device=dev, init_set=(N, args.map), fixed_level=True)
             learner = Learner(buf, device=dev, batch_size=192)
-            for _ in range(2):
-                learner.update()
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            t1 = time.perf_counter()
-            for _ in range(args.dqn_updates):
-                learner.update()
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            dt_upd = (time.perf_counter() - t1) / args.dqn_updates
-            actor = VecActor(env, learner.model, None, seed=rank, density=args.density)
-            actor.step()
+            actor = VecActor(env, learner.model, buf, seed=rank, density=args.density)
+            for _ in range(260):
+                actor.step()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.dqn_actor_iters):
                 actor.step()
             torch.cuda.synchronize()
             dt_act = (time.perf_counter() - t1) / args.dqn_actor_iters
+            assert len(buf) >= 192 * 18, "the actor loop did not fill the replay"
+
+            def timed_updates():
+                for _ in range(2):
+                    learner.update()
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                t_ = time.perf_counter()
+                for _ in range(args.dqn_updates):
+                    learner.update()
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                return (time.perf_counter() - t_) / args.dqn_updates
+
+            dt_upd = timed_updates()
+            Network.PRUNE_UNREACHABLE = False  # the same update with every observation of the window encoded (as the reference does)
+            learner._drop_prefetch()
+            dt_upd_all = timed_updates()
+            Network.PRUNE_UNREACHABLE = True
+            learner._drop_prefetch()
+            probe = buf.sample_batch(192)
+            reach = float(relevance(probe[7][:, :-2], probe[5]).float().mean())
             # interleaved: the loop train.py runs (one update per actor iteration)
             actor.step()
             learner.update()
@@ -335,9 +343,9 @@ def main():
             dt_train = (time.perf_counter() - t1) / args.train_iters
             env.check_status()
             if world > 1:
-                tt = torch.tensor([dt_upd, dt_act, dt_train], dtype=torch.float64, device=dev)
+                tt = torch.tensor([dt_upd, dt_act, dt_train, dt_upd_all], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dt_upd, dt_act, dt_train = [float(v) for v in tt.tolist()]
+                dt_upd, dt_act, dt_train, dt_upd_all = [float(v) for v in tt.tolist()]
             # the dominant kernel of the actor loop: the fused inference encoder (MFMA-bound), timed alone on the
             # actor's batch with HIP events on the launch stream
             obs_flat = actor.obs.reshape(E * N, 6, 9, 9)
@@ -353,11 +361,16 @@ def main():
             enc_flop = 2.0 * (49 * 128 * 54 + 6 * 49 * 128 * 1152 + 49 * 16 * 128) * E * N  # 87.6 MFLOP per observation
             result.update({
                 "learner_updates_per_sec": 1.0 / dt_upd, "learner_ms_per_update": dt_upd * 1e3,
-                "learner_config": "B=192 x T=18 x A=%d windows per rank from the device replay, bf16 autocast, Adam, %s" % (
+                "learner_ms_per_update_all_observations": dt_upd_all * 1e3,
+                "learner_reachable_fraction": reach,
+                "learner_note": "only agent 0's Q-value is learned from (reference model.py:248): an update encodes the observations that can "
+                                "reach it through the communication masks (same Q-values bit for bit, tests/test_relevance_gpu.py); "
+                                "learner_ms_per_update_all_observations = the same update encoding every observation of the window",
+                "learner_config": "B=192 x T=18 x A=%d windows per rank from the device replay (episodes of the actor loop), bf16 autocast, Adam, %s" % (
                     N, "flat-bucket RCCL all-reduce x%d (synchronous data parallel: this is the job's update rate, global batch %d)" % (
                         world, 192 * world) if world > 1 else "1 GPU"),
                 "actor_loop_env_steps_per_sec": world * E / dt_act, "actor_loop_ms_per_iter": dt_act * 1e3,
-                "actor_loop_config": "Network.step_batch (bf16) + mapf_step + local-buffer recording, %d envs x %d agents per GPU" % (E, N),
+                "actor_loop_config": "Network.step_batch (bf16) + mapf_step + local-buffer recording + episode flush into the device replay, %d envs x %d agents per GPU" % (E, N),
                 "train_loop_updates_per_sec": 1.0 / dt_train, "train_loop_env_steps_per_sec": world * E / dt_train,
                 "train_loop_ms_per_iter": dt_train * 1e3,
                 "train_loop_config": "one actor iteration (%d envs/GPU) + one learner update per iteration, same stream order as train.py" % E,

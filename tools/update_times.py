@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Host-enqueue time vs wall time of one learner update on replay windows produced by the actor loop (so that the communication
+masks -- and with them the share of observations that can reach agent 0's Q-value -- are real), with and without the pruning of
+unreachable observations.  Usage: update_times.py [agents] [map] [envs]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import mapf_rl_amd as M  # noqa: E402
+from mapf_rl_amd.actor import VecActor  # noqa: E402
+from mapf_rl_amd.learner import Learner  # noqa: E402
+from mapf_rl_amd.model import Network, relevance  # noqa: E402
+from mapf_rl_amd.replay import GlobalBuffer  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+E = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
+dev = torch.device("cuda")
+torch.manual_seed(0)
+buf = GlobalBuffer(4096, max_agents=max(N, 6), device=dev, init_set=(N, L), fixed_level=True)
+lr = Learner(buf, device=dev, batch_size=192)
+env = M.VecEnvironment(E, L, N, device=dev)
+maps, agents, goals, _ = M.generate_scenarios(E, L, N, 0.3, seed=1)
+env.load(maps, agents, goals)
+actor = VecActor(env, lr.model, buf, seed=0)
+for _ in range(300):
+    actor.step()
+b = buf.sample_batch(192)
+rel = relevance(b[7][:, :-2], b[5])
+print("%d agents, %dx%d: %.3f of the online window's (step, agent) entries can reach agent 0" % (N, L, L, float(rel.float().mean())))
+for prune in (False, True):
+    Network.PRUNE_UNREACHABLE = prune
+    for _ in range(3):
+        lr.update()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        lr.update()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print("prune=%-5s update %.2f ms wall (host enqueue %.2f ms)" % (prune, (t2 - t0) / 20 * 1e3, (t1 - t0) / 20 * 1e3), flush=True)
+if os.environ.get("PROFILE_HOST"):
+    import cProfile
+    import pstats
+
+    Network.PRUNE_UNREACHABLE = True
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(20):
+        lr.update()
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
