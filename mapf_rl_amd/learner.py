@@ -95,11 +95,13 @@ class Learner:
         self.loss = 0.0
         self.done = False
         # Pipelining across updates (the reference prepares batches ahead too, in a background thread: worker.py:47-58): as soon
-        # as update k has written its priorities, batch k + 1 is sampled and its TARGET-network forward -- which depends on
-        # nothing update k still has to do -- is launched on a second HIP stream, where it fills the chip while update k's
-        # backward runs its low-occupancy tail (192-workgroup recurrence kernels, split-K GEMMs, reductions, optimizer).
-        # Same numbers as the sequential order: priorities are written before the sample, and the step that syncs the target
-        # network does not prefetch.
+        # as update k has written its priorities, batch k + 1 is sampled and PLANNED: the rows of its two windows that can reach
+        # agent 0's Q-value (model.relevance) are marked on the device and their counts copied to pinned host memory, so that
+        # update k + 1 knows its encoder batch sizes without waiting for the GPU.  Update k + 1 then runs the TARGET-network
+        # forward on a second HIP stream beside the online forward.  Same numbers as the sequential order: priorities are
+        # written before the sample.
+        # (Round 1 launched the target forward of batch k + 1 already during update k's backward; with ~1/9 of the observations
+        # left to encode, the host's wait for the row count cost more than that overlap gave.)
         # (Measured, tools/learner_modes.py: 39.5 ms per update without prefetch, 38.7 with it; sampling one update EARLIER and
         # running the update on a high-priority stream -- so that the target forward would only fill idle CUs -- gave 39.7: the chip
         # is saturated by the update's own kernels, the update is ~39.5 ms of work whichever way it is ordered.)
@@ -108,60 +110,102 @@ class Learner:
         self._pre = None
 
     # ------------------------------------------------------------------ one update
-    def target_q(self, batch):
+    def target_q(self, batch, rows=None):
         """(1 - done) max_a Q_target(s_{t+steps}) [B,1] (worker.py:300-303): the part of an update that needs no gradient."""
         b_obs, _, _, b_done, b_steps, b_bt_steps, b_hidden, b_comm_mask = batch[:8]
         b_next_bt_steps = b_bt_steps + b_steps.view(-1).to(b_bt_steps.dtype)
         with torch.no_grad():
-            q_tar = self.tar_model.bootstrap(b_obs, b_next_bt_steps, b_hidden, b_comm_mask)
+            q_tar = self.tar_model.bootstrap(b_obs, b_next_bt_steps, b_hidden, b_comm_mask, rows=rows)
             if self.double_q:
-                pick = self.model.bootstrap(b_obs, b_next_bt_steps, b_hidden, b_comm_mask).argmax(1, keepdim=True)
+                pick = self.model.bootstrap(b_obs, b_next_bt_steps, b_hidden, b_comm_mask, rows=rows).argmax(1, keepdim=True)
                 return (1 - b_done) * q_tar.gather(1, pick)
             return (1 - b_done) * q_tar.max(1, keepdim=True)[0]
 
-    def compute_td(self, batch, q_next=None):
-        """worker.py:296-306 on an 11-tuple from GlobalBuffer.sample_batch. Returns (td_error [B,1], q [B,1], q_next [B,1])."""
+    def compute_td(self, batch, q_next=None, rows=None):
+        """worker.py:296-306 on an 11-tuple from GlobalBuffer.sample_batch. Returns (td_error [B,1], q [B,1], q_next [B,1]).
+        `q_next` may be a callable that yields it (the learner's side-stream hand-over); `rows`: see Network.bootstrap."""
         b_obs, b_action, b_reward, b_done, b_steps, b_bt_steps, b_hidden, b_comm_mask = batch[:8]
         if q_next is None:
             q_next = self.target_q(batch)
-        q = self.model.bootstrap(b_obs[:, :-FORWARD_STEPS], b_bt_steps, b_hidden, b_comm_mask[:, :-FORWARD_STEPS]).gather(1, b_action)
+        q = self.model.bootstrap(b_obs[:, :-FORWARD_STEPS], b_bt_steps, b_hidden, b_comm_mask[:, :-FORWARD_STEPS], rows=rows).gather(1, b_action)
+        if callable(q_next):
+            q_next = q_next()
         td = q - (b_reward + (GAMMA ** b_steps) * q_next)
         return td, q, q_next
+
+    # -- which observations an update has to encode, known one update ahead --
+    def _plan(self, batch):
+        """Marks the reachable rows of the batch's online and target windows (model.relevance) and starts the copy of their counts
+        to pinned host memory; nothing here waits for the GPU."""
+        from .model import Network, relevance
+
+        if not (Network.PRUNE_UNREACHABLE and batch[7].is_cuda):
+            return None
+        comm, bt, steps = batch[7], batch[5], batch[4].view(-1)
+        rel_o = relevance(comm[:, :-FORWARD_STEPS], bt).view(-1)
+        rel_t = relevance(comm, bt + steps.to(bt.dtype)).view(-1)
+        counts = torch.stack([rel_o.sum(), rel_t.sum()])
+        host = torch.empty(2, dtype=counts.dtype, pin_memory=True)
+        host.copy_(counts, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        return rel_o, rel_t, host, done, counts
+
+    @staticmethod
+    def _rows(plan):
+        """Row indices of a planned batch: (online window, target window).  Waits for the count copy -- long finished when the
+        batch was planned during the update before."""
+        if plan is None:
+            return None, None
+        rel_o, rel_t, host, done, _ = plan
+        done.synchronize()
+        n_o, n_t = (int(v) for v in host.tolist())
+        return torch.nonzero_static(rel_o, size=n_o).squeeze(1), torch.nonzero_static(rel_t, size=n_t).squeeze(1)
 
     def update(self, batch=None):
         """One Learner.train iteration (worker.py:287-338).  `batch` defaults to a fresh prioritized sample."""
         return self._update(batch)
 
     def _launch_prefetch(self):
-        cur = torch.cuda.current_stream(self.device)
         nxt = self.buffer.sample_batch(self.batch_size)
-        self._side.wait_stream(cur)
-        for t in nxt:  # allocated on this stream, read on the side stream: keep the allocator from reusing them early
-            if torch.is_tensor(t) and t.is_cuda:
-                t.record_stream(self._side)
-        with torch.cuda.stream(self._side):
-            qn = self.target_q(nxt)
-            ready = torch.cuda.Event()
-            ready.record(self._side)
-        qn.record_stream(cur)  # allocated on the side stream, consumed on this one
-        self._pre = (nxt, qn, ready)
+        self._pre = (nxt, self._plan(nxt))
 
     def _update(self, batch=None):
         own_batch = batch is None
-        q_next = None
+        plan = None
         if own_batch and self._pre is not None:
-            batch, q_next, ready = self._pre
+            batch, plan = self._pre
             self._pre = None
-            torch.cuda.current_stream(self.device).wait_event(ready)
         elif own_batch:
             batch = self.buffer.sample_batch(self.batch_size)
+        q_next = None
+        rows_o = None
+        if own_batch and self.prefetch:
+            if plan is None:
+                plan = self._plan(batch)
+            rows_o, rows_t = self._rows(plan)
+            # the target network's forward on the second stream, beside the online forward
+            cur = torch.cuda.current_stream(self.device)
+            self._side.wait_stream(cur)
+            for t in list(batch) + [rows_t]:  # allocated on this stream, read on the side stream: keep the allocator from reusing them early
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(self._side)
+            with torch.cuda.stream(self._side):
+                qn = self.target_q(batch, rows_t)
+                ready = torch.cuda.Event()
+                ready.record(self._side)
+            qn.record_stream(cur)  # allocated on the side stream, consumed on this one
+
+            def q_next():
+                cur.wait_event(ready)
+                return qn
         idxes, weights, old_ptr = batch[8], batch[9], batch[10]
-        td, q, q_next = self.compute_td(batch, q_next)
+        td, q, q_next = self.compute_td(batch, q_next, rows_o)
         priorities = td.detach().view(-1).abs().clamp(1e-6)                                      # worker.py:308
         loss = (weights * huber_loss(td)).mean()                                                 # worker.py:310
         if self.buffer is not None and idxes is not None:
             self.buffer.update_priorities(idxes, priorities, old_ptr)                            # worker.py:331 (values known here)
-        if self.prefetch and own_batch and (self.counter + 1) % TARGET_SYNC != 0:
+        if self.prefetch and own_batch:
             self._launch_prefetch()
         self.bucket.zero()
         loss.backward()
@@ -178,18 +222,15 @@ class Learner:
                     q_next=q_next)
 
     def _drop_prefetch(self):
-        """A prefetched batch carries Q-values of the target network as it was: void it when that network changes."""
-        if self._pre is not None:
-            torch.cuda.current_stream(self.device).wait_event(self._pre[2])
-            self._pre = None
+        """Forget the batch sampled ahead (it carries no network output, so a weight change does not invalidate it; for callers
+        that change what a plan means, e.g. Network.PRUNE_UNREACHABLE)."""
+        self._pre = None
 
     def sync_target(self):
-        self._drop_prefetch()
         self.tar_model.load_state_dict(self.model.state_dict())
 
     def load_state_dict(self, state_dict, sync_target=True):
         """Loads online-network weights (reference key names) and, by default, copies them to the target network."""
-        self._drop_prefetch()
         self.model.load_state_dict(state_dict)
         if sync_target:
             self.tar_model.load_state_dict(self.model.state_dict())

@@ -276,6 +276,24 @@ def comm_mask_from_pos(pos: torch.Tensor, obs_radius: int = OBS_RADIUS, max_comm
     return in_fov & near
 
 
+class _SparseRows:
+    """Latents of the reachable observations only: `rows` index the time-major [T*B*N] rows, every other row is zero."""
+
+    def __init__(self, values, rows, tbn):
+        self.values, self.rows, self.shape = values, rows, tuple(tbn) + (values.shape[1],)
+
+    def dense(self):
+        T, B, N, F_ = self.shape
+        return torch.zeros((T * B * N, F_), dtype=self.values.dtype, device=self.values.device).index_copy(0, self.rows, self.values).view(T, B, N, F_)
+
+    def project(self, fn, width):
+        """fn applied to the stored rows only ([M', F] -> [M', width]; a bias-free linear map keeps the other rows zero), scattered
+        into the dense [T, B, N, width] the recurrence kernels read."""
+        T, B, N, _ = self.shape
+        out = fn(self.values)
+        return torch.zeros((T * B * N, width), dtype=out.dtype, device=out.device).index_copy(0, self.rows, out).view(T, B, N, width)
+
+
 class Network(nn.Module):
     def __init__(self, cnn_channel: int = 64):  # `cnn_channel` is accepted and ignored like the reference (model.py:140)
         super().__init__()
@@ -420,10 +438,12 @@ class Network(nn.Module):
     PRUNE_UNREACHABLE = True  # HIP device, `bootstrap`: encode only the observations that can reach agent 0's Q-value (see `relevance`)
     FAST_RECURRENCE = True  # HIP device: hoisted input projection, fused QKV, deferred weight gradients (see _recur_fast)
 
-    def bootstrap(self, obs, steps, hidden, comm_mask):
+    def bootstrap(self, obs, steps, hidden, comm_mask, rows=None):
         """Training forward over a [B, T] window of N agents (model.py:227-263).
         obs [B, T, N, 6, 9, 9]; steps int64 [B] (1-based index of the step whose agent-0 hidden feeds the Q head);
-        hidden [B*N, 256]; comm_mask bool [B, T, N, N].  Returns q [B, 5] (float32)."""
+        hidden [B*N, 256]; comm_mask bool [B, T, N, N].  Returns q [B, 5] (float32).
+        `rows` (optional, HIP path): the indices into the time-major [T*B*N] observation rows that `relevance` marks, when the
+        caller has them already (the learner plans them one update ahead, so that their count is on the host without a wait)."""
         B, T, N = obs.shape[:3]
         with self._autocast(obs.device):
             if self.FAST_RECURRENCE and obs.is_cuda and torch.get_autocast_dtype("cuda") == torch.bfloat16:
@@ -435,13 +455,13 @@ class Network(nn.Module):
                     # agents that is ~1/9 of the window -- the encoder is 80 % of an update -- and the result is the same, not an
                     # approximation.  The other rows of the latent stay zero: their agents run through the recurrence on
                     # meaningless states that, by construction, nobody who matters reads.
-                    rows = relevance(comm_mask, steps).view(-1).nonzero().squeeze(1)  # (one host sync: the row count)
+                    if rows is None:
+                        rows = relevance(comm_mask, steps).view(-1).nonzero().squeeze(1)  # (one host sync: the row count)
                     lat = self.encode(obs_t.view(T * B * N, *OBS_SHAPE).index_select(0, rows))
-                    latent_t = torch.zeros((T * B * N, ENC_FEATURES), dtype=lat.dtype, device=lat.device).index_copy(0, rows, lat)
-                    latent_t = latent_t.view(T, B, N, ENC_FEATURES)
+                    agent0 = self._recur_fast(_SparseRows(lat, rows, (T, B, N)), hidden.to(lat.dtype), comm_mask)
                 else:
                     latent_t = self.encode(obs_t.view(T * B * N, *OBS_SHAPE)).view(T, B, N, ENC_FEATURES)
-                agent0 = self._recur_fast(latent_t, hidden.to(latent_t.dtype), comm_mask)
+                    agent0 = self._recur_fast(latent_t, hidden.to(latent_t.dtype), comm_mask)
             else:
                 latent = self.encode(obs.reshape(B * T * N, *OBS_SHAPE)).view(B, T, N, ENC_FEATURES)
                 hidden = hidden.to(latent.dtype)
@@ -465,7 +485,11 @@ class Network(nn.Module):
             self._packed_recur = PackedRecurrence()
         w, b = self._packed_recur.get(self)
         T, E, N, _ = latent_t.shape
-        gi = F.linear(latent_t.reshape(T * E * N, ENC_FEATURES), self.recurrent.weight_ih.detach().to(torch.bfloat16)).view(T, E, N, 768)
+        w_ih = self.recurrent.weight_ih.detach().to(torch.bfloat16)
+        if isinstance(latent_t, _SparseRows):  # the input projection of the reachable rows only (its bias is added in the kernel)
+            gi = latent_t.project(lambda x: F.linear(x, w_ih), 768)
+        else:
+            gi = F.linear(latent_t.reshape(T * E * N, ENC_FEATURES), w_ih).view(T, E, N, 768)
         h0 = None if hidden is None else hidden.reshape(E, N, self.latent_dim)
         return recurrent_infer(gi, h0, comm_t, w, b, want_agent0)
 
@@ -491,9 +515,14 @@ class Network(nn.Module):
             if self._packed_recur is None:
                 self._packed_recur = PackedRecurrence()
             w, b = self._packed_recur.get(self)
-            gi = _InputProj.apply(latent_t.view(T * B * N, ENC_FEATURES), self.recurrent.weight_ih, None).view(T, B, N, 3 * D)  # bias: in the kernel
+            if isinstance(latent_t, _SparseRows):
+                gi = latent_t.project(lambda x: _InputProj.apply(x, self.recurrent.weight_ih, None), 3 * D)
+            else:
+                gi = _InputProj.apply(latent_t.view(T * B * N, ENC_FEATURES), self.recurrent.weight_ih, None).view(T, B, N, 3 * D)  # bias: in the kernel
             a0 = recurrent_train(gi, hidden.reshape(B, N, D), comm_mask.transpose(0, 1), w, b, recurrence_params(self))
             return a0.transpose(0, 1)
+        if isinstance(latent_t, _SparseRows):  # the PyTorch-level recurrence (more than 128 agents) takes dense latents
+            latent_t = latent_t.dense()
         sink = _WGradSink() if grad else None
         rc, at, uc = self.recurrent, self.comm.self_attn, self.comm.update_cell
 
