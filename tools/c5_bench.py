@@ -24,38 +24,45 @@ torch.manual_seed(0)
 env = M.VecEnvironment(E, L, N, device=dev)
 env.reset_envs(None, 0.3, seed=1)
 env.check_status()
-buf = GlobalBuffer(64, max_agents=N, device=dev)
-g2 = torch.Generator(device=dev)
-g2.manual_seed(5)
-RD, CW, S = buf.row_dwords, (N + 31) // 32, 96
-for k in range(64):
-    td = torch.zeros(256, dtype=torch.float64, device=dev)
-    td[:S] = torch.rand(S, generator=g2, device=dev, dtype=torch.float64) + 0.05
-    buf.add_episode_device(
-        N, S, k % 2, torch.randint(-2**31, 2**31 - 1, (S + 1, RD), generator=g2, device=dev, dtype=torch.int32) &
-        torch.randint(-2**31, 2**31 - 1, (S + 1, RD), generator=g2, device=dev, dtype=torch.int32),
-        torch.randint(0, 2**20, (S + 1, N, CW), generator=g2, device=dev, dtype=torch.int32),
-        torch.randint(0, 5, (S,), generator=g2, device=dev, dtype=torch.uint8),
-        (torch.rand(S, generator=g2, device=dev) - 0.5).half(), (torch.randn((S, 256), generator=g2, device=dev) * 0.3).half(), td)
+from mapf_rl_amd.model import Network, relevance  # noqa: E402
+
+# the replay is filled by the actor loop (random-init policy): the learner's windows then carry real communication masks, on which
+# the share of observations that can reach agent 0's Q-value (model.relevance) -- the part an update encodes -- depends
+cap = 1 << (2 * E - 1).bit_length()
+buf = GlobalBuffer(cap, max_agents=N, device=dev, init_set=(N, L), fixed_level=True)
 learner = Learner(buf, device=dev, batch_size=192, double_q="--double-q" in sys.argv)
-for _ in range(2):
-    learner.update()
+actor = VecActor(env, learner.model, buf, seed=0, density=0.3)
+for _ in range(260):
+    actor.step()
 torch.cuda.synchronize()
-t0 = time.perf_counter()
 K = 4
-for _ in range(K):
-    learner.update()
-torch.cuda.synchronize()
-dt_upd = (time.perf_counter() - t0) / K
-actor = VecActor(env, learner.model, None, seed=0, density=0.3)
-actor.step()
-torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(K):
     actor.step()
 torch.cuda.synchronize()
 dt_act = (time.perf_counter() - t0) / K
+
+
+def timed_updates():
+    for _ in range(2):
+        learner.update()
+    torch.cuda.synchronize()
+    t_ = time.perf_counter()
+    for _ in range(K):
+        learner.update()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t_) / K
+
+
+dt_upd = timed_updates()
+Network.PRUNE_UNREACHABLE = False
+learner._drop_prefetch()
+dt_all = timed_updates()
+Network.PRUNE_UNREACHABLE = True
+probe = buf.sample_batch(192)
+reach = float(relevance(probe[7][:, :-2], probe[5]).float().mean())
 env.check_status()
-print("C5 shape %dx%d, %d agents, %d envs, double_q=%s: learner %.1f ms/update (%.2f updates/s, B=192 x T=18 x A=%d), actor loop %.2f ms/iter "
-      "(%.3g env-steps/s), peak memory %.1f GB" % (L, L, N, E, learner.double_q, dt_upd * 1e3, 1 / dt_upd, N, dt_act * 1e3, E / dt_act,
-                                                   torch.cuda.max_memory_allocated() / 1e9), flush=True)
+print("C5 shape %dx%d, %d agents, %d envs, double_q=%s: learner %.1f ms/update (%.1f updates/s, B=192 x T=18 x A=%d; %.3f of the window reachable; "
+      "%.1f ms with every observation encoded), actor loop %.2f ms/iter (%.3g env-steps/s), peak memory %.1f GB" % (
+          L, L, N, E, learner.double_q, dt_upd * 1e3, 1 / dt_upd, N, reach, dt_all * 1e3, dt_act * 1e3, E / dt_act,
+          torch.cuda.max_memory_allocated() / 1e9), flush=True)
