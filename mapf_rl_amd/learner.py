@@ -142,10 +142,10 @@ class Learner:
         if not (Network.PRUNE_UNREACHABLE and batch[7].is_cuda):
             return None
         comm, bt, steps = batch[7], batch[5], batch[4].view(-1)
-        rel_o = relevance(comm[:, :-FORWARD_STEPS], bt).view(-1)
-        rel_t = relevance(comm, bt + steps.to(bt.dtype)).view(-1)
-        counts = torch.stack([rel_o.sum(), rel_t.sum()])
-        host = torch.empty(2, dtype=counts.dtype, pin_memory=True)
+        rel_o = relevance(comm[:, :-FORWARD_STEPS], bt)
+        rel_t = relevance(comm, bt + steps.to(bt.dtype))
+        counts = torch.stack([rel_o.sum(), rel_t.sum(), rel_o[0].sum(dim=1).max(), rel_t[0].sum(dim=1).max()])
+        host = torch.empty(4, dtype=counts.dtype, pin_memory=True)
         host.copy_(counts, non_blocking=True)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.device))
@@ -157,10 +157,13 @@ class Learner:
         batch was planned during the update before."""
         if plan is None:
             return None, None
+        from .model import Reach
+
         rel_o, rel_t, host, done, _ = plan
         done.synchronize()
-        n_o, n_t = (int(v) for v in host.tolist())
-        return torch.nonzero_static(rel_o, size=n_o).squeeze(1), torch.nonzero_static(rel_t, size=n_t).squeeze(1)
+        n_o, n_t, k_o, k_t = (int(v) for v in host.tolist())
+        return (Reach(torch.nonzero_static(rel_o.view(-1), size=n_o).squeeze(1), rel_o[0], k_o),
+                Reach(torch.nonzero_static(rel_t.view(-1), size=n_t).squeeze(1), rel_t[0], k_t))
 
     def update(self, batch=None):
         """One Learner.train iteration (worker.py:287-338).  `batch` defaults to a fresh prioritized sample."""
@@ -187,8 +190,8 @@ class Learner:
             # the target network's forward on the second stream, beside the online forward
             cur = torch.cuda.current_stream(self.device)
             self._side.wait_stream(cur)
-            for t in list(batch) + [rows_t]:  # allocated on this stream, read on the side stream: keep the allocator from reusing them early
-                if torch.is_tensor(t) and t.is_cuda:
+            for t in list(batch) + ([rows_t.rows, rows_t.agents] if rows_t is not None else []):
+                if torch.is_tensor(t) and t.is_cuda:  # allocated on this stream, read on the side stream: keep the allocator from reusing them early
                     t.record_stream(self._side)
             with torch.cuda.stream(self._side):
                 qn = self.target_q(batch, rows_t)

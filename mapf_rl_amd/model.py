@@ -31,6 +31,7 @@ NUM_COMM_LAYERS = 2     # config.py:62
 NUM_COMM_HEADS = 2      # config.py:63
 ENC_FEATURES = 16 * 7 * 7
 RECUR_MAX_AGENTS = 128  # widest environment of the fused recurrence kernels (include/mapf_dqn.h); beyond it: the PyTorch-level path
+RECUR_NARROW_AGENTS = 48  # the one-workgroup-per-environment kernels (csrc/mapf_recur.hip, mapf_recur_bwd.hip); above: mapf_recur_wide*
 BPTT_MAX_AGENTS = 128
 
 
@@ -276,6 +277,32 @@ def comm_mask_from_pos(pos: torch.Tensor, obs_radius: int = OBS_RADIUS, max_comm
     return in_fov & near
 
 
+class Reach:
+    """What `relevance` marks, in the form `bootstrap` uses: rows = indices of the marked entries in the time-major [T*B*N] order;
+    agents bool [B, N] = the agents marked at step 0 (the set only grows going back in time, so these are all agents that matter
+    anywhere in the window); max_agents = the largest such set of the batch, as a host integer."""
+
+    def __init__(self, rows, agents, max_agents):
+        self.rows, self.agents, self.max_agents = rows, agents, int(max_agents)
+
+    def compact(self, lat, hidden, comm_mask):
+        """The window restricted to its marked agents, padded to a multiple of 16 per window with agents that read only themselves:
+        (latents as _SparseRows over [T, B, Nc], hidden [B*Nc, 256], comm_mask [B, T, Nc, Nc]).  Agent 0 stays agent 0."""
+        B, T, N, _ = comm_mask.shape
+        Nc = 16 * max(1, -(-self.max_agents // 16))
+        dev = comm_mask.device
+        order = torch.argsort((~self.agents).to(torch.uint8), dim=1, stable=True)[:, :Nc]      # marked agents first, ascending
+        valid = torch.arange(Nc, device=dev).view(1, Nc) < self.agents.sum(dim=1, keepdim=True)  # [B, Nc]
+        pos = torch.zeros((B, N), dtype=torch.int64, device=dev).scatter_(1, order, torch.arange(Nc, device=dev).expand(B, Nc))
+        cm = comm_mask.gather(2, order.view(B, 1, Nc, 1).expand(B, T, Nc, N)).gather(3, order.view(B, 1, 1, Nc).expand(B, T, Nc, Nc))
+        cm = (cm & valid.view(B, 1, Nc, 1) & valid.view(B, 1, 1, Nc)) | torch.eye(Nc, dtype=torch.bool, device=dev)
+        h = hidden.view(B, N, -1).gather(1, order.view(B, Nc, 1).expand(B, Nc, hidden.shape[-1])) * valid.view(B, Nc, 1).to(hidden.dtype)
+        n = self.rows % N
+        tb = self.rows // N
+        rows_c = tb * Nc + pos[tb % B, n]
+        return _SparseRows(lat, rows_c, (T, B, Nc)), h.reshape(B * Nc, -1), cm
+
+
 class _SparseRows:
     """Latents of the reachable observations only: `rows` index the time-major [T*B*N] rows, every other row is zero."""
 
@@ -442,8 +469,9 @@ class Network(nn.Module):
         """Training forward over a [B, T] window of N agents (model.py:227-263).
         obs [B, T, N, 6, 9, 9]; steps int64 [B] (1-based index of the step whose agent-0 hidden feeds the Q head);
         hidden [B*N, 256]; comm_mask bool [B, T, N, N].  Returns q [B, 5] (float32).
-        `rows` (optional, HIP path): the indices into the time-major [T*B*N] observation rows that `relevance` marks, when the
-        caller has them already (the learner plans them one update ahead, so that their count is on the host without a wait)."""
+        `rows` (optional, HIP path): a `Reach` -- the indices into the time-major [T*B*N] observation rows that `relevance` marks,
+        which agents they belong to and how many of those a window has at most -- when the caller has it already (the learner plans
+        it one update ahead, so that the two counts are on the host without a wait)."""
         B, T, N = obs.shape[:3]
         with self._autocast(obs.device):
             if self.FAST_RECURRENCE and obs.is_cuda and torch.get_autocast_dtype("cuda") == torch.bfloat16:
@@ -456,9 +484,16 @@ class Network(nn.Module):
                     # approximation.  The other rows of the latent stay zero: their agents run through the recurrence on
                     # meaningless states that, by construction, nobody who matters reads.
                     if rows is None:
-                        rows = relevance(comm_mask, steps).view(-1).nonzero().squeeze(1)  # (one host sync: the row count)
-                    lat = self.encode(obs_t.view(T * B * N, *OBS_SHAPE).index_select(0, rows))
-                    agent0 = self._recur_fast(_SparseRows(lat, rows, (T, B, N)), hidden.to(lat.dtype), comm_mask)
+                        rel = relevance(comm_mask, steps)
+                        rows = Reach(rel.view(-1).nonzero().squeeze(1), rel[0], int(rel[0].sum(dim=1).max()))  # (host syncs: two counts)
+                    lat = self.encode(obs_t.view(T * B * N, *OBS_SHAPE).index_select(0, rows.rows))
+                    if N > RECUR_NARROW_AGENTS and rows.max_agents <= RECUR_NARROW_AGENTS:
+                        # more agents than the one-workgroup-per-window kernels take (48), but the ones that matter fit: run the
+                        # recurrence on those (the closure is closed under "reads": none of them reads an agent left out)
+                        sparse, hidden_c, comm_c = rows.compact(lat, hidden, comm_mask)
+                        agent0 = self._recur_fast(sparse, hidden_c.to(lat.dtype), comm_c)
+                    else:
+                        agent0 = self._recur_fast(_SparseRows(lat, rows.rows, (T, B, N)), hidden.to(lat.dtype), comm_mask)
                 else:
                     latent_t = self.encode(obs_t.view(T * B * N, *OBS_SHAPE)).view(T, B, N, ENC_FEATURES)
                     agent0 = self._recur_fast(latent_t, hidden.to(latent_t.dtype), comm_mask)
