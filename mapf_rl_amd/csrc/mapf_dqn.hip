@@ -157,26 +157,29 @@ int pick_grid(long long nvec, int groups) {
 // pruned encoder launches it makes possible.
 __global__ void __launch_bounds__(128) window_relevance_kernel(const uint8_t *__restrict__ comm, const long long *__restrict__ steps, int T, int B,
                                                                int N, uint8_t *__restrict__ rel) {
-    __shared__ uint8_t r[128];
-    const int b = blockIdx.x, j = threadIdx.x;
+    // the set as two 64-bit words held by every thread (identical in all of them): a hop visits the few agents IN the set instead
+    // of all N rows, and the only exchange is one ballot per wave and hop
+    __shared__ unsigned long long s_ballot[2];
+    const int b = blockIdx.x, j = threadIdx.x, wv = j >> 6;
     const long long last = steps[b] - 1;
-    r[j] = 0;
-    __syncthreads();
+    unsigned long long r0 = 0, r1 = 0;
     for (int t = T - 1; t >= 0; --t) {
-        if (t == last && j == 0) r[0] = 1;
-        __syncthreads();
+        if (t == last) r0 |= 1ull;
         if (t <= last) {  // (uniform: before the window's last step the set is empty)
             const uint8_t *m = comm + ((size_t)b * T + t) * N * N;
             for (int round = 0; round < 2; ++round) {
-                uint8_t v = j < N ? r[j] : 0;
-                for (int i = 0; i < N; ++i)
-                    if (r[i] && j < N && m[i * N + j]) v = 1;
+                bool v = false;
+                for (unsigned long long w = r0; w != 0 && j < N; w &= w - 1) v |= m[(__ffsll((long long)w) - 1) * N + j] != 0;
+                for (unsigned long long w = r1; w != 0 && j < N; w &= w - 1) v |= m[(63 + __ffsll((long long)w)) * N + j] != 0;
+                const unsigned long long bal = __ballot(v);
+                __syncthreads();  // (the previous hop's words have been read)
+                if ((j & 63) == 0) s_ballot[wv] = bal;
                 __syncthreads();
-                r[j] = v;
-                __syncthreads();
+                r0 |= s_ballot[0];
+                r1 |= s_ballot[1];
             }
         }
-        if (j < N) rel[((size_t)t * B + b) * N + j] = r[j];
+        if (j < N) rel[((size_t)t * B + b) * N + j] = (uint8_t)(((j < 64 ? r0 >> j : r1 >> (j - 64)) & 1ull) != 0);
     }
 }
 
