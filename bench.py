@@ -287,16 +287,19 @@ def main():
             from mapf_rl_amd.model import Network, relevance
 
             torch.manual_seed(1234)  # identical initial weights on every rank
-            # The replay is filled by the actor loop itself (random-init policy on the bench's scenarios): the learner's windows
-            # then carry REAL communication masks.  That matters: only agent 0's Q-value is learned from, so the update encodes
-            # just the observations that can reach it through the masks (model.relevance) -- with random mask bits everything
-            # would be reachable.  Episodes enter the replay when they end or time out (256 steps), hence the 260 iterations.
+            # The replay is filled by the actor loop itself on the bench's scenarios: the learner's windows then carry REAL
+            # communication masks.  That matters: only agent 0's Q-value is learned from, so the update encodes just the
+            # observations that can reach it through the masks (model.relevance) -- with random mask bits everything would be
+            # reachable.  The agents MOVE while the replay fills: the executed actions are the tape policy's (80 % heuristic-
+            # following; the random-init network's own greedy actions leave most agents standing, which would understate the
+            # reachable share: 0.12 instead of 0.20).  Episodes enter the replay when they end or time out (256 steps), hence the
+            # 260 iterations.
             cap = 1 << (2 * E - 1).bit_length()
             buf = GlobalBuffer(cap, max_agents=max(N, 6), device=dev, init_set=(N, args.map), fixed_level=True)
             learner = Learner(buf, device=dev, batch_size=192)
             actor = VecActor(env, learner.model, buf, seed=rank, density=args.density)
             for _ in range(260):
-                actor.step()
+                actor.step(actions_override=heuristic_actions(actor.obs, gen).long())
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.dqn_actor_iters):
@@ -366,7 +369,7 @@ def main():
                 "learner_note": "only agent 0's Q-value is learned from (reference model.py:248): an update encodes the observations that can "
                                 "reach it through the communication masks (same Q-values bit for bit, tests/test_relevance_gpu.py); "
                                 "learner_ms_per_update_all_observations = the same update encoding every observation of the window",
-                "learner_config": "B=192 x T=18 x A=%d windows per rank from the device replay (episodes of the actor loop), bf16 autocast, Adam, %s" % (
+                "learner_config": "B=192 x T=18 x A=%d windows per rank from the device replay (episodes of the actor loop under the tape policy), bf16 autocast, Adam, %s" % (
                     N, "flat-bucket RCCL all-reduce x%d (synchronous data parallel: this is the job's update rate, global batch %d)" % (
                         world, 192 * world) if world > 1 else "1 GPU"),
                 "actor_loop_env_steps_per_sec": world * E / dt_act, "actor_loop_ms_per_iter": dt_act * 1e3,

@@ -487,9 +487,10 @@ class Network(nn.Module):
                         rel = relevance(comm_mask, steps)
                         rows = Reach(rel.view(-1).nonzero().squeeze(1), rel[0], int(rel[0].sum(dim=1).max()))  # (host syncs: two counts)
                     lat = self.encode(obs_t.view(T * B * N, *OBS_SHAPE).index_select(0, rows.rows))
-                    if N > RECUR_NARROW_AGENTS and rows.max_agents <= RECUR_NARROW_AGENTS:
-                        # more agents than the one-workgroup-per-window kernels take (48), but the ones that matter fit: run the
-                        # recurrence on those (the closure is closed under "reads": none of them reads an agent left out)
+                    if N > RECUR_NARROW_AGENTS and 16 * -(-rows.max_agents // 16) < N:
+                        # more agents than the one-workgroup-per-window kernels take (48): run the recurrence on the ones that
+                        # matter (the closure is closed under "reads": none of them reads an agent left out) -- through the 48-agent
+                        # kernels when at most 48 do in every window of the batch, else through the wide ones at 64 instead of 128
                         sparse, hidden_c, comm_c = rows.compact(lat, hidden, comm_mask)
                         agent0 = self._recur_fast(sparse, hidden_c.to(lat.dtype), comm_c)
                     else:

@@ -31,9 +31,11 @@ from mapf_rl_amd.model import Network, relevance  # noqa: E402
 cap = 1 << (2 * E - 1).bit_length()
 buf = GlobalBuffer(cap, max_agents=N, device=dev, init_set=(N, L), fixed_level=True)
 learner = Learner(buf, device=dev, batch_size=192, double_q="--double-q" in sys.argv)
+from bench import heuristic_actions  # noqa: E402  (the executed actions while the replay fills: 80 % heuristic-following, so that the agents move)
+hgen = torch.Generator(device=dev).manual_seed(11)
 actor = VecActor(env, learner.model, buf, seed=0, density=0.3)
 for _ in range(260):
-    actor.step()
+    actor.step(actions_override=heuristic_actions(actor.obs, hgen).long())
 torch.cuda.synchronize()
 K = 4
 t0 = time.perf_counter()

@@ -21,9 +21,11 @@ lr = Learner(buf, device=dev, batch_size=192)
 env = M.VecEnvironment(E, L, N, device=dev)
 maps, agents, goals, _ = M.generate_scenarios(E, L, N, 0.3, seed=1)
 env.load(maps, agents, goals)
+from bench import heuristic_actions  # noqa: E402  (the executed actions while the replay fills: 80 % heuristic-following, so that the agents move)
+hgen = torch.Generator(device=dev).manual_seed(11)
 actor = VecActor(env, lr.model, buf, seed=0)
 for _ in range(300):
-    actor.step()
+    actor.step(actions_override=heuristic_actions(actor.obs, hgen).long())
 torch.cuda.synchronize()
 for _ in range(int(os.environ.get("TUPD", 4))):
     lr.update()

@@ -23,9 +23,11 @@ env = M.VecEnvironment(E, L, N, device=dev)
 maps, agents, goals, _ = M.generate_scenarios(E, L, N, 0.3, seed=1)
 env.load(maps, agents, goals)
 buf = GlobalBuffer(4096, max_agents=N, device=dev, init_set=(N, L), fixed_level=True)
+from bench import heuristic_actions  # noqa: E402  (the executed actions while the replay fills: 80 % heuristic-following, so that the agents move)
+hgen = torch.Generator(device=dev).manual_seed(11)
 actor = VecActor(env, model, buf, seed=0)
 for _ in range(int(os.environ.get("STEPS", 300))):
-    actor.step()
+    actor.step(actions_override=heuristic_actions(actor.obs, hgen).long())
 print("replay transitions:", len(buf))
 for k in range(4):
     b = buf.sample_batch(192)

@@ -26,12 +26,16 @@ lr = Learner(buf, device=dev, batch_size=192)
 env = M.VecEnvironment(E, L, N, device=dev)
 maps, agents, goals, _ = M.generate_scenarios(E, L, N, 0.3, seed=1)
 env.load(maps, agents, goals)
+from bench import heuristic_actions  # noqa: E402  (the executed actions while the replay fills: 80 % heuristic-following, so that the agents move)
+hgen = torch.Generator(device=dev).manual_seed(11)
 actor = VecActor(env, lr.model, buf, seed=0)
 for _ in range(300):
-    actor.step()
+    actor.step(actions_override=heuristic_actions(actor.obs, hgen).long())
 b = buf.sample_batch(192)
 rel = relevance(b[7][:, :-2], b[5])
-print("%d agents, %dx%d: %.3f of the online window's (step, agent) entries can reach agent 0" % (N, L, L, float(rel.float().mean())))
+per_window = rel[0].sum(dim=1)
+print("%d agents, %dx%d: %.3f of the online window's (step, agent) entries can reach agent 0; agents that matter per window: mean %.1f, max %d" % (
+    N, L, L, float(rel.float().mean()), float(per_window.float().mean()), int(per_window.max())))
 for prune in (False, True):
     Network.PRUNE_UNREACHABLE = prune
     for _ in range(3):
