@@ -54,9 +54,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-dqn", action="store_true", help="skip the secondary learner / actor-loop rates")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) on real multi-GPU runs; gloo only to "
                     "exercise the multi-rank code path on a single GPU (set MAPF_BENCH_SHARE_GPU=1)")
-    ap.add_argument("--dqn-updates", type=int, default=5)
-    ap.add_argument("--dqn-actor-iters", type=int, default=3)
-    ap.add_argument("--train-iters", type=int, default=4, help="interleaved actor-step + learner-update iterations")
+    ap.add_argument("--dqn-updates", type=int, default=20)
+    ap.add_argument("--dqn-actor-iters", type=int, default=5)
+    ap.add_argument("--train-iters", type=int, default=10, help="interleaved actor-step + learner-update iterations")
     return ap.parse_args(argv)
 
 
@@ -309,7 +309,7 @@ def main():
             assert len(buf) >= 192 * 18, "the actor loop did not fill the replay"
 
             def timed_updates():
-                for _ in range(2):
+                for _ in range(5):  # (the row counts differ from batch to batch: let the caching allocator see a few)
                     learner.update()
                 torch.cuda.synchronize()
                 if world > 1:

@@ -37,7 +37,7 @@ actor = VecActor(env, learner.model, buf, seed=0, density=0.3)
 for _ in range(260):
     actor.step(actions_override=heuristic_actions(actor.obs, hgen).long())
 torch.cuda.synchronize()
-K = 4
+K = 12
 t0 = time.perf_counter()
 for _ in range(K):
     actor.step()
@@ -46,7 +46,7 @@ dt_act = (time.perf_counter() - t0) / K
 
 
 def timed_updates():
-    for _ in range(2):
+    for _ in range(5):  # (the row counts differ from batch to batch: let the caching allocator see a few)
         learner.update()
     torch.cuda.synchronize()
     t_ = time.perf_counter()
