@@ -120,6 +120,16 @@ int mapf_step(mapf_env_t *env, const int8_t *actions_dev, uint8_t *obs_dev, uint
 /* Replaces Environment.observe (environment.py:433-467) for all E environments. */
 int mapf_observe(mapf_env_t *env, uint8_t *obs_dev, uint32_t *obs_bits_dev, int16_t *pos_dev, void *stream);
 
+/*
+ * The same for the environments e with mask_dev[e] != 0 only (mask_dev == NULL: all): rows of the other environments are
+ * left as they are.  For callers whose output buffers already hold the current observation of the unflagged environments --
+ * the actor loop after mapf_step + mapf_reset_envs(mask): only the reset environments changed (reference worker.py:422-428
+ * -> environment.py:196 returns observe() of the fresh scenario).  Granularity is a workgroup: with several small environments
+ * per workgroup the unflagged neighbours of a flagged one are rewritten with identical values.
+ */
+int mapf_observe_masked(mapf_env_t *env, const uint8_t *mask_dev, uint8_t *obs_dev, uint32_t *obs_bits_dev, int16_t *pos_dev,
+                        void *stream);
+
 /* Dwords per bit-packed observation row: ceil(N*486/32) rounded up to a multiple of 4. */
 int mapf_obs_bits_row_dwords(const mapf_env_t *env);
 

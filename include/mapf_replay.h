@@ -46,7 +46,10 @@ int mapf_replay_capacity(const mapf_replay_t *r);
 int mapf_replay_ptr(const mapf_replay_t *r);         /* GlobalBuffer.ptr */
 int64_t mapf_replay_size(const mapf_replay_t *r);    /* len(GlobalBuffer): stored transitions */
 int64_t mapf_replay_counter(const mapf_replay_t *r, int reset); /* GlobalBuffer.counter (worker.py:92,226) */
-/* out = {ptr, size, counter, episodes added by the last add call}, read behind `stream` (NULL: the most recent one). */
+/* out = {ptr, size, counter, episodes added by the last add call}, read behind `stream` (NULL: the most recent one).
+ * Returns MAPF_ERR_NOT_READY (once; `out` is still filled) if a batch was sampled while the ring held no transition since the
+ * previous call: the reference's batch_sample asserts there (buffer.py:75-76); here the sample itself cannot fail without a
+ * host round trip, so it returns leaf 0 with priority 1 and raises this flag. */
 int mapf_replay_state(mapf_replay_t *r, int64_t out[4], void *stream);
 
 /*

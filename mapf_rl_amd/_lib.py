@@ -26,6 +26,7 @@ SYMBOLS = [
     ("mapf_build_navi", _i, [_vp, _vp]),
     ("mapf_step", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_observe", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("mapf_observe_masked", _i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_obs_bits_row_dwords", _i, [_vp]),
     ("mapf_load_envs", _i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     ("mapf_get_navi", _i, [_vp, _vp, _vp]),

@@ -191,7 +191,8 @@ class VecActor:
             if ids_h:
                 maps, agents, goals, _ = generate_scenarios(len(ids_h), self.env.map_length, N, self.density, self.scenario_seed)
                 self.env.load_envs(ids_h, maps, agents, goals)
-        self.obs, self.pos = self.env.observe(obs_bits_out=self.bits)
+        # obs / pos / bits already hold what env.step wrote for the environments that go on: only the reset ones are re-observed
+        self.obs, self.pos = self.env.observe(obs_bits_out=self.bits, mask=self.finished if self.on_device_reset else None)
         check(lib.mapf_actor_rewind(E, N, self.max_steps, self.RD, self.RDA, _ptr(self.finished), _ptr(self.bits), _ptr(self.t),
                                     _ptr(self.lb_obs), _ptr(self.hidden), st), "mapf_actor_rewind")
 

@@ -37,7 +37,12 @@ __device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_floa
 
 __global__ void __launch_bounds__(256) actor_record_kernel(RecordParams p) {
     const int e = blockIdx.x, tid = threadIdx.x;
-    const long long t = p.t[e];
+    // one read of the step counter for the whole block: thread 0 overwrites it below, and a wave that started late must not
+    // see the incremented value (it would record into the next row)
+    __shared__ long long s_t;
+    if (tid == 0) s_t = p.t[e];
+    __syncthreads();
+    const long long t = s_t;
     const size_t tr = (size_t)e * p.S + t;
     // worker.py:388 -> buffer.py:140-151 (agent 0's q / action / reward / hidden; the joint comm mask; the next observation)
     p.lb_hid[tr * 256 + tid] = f32_to_f16_bits(bf16_to_f32(p.hidden[(size_t)e * p.N * 256 + tid]));

@@ -76,6 +76,7 @@ struct StepParams {
     float *reward;
     uint8_t *done;
     float rtab[5];
+    const uint8_t *mask;  // observe only (optional): a workgroup none of whose environments is flagged returns at once
     int ablate;  // tuning only: bit0 skip navi loads, bit1 skip obs stores
     unsigned long long *dbg;  // diagnostic builds only: per-block phase stamps [E][8]
 };
@@ -137,6 +138,16 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
     constexpr int SPAN = WW + 1;
     const int e = blockIdx.x * G, t = threadIdx.x;  // first environment of the block
     constexpr int nt = NT;
+    if constexpr (!DO_STEP) {
+        // masked observe (the actor loop's re-observation after an auto-reset): the outputs of environments that were not reset
+        // already hold exactly what this block would write, so a block without a flagged environment has nothing to do
+        if (p.mask != nullptr) {
+            bool any = false;
+#pragma unroll
+            for (int g = 0; g < G; ++g) any |= p.mask[e + g] != 0;
+            if (!any) return;
+        }
+    }
     const int L = p.L, N1 = p.N;
     const int N = G * N1;  // (virtual) agents of the block
     const int LP = L + 2 * R;
@@ -1311,6 +1322,19 @@ int mapf_observe(mapf_env_t *h, uint8_t *obs_dev, uint32_t *obs_bits_dev, int16_
     if (!h->loaded || !h->navi_ready) return MAPF_ERR_NOT_READY;
     DeviceGuard guard(h->device);
     StepParams p = make_params(h);
+    p.obs = obs_dev;
+    p.obs_bits = obs_bits_dev;
+    p.obs_bits_rd = mapf_obs_bits_row_dwords(h);
+    p.pos_out = pos_dev;
+    return launch_step<false>(h, p, static_cast<hipStream_t>(stream));
+}
+
+int mapf_observe_masked(mapf_env_t *h, const uint8_t *mask_dev, uint8_t *obs_dev, uint32_t *obs_bits_dev, int16_t *pos_dev, void *stream) {
+    if (!h || (!obs_dev && !obs_bits_dev)) return MAPF_ERR_INVALID_ARG;
+    if (!h->loaded || !h->navi_ready) return MAPF_ERR_NOT_READY;
+    DeviceGuard guard(h->device);
+    StepParams p = make_params(h);
+    p.mask = mask_dev;
     p.obs = obs_dev;
     p.obs_bits = obs_bits_dev;
     p.obs_bits_rd = mapf_obs_bits_row_dwords(h);

@@ -90,11 +90,19 @@ __global__ void __launch_bounds__(1024) tree_update_kernel(double *tree, long lo
 }
 
 __global__ void tree_sample_kernel(const double *tree, long long capacity, int layers, const double *uniforms, int n,
-                                   int unit_uniforms, int64_t *idx_out, double *pri_out, const int64_t *state, int64_t *old_ptr_out) {
+                                   int unit_uniforms, int64_t *idx_out, double *pri_out, int64_t *state, int64_t *old_ptr_out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0 && old_ptr_out != nullptr) *old_ptr_out = state[0];  // worker.py:182: the ring pointer at sample time
     if (k >= n) return;
     const double sum = tree[0];
+    if (!(sum > 0.0)) {
+        // an empty ring (the reference's batch_sample would assert, buffer.py:75-76): no NaN weights downstream -- leaf 0 with
+        // priority 1 -- and a sticky flag that the next mapf_replay_state() turns into MAPF_ERR_NOT_READY
+        if (k == 0) state[4] = 1;
+        idx_out[k] = 0;
+        pri_out[k] = 1.0;
+        return;
+    }
     const double interval = sum / (double)n;              // buffer.py:58
     // buffer.py:60: np.random.uniform(0, interval) = interval * U(0,1); unit_uniforms: the caller passes U(0,1) and the scaling
     // happens here (same f64 product), so that it needs neither the tree's root nor a host round trip
@@ -437,7 +445,7 @@ int mapf_replay_create(int capacity_episodes, int max_agents, int device, mapf_r
     alloc(reinterpret_cast<void **>(&r->size_buf), cap * 4);
     alloc(reinterpret_cast<void **>(&r->nag_buf), cap * 4);
     alloc(reinterpret_cast<void **>(&r->tree), (size_t)(2 * leaves - 1) * 8);
-    alloc(reinterpret_cast<void **>(&r->state), 4 * 8);
+    alloc(reinterpret_cast<void **>(&r->state), 5 * 8);  // {ptr, size, counter, last flush count, sampled-while-empty flag}
     alloc(reinterpret_cast<void **>(&r->slot_of), 4);
     alloc(reinterpret_cast<void **>(&r->one), 16);
     alloc(reinterpret_cast<void **>(&r->tmp_size), 8);
@@ -477,27 +485,42 @@ int mapf_replay_destroy(mapf_replay_t *r) {
 int mapf_replay_row_dwords(const mapf_replay_t *r) { return r ? r->RD : MAPF_ERR_INVALID_ARG; }
 int mapf_replay_capacity(const mapf_replay_t *r) { return r ? r->capacity : MAPF_ERR_INVALID_ARG; }
 
-// {ptr, size, counter, last flush count}: a 32-byte read ordered behind the handle's most recent stream (blocks the host)
-int mapf_replay_state(mapf_replay_t *r, int64_t out[4], void *stream) {
-    if (!r || !out) return MAPF_ERR_INVALID_ARG;
+// {ptr, size, counter, last flush count, sampled-while-empty flag}: a 40-byte read ordered behind the handle's most recent stream
+// (blocks the host)
+static int read_state(mapf_replay_t *r, int64_t st[5], void *stream) {
     DeviceGuard guard(r->device);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : r->last_stream;
-    HIP_TRY(hipMemcpyAsync(out, r->state, 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(st, r->state, 40, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return MAPF_OK;
 }
+int mapf_replay_state(mapf_replay_t *r, int64_t out[4], void *stream) {
+    if (!r || !out) return MAPF_ERR_INVALID_ARG;
+    int64_t st[5];
+    const int rc = read_state(r, st, stream);
+    if (rc != MAPF_OK) return rc;
+    for (int i = 0; i < 4; ++i) out[i] = st[i];
+    if (st[4] != 0) {  // a sample was drawn while the sum tree was empty (flagged by tree_sample_kernel); reported once
+        DeviceGuard guard(r->device);
+        hipStream_t s = stream ? static_cast<hipStream_t>(stream) : r->last_stream;
+        HIP_TRY(hipMemsetAsync(r->state + 4, 0, 8, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return MAPF_ERR_NOT_READY;
+    }
+    return MAPF_OK;
+}
 int mapf_replay_ptr(const mapf_replay_t *r) {
-    int64_t st[4];
-    return mapf_replay_state(const_cast<mapf_replay_t *>(r), st, nullptr) == MAPF_OK ? (int)st[0] : MAPF_ERR_INVALID_ARG;
+    int64_t st[5];
+    return r && read_state(const_cast<mapf_replay_t *>(r), st, nullptr) == MAPF_OK ? (int)st[0] : MAPF_ERR_INVALID_ARG;
 }
 int64_t mapf_replay_size(const mapf_replay_t *r) {
-    int64_t st[4];
-    return mapf_replay_state(const_cast<mapf_replay_t *>(r), st, nullptr) == MAPF_OK ? st[1] : MAPF_ERR_INVALID_ARG;
+    int64_t st[5];
+    return r && read_state(const_cast<mapf_replay_t *>(r), st, nullptr) == MAPF_OK ? st[1] : MAPF_ERR_INVALID_ARG;
 }
 int64_t mapf_replay_counter(const mapf_replay_t *r, int reset) {
-    int64_t st[4];
+    int64_t st[5];
     mapf_replay_t *rr = const_cast<mapf_replay_t *>(r);
-    if (mapf_replay_state(rr, st, nullptr) != MAPF_OK) return MAPF_ERR_INVALID_ARG;
+    if (!rr || read_state(rr, st, nullptr) != MAPF_OK) return MAPF_ERR_INVALID_ARG;
     if (reset) {
         DeviceGuard guard(rr->device);
         hipLaunchKernelGGL(state_reset_counter_kernel, dim3(1), dim3(1), 0, rr->last_stream, rr->state);

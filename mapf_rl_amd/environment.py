@@ -139,9 +139,17 @@ class VecEnvironment:
                             _ptr(self.reward), _ptr(self.done), _stream(self.device)), "mapf_step")
         return obs, self.pos, self.reward, self.done, self.reward_class
 
-    def observe(self, obs_out=None, obs_bits_out=None):
+    def observe(self, obs_out=None, obs_bits_out=None, mask=None):
+        """(obs, pos) of the current state.  `mask` (uint8 tensor [E], optional): only the flagged environments' rows are
+        rewritten -- for callers whose buffers already hold the other environments' current observation (the actor loop after
+        step + reset_envs(mask))."""
         obs = self.obs if obs_out is None else obs_out
-        check(lib.mapf_observe(self._h, _ptr(obs), _ptr(obs_bits_out), _ptr(self.pos), _stream(self.device)), "mapf_observe")
+        if mask is not None:
+            assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.shape == (self.num_envs,)
+            check(lib.mapf_observe_masked(self._h, _ptr(mask), _ptr(obs), _ptr(obs_bits_out), _ptr(self.pos), _stream(self.device)),
+                  "mapf_observe_masked")
+        else:
+            check(lib.mapf_observe(self._h, _ptr(obs), _ptr(obs_bits_out), _ptr(self.pos), _stream(self.device)), "mapf_observe")
         return obs, self.pos
 
     def load_envs(self, env_ids, maps, agents_pos, goals_pos):

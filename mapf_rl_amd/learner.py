@@ -189,6 +189,11 @@ class Learner:
             rows_o, rows_t = self._rows(plan)
             # the target network's forward on the second stream, beside the online forward
             cur = torch.cuda.current_stream(self.device)
+            if self.double_q:
+                # the side stream runs the ONLINE network too (the arg-max): its packed weight images are built here, on the
+                # main stream, before the side stream starts behind it -- packing is lazy and keyed on the host, so whichever
+                # stream came first would pack and the other would read the image before the pack kernel had run
+                self.model.prepack()
             self._side.wait_stream(cur)
             for t in list(batch) + ([rows_t.rows, rows_t.agents] if rows_t is not None else []):
                 if torch.is_tensor(t) and t.is_cuda:  # allocated on this stream, read on the side stream: keep the allocator from reusing them early

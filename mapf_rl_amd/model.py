@@ -419,6 +419,20 @@ class Network(nn.Module):
         h = bias_res_relu(F.conv2d(h, enc[5].weight, None), enc[5].bias)
         return h.flatten(1)
 
+    def prepack(self):
+        """(Re)builds the fused kernels' packed weight images on the CURRENT stream if a parameter changed since the last pack.
+        For callers that run this network on two streams (the learner's double-DQN arg-max on the side stream beside the online
+        forward): packing is lazy and keyed on the host, so the first user would otherwise pack on ITS stream while the other
+        stream, seeing the key already updated, reads a half-written image."""
+        from .fused import PackedEncoder, PackedRecurrence
+
+        if self._packed is None:
+            self._packed = PackedEncoder()
+        if self._packed_recur is None:
+            self._packed_recur = PackedRecurrence()
+        self._packed.get(self.obs_encoder)
+        self._packed_recur.get(self)
+
     def q_head(self, hidden):
         adv = self.adv(hidden)
         return self.state(hidden) + adv - adv.mean(-1, keepdim=True)  # model.py:218,262

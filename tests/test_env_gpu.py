@@ -203,11 +203,12 @@ def test_packed_blocks_equal_one_block_per_environment(M, E, L, N):
     assert np.array_equal(_np(envs[0].steps()), np.full(E, T, np.int32))
 
 
-def test_full_size_config2_properties(M):
-    """BASELINE config 2 at full size (4096 x 32x32 x 40 agents): size-independent invariants on every
-    env (reference environment.py:424-428 uniqueness; obstacles never entered; observation channels
-    consistent with state) + exact oracle comparison on a sample of envs."""
-    E, L, N, T = 4096, 32, 40, 24
+@pytest.mark.parametrize("E,L,N,T,stride", [(4096, 32, 40, 24, 64), (4096, 64, 40, 16, 128), (2048, 64, 128, 10, 128)],
+                         ids=["config2", "config3", "config5"])
+def test_full_size_config_properties(M, E, L, N, T, stride):
+    """BASELINE configs 2, 3 and 5 (per GPU) at FULL size -- 4096 x 32x32 x 40 agents, 4096 x 64x64 x 40, 2048 x 64x64 x 128:
+    size-independent invariants on every environment (reference environment.py:424-428 uniqueness; obstacles never entered;
+    observation channels consistent with the state) + exact oracle comparison on every `stride`-th environment."""
     maps, agents, goals, _ = M.generate_scenarios(E, L, N, 0.3, seed=11)
     env = M.VecEnvironment(E, L, N)
     env.load(maps, agents, goals)
@@ -220,8 +221,8 @@ def test_full_size_config2_properties(M):
     env.check_status()
     p = _np(pos).astype(np.int64)
     assert p.min() >= 0 and p.max() < L
-    keys = p[..., 0] * L + p[..., 1]
-    assert all(len(np.unique(k)) == N for k in keys)  # no two agents on a cell
+    keys = np.sort(p[..., 0] * L + p[..., 1], axis=1)
+    assert np.all(keys[:, 1:] != keys[:, :-1])  # no two agents on a cell
     ee = np.arange(E)[:, None]
     assert maps[ee, p[..., 0], p[..., 1]].sum() == 0  # nobody inside an obstacle
     o = _np(obs)
@@ -232,12 +233,53 @@ def test_full_size_config2_properties(M):
     dx = np.abs(p[:, :, None, 0] - p[:, None, :, 0]) <= 4
     dy = np.abs(p[:, :, None, 1] - p[:, None, :, 1]) <= 4
     assert np.array_equal(o[:, :, 0].reshape(E, N, -1).sum(-1), (dx & dy).sum(-1) - 1)
-    sample = np.arange(0, E, 64)
+    # rewards are consistent with the classes, and a finished environment pays `finish` to everybody (environment.py:415-419)
+    rcl, dn = _np(rc), _np(done).astype(bool)
+    assert np.array_equal(_np(rew), np.array([-0.075, 0, -0.075, -0.5, 3], np.float32)[rcl])
+    assert np.array_equal((rcl == 4).all(axis=1), dn) and np.array_equal((rcl == 4).any(axis=1), dn)
+    assert np.array_equal(dn, (p == goals.astype(np.int64)).all(axis=(1, 2)))
+    assert np.array_equal(_np(env.steps()), np.full(E, T, np.int32))
+    sample = np.arange(0, E, stride)
     nv = oracle.navi_batch(maps[sample], goals[sample])
     ref = oracle.rollout(maps[sample], agents[sample], goals[sample], nv, tape[:, sample], want_obs_last=True)
     assert np.array_equal(p[sample], ref["final_agents"])
     assert np.array_equal(o[sample], ref["obs_last"])
-    assert np.array_equal(_np(env.navi_map())[sample], nv)
+    assert np.array_equal(rcl[sample], ref["rclass"][-1]) and np.array_equal(dn[sample], ref["done"][-1].astype(bool))
+    if E * N * 4 * L * L <= (1 << 30):  # the full navi read-back (one byte per flag) only where it fits comfortably
+        assert np.array_equal(_np(env.navi_map())[sample], nv)
+
+
+@pytest.mark.parametrize("E,L,N", [(64, 32, 40), (256, 20, 6), (64, 10, 1), (16, 64, 128)])
+def test_masked_observe_rewrites_only_what_changed(M, E, L, N):
+    """mapf_observe_masked (the actor loop's re-observation after an auto-reset): after step + reset_envs(mask) the caller's
+    buffers, masked-observed in place, equal a full observe; a workgroup without a flagged environment writes nothing."""
+    maps, agents, goals, _ = M.generate_scenarios(E, L, N, 0.2, seed=E + N)
+    env = M.VecEnvironment(E, L, N)
+    env.load(maps, agents, goals)
+    RD = env.obs_bits_row_dwords
+    bits = torch.zeros((E, RD), dtype=torch.int32, device="cuda")
+    rng = np.random.RandomState(3)
+    obs, pos = env.observe(obs_bits_out=bits)
+    for t in range(3):
+        obs, pos, *_ = env.step(torch.from_numpy(_heuristic_tape_step(_np(obs), rng, 0.8)).cuda(), obs_bits_out=bits)
+    mask = torch.from_numpy((rng.random_sample(E) < 0.3).astype(np.uint8)).cuda()
+    mask[0], mask[E - 1] = 1, 0
+    env.reset_envs(mask, 0.2, seed=99)
+    obs, pos = env.observe(obs_bits_out=bits, mask=mask)        # in place, on top of what step() wrote
+    got = (_np(obs).copy(), _np(pos).copy(), _np(bits).copy())
+    full_obs = torch.empty_like(obs)
+    full_bits = torch.empty_like(bits)
+    _, full_pos = env.observe(obs_out=full_obs, obs_bits_out=full_bits)
+    assert np.array_equal(got[0], _np(full_obs)) and np.array_equal(got[1], _np(full_pos)) and np.array_equal(got[2], _np(full_bits))
+    # nothing is written for workgroups without a flagged environment (G environments per workgroup for few agents: <= 8)
+    sent = torch.full_like(obs, 7)
+    env.observe(obs_out=sent, mask=mask)
+    m = _np(mask).astype(bool)
+    s = _np(sent)
+    assert np.array_equal(s[m], _np(full_obs)[m])
+    grp = m.reshape(-1, 8).any(axis=1).repeat(8) if E % 8 == 0 else np.ones(E, bool)
+    assert (s[~grp] == 7).all()
+    env.check_status()
 
 
 def test_bad_action_raises_assertion(M):

@@ -45,10 +45,13 @@ def test_device_pipeline_sample_update_priorities():
     assert abs(float(after[0]) - float(leaves.sum())) < 1e-6 * float(after[0])   # root == sum of leaves (buffer.py:30)
 
 
-def test_pipelined_target_forward_equals_sequential_order():
+@pytest.mark.parametrize("double_q", [False, True])
+def test_pipelined_target_forward_equals_sequential_order(double_q):
     """Learner(prefetch=True) samples batch k+1 and runs its target-network forward on a second stream while update k's backward
     is still in flight; the numbers must be those of the sequential order (same samples: the priorities of update k are
-    written before batch k+1 is drawn; same target: nothing the backward does touches the target network)."""
+    written before batch k+1 is drawn; same target: nothing the backward does touches the target network).  With double_q the
+    side stream also runs the ONLINE network (the arg-max) right after an optimizer step changed its weights: its packed weight
+    images must have been rebuilt before the side stream reads them (Learner._update: model.prepack())."""
     from mapf_rl_amd.learner import Learner
     from mapf_rl_amd.model import Network
     from mapf_rl_amd.replay import GlobalBuffer
@@ -67,9 +70,9 @@ def test_pipelined_target_forward_equals_sequential_order():
                             td, bool(k % 2), size, rng.random_sample((size + 1, A, A)) < 0.5)
         torch.manual_seed(7)
         torch.cuda.manual_seed(7)
-        lr = Learner(buf, device="cuda", batch_size=24, model=Network(), prefetch=prefetch)
-        assert lr.prefetch == prefetch
-        outs = [lr.update() for _ in range(4)]
+        lr = Learner(buf, device="cuda", batch_size=24, model=Network(), prefetch=prefetch, double_q=double_q)
+        assert lr.prefetch == prefetch and lr.double_q == double_q
+        outs = [lr.update() for _ in range(5)]  # back to back: no actor step repacks the weights in between
         torch.cuda.synchronize()
         return outs, [p.detach().clone() for p in lr.model.parameters()], buf.priority_tree.tree().clone()
 
@@ -80,3 +83,66 @@ def test_pipelined_target_forward_equals_sequential_order():
     for a, b in zip(p_seq, p_pre):
         assert torch.equal(a, b)
     assert torch.equal(t_seq, t_pre)
+
+
+def _fp32_module_q(net, batch, steps):
+    """Network.bootstrap through the reference-shaped module path in fp32 on the CPU (no kernels, no autocast, no pruning)."""
+    import copy
+
+    cpu = copy.deepcopy(net).float().cpu()
+    with torch.no_grad():
+        return cpu.bootstrap(batch[0].float().cpu(), steps.cpu(), batch[6].float().cpu(), batch[7].cpu())
+
+
+@pytest.mark.parametrize("tag", ["b40", "b128"])
+def test_double_q_update_on_gpu(tag):
+    """BASELINE config 5 names "double-DQN" (dead in the reference: config.py:46, worker.py:300-303 always takes max_a Q_target).
+    Learner(double_q=True) on the reference-captured batches at 40 and 128 agents (tests/golden/dqn_big.npz), pruning on:
+    q_next = (1 - done) Q_target(s', argmax_a Q_online(s', a)) against the plain formula through the fp32 module path (2e-2; where
+    the online network's top two actions are closer than the tolerance either of them is a legitimate pick), td = q - (r +
+    0.99^steps q_next) at 4e-2 (two bootstraps), and the third bootstrap -- the online network on the TARGET window's row plan --
+    is the same function with and without pruning."""
+    from mapf_rl_amd.learner import Learner
+    from mapf_rl_amd.model import Network
+    from tests import big_golden as BG
+    from tests.test_learner_cpu import _models
+
+    z = H.load_npz("dqn_big.npz")
+    base = _models("cuda")
+    lr = Learner(buffer=None, device="cuda", model=base.model, double_q=True)
+    lr.tar_model.load_state_dict(base.tar_model.state_dict())
+    b = BG.batch(z, tag, "cuda", torch.bfloat16)
+    nxt = b[5] + b[4].view(-1).long()
+    q_on = _fp32_module_q(lr.model, b, nxt).numpy().astype(np.float64)
+    q_tar = _fp32_module_q(lr.tar_model, b, nxt).numpy().astype(np.float64)
+    assert np.allclose(q_tar, z[tag + "_q_target_all"], rtol=1e-4, atol=1e-4)  # the fp32 path IS the reference's function
+    done = b[3].float().cpu().numpy().astype(np.float64).reshape(-1)
+    assert Network.PRUNE_UNREACHABLE
+    got = lr.target_q(b).float().cpu().numpy().astype(np.float64).reshape(-1)
+    tol = 2e-2
+    for i in range(len(got)):
+        picks = np.nonzero(q_on[i] >= q_on[i].max() - 2 * tol * max(1.0, abs(q_on[i].max())))[0]
+        cands = (1 - done[i]) * q_tar[i, picks]
+        assert np.min(np.abs(got[i] - cands)) <= tol * max(1.0, np.abs(cands).max()), (i, got[i], cands)
+    # the same call with every observation encoded (the third bootstrap re-uses the target window's plan for the online network)
+    try:
+        Network.PRUNE_UNREACHABLE = False
+        full = lr.target_q(b).float().cpu().numpy().astype(np.float64).reshape(-1)
+    finally:
+        Network.PRUNE_UNREACHABLE = True
+    if tag == "b40":  # <= 48 agents: same bits (tests/test_relevance_gpu.py); above, the compacted recurrence: bf16 tolerance
+        assert np.array_equal(got, full)
+    else:
+        assert np.all(np.abs(got - full) <= tol * np.maximum(1.0, np.abs(full)))
+    # one full update: td against the plain formula with the fp32 online Q of the taken action
+    bt = b[5]
+    q_sel = _fp32_module_q(lr.model, (b[0][:, :-2],) + b[1:7] + (b[7][:, :-2],), bt).numpy().astype(np.float64)
+    q_sel = np.take_along_axis(q_sel, b[1].cpu().numpy().reshape(-1, 1), axis=1).reshape(-1)
+    rew, steps = b[2].float().cpu().numpy().reshape(-1).astype(np.float64), b[4].float().cpu().numpy().reshape(-1).astype(np.float64)
+    out = lr.update(b)
+    td = out["td"].float().cpu().numpy().astype(np.float64).reshape(-1)
+    qn = out["q_next"].float().cpu().numpy().astype(np.float64).reshape(-1)
+    assert np.array_equal(qn, got)
+    want = q_sel - (rew + 0.99 ** steps * qn)  # the learner's own q_next: the pick is checked above
+    assert np.all(np.isfinite(td)) and np.all(np.abs(td - want) <= 4e-2 * np.maximum(1.0, np.abs(want))), np.abs(td - want).max()
+    assert np.isfinite(float(out["loss"])) and np.isfinite(float(out["grad_norm"])) and lr.counter == 1

@@ -133,3 +133,19 @@ def test_differential_vs_oracle(R, A, cap):
             gb.update_priorities(o[8], newp, o[10])
             ref.update_priorities(e["idxes"], newp, e["old_ptr"])
             assert np.allclose(_np(gb.priority_tree.tree()), ref.tree.tree, rtol=1e-13, atol=0)
+
+
+def test_sampling_an_empty_ring_is_reported():
+    """The reference's batch_sample asserts on an empty tree (buffer.py:75-76).  Here the sample runs without a host round trip:
+    it must not produce NaN weights, and the next state read reports MAPF_ERR_NOT_READY once."""
+    from mapf_rl_amd import _lib
+    from mapf_rl_amd.replay import GlobalBuffer
+
+    buf = GlobalBuffer(4, max_agents=3)
+    assert len(buf) == 0
+    b = buf.sample_batch(8)
+    assert bool(torch.isfinite(b[9]).all())
+    with pytest.raises(_lib.MapfError) as ei:
+        buf.state()
+    assert ei.value.status == _lib.ERR_NOT_READY
+    assert buf.state()[1] == 0  # reported once

@@ -36,6 +36,9 @@ rel = relevance(b[7][:, :-2], b[5])
 per_window = rel[0].sum(dim=1)
 print("%d agents, %dx%d: %.3f of the online window's (step, agent) entries can reach agent 0; agents that matter per window: mean %.1f, max %d" % (
     N, L, L, float(rel.float().mean()), float(per_window.float().mean()), int(per_window.max())))
+print("windows by agents that matter: <=16: %d, 17..32: %d, 33..48: %d, >48: %d of %d" % (
+    int((per_window <= 16).sum()), int(((per_window > 16) & (per_window <= 32)).sum()), int(((per_window > 32) & (per_window <= 48)).sum()),
+    int((per_window > 48).sum()), per_window.numel()), flush=True)
 for prune in (False, True):
     Network.PRUNE_UNREACHABLE = prune
     for _ in range(3):
