@@ -20,6 +20,13 @@ Prints ONE JSON line on rank 0 (see the driver contract), including `roofline` f
 (env_step_kernel, HBM-bound), `cpu_baseline` (the CPU oracle timed on the host cores of this box) and the
 system rates of the same pipeline (`learner_updates_per_sec`, `actor_loop_env_steps_per_sec`,
 `train_loop_*`) as top-level keys.
+
+Timed region: the K steps behind the W warm-up steps of the tape.  One launch is ~21 us, so K = 20 would be a 0.5 ms
+sample: the K-step stretch is replayed R times back to back (one rewind launch of the agent positions between two
+repetitions, inside the timed region and charged to it) until the region is >= ~12 ms; `steps` stays K, `timed_repeats` = R,
+`ms_per_step` = elapsed / (K R).  `roofline.frac` is the BASELINE configuration's number (4096 environments: the 84 MB of navi
+records + 80 MB of observations stay in the 256 MiB Infinity Cache between launches); `roofline.frac_out_of_cache` is the
+same kernel on 4x the environments (working set 654 MB: every launch streams from / to HBM proper).
 """
 import argparse
 import json
@@ -34,6 +41,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MIN_TIMED_S = 0.012   # the timed region is at least this long whatever --steps says (see the module docstring)
+MALL_BYTES = 256 << 20  # Infinity Cache
 
 
 def log(*a):
@@ -52,6 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time")
     ap.add_argument("--no-dqn", action="store_true", help="skip the secondary learner / actor-loop rates")
+    ap.add_argument("--no-out-of-cache", action="store_true", help="skip the 4x-environments leg (roofline.frac_out_of_cache)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) on real multi-GPU runs; gloo only to "
                     "exercise the multi-rank code path on a single GPU (set MAPF_BENCH_SHARE_GPU=1)")
     ap.add_argument("--dqn-updates", type=int, default=20)
@@ -125,6 +135,50 @@ def heuristic_actions(obs, gen, p_follow=0.8):
     return torch.where(pick, follow, uni).to(torch.int8).contiguous()
 
 
+def out_of_cache_leg(M, dev, args, rank, steps=40, warmup=8):
+    """The same kernel on a working set that does not fit the 256 MiB Infinity Cache: 4x the environments (at config 2: 16,384,
+    navi 336 MB + observations 318 MB), own scenarios and tape, HIP events around `steps` back-to-back launches."""
+    import torch
+
+    L, N = args.map, args.agents
+    wb = 4 if L <= 32 else 8
+    per_env = N * L * 4 * wb + N * 486  # navi records + observation bytes
+    E2 = 4 * args.envs
+    while E2 * per_env < 2 * MALL_BYTES:
+        E2 *= 2
+    maps, agents, goals, _ = M.generate_scenarios(E2, L, N, args.density, seed=5000 + rank)
+    env = M.VecEnvironment(E2, L, N, device=dev)
+    env.load(maps, agents, goals)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(177 + rank)
+    T = steps + warmup
+    tape = torch.empty((T, E2, N), dtype=torch.int8, device=dev)
+    obs, pos = env.observe()
+    for t in range(T):
+        tape[t] = heuristic_actions(obs, gen)
+        obs, pos, *_ = env.step(tape[t])
+    first = pos.clone()
+    a0 = torch.from_numpy(agents).to(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for rep in range(2):  # the second pass is the measured one
+        env.set_agents(a0)
+        for t in range(warmup):
+            env.step(tape[t])
+        e0.record()
+        for t in range(warmup, T):
+            env.step(tape[t])
+        e1.record()
+    torch.cuda.synchronize()
+    env.check_status()
+    assert torch.equal(env.pos, first), "out-of-cache replay diverged from its recording pass"
+    us = e0.elapsed_time(e1) * 1e3 / steps
+    alg = (L * L + 821 * N + 1) * E2
+    ach = alg / (us * 1e-6) / 1e9
+    del env
+    return {"envs_out_of_cache": E2, "working_set_out_of_cache_bytes": E2 * per_env, "kernel_avg_us_out_of_cache": us,
+            "achieved_out_of_cache": ach, "frac_out_of_cache": ach / HBM_PEAK_GBS}
+
+
 def cpu_baseline(args, maps, agents, goals, tape, final_pos, E, T):
     """The oracle (C restatement with the reference's sequential semantics), in child processes without torch and without
     the GPU: one single-threaded, pinned process per usable host core (oracle/cpu_bench.py)."""
@@ -172,12 +226,6 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.dist_backend)
-        assert dist.get_world_size() == world
 
     import mapf_rl_amd as M
 
@@ -202,26 +250,56 @@ def main():
     final_pos_first_pass = pos.clone()
     agents_dev = torch.from_numpy(agents).to(dev)
 
-    # ---- timed replay ----
+    # ---- untimed replays ----
     # (two untimed passes over the whole tape first: the recording pass above ran interleaved with the policy's own kernels, and a
     # profile of this command should be dominated by launches in the regime the timed region measures)
-    for _ in range(2):
+    e_a, e_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for rep in range(2):
         env.set_agents(agents_dev)
+        if rep:
+            e_a.record()
         for t in range(T):
             env.step(tape[t])
+    e_b.record()
+    torch.cuda.synchronize()
+    est_step_s = max(e_a.elapsed_time(e_b) * 1e-3 / T, 1e-6)
+    R = int(min(2000, max(1, -(-MIN_TIMED_S // (K * est_step_s)))))  # repetitions of the K-step stretch: timed region >= ~12 ms
+
+    # ---- CPU baseline (rank 0) BEFORE the process group exists: the other ranks then sleep in the rendezvous instead of
+    # spinning on their GPUs / holding host cores while the oracle processes are being timed ----
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, maps, agents, goals, tape, final_pos_first_pass, E, T)
+    if world > 1:
+        import datetime
+
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=20))
+        else:
+            dist.init_process_group(args.dist_backend, timeout=datetime.timedelta(minutes=20))
+        assert dist.get_world_size() == world
+        rr = torch.tensor([R], dtype=torch.int64, device=dev)
+        dist.all_reduce(rr, op=dist.ReduceOp.MAX)  # same amount of timed work on every rank
+        R = int(rr.item())
+
+    # ---- timed replay ----
     env.set_agents(agents_dev)
     for t in range(W):
         env.step(tape[t])
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    pos_w = env.agents_pos()  # state behind the warm-up steps: the rewind target of repetitions 2..R
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(R)]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    ev0.record()  # HIP events on the launch stream, around the whole timed region (no per-launch event traffic)
-    for k in range(K):
-        env.step(tape[W + k])
-    ev1.record()
+    for r in range(R):
+        if r:
+            env.set_agents(pos_w, sync=False)  # one small launch, inside the timed region
+        evs[r][0].record()  # HIP events on the launch stream around each K-launch stretch (no per-launch event traffic)
+        for k in range(K):
+            env.step(tape[W + k])
+        evs[r][1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -235,7 +313,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    kern_avg_s = ev0.elapsed_time(ev1) * 1e-3 / K  # mean launch-to-launch duration of env_step_kernel (incl. the ~1 us boundary)
+    kern_avg_s = sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / (K * R)  # mean launch-to-launch duration of env_step_kernel (incl. the ~1 us boundary)
     alg_bytes_per_env = L * L + 821 * N + 1  # fused step+observe, one byte per flag/cell
     alg_bytes = alg_bytes_per_env * E
     achieved = alg_bytes / kern_avg_s / 1e9
@@ -243,12 +321,14 @@ def main():
     backend = "none" if world == 1 else ("%s, dist.get_world_size()=%d" % (dist.get_backend(), dist.get_world_size()))
     result = {
         "metric": "env_steps_per_sec",
-        "value": world * E * K / elapsed,
+        "value": world * E * K * R / elapsed,
         "unit": "env-steps/s",
         "n_gpus": world,
         "steps": K,
         "warmup": W,
-        "ms_per_step": elapsed / K * 1e3,
+        "ms_per_step": elapsed / (K * R) * 1e3,
+        "timed_repeats": R,
+        "timed_region_ms": elapsed * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -271,8 +351,13 @@ def main():
         except Exception:
             pass
 
-    if rank == 0 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args, maps, agents, goals, tape, final_pos_first_pass, E, T)
+    if cpu is not None:
+        result["cpu_baseline"] = cpu
+    if not args.no_out_of_cache:
+        try:
+            result["roofline"].update(out_of_cache_leg(M, dev, args, rank))
+        except Exception as ex:  # (e.g. not enough free memory next to another process): the primary numbers stand
+            result["roofline"]["out_of_cache_error"] = repr(ex)[:200]
 
     # ---- system rates of the same pipeline (BASELINE metric: "env steps/sec + learner updates/sec") ----
     # learner: Learner.update on 192 x 18 x 40 windows sampled from the device replay (bf16, incl. the flat
@@ -330,6 +415,7 @@ def main():
             learner._drop_prefetch()
             probe = buf.sample_batch(192)
             reach = float(relevance(probe[7][:, :-2], probe[5]).float().mean())
+            reach_min = reach_max = reach
             # interleaved: the loop train.py runs (one update per actor iteration)
             actor.step()
             learner.update()
@@ -349,6 +435,10 @@ def main():
                 tt = torch.tensor([dt_upd, dt_act, dt_train, dt_upd_all], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dt_upd, dt_act, dt_train, dt_upd_all = [float(v) for v in tt.tolist()]
+                # the pruned update's encoder batch is data-dependent, hence per rank: make the spread visible
+                rmm = torch.tensor([reach, -reach], dtype=torch.float64, device=dev)
+                dist.all_reduce(rmm, op=dist.ReduceOp.MAX)
+                reach_max, reach_min = float(rmm[0]), -float(rmm[1])
             # the dominant kernel of the actor loop: the fused inference encoder (MFMA-bound), timed alone on the
             # actor's batch with HIP events on the launch stream
             obs_flat = actor.obs.reshape(E * N, 6, 9, 9)
@@ -365,7 +455,8 @@ def main():
             result.update({
                 "learner_updates_per_sec": 1.0 / dt_upd, "learner_ms_per_update": dt_upd * 1e3,
                 "learner_ms_per_update_all_observations": dt_upd_all * 1e3,
-                "learner_reachable_fraction": reach,
+                "learner_reachable_fraction": reach, "learner_reachable_fraction_min": reach_min,
+                "learner_reachable_fraction_max": reach_max,
                 "learner_note": "only agent 0's Q-value is learned from (reference model.py:248): an update encodes the observations that can "
                                 "reach it through the communication masks (same Q-values bit for bit, tests/test_relevance_gpu.py); "
                                 "learner_ms_per_update_all_observations = the same update encoding every observation of the window",

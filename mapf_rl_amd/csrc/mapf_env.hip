@@ -757,6 +757,16 @@ __global__ void check_positions_kernel(long long n, int L, const int16_t *a, con
     if (v < 0 || v >= L || u < 0 || u >= L) atomicOr(status, kStatusRange);
 }
 
+// mapf_set_agents in one launch: copy + range check of the positions, step counters := 0
+__global__ void set_agents_kernel(long long n, int L, int E, const int16_t *src, int16_t *dst, int32_t *steps, int32_t *status) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over E*N (row, col) pairs
+    if (idx < E) steps[idx] = 0;
+    if (idx >= n) return;
+    const short2 v = reinterpret_cast<const short2 *>(src)[idx];
+    if (v.x < 0 || v.x >= L || v.y < 0 || v.y >= L) atomicOr(status, kStatusRange);
+    reinterpret_cast<short2 *>(dst)[idx] = v;
+}
+
 // navi records -> uint8 [E][N][4][L][L]
 template <typename W>
 __global__ void unpack_navi_kernel(long long fields, int L, const NaviRec<W> *navi, uint8_t *out) {
@@ -1265,12 +1275,10 @@ int mapf_set_agents(mapf_env_t *h, const int16_t *agents_dev, void *stream) {
     if (!h->loaded) return MAPF_ERR_NOT_READY;
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t n = (size_t)h->E * h->N * 2;
-    HIP_TRY(hipMemcpyAsync(h->agents, agents_dev, n * sizeof(int16_t), hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(check_positions_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, (long long)n, h->L,
-                       h->agents, h->agents, h->status);
+    const long long n = (long long)h->E * h->N;  // one launch, nothing else on the stream: callers rewind inside timed regions
+    hipLaunchKernelGGL(set_agents_kernel, dim3(blocks_for(n > h->E ? n : h->E, 256)), dim3(256), 0, s, n, h->L, h->E, agents_dev, h->agents,
+                       h->steps, h->status);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(h->steps, 0, (size_t)h->E * sizeof(int32_t), s));
     return MAPF_OK;
 }
 

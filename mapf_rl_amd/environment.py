@@ -123,10 +123,14 @@ class VecEnvironment:
               "mapf_reset_envs")
         self._keep_mask = m
 
-    def set_agents(self, agents_pos):
+    def set_agents(self, agents_pos, sync=True):
+        """Overwrites the agent positions (rewind to the start of an action tape), steps := 0.  sync=False: asynchronous; the
+        caller keeps `agents_pos` (an int16 device tensor, used as is) alive until the stream has consumed it."""
         a = agents_pos.to(self.device, torch.int16).contiguous()
+        assert a.shape == (self.num_envs, self.num_agents, 2)
         check(lib.mapf_set_agents(self._h, _ptr(a), _stream(self.device)), "mapf_set_agents")
-        torch.cuda.current_stream(self.device).synchronize()
+        if sync:
+            torch.cuda.current_stream(self.device).synchronize()
 
     # -- the hot path --
     def step(self, actions, obs_out=None, obs_bits_out=None):

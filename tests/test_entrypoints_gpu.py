@@ -139,3 +139,11 @@ def test_bench_launches_its_own_ranks(tmp_path):
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and "dist.get_world_size()=2" in r["config"]["parallelism"] and r["steps"] == 5
     assert r["value"] > 0 and r["learner_updates_per_sec"] > 0 and "flat-bucket" in r["learner_config"]
+    # the timed region is stretched to >= ~12 ms by repeating the K-step tape; the pruning spread over ranks is reported
+    assert r["timed_repeats"] >= 1 and r["timed_region_ms"] >= 10.0
+    assert abs(r["value"] - 2 * 256 * 5 * r["timed_repeats"] / (r["timed_region_ms"] * 1e-3)) <= 1e-6 * r["value"]
+    assert 0 < r["learner_reachable_fraction_min"] <= r["learner_reachable_fraction"] * (1 + 1e-9) + 1e-12
+    assert r["learner_reachable_fraction_min"] <= r["learner_reachable_fraction_max"] <= 1
+    rf = r["roofline"]
+    assert rf["envs_out_of_cache"] >= 4 * 256 and rf["working_set_out_of_cache_bytes"] >= 2 * (256 << 20)
+    assert 0 < rf["frac_out_of_cache"] < 1 and 0 < rf["frac"] < 1.2
