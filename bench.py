@@ -211,6 +211,11 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
+    if os.environ.get("MAPF_BENCH_WATCHDOG"):  # diagnostics: dump every thread's stack and exit if the run takes longer than this
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["MAPF_BENCH_WATCHDOG"]), exit=True)
+
     import numpy as np
     import torch
 

@@ -47,8 +47,9 @@ int mapf_bias_res_relu_bwd(const uint16_t *g_dev, const uint16_t *y_dev, uint16_
 #define MAPF_ENC_OBS_U8 0            /* obs elements are bytes (0/1, any 0..255 is exact) */
 #define MAPF_ENC_OBS_BF16 1          /* obs elements are bf16 */
 
-/* w_dev / b_dev: HOST arrays of 8 DEVICE pointers (see above). */
-int mapf_encoder_pack(const float *const *w_dev, const float *const *b_dev, uint16_t *packed_dev, float *bias_dev,
+/* w_dev / b_dev: HOST arrays of 8 DEVICE pointers (see above).  weights_nhwc != 0: every weight is stored [co][kh][kw][ci]
+ * (PyTorch's channels_last memory of a [co][ci][kh][kw] tensor) instead. */
+int mapf_encoder_pack(const float *const *w_dev, const float *const *b_dev, int weights_nhwc, uint16_t *packed_dev, float *bias_dev,
                       void *stream);
 /* obs [M][6][9][9] (u8 or bf16, 4-byte aligned) -> latent bf16 [M][784] (= Flatten of [16][7][7]). */
 int mapf_encoder_forward(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev,
@@ -78,7 +79,7 @@ int mapf_encoder_forward_save(const void *obs_dev, int obs_dtype, int64_t M, con
  *            positions; the bias gradient of layer k is the sum of slab k over its middle axis (no atomics).
  */
 #define MAPF_ENC_PACKED_BWD_ELEMS 888832 /* 6*147456 + 4096 */
-int mapf_encoder_pack_bwd(const float *const *w_dev, uint16_t *packed_bwd_dev, void *stream);
+int mapf_encoder_pack_bwd(const float *const *w_dev, int weights_nhwc, uint16_t *packed_bwd_dev, void *stream);
 int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint32_t *relu_bits_dev,
                                const uint16_t *packed_bwd_dev, uint16_t *gz_dev, float *gbias_partial_dev,
                                void *stream);
@@ -185,6 +186,76 @@ int mapf_comm_mask(const int16_t *pos_dev, int E, int N, int obs_radius, int max
  * comm_dev u8 [B][T][N][N] (non-zero = allowed); steps_dev int64 [B], 1-based; rel_dev u8 [T][B][N] (time-major).  N <= 128.
  */
 int mapf_window_relevance(const uint8_t *comm_dev, const int64_t *steps_dev, int T, int B, int N, uint8_t *rel_dev, void *stream);
+
+/*
+ * ---- the glue of one batch update (reference worker.py:287-338) as a handful of launches (csrc/mapf_update.hip) ----
+ *
+ * mapf_plan_mark: mapf_window_relevance's closure plus a renumbering of every window's agents such that the agents needed at step t
+ * are a PREFIX of the order (the set only shrinks going forward in time; agent 0, needed until the window's last step, stays agent 0):
+ *   comm: window b, step t at comm_dev + b * stride_b + t * stride_t (bytes = elements), [N][N] contiguous; steps int64 [B] 1-based
+ *   (+ extra_steps f32 [B] if given: the target window ends `steps` later, worker.py:296); mark_all != 0: no pruning -- every agent
+ *   at every step up to the window's last one (what the reference encodes);
+ *   rel_dev u8 [T][B][N] optional; slot int16 [B][N] position of agent j (-1: never needed); order int16 [B][N] agent at position i;
+ *   nact int32 [T][B] agents needed at step t; cnt int32 [B] = sum_t nact (observations of the window to encode); nag int32 [B] = nact[0].
+ * mapf_plan_rows: everything the encoder / recurrence launches need in the compact numbering, Nc (multiple of 16, >= max nag) agent
+ * positions per window; rows are numbered window by window, step by step, position by position:
+ *   gidx int32 [T][B][Nc] row of (t, b, position) or -1; comm_c u8 [T][B][Nc][Nc] (positions >= nact[t][b] read only themselves);
+ *   h0_c bf16 [B][Nc][256] from hidden f16 (or bf16) [B*N][256]; row_src int64 [num_rows] element offset of every row's observation
+ *   in the bf16 observations (window b, step t at obs + b * obs_stride_b + t * obs_stride_t elements, [N][486] contiguous) and
+ *   obs_rows bf16 [num_rows][486] the rows themselves (both optional; num_rows = sum of cnt, known to the caller).
+ */
+#define MAPF_PLAN_MAX_STEPS 20
+int mapf_plan_mark(const uint8_t *comm_dev, int64_t stride_b, int64_t stride_t, const int64_t *steps_dev, const float *extra_steps_dev,
+                   int T, int B, int N, int mark_all, uint8_t *rel_dev, int16_t *slot_dev, int16_t *order_dev, int32_t *nact_dev, int32_t *cnt_dev, int32_t *nag_dev,
+                   void *stream);
+int mapf_plan_rows(int T, int B, int N, int Nc, const int16_t *order_dev, const int32_t *nact_dev, const int32_t *cnt_dev,
+                   const int32_t *nag_dev, const uint8_t *comm_dev, int64_t comm_stride_b, int64_t comm_stride_t,
+                   const uint16_t *hidden_dev, int hidden_is_bf16, const uint16_t *obs_bf16_dev, int64_t obs_stride_b, int64_t obs_stride_t,
+                   int32_t *gidx_dev, uint8_t *comm_c_dev, uint16_t *h0_c_dev, int64_t num_rows, int64_t *row_src_dev,
+                   uint16_t *obs_rows_dev, void *stream);
+/* dense[r][:] = idx[r] >= 0 ? rows[idx[r]][:] : 0 (to_dense != 0)  /  rows[idx[r]][:] = dense[r][:] where idx[r] >= 0 (to_dense == 0);
+ * R dense rows of row_bytes (multiple of 16) bytes. */
+int mapf_rows_scatter(void *rows_dev, const int32_t *idx_dev, void *dense_dev, int64_t R, int row_bytes, int to_dense, void *stream);
+
+/*
+ * Dueling head of both networks, TD error, priorities and Huber loss of a batch, forward AND backward (model.py:259-262,
+ * worker.py:296-310,341-344), fp32 from the bf16 states:
+ *   a0_online bf16 [To][B][256] / a0_target bf16 [Tt][B][256]: agent 0's state after every step (mapf_recurrent_*'s agent0_out) of
+ *   the online window under the online network / the target window under the target network; a0_online_next bf16 [Tt][B][256] or
+ *   NULL: the online network on the target window -- double-DQN, it picks the action the target network values (NULL: the
+ *   reference's max_a Q_target, worker.py:300-303); bt_steps int64 [B], steps f32 [B], action int64 [B], reward / done / weights f32 [B];
+ *   head_online / head_target: HOST arrays of 4 DEVICE pointers {adv.weight [5][256], adv.bias [5], state.weight [256], state.bias [1]} fp32.
+ * Outputs: q (of the taken action), q_next, td f32 [B]; prio f64 [B] = max(|td|, 1e-6); loss f32 [1] = mean(w huber(td));
+ *   d_a0 bf16 [To][B][256] gradient of the loss w.r.t. a0_online; head_grads: HOST array of 4 DEVICE pointers, ACCUMULATED into.
+ *   scratch f32 [9 B].
+ */
+int mapf_dqn_head_loss(int B, int To, int Tt, const uint16_t *a0_online_dev, const uint16_t *a0_target_dev,
+                       const uint16_t *a0_online_next_dev, const int64_t *bt_steps_dev, const float *steps_dev,
+                       const int64_t *action_dev, const float *reward_dev, const float *done_dev, const float *weights_dev,
+                       const float *const *head_online, const float *const *head_target, float gamma, float *q_dev,
+                       float *q_next_dev, float *td_dev, double *prio_dev, float *loss_dev, float *scratch_dev, uint16_t *d_a0_dev,
+                       float *const *head_grads, void *stream);
+
+/*
+ * fp32 parameters -> the fragment images of the recurrence kernels, one launch each: weights_dev / bias_dev as mapf_recurrent_infer
+ * takes them (either both or neither), weights_t_dev as mapf_recurrent_backward takes it (optional).  params_dev: HOST array of 14
+ * DEVICE pointers (fp32, row-major contiguous): recurrent.weight_hh, .bias_ih, .bias_hh, W_Q.weight, W_K.weight, W_V.weight, W_Q.bias,
+ * W_K.bias, W_V.bias, W_O.weight, update_cell.weight_ih, .weight_hh, .bias_ih, .bias_hh.
+ */
+int mapf_recurrent_pack(const float *const *params_dev, uint16_t *weights_dev, float *bias_dev, uint16_t *weights_t_dev, void *stream);
+/* Bias gradients of the recurrence from mapf_recurrent_backward's bsum [E][MAPF_RECUR_BSUM_ELEMS], ACCUMULATED into grads_dev: HOST
+ * array of 7 DEVICE pointers {recurrent.bias_ih, .bias_hh, W_Q.bias, W_K.bias, W_V.bias, update_cell.bias_ih, .bias_hh}. */
+int mapf_recurrent_bias_grads(const float *bsum_dev, int E, float *const *grads_dev, void *stream);
+
+/*
+ * torch.nn.utils.clip_grad_norm_(max_norm) + one torch.optim.Adam step (worker.py:260,319-322) over flat fp32 buffers of n elements:
+ * the gradients are scaled in place by min(1, max_norm / (||g|| + 1e-6)); norm_out f32 [1] receives ||g|| before clipping;
+ * params_bf16_dev (optional) receives the bf16 copy of the new parameters; scratch f32 [256]; step = 1-based count of this step.
+ */
+int mapf_adam_step(int64_t n, float *params_dev, float *grads_dev, float *exp_avg_dev, float *exp_avg_sq_dev,
+                   uint16_t *params_bf16_dev, float *scratch_dev, float *norm_out_dev, float lr, float beta1, float beta2, float eps,
+                   int64_t step, float max_norm, void *stream);
+int mapf_to_bf16(const float *src_dev, uint16_t *dst_dev, int64_t n, void *stream);
 
 #ifdef __cplusplus
 }

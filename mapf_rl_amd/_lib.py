@@ -67,14 +67,24 @@ SYMBOLS = [
     ("mapf_recurrent_backward", _i, [ctypes.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(_vp), _vp]),
     ("mapf_comm_mask", _i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     ("mapf_window_relevance", _i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
-    ("mapf_encoder_pack", _i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp, _vp]),
+    ("mapf_encoder_pack", _i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _vp, _vp, _vp]),
     ("mapf_encoder_forward", _i, [_vp, _i, ctypes.c_int64, _vp, _vp, _vp, _vp]),
-    ("mapf_encoder_pack_bwd", _i, [ctypes.POINTER(_vp), _vp, _vp]),
+    ("mapf_encoder_pack_bwd", _i, [ctypes.POINTER(_vp), _i, _vp, _vp]),
     ("mapf_encoder_backward_data", _i, [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_encoder_wgrad0", _i, [_vp, _vp, _i, ctypes.c_int64, _vp, _vp]),
     ("mapf_encoder_backward", _i, [_vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_encoder_wgrad", _i, [_vp, _vp, ctypes.c_int64, _vp, _vp]),
     ("mapf_encoder_forward_save", _i, [_vp, _i, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("mapf_plan_mark", _i, [_vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("mapf_plan_rows", _i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _i, _vp, ctypes.c_int64, ctypes.c_int64,
+                            _vp, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp]),
+    ("mapf_rows_scatter", _i, [_vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp]),
+    ("mapf_dqn_head_loss", _i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _f,
+                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_vp), _vp]),
+    ("mapf_recurrent_pack", _i, [ctypes.POINTER(_vp), _vp, _vp, _vp, _vp]),
+    ("mapf_recurrent_bias_grads", _i, [_vp, _i, ctypes.POINTER(_vp), _vp]),
+    ("mapf_adam_step", _i, [ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, ctypes.c_int64, _f, _vp]),
+    ("mapf_to_bf16", _i, [_vp, _vp, ctypes.c_int64, _vp]),
     # include/mapf_search.h
     ("mapf_find_path", _i, [_i, _i, _vp, _vp, _vp, ctypes.c_double, _i, _vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     ("mapf_distance_field", _i, [_i, _vp, _i, _i, _vp]),

@@ -369,7 +369,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
 struct PackArgs {
     const float *w[8];
     const float *b[8];
+    int nhwc;  // weights stored [co][kh][kw][ci] (PyTorch channels_last memory) instead of [co][ci][kh][kw]
 };
+
+// element (co, ci, tap) of a [co][CI][3][3] weight in either memory order
+__device__ __forceinline__ float wread(const float *w, int nhwc, int CI, int co, int ci, int tap) {
+    return nhwc ? w[(co * 9 + tap) * CI + ci] : w[(co * CI + ci) * 9 + tap];
+}
 
 __global__ void __launch_bounds__(256) encoder_pack_kernel(PackArgs pa, uint16_t *__restrict__ wp, float *__restrict__ bias) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -384,13 +390,13 @@ __global__ void __launch_bounds__(256) encoder_pack_kernel(PackArgs pa, uint16_t
     if (i < WP_RES) {  // conv0: [s=2][c=8][l][j], k = 32 s + 8 h + j = ci*9 + tap
         const int c = (i >> 9) & 7, s = i >> 12;
         const int k = 32 * s + 8 * h + j, co = 16 * c + r;
-        if (k < 54) v = pa.w[0][co * 54 + k];
+        if (k < 54) v = wread(pa.w[0], pa.nhwc, 6, co, k / 9, k % 9);
     } else if (i < WP_L7) {  // 3x3 layers: [s=36][c=8][l][j], s = tap*4 + chunk, ci = 32 chunk + 8 h + j
         const int e = i - WP_RES, layer = e / WP_RES_SIZE, f = e - layer * WP_RES_SIZE;
         const int c = (f >> 9) & 7, s = f >> 12;
         const int tap = s >> 2, chunk = s & 3;
         const int ci = 32 * chunk + 8 * h + j, co = 16 * c + r;
-        v = pa.w[1 + layer][(co * 128 + ci) * 9 + tap];
+        v = wread(pa.w[1 + layer], pa.nhwc, 128, co, ci, tap);
     } else {  // 1x1: [s=4][l][j], ci = 32 s + 8 h + j, co = r
         const int f = i - WP_L7, s = f >> 9;
         v = pa.w[7][r * 128 + 32 * s + 8 * h + j];
@@ -636,7 +642,7 @@ __global__ void __launch_bounds__(256) encoder_pack_bwd_kernel(PackArgs pa, uint
         const int c = (f >> 9) & 7, s = f >> 12;
         const int tap = s >> 2, chunk = s & 3;
         const int i = 32 * chunk + 8 * h + j, o = 16 * c + r;
-        v = pa.w[1 + layer][(i * 128 + o) * 9 + (8 - tap)];
+        v = wread(pa.w[1 + layer], pa.nhwc, 128, i, o, 8 - tap);
     } else {
         const int c = ((idx - WPT_L7) >> 9) & 7, k = 8 * h + j, o = 16 * c + r;
         if (k < 16) v = pa.w[7][k * 128 + o];
@@ -657,9 +663,10 @@ __global__ void __launch_bounds__(256) encoder_pack_bwd_kernel(PackArgs pa, uint
 
 extern "C" {
 
-int mapf_encoder_pack(const float *const *w_dev, const float *const *b_dev, uint16_t *packed_dev, float *bias_dev, void *stream) {
+int mapf_encoder_pack(const float *const *w_dev, const float *const *b_dev, int weights_nhwc, uint16_t *packed_dev, float *bias_dev, void *stream) {
     if (!w_dev || !b_dev || !packed_dev || !bias_dev) return MAPF_ERR_INVALID_ARG;
     PackArgs pa;
+    pa.nhwc = weights_nhwc != 0;
     for (int i = 0; i < 8; ++i) {
         if (!w_dev[i] || !b_dev[i]) return MAPF_ERR_INVALID_ARG;
         pa.w[i] = w_dev[i];
@@ -708,9 +715,10 @@ int mapf_encoder_forward_save(const void *obs_dev, int obs_dtype, int64_t M, con
     return encoder_launch(obs_dev, obs_dtype, M, packed_dev, bias_dev, latent_dev, acts_dev, relu_bits_dev, true, stream);
 }
 
-int mapf_encoder_pack_bwd(const float *const *w_dev, uint16_t *packed_bwd_dev, void *stream) {
+int mapf_encoder_pack_bwd(const float *const *w_dev, int weights_nhwc, uint16_t *packed_bwd_dev, void *stream) {
     if (!w_dev || !packed_bwd_dev || (reinterpret_cast<uintptr_t>(packed_bwd_dev) & 15)) return MAPF_ERR_INVALID_ARG;
     PackArgs pa;
+    pa.nhwc = weights_nhwc != 0;
     for (int i = 0; i < 8; ++i) {
         if (!w_dev[i]) return MAPF_ERR_INVALID_ARG;
         pa.w[i] = w_dev[i];

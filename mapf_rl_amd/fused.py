@@ -32,6 +32,26 @@ def _is_nhwc(t):
     return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
 
 
+MM_ROW_CHUNK = 32768
+
+
+def mm_rows(x, w, transpose_w=True):
+    """x [n, k] @ w^T (w [m, k]; transpose_w=False: x @ w, w [k, m]) in bf16, in chunks of MM_ROW_CHUNK rows.
+    Why chunks: for n beyond ~10^5 rows hipBLASLt selects a STREAM-K kernel (`..._SK3_...MT256x256x64`): a persistent grid whose
+    workgroups spin-wait on partial tiles of peer workgroups, i.e. it assumes all of them are resident.  Next to other resident
+    work -- the learner's second stream, a second process on the GPU -- that is not guaranteed, and two ranks sharing a GPU did hang
+    in exactly these GEMMs (round 3, tools/hang_repro.py).  At <= 32,768 rows the library picks plain tiled kernels."""
+    n = x.shape[0]
+    if n <= MM_ROW_CHUNK:
+        return torch.mm(x, w.t() if transpose_w else w)
+    out = torch.empty((n, w.shape[0] if transpose_w else w.shape[1]), dtype=x.dtype, device=x.device)
+    parts = -(-n // MM_ROW_CHUNK)
+    step = -(-n // parts)
+    for i in range(0, n, step):
+        torch.mm(x[i:i + step], w.t() if transpose_w else w, out=out[i:i + step])
+    return out
+
+
 class _BiasResReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, bias, res):
@@ -80,33 +100,61 @@ def encoder_convs(obs_encoder):
     return [e[0], e[2].block1, e[2].block2, e[3].block1, e[3].block2, e[4].block1, e[4].block2, e[5]]
 
 
+def _conv_weight_ptrs(convs):
+    """(tensors kept alive, nhwc flag, host array of 8 device pointers) for the pack kernels: fp32 weights are used where they
+    lie -- PyTorch's channels_last memory ([co][kh][kw][ci]: how Network stores them) or plain contiguous --, anything else is copied."""
+    ws = [c.weight.detach() for c in convs]
+    if all(w.dtype == torch.float32 and w.is_contiguous(memory_format=torch.channels_last) for w in ws):
+        nhwc = 1
+    else:
+        nhwc = 0
+        ws = [w.to(torch.float32).contiguous() for w in ws]
+    return ws, nhwc, (ctypes.c_void_p * 8)(*[w.data_ptr() for w in ws])
+
+
 class PackedEncoder:
     """bf16 MFMA-fragment image of an encoder's weights; re-packed (one small kernel) whenever a parameter changed
-    (optimizer step, load_state_dict, .to()), detected through the tensors' version counters and storage pointers."""
+    (optimizer step, load_state_dict, .to()), detected through the tensors' version counters and storage pointers and the owner's
+    `epoch` (the learner's fused Adam kernel writes the parameters without passing through a PyTorch operation)."""
 
     def __init__(self):
         self.key = None
         self.weights = None
         self.bias = None
 
-    def get(self, obs_encoder):
+    def get(self, obs_encoder, epoch=0):
         convs = encoder_convs(obs_encoder)
         params = [c.weight for c in convs] + [c.bias for c in convs]
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = (epoch,) + tuple((p.data_ptr(), p._version) for p in params)
         if key != self.key:
             dev = params[0].device
             assert dev.type == "cuda", "the fused encoder needs a HIP device"
-            ws = [c.weight.detach().to(torch.float32).contiguous() for c in convs]  # standard [co][ci][kh][kw] order
+            ws, nhwc, wp = _conv_weight_ptrs(convs)
             bs = [c.bias.detach().to(torch.float32).contiguous() for c in convs]
             assert [tuple(w.shape) for w in ws] == [(128, 6, 3, 3)] + [(128, 128, 3, 3)] * 6 + [(16, 128, 1, 1)]
             if self.weights is None or self.weights.device != dev:
                 self.weights = torch.empty(ENC_PACKED_ELEMS, dtype=torch.bfloat16, device=dev)
                 self.bias = torch.empty(ENC_BIAS_ELEMS, dtype=torch.float32, device=dev)
-            wp = (ctypes.c_void_p * 8)(*[w.data_ptr() for w in ws])
             bp = (ctypes.c_void_p * 8)(*[b.data_ptr() for b in bs])
-            check(lib.mapf_encoder_pack(wp, bp, _ptr(self.weights), _ptr(self.bias), _stream(dev)), "mapf_encoder_pack")
+            check(lib.mapf_encoder_pack(wp, bp, nhwc, _ptr(self.weights), _ptr(self.bias), _stream(dev)), "mapf_encoder_pack")
             self.key = key  # `ws`/`bs` temporaries stay alive until the stream has consumed them (caching allocator)
         return self.weights, self.bias
+
+
+def pack_encoder_backward(obs_encoder_or_params):
+    """bf16 image of the TRANSPOSED convolutions for mapf_encoder_backward (one kernel; no copies for channels_last fp32 weights)."""
+    if isinstance(obs_encoder_or_params, (list, tuple)):
+        class _C:  # the 8 weights of a saved parameter list [w0, b0, w1, b1, ...]
+            def __init__(self, w):
+                self.weight = w
+        convs = [_C(obs_encoder_or_params[2 * i]) for i in range(8)]
+    else:
+        convs = encoder_convs(obs_encoder_or_params)
+    ws, nhwc, wp = _conv_weight_ptrs(convs)
+    dev = ws[0].device
+    wpt = torch.empty(ENC_PACKED_BWD_ELEMS, dtype=torch.bfloat16, device=dev)
+    check(lib.mapf_encoder_pack_bwd(wp, nhwc, _ptr(wpt), _stream(dev)), "mapf_encoder_pack_bwd")
+    return wpt
 
 
 def encoder_forward(obs, packed_weights, packed_bias):
@@ -179,10 +227,7 @@ class _EncoderTrain(torch.autograd.Function):
         gws = [None] * 8
         # the whole backward-data chain in one kernel: ReLU mask of the 1x1 layer on the incoming gradient, then the masked
         # pre-activation gradients of all 7 layers below it and per-workgroup bias-gradient partials
-        w32 = [params[2 * i].detach().to(torch.float32).contiguous() for i in range(8)]
-        wpt = torch.empty(ENC_PACKED_BWD_ELEMS, dtype=torch.bfloat16, device=dev)
-        check(lib.mapf_encoder_pack_bwd((ctypes.c_void_p * 8)(*[w.data_ptr() for w in w32]), _ptr(wpt), _stream(dev)),
-              "mapf_encoder_pack_bwd")
+        wpt = pack_encoder_backward(list(params))
         g = g.to(torch.bfloat16).contiguous()
         nblk = -(-M // ENC_OBS_PER_BLOCK)
         gz = torch.empty_like(acts)
@@ -219,14 +264,14 @@ class _EncoderTrain(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
-def encoder_forward_train(obs, obs_encoder, packed: PackedEncoder):
+def encoder_forward_train(obs, obs_encoder, packed: PackedEncoder, epoch=0):
     """obs [M, 6, 9, 9] uint8 / bool / bf16 -> latent bf16 [M, 784] with autograd into the encoder's parameters."""
     assert obs.dim() == 4 and tuple(obs.shape[1:]) == (6, 9, 9) and obs.is_cuda
     if obs.dtype == torch.bool:
         obs = obs.view(torch.uint8)
     if obs.dtype not in (torch.uint8, torch.bfloat16):
         obs = obs.to(torch.bfloat16)
-    wp, bp = packed.get(obs_encoder)
+    wp, bp = packed.get(obs_encoder, epoch)
     params = [t for c in encoder_convs(obs_encoder) for t in (c.weight, c.bias)]
     return _EncoderTrain.apply(obs.contiguous(), wp, bp, *params)
 
@@ -238,9 +283,15 @@ RECUR_MAX_AGENTS = 128         # include/mapf_dqn.h: the fused recurrence kernel
 RECUR_NARROW_AGENTS = 48       # up to here one workgroup keeps every image in LDS and the forward saves the attention weights P
 
 
+def _recurrence_param_ptrs(params):
+    """(tensors kept alive, host array of 14 device pointers) of `recurrence_params(net)` as fp32 contiguous tensors."""
+    ts = [p.detach() if (p.dtype == torch.float32 and p.is_contiguous()) else p.detach().to(torch.float32).contiguous() for p in params]
+    return ts, (ctypes.c_void_p * 14)(*[t.data_ptr() for t in ts])
+
+
 class PackedRecurrence:
-    """bf16 row-major weight image + f32 biases of Network.recurrent / Network.comm for mapf_recurrent_infer;
-    rebuilt when a parameter changed (same rule as PackedEncoder)."""
+    """bf16 fragment image + f32 biases of Network.recurrent / Network.comm for mapf_recurrent_infer (one kernel:
+    mapf_recurrent_pack); rebuilt when a parameter changed (same rule as PackedEncoder)."""
 
     def __init__(self):
         self.key = None
@@ -248,20 +299,21 @@ class PackedRecurrence:
         self.bias = None
 
     def get(self, net):
-        rc, at, uc = net.recurrent, net.comm.self_attn, net.comm.update_cell
-        ws = [rc.weight_hh, at.W_Q.weight, at.W_K.weight, at.W_V.weight, at.W_O.weight, uc.weight_ih, uc.weight_hh]
-        bs = [rc.bias_ih, rc.bias_hh, at.W_Q.bias, at.W_K.bias, at.W_V.bias, uc.bias_ih, uc.bias_hh]
-        key = tuple((p.data_ptr(), p._version) for p in ws + bs)
+        params = recurrence_params(net)
+        key = (getattr(net, "weights_epoch", 0),) + tuple((p.data_ptr(), p._version) for p in params)
         if key != self.key:
-            # each [O, K] matrix in MFMA A-fragment order [O/16][K/32][lane = 16*(k%32)//8 + o%16][k%8]
-            qkv = torch.cat([w.detach() for w in ws[1:4]], dim=0)
-            mats = [ws[0].detach(), qkv, ws[4].detach(), ws[5].detach(), ws[6].detach()]
-            self.weights = torch.cat([m.reshape(m.shape[0] // 16, 16, m.shape[1] // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1)
-                                      for m in mats]).to(torch.bfloat16).contiguous()
-            self.bias = torch.cat([b.detach().reshape(-1) for b in bs]).to(torch.float32).contiguous()
-            assert self.weights.numel() == 548864 and self.bias.numel() == 3456
+            dev = params[0].device
+            ts, ptrs = _recurrence_param_ptrs(params)
+            # fresh buffers per pack: a launch of the stream that packed before may still be reading the old image
+            self.weights = torch.empty(RECUR_WEIGHT_ELEMS, dtype=torch.bfloat16, device=dev)
+            self.bias = torch.empty(RECUR_BIAS_ELEMS, dtype=torch.float32, device=dev)
+            check(lib.mapf_recurrent_pack(ptrs, _ptr(self.weights), _ptr(self.bias), None, _stream(dev)), "mapf_recurrent_pack")
             self.key = key
         return self.weights, self.bias
+
+
+RECUR_WEIGHT_ELEMS = 548864
+RECUR_BIAS_ELEMS = 3456
 
 
 def recurrent_infer(gi, h0, comm, weights, bias, want_agent0=False):
@@ -298,7 +350,15 @@ def recurrence_params(net):
 
 
 def pack_recurrence_transposed(params):
-    """The transposed matrices of the backward kernel in fragment order (see include/mapf_dqn.h)."""
+    """The transposed matrices of the backward kernel in fragment order (include/mapf_dqn.h), one kernel."""
+    ts, ptrs = _recurrence_param_ptrs(params)
+    out = torch.empty(RECUR_WEIGHT_ELEMS, dtype=torch.bfloat16, device=ts[0].device)
+    check(lib.mapf_recurrent_pack(ptrs, None, None, _ptr(out), _stream(out.device)), "mapf_recurrent_pack")
+    return out
+
+
+def pack_recurrence_transposed_torch(params):
+    """The same image through PyTorch operations (the statement the pack kernel is tested against)."""
     w_hh, _, _, wq, wk, wv, _, _, _, w_o, u_ih, u_hh, _, _ = [p.detach() for p in params]
     parts = [_pack_frag(u_ih[256 * g:256 * (g + 1)].t().contiguous()) for g in range(3)]
     parts += [_pack_frag(u_hh[256 * g:256 * (g + 1)].t().contiguous()) for g in range(3)]
@@ -307,6 +367,15 @@ def pack_recurrence_transposed(params):
     out = torch.cat(parts).to(torch.bfloat16).contiguous()
     assert out.numel() == 548864
     return out
+
+
+def pack_recurrence_torch(params):
+    """Forward image + biases through PyTorch operations (tests)."""
+    w_hh, b_ih, b_hh, wq, wk, wv, bq, bk, bv, w_o, u_ih, u_hh, ub_ih, ub_hh = [p.detach() for p in params]
+    mats = [w_hh, torch.cat([wq, wk, wv], dim=0), w_o, u_ih, u_hh]
+    w = torch.cat([_pack_frag(m) for m in mats]).to(torch.bfloat16).contiguous()
+    b = torch.cat([t.reshape(-1) for t in (b_ih, b_hh, bq, bk, bv, ub_ih, ub_hh)]).to(torch.float32).contiguous()
+    return w, b
 
 
 class _RecurTrain(torch.autograd.Function):

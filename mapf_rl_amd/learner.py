@@ -75,7 +75,21 @@ class FlatGradBucket:
             self.flat.div_(dist.get_world_size(group))
 
 
+class _FlatView:
+    """FlatGradBucket's interface over a gradient buffer that already is flat (update.FlatParams.grads)."""
+
+    def __init__(self, flat):
+        self.flat = flat
+
+    def zero(self):
+        self.flat.zero_()
+
+    all_reduce_mean = FlatGradBucket.all_reduce_mean
+
+
 class Learner:
+    FUSED_UPDATE = True  # HIP device: the update as an explicit forward / backward over the kernels (update.FusedUpdate)
+
     def __init__(self, buffer=None, device=None, batch_size=192, lr=1e-4, milestones=(100000, 300000), save_path="./models",
                  model=None, prefetch=True, double_q=False):
         self.device = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
@@ -83,9 +97,20 @@ class Learner:
         self.tar_model = deepcopy(self.model)
         for p in self.tar_model.parameters():
             p.requires_grad_(False)
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr)                       # worker.py:260
-        self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=list(milestones), gamma=0.5)  # :261
-        self.bucket = FlatGradBucket(self.model.parameters())
+        self.base_lr, self.milestones = lr, tuple(milestones)
+        self.grad_hook = None  # tests: called with the learner after backward (+ all-reduce), before the clip (worker.py:316-319)
+        self._fused = None
+        if self.device.type == "cuda" and self.FUSED_UPDATE:
+            from .update import FusedUpdate
+
+            # parameters, gradients and Adam moments as flat buffers; clip + Adam (worker.py:260,319-322) are one kernel pair there
+            self._fused = FusedUpdate(self)
+            self.bucket = _FlatView(self._fused.flat.grads)
+            self.optimizer = self.scheduler = None
+        else:
+            self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr)                       # worker.py:260
+            self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=list(milestones), gamma=0.5)  # :261
+            self.bucket = FlatGradBucket(self.model.parameters())
         self.buffer, self.batch_size, self.save_path = buffer, batch_size, save_path
         # config.double_q (config.py:46) is dead in the reference (quirk Q6: worker.py:300-303 always takes max_a Q_target).
         # Opt-in here for BASELINE config 5 ("prioritized replay + double-DQN"): the ONLINE network picks the action, the
@@ -108,6 +133,10 @@ class Learner:
         self.prefetch = bool(prefetch) and buffer is not None and self.device.type == "cuda"
         self._side = torch.cuda.Stream(device=self.device) if self.prefetch else None
         self._pre = None
+
+    def current_lr(self):
+        """MultiStepLR(milestones, gamma = 0.5) (worker.py:261) for the step that follows `counter` completed ones."""
+        return self.base_lr * 0.5 ** sum(1 for m in self.milestones if m <= self.counter)
 
     # ------------------------------------------------------------------ one update
     def target_q(self, batch, rows=None):
@@ -139,6 +168,8 @@ class Learner:
         to pinned host memory; nothing here waits for the GPU."""
         from .model import Network, relevance
 
+        if self._fused is not None and self._fused.usable(batch):
+            return self._fused.plan(batch)
         if not (Network.PRUNE_UNREACHABLE and batch[7].is_cuda):
             return None
         comm, bt, steps = batch[7], batch[5], batch[4].view(-1)
@@ -181,6 +212,19 @@ class Learner:
             self._pre = None
         elif own_batch:
             batch = self.buffer.sample_batch(self.batch_size)
+        if self._fused is not None and self._fused.usable(batch):
+            out = self._fused.run(batch, plan if isinstance(plan, dict) else None, own_batch)
+            self.counter += 1
+            self._last = (out["loss"], out["grad_norm"])
+            if self.counter % TARGET_SYNC == 0:                                                  # worker.py:336-338
+                self.sync_target()
+                self.save()
+            return out
+        if isinstance(plan, dict):
+            plan = None
+        if self.optimizer is None:  # a batch outside the fused kernels' limits on a Learner that was built for them
+            self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.base_lr)
+            self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=list(self.milestones), gamma=0.5)
         q_next = None
         rows_o = None
         if own_batch and self.prefetch:
@@ -218,6 +262,8 @@ class Learner:
         self.bucket.zero()
         loss.backward()
         self.bucket.all_reduce_mean()                                                            # the only collective
+        if self.grad_hook is not None:
+            self.grad_hook(self)
         grad_norm = nn.utils.clip_grad_norm_(self.model.parameters(), GRAD_CLIP)                 # worker.py:319
         self.optimizer.step()
         self.scheduler.step()
@@ -239,7 +285,7 @@ class Learner:
 
     def load_state_dict(self, state_dict, sync_target=True):
         """Loads online-network weights (reference key names) and, by default, copies them to the target network."""
-        self.model.load_state_dict(state_dict)
+        self.model.load_state_dict(state_dict)  # (in place: the parameters stay views of the flat buffers)
         if sync_target:
             self.tar_model.load_state_dict(self.model.state_dict())
 

@@ -165,16 +165,26 @@ class _InputProj(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b):
+        from .fused import mm_rows
+
         w_lp = w.detach().to(x.dtype)
         ctx.save_for_backward(x, w_lp)
         ctx.has_bias = b is not None
+        if x.is_cuda and x.dtype == torch.bfloat16:  # row-chunked (fused.mm_rows): no stream-K GEMM next to the second stream
+            y = mm_rows(x, w_lp)
+            return y if b is None else y + b.detach().to(x.dtype)
         return F.linear(x, w_lp, None if b is None else b.detach().to(x.dtype))
 
     @staticmethod
     def backward(ctx, dy):
         x, w_lp = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = F.linear(dy, w_lp.t().contiguous()) if ctx.needs_input_grad[0] else None
+        if dy.is_cuda and dy.dtype == torch.bfloat16:
+            from .fused import mm_rows
+
+            dx = mm_rows(dy, w_lp, transpose_w=False) if ctx.needs_input_grad[0] else None
+        else:
+            dx = F.linear(dy, w_lp.t().contiguous()) if ctx.needs_input_grad[0] else None
         dw = _tall_tn(dy, x, rows=4096)
         db = dy.sum(dim=0, dtype=torch.float32) if ctx.has_bias else None
         return dx, dw, db
@@ -342,6 +352,7 @@ class Network(nn.Module):
         self.hidden = None
         self._packed = None  # PackedEncoder of the fused inference kernel, built on first use
         self._packed_recur = None  # PackedRecurrence of the fused recurrence kernel
+        self.weights_epoch = 0  # bumped by whoever writes the parameters behind PyTorch's back (the learner's fused Adam kernel)
         # model.py:174-178: Xavier-uniform weights / zero bias on Linear and Conv2d only
         for m in self.modules():
             if isinstance(m, (nn.Linear, nn.Conv2d)):
@@ -380,7 +391,7 @@ class Network(nn.Module):
 
             if self._packed is None:
                 self._packed = PackedEncoder()
-            wp, bp = self._packed.get(self.obs_encoder)
+            wp, bp = self._packed.get(self.obs_encoder, self.weights_epoch)
             return encoder_forward(obs, wp, bp)
         if nhwc and self.FUSED_TRAINING and bf16_autocast and torch.is_grad_enabled():
             # learner: the same kernel also stores the layer outputs the backward chain needs
@@ -388,7 +399,7 @@ class Network(nn.Module):
 
             if self._packed is None:
                 self._packed = PackedEncoder()
-            return encoder_forward_train(obs, self.obs_encoder, self._packed)
+            return encoder_forward_train(obs, self.obs_encoder, self._packed, self.weights_epoch)
 
         fused = nhwc and self.FUSED_EPILOGUE and bf16_autocast
 
@@ -430,7 +441,7 @@ class Network(nn.Module):
             self._packed = PackedEncoder()
         if self._packed_recur is None:
             self._packed_recur = PackedRecurrence()
-        self._packed.get(self.obs_encoder)
+        self._packed.get(self.obs_encoder, self.weights_epoch)
         self._packed_recur.get(self)
 
     def q_head(self, hidden):
@@ -536,10 +547,12 @@ class Network(nn.Module):
         w, b = self._packed_recur.get(self)
         T, E, N, _ = latent_t.shape
         w_ih = self.recurrent.weight_ih.detach().to(torch.bfloat16)
+        from .fused import mm_rows  # (row-chunked: see there why one big GEMM call is avoided)
+
         if isinstance(latent_t, _SparseRows):  # the input projection of the reachable rows only (its bias is added in the kernel)
-            gi = latent_t.project(lambda x: F.linear(x, w_ih), 768)
+            gi = latent_t.project(lambda x: mm_rows(x, w_ih), 768)
         else:
-            gi = F.linear(latent_t.reshape(T * E * N, ENC_FEATURES), w_ih).view(T, E, N, 768)
+            gi = mm_rows(latent_t.reshape(T * E * N, ENC_FEATURES), w_ih).view(T, E, N, 768)
         h0 = None if hidden is None else hidden.reshape(E, N, self.latent_dim)
         return recurrent_infer(gi, h0, comm_t, w, b, want_agent0)
 

@@ -62,18 +62,13 @@ def test_update_bf16_kernels_vs_reference(tag):
         q_tar = lr.tar_model.bootstrap(b[0], nxt, b[6], b[7])
     assert _close(q_tar.cpu().numpy(), z[pre + "q_target_all"], 2e-2), np.abs(q_tar.cpu().numpy() - z[pre + "q_target_all"]).max()
     grads = {}
-    orig_clip = torch.nn.utils.clip_grad_norm_
 
-    def grab(params, max_norm):  # gradients as the reference sees them: after backward, before the clip (worker.py:316-319)
-        for k, p in lr.model.named_parameters():
+    def grab(learner):  # gradients as the reference sees them: after backward, before the clip (worker.py:316-319)
+        for k, p in learner.model.named_parameters():
             grads[k] = p.grad.detach().float().cpu().numpy()
-        return orig_clip(lr.model.parameters(), max_norm)
 
-    torch.nn.utils.clip_grad_norm_ = grab
-    try:
-        out = lr.update(b)
-    finally:
-        torch.nn.utils.clip_grad_norm_ = orig_clip
+    lr.grad_hook = grab
+    out = lr.update(b)
     td, ref = out["td"].float().cpu().numpy(), z[pre + "td"]
     assert np.all(np.isfinite(td))
     assert _close(td, ref, 4e-2), np.abs(td - ref).max()  # 2 bootstraps: 2 x 2e-2

@@ -323,7 +323,7 @@ def test_backward_with_head_equals_backward_data(M):
     w32 = [c.weight.detach().float().contiguous() for c in _convs(net)]
     import ctypes
     wpt = torch.empty(ENC_PACKED_BWD_ELEMS, dtype=torch.bfloat16, device="cuda")
-    check(lib.mapf_encoder_pack_bwd((ctypes.c_void_p * 8)(*[w.data_ptr() for w in w32]), wpt.data_ptr(), None), "mapf_encoder_pack_bwd")
+    check(lib.mapf_encoder_pack_bwd((ctypes.c_void_p * 8)(*[w.data_ptr() for w in w32]), 0, wpt.data_ptr(), None), "mapf_encoder_pack_bwd")
     nblk = -(-M // 4)
     # reference chain: mask + transpose in PyTorch, then the kernel without the head
     gz7_ref = torch.where(lat.view(M, 16, 49) > 0, glat.view(M, 16, 49), torch.zeros((), dtype=torch.bfloat16, device="cuda"))

@@ -1,0 +1,357 @@
+"""GPU: the kernels of csrc/mapf_update.hip (plan, dueling head + loss, weight packing, bias gradients, clip + Adam) against plain
+PyTorch statements of the same reference code (worker.py:296-324,341-344; model.py:242-262), and `update.FusedUpdate` -- the explicit
+forward / backward `Learner.update` runs on a HIP device -- against the autograd path over `Network.bootstrap` on the
+reference-captured batches."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from tests import big_golden as BG
+from tests import helpers as H
+from tests.test_learner_cpu import _batch, _models
+from tests.test_relevance_gpu import _torch_relevance
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _plan_mark(comm, steps, extra=None, mark_all=0, want_rel=True):
+    from mapf_rl_amd._lib import check, lib
+
+    B, T, N, _ = comm.shape
+    cm = comm.view(torch.uint8)
+    rel = torch.empty((T, B, N), dtype=torch.uint8, device="cuda") if want_rel else None
+    slot = torch.empty((B, N), dtype=torch.int16, device="cuda")
+    order = torch.empty((B, N), dtype=torch.int16, device="cuda")
+    nact = torch.empty((T, B), dtype=torch.int32, device="cuda")
+    cnt = torch.empty(B, dtype=torch.int32, device="cuda")
+    nag = torch.empty(B, dtype=torch.int32, device="cuda")
+    check(lib.mapf_plan_mark(_p(cm), cm.stride(0), cm.stride(1), _p(steps), _p(extra), T, B, N, mark_all, _p(rel), _p(slot), _p(order), _p(nact),
+                             _p(cnt), _p(nag), None), "mapf_plan_mark")
+    torch.cuda.synchronize()
+    return rel, slot, order, nact, cnt, nag
+
+
+def _random_windows(B, T, N, p, seed, time_major=False):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    shape = (T, B, N, N) if time_major else (B, T, N, N)
+    comm = (torch.rand(shape, device="cuda", generator=g) < p) | torch.eye(N, dtype=torch.bool, device="cuda")
+    if time_major:
+        comm = comm.transpose(0, 1)  # [B, T, N, N] view of time-major memory: the device replay's layout
+    steps = torch.randint(1, T + 1, (B,), device="cuda", generator=g)
+    return comm, steps, g
+
+
+@pytest.mark.parametrize("B,T,N,p,tm", [(192, 16, 40, 0.04, True), (7, 18, 128, 0.01, False), (33, 18, 6, 0.2, True), (5, 3, 1, 1.0, False),
+                                        (64, 18, 49, 0.0, False), (16, 20, 70, 0.02, True)])
+def test_plan_mark_is_the_closure_in_prefix_order(B, T, N, p, tm):
+    comm, steps, _ = _random_windows(B, T, N, p, B + N, tm)
+    rel, slot, order, nact, cnt, nag = _plan_mark(comm, steps)
+    want = _torch_relevance(comm, steps)
+    assert torch.equal(rel.bool(), want)
+    w = want.cpu().numpy()  # [T, B, N]
+    slot, order, nact, cnt, nag = [x.cpu().numpy() for x in (slot, order, nact, cnt, nag)]
+    assert np.array_equal(cnt, w.sum(axis=(0, 2))) and np.array_equal(nag, w.any(axis=0).sum(axis=1)) and np.array_equal(nact, w.sum(axis=2))
+    for b in range(B):
+        n = nag[b]
+        assert order[b, 0] == 0 and slot[b, 0] == 0  # agent 0 stays agent 0
+        assert sorted(order[b, :n].tolist()) == np.nonzero(w[:, b].any(axis=0))[0].tolist() and (order[b, n:] == -1).all()
+        assert all(slot[b, order[b, i]] == i for i in range(n)) and (slot[b][~w[:, b].any(axis=0)] == -1).all()
+        for t in range(T):  # the agents needed at step t are a prefix of the order
+            assert set(order[b, :nact[t, b]].tolist()) == set(np.nonzero(w[t, b])[0].tolist())
+
+
+def test_plan_mark_extra_steps_and_mark_all():
+    B, T, N = 24, 18, 40
+    comm, bt, g = _random_windows(B, T, N, 0.05, 3)
+    bt = torch.clamp(bt, max=T - 2)
+    extra = torch.randint(1, 3, (B,), device="cuda", generator=g).float()
+    rel = _plan_mark(comm, bt, extra)[0]
+    assert torch.equal(rel.bool(), _torch_relevance(comm, bt + extra.long()))
+    rel, slot, order, nact, cnt, nag = _plan_mark(comm, bt, None, mark_all=1)
+    last = (bt - 1).cpu().numpy()
+    w = rel.cpu().numpy().astype(bool)
+    assert all(w[:last[b] + 1, b].all() and not w[last[b] + 1:, b].any() for b in range(B))
+    assert np.array_equal(order.cpu().numpy(), np.tile(np.arange(N), (B, 1))) and (nag.cpu().numpy() == N).all()
+
+
+@pytest.mark.parametrize("B,T,N,p,tm", [(48, 16, 40, 0.04, True), (5, 18, 128, 0.01, False), (9, 18, 6, 0.3, True)])
+def test_plan_rows_compact_layout(B, T, N, p, tm):
+    from mapf_rl_amd._lib import check, lib
+
+    comm, steps, g = _random_windows(B, T, N, p, 11 + N, tm)
+    rel, slot, order, nact, cnt, nag = _plan_mark(comm, steps)
+    obs_shape = (T, B, N, 486) if tm else (B, T, N, 486)
+    obs = torch.rand(obs_shape, device="cuda", generator=g).to(torch.bfloat16)  # distinct rows
+    if tm:
+        obs = obs.transpose(0, 1)
+    hidden = (torch.randn((B * N, 256), device="cuda", generator=g) * 0.3).to(torch.float16)
+    Nc = 16 * -(-int(nag.max()) // 16)
+    rows = int(cnt.sum())
+    gidx = torch.empty((T, B, Nc), dtype=torch.int32, device="cuda")
+    comm_c = torch.empty((T, B, Nc, Nc), dtype=torch.uint8, device="cuda")
+    h0_c = torch.empty((B, Nc, 256), dtype=torch.bfloat16, device="cuda")
+    obs_rows = torch.empty((rows, 486), dtype=torch.bfloat16, device="cuda")
+    row_src = torch.empty(rows, dtype=torch.int64, device="cuda")
+    cm = comm.view(torch.uint8)
+    check(lib.mapf_plan_rows(T, B, N, Nc, _p(order), _p(nact), _p(cnt), _p(nag), _p(cm), cm.stride(0), cm.stride(1), _p(hidden), 0, _p(obs),
+                             obs.stride(0), obs.stride(1), _p(gidx), _p(comm_c), _p(h0_c), rows, _p(row_src), _p(obs_rows), None), "mapf_plan_rows")
+    torch.cuda.synchronize()
+    G, O, NA = gidx.cpu().numpy(), order.cpu().numpy().astype(np.int64), nact.cpu().numpy()
+    flat = [G[t, b, i] for b in range(B) for t in range(T) for i in range(NA[t, b])]
+    assert flat == list(range(rows))  # window by window, step by step, position by position
+    assert (G >= 0).sum() == rows and all((G[t, b, NA[t, b]:] == -1).all() for t in range(T) for b in range(B))
+    ob, orows, cc, cmn = obs.float().cpu().numpy(), obs_rows.float().cpu().numpy(), comm_c.cpu().numpy(), comm.cpu().numpy()
+    h0, hid = h0_c.float().cpu().numpy(), hidden.to(torch.bfloat16).float().cpu().numpy().reshape(B, N, 256)
+    for b in range(0, B, max(1, B // 7)):
+        n = int(nag[b])
+        assert np.array_equal(h0[b, :n], hid[b, O[b, :n]]) and not h0[b, n:].any()
+        for t in range(T):
+            na = NA[t, b]
+            for i in range(na):
+                assert np.array_equal(orows[G[t, b, i]], ob[b, t, O[b, i]])
+            want = np.eye(Nc, dtype=np.uint8)
+            want[:na, :na] = cmn[b, t][np.ix_(O[b, :na], O[b, :na])]
+            assert np.array_equal(cc[t, b], want)
+
+
+def test_rows_scatter_round_trip():
+    from mapf_rl_amd._lib import check, lib
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    R, n = 1000, 300
+    idx = torch.full((R,), -1, dtype=torch.int32, device="cuda")
+    pos = torch.randperm(R, device="cuda", generator=g)[:n]
+    idx[pos] = torch.arange(n, dtype=torch.int32, device="cuda")
+    rows = torch.randn((n, 768), device="cuda", generator=g).to(torch.bfloat16)
+    dense = torch.empty((R, 768), dtype=torch.bfloat16, device="cuda")
+    check(lib.mapf_rows_scatter(_p(rows), _p(idx), _p(dense), R, 1536, 1, None), "mapf_rows_scatter")
+    want = torch.zeros((R, 768), dtype=torch.bfloat16, device="cuda")
+    want[pos] = rows
+    assert torch.equal(dense, want)
+    back = torch.zeros_like(rows)
+    check(lib.mapf_rows_scatter(_p(back), _p(idx), _p(dense), R, 1536, 0, None), "mapf_rows_scatter")
+    assert torch.equal(back, rows)
+
+
+def test_recurrence_pack_kernel_equals_torch_statement():
+    from mapf_rl_amd.fused import PackedRecurrence, pack_recurrence_torch, pack_recurrence_transposed, pack_recurrence_transposed_torch, recurrence_params
+    from mapf_rl_amd.model import Network
+
+    torch.manual_seed(3)
+    net = Network().cuda()
+    for p in net.parameters():
+        p.data.normal_(0, 0.3)
+    w, b = PackedRecurrence().get(net)
+    w_ref, b_ref = pack_recurrence_torch(recurrence_params(net))
+    assert torch.equal(w, w_ref) and torch.equal(b, b_ref)
+    assert torch.equal(pack_recurrence_transposed(recurrence_params(net)), pack_recurrence_transposed_torch(recurrence_params(net)))
+
+
+def test_encoder_pack_reads_channels_last_weights_in_place():
+    from mapf_rl_amd.fused import PackedEncoder, encoder_convs, pack_encoder_backward
+    from mapf_rl_amd.model import Network
+
+    torch.manual_seed(4)
+    net = Network().cuda()  # convolution weights are stored channels_last
+    assert all(c.weight.is_contiguous(memory_format=torch.channels_last) for c in encoder_convs(net.obs_encoder))
+    wp, bp = PackedEncoder().get(net.obs_encoder)
+    wpt = pack_encoder_backward(net.obs_encoder)
+    plain = Network().cuda()
+    plain.load_state_dict(net.state_dict())
+    plain.obs_encoder.to(memory_format=torch.contiguous_format)
+    for c in encoder_convs(plain.obs_encoder):
+        c.weight.data = c.weight.data.contiguous()
+    assert not encoder_convs(plain.obs_encoder)[1].weight.is_contiguous(memory_format=torch.channels_last)
+    wp2, bp2 = PackedEncoder().get(plain.obs_encoder)
+    assert torch.equal(wp, wp2) and torch.equal(bp, bp2) and torch.equal(wpt, pack_encoder_backward(plain.obs_encoder))
+
+
+def _head_reference(a0, a0_tg, a0_on2, bt, steps, action, reward, done, weights, head, head_t):
+    """worker.py:296-310,341-344 + model.py:259-262 in fp32 with autograd."""
+    B = a0.shape[1]
+    ar = torch.arange(B, device=a0.device)
+    head = [h.detach().clone().requires_grad_(True) for h in head]
+
+    def q_of(x, h):
+        adv = x @ h[0].t() + h[1]
+        return x @ h[2].t() + h[3] + adv - adv.mean(1, keepdim=True)
+
+    x = a0.float().detach().requires_grad_(True)
+    q_on = q_of(x[bt - 1, ar], head)
+    nxt = bt + steps.long() - 1
+    q_tg = q_of(a0_tg.float()[nxt, ar], head_t)
+    pick = (q_of(a0_on2.float()[nxt, ar], head) if a0_on2 is not None else q_tg).argmax(1, keepdim=True)
+    q_next = (1 - done.view(-1, 1)) * q_tg.gather(1, pick)
+    q = q_on.gather(1, action.view(-1, 1))
+    td = q - (reward.view(-1, 1) + 0.99 ** steps.view(-1, 1) * q_next.detach())
+    a = td.abs()
+    flag = (a < 1).float()
+    loss = (weights.view(-1, 1) * (flag * a.pow(2) * 0.5 + (1 - flag) * (a - 0.5))).mean()
+    grads = torch.autograd.grad(loss, [x] + list(head))
+    return q.view(-1), q_next.view(-1), td.view(-1).detach(), loss.detach(), grads
+
+
+@pytest.mark.parametrize("double_q", [False, True])
+def test_head_loss_kernel_vs_pytorch(double_q):
+    from mapf_rl_amd._lib import check, lib
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, To, Tt = 192, 16, 18
+    rn = lambda *s: torch.randn(s, device="cuda", generator=g)
+    a0, a0_tg = (rn(To, B, 256) * 0.5).to(torch.bfloat16), (rn(Tt, B, 256) * 0.5).to(torch.bfloat16)
+    a0_on2 = (rn(Tt, B, 256) * 0.5).to(torch.bfloat16) if double_q else None
+    bt = torch.randint(1, To + 1, (B,), device="cuda", generator=g)
+    steps = torch.randint(1, 3, (B,), device="cuda", generator=g).float()
+    action = torch.randint(0, 5, (B,), device="cuda", generator=g)
+    reward = torch.tensor([-0.075, -0.5, 3.0], device="cuda")[torch.randint(0, 3, (B,), device="cuda", generator=g)] * 4  # some |td| > 1
+    done = (torch.rand(B, device="cuda", generator=g) < 0.2).float()
+    weights = torch.rand(B, device="cuda", generator=g) + 0.1
+    head = [rn(5, 256) * 0.2, rn(5) * 0.1, rn(1, 256) * 0.2, rn(1) * 0.1]
+    head_t = [rn(5, 256) * 0.2, rn(5) * 0.1, rn(1, 256) * 0.2, rn(1) * 0.1]
+    outs = torch.empty((3, B), device="cuda")
+    prio = torch.empty(B, dtype=torch.float64, device="cuda")
+    loss = torch.empty(1, device="cuda")
+    scratch = torch.empty(9 * B, device="cuda")
+    d_a0 = torch.empty((To, B, 256), dtype=torch.bfloat16, device="cuda")
+    hg = [torch.ones_like(h) for h in head]  # accumulated into
+    arr = lambda ts: (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts])
+    check(lib.mapf_dqn_head_loss(B, To, Tt, _p(a0), _p(a0_tg), _p(a0_on2), _p(bt), _p(steps), _p(action), _p(reward), _p(done), _p(weights), arr(head),
+                                 arr(head_t), 0.99, _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(prio), _p(loss), _p(scratch), _p(d_a0), arr(hg), None),
+          "mapf_dqn_head_loss")
+    q, q_next, td, want_loss, grads = _head_reference(a0, a0_tg, a0_on2, bt, steps, action, reward, done, weights, head, head_t)
+    close = lambda a, b, tol=1e-4: bool(((a - b).abs() <= tol * torch.clamp(b.abs(), min=1.0)).all())
+    assert close(outs[0], q) and close(outs[1], q_next) and close(outs[2], td)
+    assert close(prio.float(), td.abs().clamp(min=1e-6)) and close(loss[0], want_loss)
+    assert float((td.abs() > 1).float().mean()) > 0.05  # both Huber branches exercised
+    assert float((d_a0.float() - grads[0]).abs().max()) <= 1e-2 * float(grads[0].abs().max())  # bf16 output
+    ar = torch.arange(B, device="cuda")
+    nz = torch.zeros((To, B), dtype=torch.bool, device="cuda")
+    nz[bt - 1, ar] = True
+    assert not d_a0[~nz].float().abs().any()
+    for got, want in zip(hg, grads[1:]):
+        assert close(got - 1, want.view_as(got), 1e-4)
+
+
+def test_adam_kernel_vs_torch_optim():
+    from mapf_rl_amd._lib import check, lib
+
+    g = torch.Generator(device="cuda").manual_seed(6)
+    n = 100003
+    p0 = torch.randn(n, device="cuda", generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    pb = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    scratch, norm = torch.empty(256, device="cuda"), torch.empty(1, device="cuda")
+    for step in range(1, 6):
+        grad = torch.randn(n, device="cuda", generator=g) * (3.0 if step % 2 else 0.01)  # norm ~950 (clipped at 40) / ~3 (not clipped)
+        ref.grad = grad.clone()
+        want_norm = torch.nn.utils.clip_grad_norm_([ref], 40.0)
+        opt.step()
+        gg = grad.clone()
+        check(lib.mapf_adam_step(n, _p(p), _p(gg), _p(m), _p(v), _p(pb), _p(scratch), _p(norm), 1e-3, 0.9, 0.999, 1e-8, step, 40.0, None), "mapf_adam_step")
+        assert abs(float(norm) - float(want_norm)) <= 1e-5 * float(want_norm)
+        assert torch.allclose(gg, ref.grad, rtol=1e-5, atol=1e-8)
+        assert torch.allclose(p, ref.detach(), rtol=1e-5, atol=1e-6), float((p - ref.detach()).abs().max())
+        assert torch.equal(pb, p.to(torch.bfloat16))
+
+
+def _grads_of(lr):
+    out = {}
+
+    def grab(learner):
+        for k, p in learner.model.named_parameters():
+            out[k] = p.grad.detach().float().clone()
+
+    lr.grad_hook = grab
+    return out
+
+
+@pytest.mark.parametrize("tag", ["b40", "b6", "b128", "upd"])
+def test_fused_update_equals_autograd_update(tag):
+    """Learner.update through update.FusedUpdate against the same update through autograd over Network.bootstrap (both bf16 kernels
+    underneath; the fused path computes the dueling head and the loss in fp32 instead of bf16 autocast): TD errors, loss, gradient
+    norm, every parameter's gradient and the parameters after the Adam step."""
+    from mapf_rl_amd.learner import Learner
+
+    if tag == "upd":
+        z = H.load_npz("dqn_update.npz")
+        mk = lambda: _batch(z, "cuda", torch.bfloat16)
+    else:
+        z = H.load_npz("dqn_big.npz")
+        mk = lambda: BG.batch(z, tag, "cuda", torch.bfloat16)
+    res = {}
+    for fused in (False, True):
+        Learner.FUSED_UPDATE = fused
+        try:
+            lr = _models("cuda")
+        finally:
+            Learner.FUSED_UPDATE = True
+        assert (lr._fused is not None) == fused
+        grads = _grads_of(lr)
+        out = lr.update(mk())
+        torch.cuda.synchronize()
+        res[fused] = (out, grads, {k: v.detach().clone() for k, v in lr.model.state_dict().items()})
+    (o0, g0, s0), (o1, g1, s1) = res[False], res[True]
+    for k in ("td", "q", "q_next"):
+        a, b = o0[k].float().view(-1), o1[k].float().view(-1)
+        assert bool(((a - b).abs() <= 2e-2 * torch.clamp(a.abs(), min=1.0)).all()), (k, float((a - b).abs().max()))
+    assert abs(float(o0["loss"]) - float(o1["loss"])) <= 2e-2 * max(1.0, float(o0["loss"]))
+    assert abs(float(o0["grad_norm"]) - float(o1["grad_norm"])) <= 3e-2 * float(o0["grad_norm"])
+    tot = float(torch.sqrt(sum((v ** 2).sum() for v in g0.values())))
+    assert set(g0) == set(g1) and len(g0) == 35
+    for k in g0:
+        d, n = float((g0[k] - g1[k]).norm()), float(g0[k].norm())
+        assert d <= 5e-2 * n + 2e-3 * tot, (k, d, n)
+    for k in s0:  # one Adam step of size 1e-4 from identical weights
+        assert torch.allclose(s0[k], s1[k], rtol=0, atol=2.5e-4), k
+
+
+def test_fused_update_pruning_is_dead_code_elimination():
+    """The same fused update with every observation of the window encoded (Network.PRUNE_UNREACHABLE = False: mapf_plan_mark's
+    mark_all) and with only the entries that can reach agent 0's Q-value: same TD errors and gradients up to the order of sums."""
+    from mapf_rl_amd.model import Network
+
+    z = H.load_npz("dqn_big.npz")
+    res = {}
+    try:
+        for prune in (True, False):
+            Network.PRUNE_UNREACHABLE = prune
+            lr = _models("cuda")
+            grads = _grads_of(lr)
+            out = lr.update(BG.batch(z, "b40", "cuda", torch.bfloat16))
+            torch.cuda.synchronize()
+            res[prune] = (out, grads)
+    finally:
+        Network.PRUNE_UNREACHABLE = True
+    (o0, g0), (o1, g1) = res[False], res[True]
+    a, b = o0["td"].view(-1), o1["td"].view(-1)
+    assert bool(((a - b).abs() <= 1e-2 * torch.clamp(a.abs(), min=1.0)).all()), float((a - b).abs().max())
+    tot = float(torch.sqrt(sum((v ** 2).sum() for v in g0.values())))
+    for k in g0:
+        assert float((g0[k] - g1[k]).norm()) <= 2e-2 * float(g0[k].norm()) + 1e-3 * tot, k
+
+
+def test_fused_update_survives_state_dict_round_trip(tmp_path):
+    """Parameters are views of flat buffers: state_dict / load_state_dict / save keep the reference's keys and the bf16 copy follows."""
+    from mapf_rl_amd.learner import Learner
+    from mapf_rl_amd.model import Network
+
+    z = H.load_npz("dqn_update.npz")
+    lr = _models("cuda")
+    sd0 = {k: v.detach().clone() for k, v in lr.model.state_dict().items()}
+    out0 = lr.update(_batch(z, "cuda", torch.bfloat16))
+    path = lr.save(str(tmp_path / "m.pth"))
+    assert set(torch.load(path).keys()) == set(Network().state_dict().keys())
+    lr.load_state_dict(sd0)  # back to the initial weights (target network too): the same update must come out again
+    lr.tar_model.load_state_dict(_models("cpu").tar_model.state_dict())
+    lr._fused.flat.exp_avg.zero_(), lr._fused.flat.exp_avg_sq.zero_()
+    lr._fused.flat.step = 0
+    out1 = lr.update(_batch(z, "cuda", torch.bfloat16))
+    assert torch.equal(out0["td"], out1["td"]) and float(out0["loss"]) == float(out1["loss"])
