@@ -133,12 +133,18 @@ int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M
  *               update_cell.bias_hh
  *   h_out_dev   bf16 [E][N][256] hidden state after the last step;  agent0_out_dev bf16 [T][E][256] or NULL: agent 0's
  *               state after every step (what `bootstrap` feeds the Q head, model.py:248).
+ *
+ * Compact rows (row_index_dev != NULL; N <= 48 only, else MAPF_ERR_UNSUPPORTED): gi_dev holds num_rows rows [num_rows][768] and
+ * row_index_dev int32 [T][E][N] names the row of every (step, environment, agent) entry that has one, -1 for the others (an agent
+ * without a row gets no input projection); this is mapf_plan_rows' gidx -- only the entries of a training window that can reach
+ * agent 0's Q-value are projected at all.  row_index_dev == NULL: gi_dev is dense [T][E][N][768].
  */
+#define MAPF_RECUR_BSUM_ELEMS 2432
 #define MAPF_RECUR_WEIGHT_ELEMS 548864 /* 196608 + 98304 + 8192 + 49152 + 196608 */
 #define MAPF_RECUR_BIAS_ELEMS 3456     /* 768 + 768 + 384 + 768 + 768 */
 int mapf_recurrent_infer(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev,
                          const uint16_t *weights_dev, const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev,
-                         uint16_t *agent0_out_dev, void *stream);
+                         uint16_t *agent0_out_dev, const int32_t *row_index_dev, int64_t num_rows, void *stream);
 
 /*
  * Training pair of mapf_recurrent_infer (csrc/mapf_recur.hip, csrc/mapf_recur_bwd.hip): the same forward, additionally
@@ -158,13 +164,17 @@ int mapf_recurrent_infer(const uint16_t *gi_dev, const uint16_t *h0_dev, const u
  *     (f32) 6 bsum [E][MAPF_RECUR_BSUM_ELEMS]: per-environment column sums over steps and agents of
  *     [update cell: dr | dz | dn | dn r] (both rounds) [recurrent cell: dr | dz | dn | dn r] [d_qkv: 384]; summed over E
  *     they are the bias gradients (b_ih: dr, dz, dn; b_hh: dr, dz, dn r).
+ * Compact rows (row_index_dev != NULL, N <= 48; see mapf_recurrent_infer): R = num_rows instead of T*E*N in every saved tensor and
+ * every output above, row = row_index[t][e][agent]; nothing is saved / written for entries without a row (their gradient is zero;
+ * d_agent0_dev must be zero at the steps where agent 0 has no row, i.e. behind the window's last step).
  */
-#define MAPF_RECUR_BSUM_ELEMS 2432
 int mapf_recurrent_forward_save(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev,
                                 const uint16_t *weights_dev, const float *bias_dev, int T, int E, int N,
-                                uint16_t *h_out_dev, uint16_t *agent0_out_dev, uint16_t *const *save_dev, void *stream);
+                                uint16_t *h_out_dev, uint16_t *agent0_out_dev, uint16_t *const *save_dev,
+                                const int32_t *row_index_dev, int64_t num_rows, void *stream);
 int mapf_recurrent_backward(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev,
-                            const uint16_t *weights_t_dev, int T, int E, int N, void *const *out_dev, void *stream);
+                            const uint16_t *weights_t_dev, int T, int E, int N, void *const *out_dev,
+                            const int32_t *row_index_dev, int64_t num_rows, void *stream);
 
 /*
  * Communication mask of `Network.step` (reference model.py:195-208): mask[e][i][j] = j lies inside i's FOV square
@@ -256,6 +266,9 @@ int mapf_adam_step(int64_t n, float *params_dev, float *grads_dev, float *exp_av
                    uint16_t *params_bf16_dev, float *scratch_dev, float *norm_out_dev, float lr, float beta1, float beta2, float eps,
                    int64_t step, float max_norm, void *stream);
 int mapf_to_bf16(const float *src_dev, uint16_t *dst_dev, int64_t n, void *stream);
+/* rows [first_row, last_row) of n <= 16 row-major device buffers := 0; bufs_dev: HOST array of DEVICE pointers (16-byte aligned),
+ * row_bytes: HOST array of row sizes (multiples of 16). */
+int mapf_zero_rows(void *const *bufs_dev, const int *row_bytes, int n, int64_t first_row, int64_t last_row, void *stream);
 
 #ifdef __cplusplus
 }

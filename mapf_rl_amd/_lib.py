@@ -62,9 +62,9 @@ SYMBOLS = [
     # include/mapf_dqn.h
     ("mapf_bias_res_relu_fwd", _i, [_vp, _vp, _vp, ctypes.c_int64, _i, _vp]),
     ("mapf_bias_res_relu_bwd", _i, [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp]),
-    ("mapf_recurrent_infer", _i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
-    ("mapf_recurrent_forward_save", _i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, ctypes.POINTER(_vp), _vp]),
-    ("mapf_recurrent_backward", _i, [ctypes.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(_vp), _vp]),
+    ("mapf_recurrent_infer", _i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, ctypes.c_int64, _vp]),
+    ("mapf_recurrent_forward_save", _i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, ctypes.POINTER(_vp), _vp, ctypes.c_int64, _vp]),
+    ("mapf_recurrent_backward", _i, [ctypes.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(_vp), _vp, ctypes.c_int64, _vp]),
     ("mapf_comm_mask", _i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     ("mapf_window_relevance", _i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     ("mapf_encoder_pack", _i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _vp, _vp, _vp]),
@@ -85,6 +85,7 @@ SYMBOLS = [
     ("mapf_recurrent_bias_grads", _i, [_vp, _i, ctypes.POINTER(_vp), _vp]),
     ("mapf_adam_step", _i, [ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, ctypes.c_int64, _f, _vp]),
     ("mapf_to_bf16", _i, [_vp, _vp, ctypes.c_int64, _vp]),
+    ("mapf_zero_rows", _i, [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, ctypes.c_int64, ctypes.c_int64, _vp]),
     # include/mapf_search.h
     ("mapf_find_path", _i, [_i, _i, _vp, _vp, _vp, ctypes.c_double, _i, _vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     ("mapf_distance_field", _i, [_i, _vp, _i, _i, _vp]),

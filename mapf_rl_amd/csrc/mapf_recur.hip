@@ -60,7 +60,8 @@ constexpr int OFF_INFO = OFF_CTX + NA * CTX_ROW;
 constexpr int OFF_S = OFF_INFO + NA * INFO_ROW;
 constexpr int OFF_UPD = OFF_S + 2 * NA * S_ROW * 4;
 constexpr int OFF_MB = OFF_UPD + 64 * 4;     // comm mask of the step as bits: 2 words per agent row
-constexpr int LDS_BYTES = OFF_MB + NA * 2 * 4;
+constexpr int OFF_RIDX = OFF_MB + NA * 2 * 4;  // global row of every agent at this step (-1: none), see recurrent_infer_kernel
+constexpr int LDS_BYTES = OFF_RIDX + NA * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(OFF_S % 16 == 0 && OFF_UPD % 16 == 0, "");
 
@@ -136,13 +137,14 @@ __device__ __forceinline__ void gemm3x16(f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], f
 
 // One GRU cell for the 16-channel block `cblk`, all agents: gates from registers, pointwise math, new state to Hout.
 //   r = s(gi_r + b_ir + W_hr h + b_hr), z likewise, n = tanh(gi_n + b_in + r (W_hn h + b_hn)), h' = (1-z) n + z h
-// gi_* comes either from global memory (GI_GLOBAL: precomputed input projection, bf16 [agent][768]) or from a GEMM of
+// gi_* comes either from global memory (GI_GLOBAL: precomputed input projection, bf16 [row][768]) or from a GEMM of
 // W_i (ldwi = KI*32 columns) with the LDS image Xi.  `upd` (LDS int per agent, or nullptr): keep h where it is 0.
+// `ridx` (LDS int per agent): the agent's row in gi_glob / gsave at this step, -1 = none (no input projection, nothing saved).
 template <bool GI_GLOBAL, int KI>
 __device__ __forceinline__ void gru_block(int cblk, const uint16_t *__restrict__ gi_glob, const uint16_t *__restrict__ Wi,
                                           const unsigned char *Xi, int xirow, const uint16_t *__restrict__ Wh, const float *__restrict__ bi,
                                           const float *__restrict__ bh, const unsigned char *Hin, unsigned char *Hout, const int *upd,
-                                          int nagents, int lr, int lh, uint16_t *__restrict__ gsave = nullptr) {
+                                          const int *ridx, int lr, int lh, uint16_t *__restrict__ gsave = nullptr) {
     f32x4 ar[NT], az[NT], ani[NT], anh[NT];
     const int c0 = 16 * cblk + 4 * lh;  // this lane's 4 channels
     const float4 bir = *reinterpret_cast<const float4 *>(bi + c0), biz = *reinterpret_cast<const float4 *>(bi + 256 + c0),
@@ -156,9 +158,9 @@ __device__ __forceinline__ void gru_block(int cblk, const uint16_t *__restrict__
         ani[n] = f32x4{bin.x, bin.y, bin.z, bin.w};
         anh[n] = f32x4{bhn.x, bhn.y, bhn.z, bhn.w};
         if (GI_GLOBAL) {
-            const int agent = 16 * n + lr;
-            if (agent < nagents) {
-                const uint16_t *g = gi_glob + (long long)agent * 768 + c0;
+            const int row = ridx[16 * n + lr];
+            if (row >= 0) {
+                const uint16_t *g = gi_glob + (long long)row * 768 + c0;
                 const uint2 gr = *reinterpret_cast<const uint2 *>(g), gz = *reinterpret_cast<const uint2 *>(g + 256),
                             gn = *reinterpret_cast<const uint2 *>(g + 512);
                 ar[n] += f32x4{bf16_lo(gr.x), bf16_hi(gr.x), bf16_lo(gr.y), bf16_hi(gr.y)};
@@ -184,8 +186,8 @@ __device__ __forceinline__ void gru_block(int cblk, const uint16_t *__restrict__
             zg4[r] = zg;
             ng4[r] = ng;
         }
-        if (gsave != nullptr && agent < nagents) {  // training forward: r, z, n, W_hn h + b_hn of this cell for the backward pass
-            uint16_t *gs = gsave + (long long)agent * 1024 + c0;
+        if (gsave != nullptr && ridx[agent] >= 0) {  // training forward: r, z, n, W_hn h + b_hn of this cell for the backward pass
+            uint16_t *gs = gsave + (long long)ridx[agent] * 1024 + c0;
             *reinterpret_cast<uint2 *>(gs) = make_uint2(pack2_bf16(rg4[0], rg4[1]), pack2_bf16(rg4[2], rg4[3]));
             *reinterpret_cast<uint2 *>(gs + 256) = make_uint2(pack2_bf16(zg4[0], zg4[1]), pack2_bf16(zg4[2], zg4[3]));
             *reinterpret_cast<uint2 *>(gs + 512) = make_uint2(pack2_bf16(ng4[0], ng4[1]), pack2_bf16(ng4[2], ng4[3]));
@@ -201,7 +203,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                                                                   const uint8_t *__restrict__ comm, const uint16_t *__restrict__ W,
                                                                   const float *__restrict__ bias, int T, int E, int N,
                                                                   uint16_t *__restrict__ h_out, uint16_t *__restrict__ agent0_out,
-                                                                  RecurSave sv) {
+                                                                  RecurSave sv, const int32_t *__restrict__ rowidx, long long nrows) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lh = lane >> 4;
     const int e = blockIdx.x;
@@ -223,33 +225,37 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
     int *upd = reinterpret_cast<int *>(smem + OFF_UPD);
     float *S = reinterpret_cast<float *>(smem + OFF_S);
     uint32_t *mb = reinterpret_cast<uint32_t *>(smem + OFF_MB);
+    int *ridx = reinterpret_cast<int *>(smem + OFF_RIDX);
     const float scale = 0.125f;  // 1 / sqrt(64)
 
-    const long long RTOT = (long long)T * E * N;
-    auto save_hidden = [&](uint16_t *dst_rows, const unsigned char *H) {  // N rows of 256 bf16 from an LDS hidden image
+    // Rows of gi and of the saved tensors: dense (rowidx == nullptr) -- agent a of (step t, environment e) is row (t E + e) N + a of
+    // T E N rows -- or compact: rowidx [T][E][N] names the row of every entry that matters among `nrows` rows, -1 for the others
+    // (include/mapf_dqn.h: mapf_plan_rows' gidx; such an agent gets no input projection and nothing of it is saved).
+    const long long RTOT = rowidx ? nrows : (long long)T * E * N;
+    auto save_hidden = [&](uint16_t *dst, const unsigned char *H) {  // the step's rows of 256 bf16 from an LDS hidden image
         for (int i = tid; i < N * 32; i += NTHR) {
-            const int a = i >> 5, ch = i & 31;
-            *reinterpret_cast<uint4 *>(dst_rows + (long long)a * D + ch * 8) = *reinterpret_cast<const uint4 *>(H + a * H_ROW + ch * 16);
+            const int a = i >> 5, ch = i & 31, row = ridx[a];
+            if (row >= 0) *reinterpret_cast<uint4 *>(dst + (long long)row * D + ch * 8) = *reinterpret_cast<const uint4 *>(H + a * H_ROW + ch * 16);
         }
     };
     for (int t = 0; t < T; ++t) {
-        const long long row0 = ((long long)t * E + e) * N;  // first saved row of this (step, environment)
-        if (SAVE) save_hidden(sv.hin0 + row0 * D, Hc);
+        const long long row0 = ((long long)t * E + e) * N;  // first dense row of this (step, environment)
         // ---------------- this step's communication mask -> bit rows in LDS (the softmax loops must not touch global memory:
         // 120 dependent byte loads per row made the first version 10x slower than its MFMAs) ----------------
         const uint8_t *comm_t = comm + ((long long)t * E + e) * N * N;
         if (tid < NA * 2) mb[tid] = 0u;
+        if (tid < NA) ridx[tid] = tid < N ? (rowidx ? rowidx[row0 + tid] : (int)(row0 + tid)) : -1;
         __syncthreads();
+        if (SAVE) save_hidden(sv.hin0, Hc);
         for (int idx = tid; idx < N * N; idx += NTHR)
             if (comm_t[idx] != 0) {
                 const int i = idx / N, j = idx - i * N;
                 atomicOr(&mb[2 * i + (j >> 5)], 1u << (j & 31));
             }
         // ---------------- recurrent GRU cell: Hc -> Hn (the barrier behind it also publishes the mask bits) ----------------
-        const uint16_t *gi_t = gi + ((long long)t * E + e) * N * 768;
         for (int c = w; c < 16 && !(MAPF_RECUR_ABLATE & 1); c += NTHR / 64)
-            gru_block<true, 1>((c + rot) & 15, gi_t, nullptr, nullptr, 0, W + W_HH, bias + B_IH, bias + B_HH, Hc, Hn, nullptr, N, lr, lh,
-                               SAVE ? sv.g1 + row0 * 1024 : nullptr);
+            gru_block<true, 1>((c + rot) & 15, gi, nullptr, nullptr, 0, W + W_HH, bias + B_IH, bias + B_HH, Hc, Hn, nullptr, ridx, lr, lh,
+                               SAVE ? sv.g1 : nullptr);
         __syncthreads();
         {
             unsigned char *tmp = Hc;
@@ -258,7 +264,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
         }
         // ---------------- two communication rounds (shared weights): Hc -> Hn -> swap ----------------
         for (int round = 0; round < 2; ++round) {
-            if (SAVE) save_hidden(sv.hr + ((long long)round * RTOT + row0) * D, Hc);
+            if (SAVE) save_hidden(sv.hr + (long long)round * RTOT * D, Hc);
             // q | k | v = W_qkv h + b: 24 output tiles of 16
             for (int wq0 = w; wq0 < 8 && !(MAPF_RECUR_ABLATE & 2); wq0 += NTHR / 64) {
                 const int wq = (wq0 + rot) & 7;
@@ -285,8 +291,8 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                     vt[VT_ROW / 2] = (uint16_t)(p01 >> 16);
                     vt[2 * (VT_ROW / 2)] = (uint16_t)(p23 & 0xFFFFu);
                     vt[3 * (VT_ROW / 2)] = (uint16_t)(p23 >> 16);
-                    if (SAVE && agent < N) {
-                        uint16_t *qs = sv.qkv + ((long long)round * RTOT + row0 + agent) * 384 + c0;
+                    if (SAVE && ridx[agent] >= 0) {
+                        uint16_t *qs = sv.qkv + ((long long)round * RTOT + ridx[agent]) * 384 + c0;
                         *reinterpret_cast<uint2 *>(qs) = make_uint2(pack2_bf16(acc[0][n][0], acc[0][n][1]), pack2_bf16(acc[0][n][2], acc[0][n][3]));
                         *reinterpret_cast<uint2 *>(qs + 128) = make_uint2(pack2_bf16(acc[1][n][0], acc[1][n][1]), pack2_bf16(acc[1][n][2], acc[1][n][3]));
                         *reinterpret_cast<uint2 *>(qs + 256) = make_uint2(p01, p23);
@@ -381,8 +387,8 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                 for (int n = 0; n < NT; ++n) {
                     const uint2 v = make_uint2(pack2_bf16(acc[n][0], acc[n][1]), pack2_bf16(acc[n][2], acc[n][3]));
                     *reinterpret_cast<uint2 *>(smem + OFF_CTX + (16 * n + lr) * CTX_ROW + (hd * HD + 16 * td + 4 * lh) * 2) = v;
-                    if (SAVE && 16 * n + lr < N)
-                        *reinterpret_cast<uint2 *>(sv.ctx + ((long long)round * RTOT + row0 + 16 * n + lr) * 128 + hd * HD + 16 * td + 4 * lh) = v;
+                    if (SAVE && ridx[16 * n + lr] >= 0)
+                        *reinterpret_cast<uint2 *>(sv.ctx + ((long long)round * RTOT + ridx[16 * n + lr]) * 128 + hd * HD + 16 * td + 4 * lh) = v;
                 }
             }
             __syncthreads();
@@ -396,14 +402,15 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                 for (int n = 0; n < NT; ++n) {
                     const uint2 v = make_uint2(pack2_bf16(acc[n][0], acc[n][1]), pack2_bf16(acc[n][2], acc[n][3]));
                     *reinterpret_cast<uint2 *>(smem + OFF_INFO + (16 * n + lr) * INFO_ROW + (16 * ot + 4 * lh) * 2) = v;
-                    if (SAVE && 16 * n + lr < N) *reinterpret_cast<uint2 *>(sv.info + ((long long)round * RTOT + row0 + 16 * n + lr) * 64 + 16 * ot + 4 * lh) = v;
+                    if (SAVE && ridx[16 * n + lr] >= 0)
+                        *reinterpret_cast<uint2 *>(sv.info + ((long long)round * RTOT + ridx[16 * n + lr]) * 64 + 16 * ot + 4 * lh) = v;
                 }
             }
             __syncthreads();
             // update cell: Hc -> Hn where the agent has a partner
             for (int c = w; c < 16 && !(MAPF_RECUR_ABLATE & 16); c += NTHR / 64)
-                gru_block<false, 2>((c + rot) & 15, nullptr, W + U_IH, smem + OFF_INFO, INFO_ROW, W + U_HH, bias + UB_IH, bias + UB_HH, Hc, Hn, upd, N, lr, lh,
-                                    SAVE ? sv.g2 + ((long long)round * RTOT + row0) * 1024 : nullptr);
+                gru_block<false, 2>((c + rot) & 15, nullptr, W + U_IH, smem + OFF_INFO, INFO_ROW, W + U_HH, bias + UB_IH, bias + UB_HH, Hc, Hn, upd, ridx, lr, lh,
+                                    SAVE ? sv.g2 + (long long)round * RTOT * 1024 : nullptr);
             __syncthreads();
             unsigned char *tmp = Hc;
             Hc = Hn;
@@ -432,7 +439,8 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
 extern "C" {
 
 int mapf_recurrent_infer(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
-                         const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev, void *stream) {
+                         const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev, const int32_t *row_index_dev,
+                         int64_t num_rows, void *stream) {
     if (T < 1 || E < 0 || N < 1 || N > MAPF_RECUR_MAX_AGENTS || !gi_dev || !comm_dev || !weights_dev || !bias_dev || !h_out_dev)
         return MAPF_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(gi_dev) & 7) || (reinterpret_cast<uintptr_t>(h0_dev) & 15) || (reinterpret_cast<uintptr_t>(weights_dev) & 15) ||
@@ -440,18 +448,19 @@ int mapf_recurrent_infer(const uint16_t *gi_dev, const uint16_t *h0_dev, const u
         (reinterpret_cast<uintptr_t>(agent0_out_dev) & 15))
         return MAPF_ERR_INVALID_ARG;
     if (E == 0) return MAPF_OK;
+    if (row_index_dev && (N > NA || num_rows < 1)) return MAPF_ERR_UNSUPPORTED;  // compact rows: the <= 48-agent kernels only
     if (N > NA)  // 49..128 agents: csrc/mapf_recur_wide.hip
         return mapf_recur_wide_forward(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, nullptr,
                                        static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(recurrent_infer_kernel<false>, dim3(E), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
-                       weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, RecurSave{});
+                       weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, RecurSave{}, row_index_dev, (long long)num_rows);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }
 
 int mapf_recurrent_forward_save(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
                                 const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev,
-                                uint16_t *const *save_dev, void *stream) {
+                                uint16_t *const *save_dev, const int32_t *row_index_dev, int64_t num_rows, void *stream) {
     if (T < 1 || E < 0 || N < 1 || N > MAPF_RECUR_MAX_AGENTS || !gi_dev || !comm_dev || !weights_dev || !bias_dev || !h_out_dev ||
         !agent0_out_dev || !save_dev)
         return MAPF_ERR_INVALID_ARG;
@@ -459,11 +468,12 @@ int mapf_recurrent_forward_save(const uint16_t *gi_dev, const uint16_t *h0_dev, 
         if (!save_dev[i] || (reinterpret_cast<uintptr_t>(save_dev[i]) & 15)) return MAPF_ERR_INVALID_ARG;
     if (E == 0) return MAPF_OK;
     const RecurSave sv{save_dev[0], save_dev[1], save_dev[2], save_dev[3], save_dev[4], save_dev[5], save_dev[6], save_dev[7]};
+    if (row_index_dev && (N > NA || num_rows < 1)) return MAPF_ERR_UNSUPPORTED;
     if (N > NA)
         return mapf_recur_wide_forward(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, &sv,
                                        static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(recurrent_infer_kernel<true>, dim3(E), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
-                       weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, sv);
+                       weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, sv, row_index_dev, (long long)num_rows);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }

@@ -62,7 +62,8 @@ constexpr int OFF_DSI = OFF_PI + 64 * IMG_ROW;
 constexpr int OFF_SF = OFF_DSI + 64 * IMG_ROW;
 constexpr int UNION_BYTES = (OFF_SF + NA * SF_ROW * 4 - OFF_G) > NA * G_ROW ? (OFF_SF + NA * SF_ROW * 4 - OFF_G) : NA * G_ROW;
 constexpr int OFF_UPD = OFF_G + UNION_BYTES;
-constexpr int OFF_BSUM = OFF_UPD + 64 * 4;  // fp32 column sums over (steps, agents): [update cell | recurrent cell][dr|dz|dn|dn r][256], d_qkv[384]
+constexpr int OFF_RIDX = OFF_UPD + 64 * 4;  // global row of every agent at this step (-1: none), as in the forward kernel
+constexpr int OFF_BSUM = OFF_RIDX + 64 * 4;  // fp32 column sums over (steps, agents): [update cell | recurrent cell][dr|dz|dn|dn r][256], d_qkv[384]
 constexpr int NBSUM = MAPF_RECUR_BSUM_ELEMS;
 static_assert(NBSUM == 2 * 1024 + 384, "header constant out of date");
 constexpr int LDS_BYTES = OFF_BSUM + NBSUM * 4;
@@ -191,6 +192,8 @@ struct BwdArgs {
     uint16_t *d_qkv;          // [2][R][384]
     float *bsum;              // [E][NBSUM] per-environment column sums (bias gradients)
     int T, E, N;
+    const int32_t *rowidx;    // [T][E][N] compact rows (see csrc/mapf_recur.hip) or nullptr: dense
+    long long nrows;
 };
 
 __device__ __forceinline__ void unpack8(const uint4 v, float (&f)[8]) {
@@ -214,16 +217,16 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
 // G (LDS; zero for agents >= N: G shares its LDS with the attention images) and DH <- (upd ? d z : DH).
 __device__ __forceinline__ void gru_bwd_elementwise(unsigned char *DH, unsigned char *G, const uint16_t *__restrict__ gates,
                                                     const uint16_t *__restrict__ hin, const int *upd, uint16_t *__restrict__ dgi,
-                                                    uint16_t *__restrict__ dgh, int N, int tid) {
+                                                    uint16_t *__restrict__ dgh, const int *ridx, int tid) {
     constexpr int NTASK = NA * 32 / NTHR;  // 3
     // all 15 global loads of the thread's three tasks are issued before any of them is used (the phase sits between two
-    // barriers with nothing to overlap: one exposed HBM latency instead of three); agents >= N read agent 0's rows and are
-    // zeroed afterwards, so that the loads carry no control dependence
+    // barriers with nothing to overlap: one exposed HBM latency instead of three); agents without a row read agent 0's rows and
+    // are zeroed afterwards, so that the loads carry no control dependence
     uint4 vr[NTASK], vz[NTASK], vn[NTASK], vh[NTASK], vx[NTASK];
 #pragma unroll
     for (int it = 0; it < NTASK; ++it) {
         const int task = tid + it * NTHR, agent = task >> 5, c0 = 8 * (task & 31);
-        const int src = agent < N ? agent : 0;
+        const int src = ridx[agent] >= 0 ? ridx[agent] : 0;  // (any valid row: the values are discarded)
         const uint16_t *g = gates + (long long)src * 1024 + c0;
         vr[it] = *reinterpret_cast<const uint4 *>(g);
         vz[it] = *reinterpret_cast<const uint4 *>(g + 256);
@@ -235,7 +238,8 @@ __device__ __forceinline__ void gru_bwd_elementwise(unsigned char *DH, unsigned 
     for (int it = 0; it < NTASK; ++it) {
         const int task = tid + it * NTHR, agent = task >> 5, c0 = 8 * (task & 31);
         uint4 *grow = reinterpret_cast<uint4 *>(G + agent * G_ROW + c0 * 2);  // gate g at + 32 g (512 bytes apart)
-        if (agent >= N) {
+        const int row = ridx[agent];
+        if (row < 0) {
             grow[0] = grow[32] = grow[64] = grow[96] = make_uint4(0, 0, 0, 0);
             continue;
         }
@@ -258,7 +262,7 @@ __device__ __forceinline__ void gru_bwd_elementwise(unsigned char *DH, unsigned 
             dnr[k] = dn[k] * r[k];
             dpass[k] = on ? dd * z[k] : d[k];
         }
-        uint16_t *gi = dgi + (long long)agent * 768 + c0, *gh = dgh + (long long)agent * 768 + c0;
+        uint16_t *gi = dgi + (long long)row * 768 + c0, *gh = dgh + (long long)row * 768 + c0;
         const uint4 pr = pack8(dr), pz = pack8(dz), pn = pack8(dn), pnr = pack8(dnr);
         *reinterpret_cast<uint4 *>(gi) = pr;
         *reinterpret_cast<uint4 *>(gi + 256) = pz;
@@ -305,9 +309,10 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lh = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: weight-tile addresses become scalar base + lane offset
     const int e = blockIdx.x, T = A.T, E = A.E, N = A.N;
-    const long long RTOT = (long long)T * E * N;
+    const long long RTOT = A.rowidx ? A.nrows : (long long)T * E * N;
     unsigned char *DH = smem + OFF_DH;
     int *upd = reinterpret_cast<int *>(smem + OFF_UPD);
+    int *ridx = reinterpret_cast<int *>(smem + OFF_RIDX);
     float *SF = reinterpret_cast<float *>(smem + OFF_SF);
     const unsigned char *WTB = reinterpret_cast<const unsigned char *>(A.WT);
 
@@ -327,6 +332,9 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
             *cell = pack4(o);
         } else if (tid < 128) {
             upd[tid - 64] = 0;
+        } else if (tid < 192) {
+            const int a = tid - 128;
+            ridx[a] = a < N ? (A.rowidx ? A.rowidx[row0 + a] : (int)(row0 + a)) : -1;
         }
         __syncthreads();
         {
@@ -339,10 +347,10 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
         __syncthreads();
 
         for (int q = 1; q >= 0; --q) {
-            const long long rq = (long long)q * RTOT + row0;
+            const long long rq = (long long)q * RTOT;  // first row of round q's tensors
             uint16_t *dgi2 = A.d_gi2 + rq * 768, *dgh2 = A.d_gh2 + rq * 768;
             // (1) update-cell backward
-            if (!(MAPF_RBWD_ABLATE & 1)) gru_bwd_elementwise(DH, smem + OFF_G, A.g2 + rq * 1024, A.hr + rq * D, upd, dgi2, dgh2, N, tid);
+            if (!(MAPF_RBWD_ABLATE & 1)) gru_bwd_elementwise(DH, smem + OFF_G, A.g2 + rq * 1024, A.hr + rq * D, upd, dgi2, dgh2, ridx, tid);
             __syncthreads();
             // (2) DH += U_hh^T d_gh (2 output tiles per wave); d_info = U_ih^T d_gi (waves 0-3, one tile each)
             if (!(MAPF_RBWD_ABLATE & 1)) bias_colsum(smem + OFF_G, reinterpret_cast<float *>(smem + OFF_BSUM), tid);
@@ -365,7 +373,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
                         const float o[4] = {acci[n][0], acci[n][1], acci[n][2], acci[n][3]};
                         const uint2 v = pack4(o);
                         *reinterpret_cast<uint2 *>(smem + OFF_DINFO + agent * INFO_ROW + (16 * w + 4 * lh) * 2) = v;
-                        if (agent < N) *reinterpret_cast<uint2 *>(A.d_info + (rq + agent) * 64 + 16 * w + 4 * lh) = v;
+                        if (ridx[agent] >= 0) *reinterpret_cast<uint2 *>(A.d_info + (rq + ridx[agent]) * 64 + 16 * w + 4 * lh) = v;
                     }
                 }
             }
@@ -391,8 +399,8 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
                     const uint16_t *ps = A.P + ((((long long)q * T + t) * E + e) * 2 + hd) * (NA * 64);
                     const int a = (tid >> 3) & 63, ch = tid & 7;  // every thread: row a, chunk ch of q, of k, of v and of P
                     uint4 vq = make_uint4(0, 0, 0, 0), vk = vq, vv = vq, vp = vq;
-                    if (a < N) {
-                        const uint16_t *row = A.qkv + (rq + a) * 384 + hd * HD + ch * 8;
+                    if (ridx[a] >= 0) {
+                        const uint16_t *row = A.qkv + (rq + ridx[a]) * 384 + hd * HD + ch * 8;
                         vq = *reinterpret_cast<const uint4 *>(row);
                         vk = *reinterpret_cast<const uint4 *>(row + 128);
                         vv = *reinterpret_cast<const uint4 *>(row + 256);
@@ -493,7 +501,8 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
             }
             for (int i = tid; i < N * 48; i += NTHR) {
                 const int a = i / 48, ch = i - a * 48;
-                *reinterpret_cast<uint4 *>(A.d_qkv + (rq + a) * 384 + ch * 8) = *reinterpret_cast<const uint4 *>(smem + OFF_DQKV + a * QKV_ROW + ch * 16);
+                if (ridx[a] >= 0)
+                    *reinterpret_cast<uint4 *>(A.d_qkv + (rq + ridx[a]) * 384 + ch * 8) = *reinterpret_cast<const uint4 *>(smem + OFF_DQKV + a * QKV_ROW + ch * 16);
             }
             if (!(MAPF_RBWD_ABLATE & 8)) {
                 f32x4 acc0[NT], acc1[NT];
@@ -506,8 +515,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
             __syncthreads();
         }
         // ---- recurrent cell backward: d_gi1 is the gradient w.r.t. the GRU input projection ----
-        uint16_t *dgi1 = A.d_gi1 + row0 * 768, *dgh1 = A.d_gh1 + row0 * 768;
-        if (!(MAPF_RBWD_ABLATE & 16)) gru_bwd_elementwise(DH, smem + OFF_G, A.g1 + row0 * 1024, A.hin0 + row0 * D, nullptr, dgi1, dgh1, N, tid);
+        if (!(MAPF_RBWD_ABLATE & 16)) gru_bwd_elementwise(DH, smem + OFF_G, A.g1, A.hin0, nullptr, A.d_gi1, A.d_gh1, ridx, tid);
         __syncthreads();
         if (!(MAPF_RBWD_ABLATE & 16)) {
             bias_colsum(smem + OFF_G, reinterpret_cast<float *>(smem + OFF_BSUM) + 1024, tid);
@@ -541,7 +549,8 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
 extern "C" {
 
 int mapf_recurrent_backward(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev,
-                            const uint16_t *weights_t_dev, int T, int E, int N, void *const *out_dev, void *stream) {
+                            const uint16_t *weights_t_dev, int T, int E, int N, void *const *out_dev, const int32_t *row_index_dev,
+                            int64_t num_rows, void *stream) {
     if (T < 1 || E < 0 || N < 1 || N > MAPF_RECUR_MAX_AGENTS || !saved_dev || !comm_dev || !d_agent0_dev || !weights_t_dev || !out_dev)
         return MAPF_ERR_INVALID_ARG;
     for (int i = 0; i < 8; ++i)
@@ -572,6 +581,9 @@ int mapf_recurrent_backward(const uint16_t *const *saved_dev, const uint8_t *com
     a.T = T;
     a.E = E;
     a.N = N;
+    a.rowidx = row_index_dev;
+    a.nrows = num_rows;
+    if (row_index_dev && (N > NA || num_rows < 1)) return MAPF_ERR_UNSUPPORTED;  // compact rows: the <= 48-agent kernels only
     if (N > NA) {  // 49..128 agents: csrc/mapf_recur_wide_bwd.hip
         RecurBwdArgs b{};
         b.hin0 = a.hin0, b.g1 = a.g1, b.hr = a.hr, b.qkv = a.qkv, b.ctx_unused = a.ctx_unused, b.info_unused = a.info_unused, b.g2 = a.g2, b.P = a.P;

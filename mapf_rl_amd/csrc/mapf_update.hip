@@ -496,6 +496,22 @@ __global__ void __launch_bounds__(256) dense_to_rows_kernel(const uint4 *__restr
     }
 }
 
+// rows [first, last) of up to 16 row-major buffers := 0 (the padding rows behind the compact rows of the recurrence's saved tensors /
+// gradient outputs: they enter the weight-gradient GEMMs, whose K is padded to a multiple of the split size)
+struct ZeroRowsArgs {
+    void *ptr[16];
+    int row_bytes[16];  // multiples of 16
+    int n;
+    long long first, last;
+};
+__global__ void __launch_bounds__(256) zero_rows_kernel(ZeroRowsArgs a) {
+    const int k = blockIdx.y;
+    if (k >= a.n) return;
+    const long long chunks = (a.last - a.first) * (a.row_bytes[k] / 16);
+    uint4 *dst = reinterpret_cast<uint4 *>(static_cast<unsigned char *>(a.ptr[k]) + a.first * a.row_bytes[k]);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long long)gridDim.x * 256) dst[i] = make_uint4(0, 0, 0, 0);
+}
+
 __global__ void __launch_bounds__(256) to_bf16_kernel(const float *__restrict__ src, uint16_t *__restrict__ dst, long long n) {
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = (uint16_t)f32_to_bf16(src[i]);
@@ -688,6 +704,23 @@ int mapf_rows_scatter(void *rows_dev, const int32_t *idx_dev, void *dense_dev, i
     else
         hipLaunchKernelGGL(dense_to_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint4 *>(dense_dev), idx_dev,
                            static_cast<uint4 *>(rows_dev), (long long)R, chunks);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+int mapf_zero_rows(void *const *bufs_dev, const int *row_bytes, int n, int64_t first_row, int64_t last_row, void *stream) {
+    if (!bufs_dev || !row_bytes || n < 0 || n > 16 || first_row < 0 || last_row < first_row) return MAPF_ERR_INVALID_ARG;
+    if (n == 0 || last_row == first_row) return MAPF_OK;
+    ZeroRowsArgs a{};
+    for (int i = 0; i < n; ++i) {
+        if (!bufs_dev[i] || row_bytes[i] < 16 || (row_bytes[i] & 15) || (reinterpret_cast<uintptr_t>(bufs_dev[i]) & 15)) return MAPF_ERR_INVALID_ARG;
+        a.ptr[i] = bufs_dev[i];
+        a.row_bytes[i] = row_bytes[i];
+    }
+    a.n = n;
+    a.first = first_row;
+    a.last = last_row;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3(16, n), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }

@@ -329,7 +329,7 @@ def recurrent_infer(gi, h0, comm, weights, bias, want_agent0=False):
         h0 = h0.to(torch.bfloat16).reshape(E, N, 256).contiguous()
     h_out = torch.empty((E, N, 256), dtype=torch.bfloat16, device=gi.device)
     a0 = torch.empty((T, E, 256), dtype=torch.bfloat16, device=gi.device) if want_agent0 else None
-    check(lib.mapf_recurrent_infer(_ptr(gi), _ptr(h0), _ptr(comm), _ptr(weights), _ptr(bias), T, E, N, _ptr(h_out), _ptr(a0),
+    check(lib.mapf_recurrent_infer(_ptr(gi), _ptr(h0), _ptr(comm), _ptr(weights), _ptr(bias), T, E, N, _ptr(h_out), _ptr(a0), None, 0,
                                    _stream(gi.device)), "mapf_recurrent_infer")
     return h_out, a0
 
@@ -396,7 +396,7 @@ class _RecurTrain(torch.autograd.Function):
         a0 = torch.empty((T, E, 256), dtype=bf, device=dev)
         sp = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in saves])
         check(lib.mapf_recurrent_forward_save(_ptr(gi), _ptr(h0), _ptr(comm), _ptr(w_pack), _ptr(b_pack), T, E, N, _ptr(h_out), _ptr(a0), sp,
-                                              _stream(dev)), "mapf_recurrent_forward_save")
+                                              None, 0, _stream(dev)), "mapf_recurrent_forward_save")
         ctx.save_for_backward(comm, *saves, *params)
         ctx.shape = (T, E, N)
         return a0
@@ -418,7 +418,7 @@ class _RecurTrain(torch.autograd.Function):
         g_a0 = g_a0.to(bf).contiguous()
         sp = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in saves])
         op = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in outs])
-        check(lib.mapf_recurrent_backward(sp, _ptr(comm), _ptr(g_a0), _ptr(wt), T, E, N, op, _stream(dev)), "mapf_recurrent_backward")
+        check(lib.mapf_recurrent_backward(sp, _ptr(comm), _ptr(g_a0), _ptr(wt), T, E, N, op, None, 0, _stream(dev)), "mapf_recurrent_backward")
         d_gi1, d_gh1, d_gi2, d_gh2, d_info, d_qkv, bsum = outs
         hin0, _, hr, _, ctxs, info, _, _ = saves
         d_gi2f, d_gh2f, d_qkvf, hrf = d_gi2.view(2 * R, 768), d_gh2.view(2 * R, 768), d_qkv.view(2 * R, 384), hr.view(2 * R, 256)

@@ -30,6 +30,7 @@ from .fused import (ENC_OBS_PER_BLOCK, ENC_WGRAD0_PARTS, ENC_WGRAD_PARTS, RECUR_
 
 GAMMA = 0.99
 GRAD_CLIP = 40.0
+WGRAD_SPLIT = 2048  # rows per batch of the recurrence's split-K weight-gradient GEMMs (compact rows are padded to a multiple)
 FORWARD_STEPS = 2
 BETAS, EPS = (0.9, 0.999), 1e-8  # torch.optim.Adam defaults (worker.py:260)
 
@@ -267,13 +268,15 @@ class FusedUpdate:
         w, b = prec.get(net)
         lat = torch.empty((p.rows, 784), dtype=torch.bfloat16, device=dev)
         check(lib.mapf_encoder_forward(_ptr(p.obs_rows), 1, p.rows, _ptr(wp), _ptr(bp), _ptr(lat), st), "mapf_encoder_forward")
-        gi_rows = mm_rows(lat, self._w_ih(net, own))
-        gi = torch.empty((T, B, Nc, 768), dtype=torch.bfloat16, device=dev)
-        check(lib.mapf_rows_scatter(_ptr(gi_rows), _ptr(p.gidx), _ptr(gi), T * B * Nc, 1536, 1, st), "mapf_rows_scatter")
+        gi = mm_rows(lat, self._w_ih(net, own))  # [rows, 768]
+        compact = Nc <= RECUR_NARROW_AGENTS  # the <= 48-agent kernels read / write the rows that exist (gidx); the wide ones are dense
+        if not compact:
+            gi_rows, gi = gi, torch.empty((T, B, Nc, 768), dtype=torch.bfloat16, device=dev)
+            check(lib.mapf_rows_scatter(_ptr(gi_rows), _ptr(p.gidx), _ptr(gi), T * B * Nc, 1536, 1, st), "mapf_rows_scatter")
         h_out = torch.empty((B, Nc, 256), dtype=torch.bfloat16, device=dev)
         a0 = torch.empty((T, B, 256), dtype=torch.bfloat16, device=dev)
-        check(lib.mapf_recurrent_infer(_ptr(gi), _ptr(p.h0_c), _ptr(p.comm_c), _ptr(w), _ptr(b), T, B, Nc, _ptr(h_out), _ptr(a0), st),
-              "mapf_recurrent_infer")
+        check(lib.mapf_recurrent_infer(_ptr(gi), _ptr(p.h0_c), _ptr(p.comm_c), _ptr(w), _ptr(b), T, B, Nc, _ptr(h_out), _ptr(a0),
+                                       _ptr(p.gidx) if compact else None, p.rows if compact else 0, st), "mapf_recurrent_infer")
         return a0
 
     # ------------------------------------------------------------------ the update
@@ -328,9 +331,17 @@ class FusedUpdate:
               "mapf_encoder_forward_save")
         w_ih = self._w_ih(model, True)
         gi_rows = mm_rows(lat, w_ih)
-        R = To * B * Nc
-        gi = torch.empty((To, B, Nc, 768), dtype=bf, device=dev)
-        check(lib.mapf_rows_scatter(_ptr(gi_rows), _ptr(po.gidx), _ptr(gi), R, 1536, 1, st), "mapf_rows_scatter")
+        compact = Nc <= RECUR_NARROW_AGENTS
+        # rows of the recurrence's saved tensors / gradient outputs: the M rows that exist (compact: the <= 48-agent kernels address
+        # them through gidx) or all To x B x Nc (step, window, position) entries (the wide kernels)
+        # (compact: padded to a multiple of the weight-gradient GEMMs' split size, the padding rows zeroed below)
+        R = -(-M // WGRAD_SPLIT) * WGRAD_SPLIT if compact else To * B * Nc
+        ridx, nrows = (_ptr(po.gidx), R) if compact else (None, 0)
+        if compact:
+            gi = gi_rows
+        else:
+            gi = torch.empty((To, B, Nc, 768), dtype=bf, device=dev)
+            check(lib.mapf_rows_scatter(_ptr(gi_rows), _ptr(po.gidx), _ptr(gi), To * B * Nc, 1536, 1, st), "mapf_rows_scatter")
         saves = [torch.empty((R, 256), dtype=bf, device=dev), torch.empty((R, 1024), dtype=bf, device=dev),
                  torch.empty((2, R, 256), dtype=bf, device=dev), torch.empty((2, R, 384), dtype=bf, device=dev),
                  torch.empty((2, R, 128), dtype=bf, device=dev), torch.empty((2, R, 64), dtype=bf, device=dev),
@@ -340,7 +351,7 @@ class FusedUpdate:
         a0 = torch.empty((To, B, 256), dtype=bf, device=dev)
         sp = _ptr_array(saves)
         check(lib.mapf_recurrent_forward_save(_ptr(gi), _ptr(po.h0_c), _ptr(po.comm_c), _ptr(w_rec), _ptr(b_rec), To, B, Nc, _ptr(h_out), _ptr(a0), sp,
-                                              st), "mapf_recurrent_forward_save")
+                                              ridx, nrows, st), "mapf_recurrent_forward_save")
         # ---- dueling heads, TD error, priorities, loss and their gradients ----
         if side is not None:
             cur.wait_event(ready)
@@ -374,21 +385,31 @@ class FusedUpdate:
                   torch.empty((2, R, 768), dtype=bf, device=dev), torch.empty((2, R, 768), dtype=bf, device=dev),
                   torch.empty((2, R, 64), dtype=bf, device=dev), torch.empty((2, R, 384), dtype=bf, device=dev),
                   torch.empty((B, 2432), dtype=torch.float32, device=dev)]
-        check(lib.mapf_recurrent_backward(sp, _ptr(po.comm_c), _ptr(d_a0), _ptr(wt), To, B, Nc, _ptr_array(outs_b), st), "mapf_recurrent_backward")
+        check(lib.mapf_recurrent_backward(sp, _ptr(po.comm_c), _ptr(d_a0), _ptr(wt), To, B, Nc, _ptr_array(outs_b), ridx, nrows, st),
+              "mapf_recurrent_backward")
+        if compact and R > M:  # rows M..R of every GEMM operand (both rounds of the [2, R, w] tensors)
+            ops = [saves[0], saves[2][0], saves[2][1], saves[4][0], saves[4][1], saves[5][0], saves[5][1], outs_b[1], outs_b[2][0], outs_b[2][1],
+                   outs_b[3][0], outs_b[3][1], outs_b[4][0], outs_b[4][1], outs_b[5][0], outs_b[5][1]]
+            rb = (ctypes.c_int * len(ops))(*[t.shape[-1] * 2 for t in ops])
+            check(lib.mapf_zero_rows(_ptr_array(ops), rb, len(ops), M, R, st), "mapf_zero_rows")
         d_gi1, d_gh1, d_gi2, d_gh2, d_info, d_qkv, bsum = outs_b
         hin0, _, hr, _, ctxs, info, _, _ = saves
         hrf = hr.view(2 * R, 256)
-        _tall_tn_into(flat.mem(G, "recurrent.weight_hh"), d_gh1, hin0)
-        _tall_tn_into(flat.span(G, "comm.self_attn.W_Q.weight", "comm.self_attn.W_V.weight"), d_qkv.view(2 * R, 384), hrf)
-        _tall_tn_into(flat.mem(G, "comm.self_attn.W_O.weight"), d_info.view(2 * R, 64), ctxs.view(2 * R, 128))
-        _tall_tn_into(flat.mem(G, "comm.update_cell.weight_ih"), d_gi2.view(2 * R, 768), info.view(2 * R, 64))
-        _tall_tn_into(flat.mem(G, "comm.update_cell.weight_hh"), d_gh2.view(2 * R, 768), hrf)
+        rows_k = WGRAD_SPLIT if compact else 8192
+        _tall_tn_into(flat.mem(G, "recurrent.weight_hh"), d_gh1, hin0, rows_k)
+        _tall_tn_into(flat.span(G, "comm.self_attn.W_Q.weight", "comm.self_attn.W_V.weight"), d_qkv.view(2 * R, 384), hrf, rows_k)
+        _tall_tn_into(flat.mem(G, "comm.self_attn.W_O.weight"), d_info.view(2 * R, 64), ctxs.view(2 * R, 128), rows_k)
+        _tall_tn_into(flat.mem(G, "comm.update_cell.weight_ih"), d_gi2.view(2 * R, 768), info.view(2 * R, 64), rows_k)
+        _tall_tn_into(flat.mem(G, "comm.update_cell.weight_hh"), d_gh2.view(2 * R, 768), hrf, rows_k)
         bias_names = ("recurrent.bias_ih", "recurrent.bias_hh", "comm.self_attn.W_Q.bias", "comm.self_attn.W_K.bias", "comm.self_attn.W_V.bias",
                       "comm.update_cell.bias_ih", "comm.update_cell.bias_hh")
         check(lib.mapf_recurrent_bias_grads(_ptr(bsum), B, _ptr_array([flat.mem(G, k) for k in bias_names]), st), "mapf_recurrent_bias_grads")
         # ---- input projection ----
-        d_gi_rows = torch.empty((M, 768), dtype=bf, device=dev)
-        check(lib.mapf_rows_scatter(_ptr(d_gi_rows), _ptr(po.gidx), _ptr(d_gi1), R, 1536, 0, st), "mapf_rows_scatter")
+        if compact:
+            d_gi_rows = d_gi1[:M]
+        else:
+            d_gi_rows = torch.empty((M, 768), dtype=bf, device=dev)
+            check(lib.mapf_rows_scatter(_ptr(d_gi_rows), _ptr(po.gidx), _ptr(d_gi1), R, 1536, 0, st), "mapf_rows_scatter")
         g_lat = mm_rows(d_gi_rows, w_ih, transpose_w=False)
         _tall_tn_into(flat.mem(G, "recurrent.weight_ih"), d_gi_rows, lat, rows=4096)
         # ---- encoder: backward-data chain in one kernel, then the weight-gradient kernels ----

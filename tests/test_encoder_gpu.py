@@ -359,12 +359,12 @@ def test_backward_argument_checks():
     import ctypes
     sv = (ctypes.c_void_p * 8)(*[p] * 8)
     out = (ctypes.c_void_p * 7)(*[p] * 7)
-    assert lib.mapf_recurrent_backward(sv, p, p, p, 0, 1, 4, out, None) == ERR_INVALID_ARG        # T < 1
-    assert lib.mapf_recurrent_backward(sv, p, p, p, 2, 1, 129, out, None) == ERR_INVALID_ARG      # more than 128 agents
-    assert lib.mapf_recurrent_backward(sv, p, p, p, 2, 0, 4, out, None) == 0                      # no environments: nothing to do
+    assert lib.mapf_recurrent_backward(sv, p, p, p, 0, 1, 4, out, None, 0, None) == ERR_INVALID_ARG        # T < 1
+    assert lib.mapf_recurrent_backward(sv, p, p, p, 2, 1, 129, out, None, 0, None) == ERR_INVALID_ARG      # more than 128 agents
+    assert lib.mapf_recurrent_backward(sv, p, p, p, 2, 0, 4, out, None, 0, None) == 0                      # no environments: nothing to do
     bad = (ctypes.c_void_p * 7)(*([p] * 6 + [None]))
-    assert lib.mapf_recurrent_backward(sv, p, p, p, 2, 1, 4, bad, None) == ERR_INVALID_ARG
-    assert lib.mapf_recurrent_forward_save(p, None, p, p, p, 2, 1, 129, p, p, sv, None) == ERR_INVALID_ARG
+    assert lib.mapf_recurrent_backward(sv, p, p, p, 2, 1, 4, bad, None, 0, None) == ERR_INVALID_ARG
+    assert lib.mapf_recurrent_forward_save(p, None, p, p, p, 2, 1, 129, p, p, sv, None, 0, None) == ERR_INVALID_ARG
 
 
 @pytest.mark.parametrize("M,dtype", [(1, "u8"), (2, "u8"), (3, "bf16"), (255, "u8"), (257, "bf16"), (1500, "u8")])

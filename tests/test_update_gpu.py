@@ -355,3 +355,73 @@ def test_fused_update_survives_state_dict_round_trip(tmp_path):
     lr._fused.flat.step = 0
     out1 = lr.update(_batch(z, "cuda", torch.bfloat16))
     assert torch.equal(out0["td"], out1["td"]) and float(out0["loss"]) == float(out1["loss"])
+
+
+@pytest.mark.parametrize("B,T,N,p", [(24, 16, 40, 0.05), (6, 18, 16, 0.3), (5, 4, 3, 0.5)])
+def test_recurrence_kernels_compact_rows_equal_dense_rows(B, T, N, p):
+    """mapf_recurrent_forward_save / _infer / _backward with compact rows (row_index = mapf_plan_rows' gidx: only the entries that
+    can reach agent 0's Q-value have a row in gi, the saved tensors and the gradient outputs) against the same launches on dense
+    [T][E][N] rows: agent-0 states and every row that exists are the same bits."""
+    from mapf_rl_amd._lib import check, lib
+    from mapf_rl_amd.fused import PackedRecurrence, pack_recurrence_transposed, recurrence_params
+    from mapf_rl_amd.model import Network
+
+    torch.manual_seed(B)
+    net = Network().cuda()
+    w, b = PackedRecurrence().get(net)
+    wt = pack_recurrence_transposed(recurrence_params(net))
+    comm, steps, g = _random_windows(B, T, N, p, 5 + N)
+    rel, slot, order, nact, cnt, nag = _plan_mark(comm, steps)
+    Nc = 16 * -(-int(nag.max()) // 16)
+    rows = int(cnt.sum())
+    gidx = torch.empty((T, B, Nc), dtype=torch.int32, device="cuda")
+    comm_c = torch.empty((T, B, Nc, Nc), dtype=torch.uint8, device="cuda")
+    h0_c = torch.empty((B, Nc, 256), dtype=torch.bfloat16, device="cuda")
+    hidden = (torch.randn((B * N, 256), device="cuda", generator=g) * 0.3).to(torch.float16)
+    cm = comm.view(torch.uint8)
+    check(lib.mapf_plan_rows(T, B, N, Nc, _p(order), _p(nact), _p(cnt), _p(nag), _p(cm), cm.stride(0), cm.stride(1), _p(hidden), 0, None, 0, 0,
+                             _p(gidx), _p(comm_c), _p(h0_c), 0, None, None, None), "mapf_plan_rows")
+    gi_rows = (torch.randn((rows, 768), device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    gi_dense = torch.empty((T, B, Nc, 768), dtype=torch.bfloat16, device="cuda")
+    check(lib.mapf_rows_scatter(_p(gi_rows), _p(gidx), _p(gi_dense), T * B * Nc, 1536, 1, None), "mapf_rows_scatter")
+    d_a0 = (torch.randn((T, B, 256), device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    # (an entry without a row must not receive an external gradient: behind the window's last step agent 0 has none)
+    d_a0 = d_a0 * (torch.arange(T, device="cuda").view(T, 1, 1) < steps.view(1, B, 1)).to(torch.bfloat16)
+    bf = torch.bfloat16
+    widths_s = [(1, 256), (1, 1024), (2, 256), (2, 384), (2, 128), (2, 64), (2, 1024)]
+    widths_o = [(1, 768), (1, 768), (2, 768), (2, 768), (2, 64), (2, 384)]
+
+    def run(compact):
+        R = rows if compact else T * B * Nc
+        saves = [torch.zeros((k, R, wd), dtype=bf, device="cuda") for k, wd in widths_s] + [torch.zeros((2, T * B, 2, 48, 64), dtype=bf, device="cuda")]
+        outs = [torch.zeros((k, R, wd), dtype=bf, device="cuda") for k, wd in widths_o] + [torch.zeros((B, 2432), dtype=torch.float32, device="cuda")]
+        h_out = torch.empty((B, Nc, 256), dtype=bf, device="cuda")
+        a0 = torch.empty((T, B, 256), dtype=bf, device="cuda")
+        a0i = torch.empty((T, B, 256), dtype=bf, device="cuda")
+        sp = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in saves])
+        op = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in outs])
+        gi = gi_rows if compact else gi_dense
+        ri, nr = (_p(gidx), rows) if compact else (None, 0)
+        check(lib.mapf_recurrent_infer(_p(gi), _p(h0_c), _p(comm_c), _p(w), _p(b), T, B, Nc, _p(h_out), _p(a0i), ri, nr, None), "mapf_recurrent_infer")
+        check(lib.mapf_recurrent_forward_save(_p(gi), _p(h0_c), _p(comm_c), _p(w), _p(b), T, B, Nc, _p(h_out), _p(a0), sp, ri, nr, None),
+              "mapf_recurrent_forward_save")
+        check(lib.mapf_recurrent_backward(sp, _p(comm_c), _p(d_a0), _p(wt), T, B, Nc, op, ri, nr, None), "mapf_recurrent_backward")
+        torch.cuda.synchronize()
+        return a0i, a0, saves, outs
+
+    a0i_d, a0_d, sv_d, out_d = run(False)
+    a0i_c, a0_c, sv_c, out_c = run(True)
+    assert torch.equal(a0_d, a0_c) and torch.equal(a0i_d, a0i_c) and torch.equal(a0_c, a0i_c)
+    sel = (gidx.view(-1) >= 0).nonzero().view(-1)          # dense rows that exist, in row order? no: gather through gidx
+    dense_of_row = torch.empty(rows, dtype=torch.int64, device="cuda")
+    dense_of_row[gidx.view(-1)[sel].long()] = sel
+    for k, (d, c) in enumerate(zip(sv_d[:7] + out_d[:6], sv_c[:7] + out_c[:6])):
+        bad = (d[:, dense_of_row] != c).any(dim=2).nonzero()
+        assert bad.numel() == 0, (k, bad[:8].tolist(), gidx.view(-1, Nc)[:3].tolist(), nact[:, 0].tolist())
+    assert torch.equal(sv_d[7], sv_c[7])
+    assert torch.allclose(out_d[6], out_c[6], rtol=1e-5, atol=1e-6)  # bias column sums (same order of addition; zero rows skipped)
+    # rows that do not exist carry no gradient in the dense launch either: pruning is dead-code elimination
+    mask = torch.ones(T * B * Nc, dtype=torch.bool, device="cuda")
+    mask[sel] = False
+    for d in out_d[:6]:
+        assert not d[:, mask].float().abs().any()
