@@ -30,6 +30,7 @@ from .fused import (ENC_OBS_PER_BLOCK, ENC_WGRAD0_PARTS, ENC_WGRAD_PARTS, RECUR_
 
 GAMMA = 0.99
 GRAD_CLIP = 40.0
+SIDE_STREAM_MAX_ROWS = 262144
 WGRAD_SPLIT = 2048  # rows per batch of the recurrence's split-K weight-gradient GEMMs (compact rows are padded to a multiple)
 FORWARD_STEPS = 2
 BETAS, EPS = (0.9, 0.999), 1e-8  # torch.optim.Adam defaults (worker.py:260)
@@ -307,7 +308,9 @@ class FusedUpdate:
         check(lib.mapf_recurrent_pack(_ptr_array([p.detach() for p in recurrence_params(model)]), None, None, _ptr(wt), st), "mapf_recurrent_pack")
         wpt = pack_encoder_backward(model.obs_encoder)
         # ---- target network (and double-DQN's online arg-max) on the second stream ----
-        side = lr._side
+        # (beyond ~260 k rows -- every observation of 128-agent windows -- either network's kernels fill the chip for tens of
+        # milliseconds: a second stream buys nothing there and doubles the transient allocations)
+        side = lr._side if max(po.rows, pt.rows) <= SIDE_STREAM_MAX_ROWS else None
         a0_on2 = None
         if side is not None:
             side.wait_stream(cur)
