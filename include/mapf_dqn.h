@@ -217,12 +217,27 @@ int mapf_window_relevance(const uint8_t *comm_dev, const int64_t *steps_dev, int
 #define MAPF_PLAN_MAX_STEPS 20
 int mapf_plan_mark(const uint8_t *comm_dev, int64_t stride_b, int64_t stride_t, const int64_t *steps_dev, const float *extra_steps_dev,
                    int T, int B, int N, int mark_all, uint8_t *rel_dev, int16_t *slot_dev, int16_t *order_dev, int32_t *nact_dev, int32_t *cnt_dev, int32_t *nag_dev,
-                   void *stream);
+                   int32_t *ucnt_dev, void *stream);
 int mapf_plan_rows(int T, int B, int N, int Nc, const int16_t *order_dev, const int32_t *nact_dev, const int32_t *cnt_dev,
                    const int32_t *nag_dev, const uint8_t *comm_dev, int64_t comm_stride_b, int64_t comm_stride_t,
                    const uint16_t *hidden_dev, int hidden_is_bf16, const uint16_t *obs_bf16_dev, int64_t obs_stride_b, int64_t obs_stride_t,
                    int32_t *gidx_dev, uint8_t *comm_c_dev, uint16_t *h0_c_dev, int64_t num_rows, int64_t *row_src_dev,
-                   uint16_t *obs_rows_dev, void *stream);
+                   uint16_t *obs_rows_dev, const uint8_t *dup_dev, const int32_t *ucnt_dev, int32_t *umap_dev, int32_t *row_tbp_dev,
+                   void *stream);
+/*
+ * Repeated observations (exact reuse: the encoder is a deterministic per-observation function).  mapf_obs_dup: dup u8 [T][B][N] = the
+ * entry (in the target window's closure) carries the same 486 values as the same agent one step earlier; ucnt_online / ucnt_target
+ * int32 [B] (zeroed by mapf_plan_mark when given there) += the DISTINCT observations of either closure per window.  With dup_dev,
+ * mapf_plan_rows numbers the distinct observations like the rows (duplicates skipped): umap int32 [rows] = the distinct row an entry
+ * uses, row_src / obs_rows then hold the num_rows = sum(ucnt) DISTINCT observations only; row_tbp int32 [rows] (optional) =
+ * (t << 24) | (position << 16) | window of every row.  mapf_dedup_sum: d_unique[u] = sum of d_rows[r] over the entries r with
+ * umap[r] == u (fp32 sum, fixed order), the gradient of a shared row.
+ */
+int mapf_obs_dup(int T, int To, int B, int N, const uint16_t *obs_bf16_dev, int64_t obs_stride_b, int64_t obs_stride_t,
+                 const int16_t *slot_online_dev, const int16_t *slot_target_dev, const int32_t *nact_online_dev,
+                 const int32_t *nact_target_dev, uint8_t *dup_dev, int32_t *ucnt_online_dev, int32_t *ucnt_target_dev, void *stream);
+int mapf_dedup_sum(int T, int B, int Nc, int64_t rows, int row_bytes, const int32_t *gidx_dev, const int32_t *umap_dev,
+                   const int32_t *row_tbp_dev, const void *d_rows_dev, void *d_unique_dev, void *stream);
 /* dense[r][:] = idx[r] >= 0 ? rows[idx[r]][:] : 0 (to_dense != 0)  /  rows[idx[r]][:] = dense[r][:] where idx[r] >= 0 (to_dense == 0);
  * R dense rows of row_bytes (multiple of 16) bytes. */
 int mapf_rows_scatter(void *rows_dev, const int32_t *idx_dev, void *dense_dev, int64_t R, int row_bytes, int to_dense, void *stream);

@@ -48,6 +48,7 @@ struct PlanMarkArgs {
     int32_t *nact;   // [T][B]  agents needed at step t = a prefix of the order
     int32_t *cnt;    // [B]     sum over t of nact = observations of the window to encode
     int32_t *nag;    // [B]     agents needed anywhere in the window (= nact[0][b])
+    int32_t *ucnt;   // [B]     optional: := 0 (obs_dup_kernel counts the window's DISTINCT observations into it)
 };
 
 __global__ void __launch_bounds__(128) plan_mark_kernel(PlanMarkArgs p) {
@@ -105,6 +106,50 @@ __global__ void __launch_bounds__(128) plan_mark_kernel(PlanMarkArgs p) {
         for (int t = 0; t < T; ++t) tot += s_cnt[t];
         p.cnt[b] = tot;
         p.nag[b] = s_cnt[0];
+        if (p.ucnt) p.ucnt[b] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// obs_dup: an agent that stands still in an unchanged neighbourhood has the SAME observation at consecutive steps of a window, and
+// the encoder is a deterministic per-observation function: 34-37 % of the rows a batch would encode repeat the row of the same
+// agent one step earlier (tools/obs_reuse_probe.py).  One wavefront per (step >= 1, window, agent) entry that is needed (in the
+// target window's closure, a superset of the online window's): dup = the 486 values equal the previous step's; the distinct
+// observations of every window are counted for both closures.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct ObsDupArgs {
+    int T, To, B, N;  // target window steps, online window steps
+    const uint16_t *obs;
+    long long o_sB, o_sT;
+    const int16_t *slot_o, *slot_t;  // [B][N]
+    const int32_t *nact_o, *nact_t;  // [To][B], [T][B]
+    uint8_t *dup;                    // [T][B][N]
+    int32_t *ucnt_o, *ucnt_t;        // [B]
+};
+
+__global__ void __launch_bounds__(256) obs_dup_kernel(ObsDupArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long long total = (long long)p.T * p.B * p.N;
+    for (long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); w < total; w += (long long)gridDim.x * 4) {
+        const int j = (int)(w % p.N), b = (int)((w / p.N) % p.B), t = (int)(w / ((long long)p.N * p.B));
+        const int st = p.slot_t[(size_t)b * p.N + j];
+        const bool in_t = st >= 0 && st < p.nact_t[(size_t)t * p.B + b];
+        bool same = false;
+        if (in_t && t > 0) {  // (wave-uniform)
+            const uint32_t *cur = reinterpret_cast<const uint32_t *>(p.obs + (long long)b * p.o_sB + (long long)t * p.o_sT + (long long)j * 486);
+            const uint32_t *prv = reinterpret_cast<const uint32_t *>(p.obs + (long long)b * p.o_sB + (long long)(t - 1) * p.o_sT + (long long)j * 486);
+            bool diff = false;
+            for (int d = lane; d < 243; d += 64) diff |= cur[d] != prv[d];
+            same = __ballot(diff) == 0ull;
+        }
+        if (lane == 0) {
+            p.dup[w] = (uint8_t)same;
+            if (in_t && !same) {
+                atomicAdd(&p.ucnt_t[b], 1);
+                const int so = p.slot_o[(size_t)b * p.N + j];
+                if (t < p.To && so >= 0 && so < p.nact_o[(size_t)t * p.B + b]) atomicAdd(&p.ucnt_o[b], 1);
+            }
+        }
     }
 }
 
@@ -125,10 +170,51 @@ struct PlanRowsArgs {
     int32_t *gidx;       // [T][B][Nc] row of (t, b, position) or -1
     uint8_t *comm_c;     // [T][B][Nc][Nc] masks in the compact numbering; positions >= nact[t][b] read only themselves
     uint16_t *h0_c;      // [B][Nc][256] bf16
-    long long *row_src;  // [rows] element offset of the row's observation in `obs` (the gather itself: obs_gather_kernel)
+    long long *row_src;  // [rows] ([urows] with dup) element offset of a row's observation in `obs` (the gather: obs_gather_kernel)
+    const uint8_t *dup;  // optional [>= T][B][N] from obs_dup_kernel: the entry repeats the same agent's observation of the step before
+    const int32_t *ucnt; // [B] distinct observations per window (with dup)
+    int32_t *umap;       // [rows] with dup: the row of DISTINCT observations (numbered like the rows, duplicates skipped) an entry uses
+    int32_t *row_tbp;    // [rows] optional: (t << 24) | (position << 16) | window of every row
 };
 
 constexpr int OBS_DWORDS = 243;  // 486 bf16
+
+// masks and initial hidden states in the compact numbering: workgroup (window b, step t) gathers comm_c[t][b], workgroup (b, T) h0_c[b]
+// (apart from plan_rows_kernel, whose per-window work is a short serial chain: 20 x more, small, independent workgroups)
+__global__ void __launch_bounds__(256) plan_masks_kernel(PlanRowsArgs p) {
+    __shared__ short s_ord[128];
+    const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, T = p.T, B = p.B, N = p.N, Nc = p.Nc;
+    if (tid < N) s_ord[tid] = p.order[(size_t)b * N + tid];
+    __syncthreads();
+    if (t < T) {
+        const int na = p.nact[(size_t)t * B + b];
+        const uint8_t *src = p.comm + (long long)b * p.c_sB + (long long)t * p.c_sT;
+        uint8_t *dst = p.comm_c + ((size_t)t * B + b) * Nc * Nc;
+        for (int idx = tid; idx < Nc * Nc; idx += 256) {
+            const int i = idx / Nc, j = idx - i * Nc;
+            uint8_t v = (uint8_t)(i == j);
+            if (i < na && j < na) v = src[(long long)s_ord[i] * N + s_ord[j]] != 0;
+            dst[idx] = v;
+        }
+        return;
+    }
+    const int nag = p.nag[b];
+    for (int idx = tid; idx < Nc * 32; idx += 256) {  // 8 channels per task
+        const int i = idx >> 5, ch = idx & 31;
+        uint4 o = make_uint4(0, 0, 0, 0);
+        if (i < nag) {
+            const uint4 h = *reinterpret_cast<const uint4 *>(p.hidden + ((size_t)b * N + s_ord[i]) * 256 + ch * 8);
+            const uint32_t w[4] = {h.x, h.y, h.z, h.w};
+            uint32_t r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                r[k] = p.hidden_bf16 ? w[k]
+                                     : (f32_to_bf16(f16_to_f32((uint16_t)(w[k] & 0xFFFFu))) | (f32_to_bf16(f16_to_f32((uint16_t)(w[k] >> 16))) << 16));
+            o = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+        *reinterpret_cast<uint4 *>(p.h0_c + ((size_t)b * Nc + i) * 256 + ch * 8) = o;
+    }
+}
 
 __global__ void __launch_bounds__(256) plan_rows_kernel(PlanRowsArgs p) {
     __shared__ int s_red[256];
@@ -156,40 +242,99 @@ __global__ void __launch_bounds__(256) plan_rows_kernel(PlanRowsArgs p) {
         s_base[T] = acc;
     }
     __syncthreads();
-    const int rows = s_base[T], nag = p.nag[b];
+    const int rows = s_base[T];
     for (int idx = tid; idx < T * Nc; idx += 256) {
         const int t = idx / Nc, i = idx - t * Nc;
         const bool on = i < s_nact[t];
         p.gidx[((size_t)t * B + b) * Nc + i] = on ? offset + s_base[t] + i : -1;
-        if (on) s_map[s_base[t] + i] = (unsigned short)((t << 8) | i);
-    }
-    for (int idx = tid; idx < T * Nc * Nc; idx += 256) {
-        const int t = idx / (Nc * Nc), r = idx - t * Nc * Nc, i = r / Nc, j = r - i * Nc, na = s_nact[t];
-        uint8_t v = (uint8_t)(i == j);
-        if (i < na && j < na) v = p.comm[(long long)b * p.c_sB + (long long)t * p.c_sT + (long long)s_ord[i] * N + s_ord[j]] != 0;
-        p.comm_c[(((size_t)t * B + b) * Nc + i) * Nc + j] = v;
-    }
-    for (int idx = tid; idx < Nc * 32; idx += 256) {  // 8 channels per task
-        const int i = idx >> 5, ch = idx & 31;
-        uint4 o = make_uint4(0, 0, 0, 0);
-        if (i < nag) {
-            const uint4 h = *reinterpret_cast<const uint4 *>(p.hidden + ((size_t)b * N + s_ord[i]) * 256 + ch * 8);
-            const uint32_t w[4] = {h.x, h.y, h.z, h.w};
-            uint32_t r[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                r[k] = p.hidden_bf16 ? w[k]
-                                     : (f32_to_bf16(f16_to_f32((uint16_t)(w[k] & 0xFFFFu))) | (f32_to_bf16(f16_to_f32((uint16_t)(w[k] >> 16))) << 16));
-            o = make_uint4(r[0], r[1], r[2], r[3]);
+        if (on) {
+            s_map[s_base[t] + i] = (unsigned short)((t << 8) | i);
+            if (p.row_tbp) p.row_tbp[offset + s_base[t] + i] = (t << 24) | (i << 16) | b;
         }
-        *reinterpret_cast<uint4 *>(p.h0_c + ((size_t)b * Nc + i) * 256 + ch * 8) = o;
     }
     __syncthreads();
-    if (p.row_src)
-        for (int r = tid; r < rows; r += 256) {
-            const int t = s_map[r] >> 8, i = s_map[r] & 255;
-            p.row_src[offset + r] = (long long)b * p.o_sB + (long long)t * p.o_sT + (long long)s_ord[i] * 486;
+    if (p.dup == nullptr) {
+        if (p.row_src)
+            for (int r = tid; r < rows; r += 256) {
+                const int t = s_map[r] >> 8, i = s_map[r] & 255;
+                p.row_src[offset + r] = (long long)b * p.o_sB + (long long)t * p.o_sT + (long long)s_ord[i] * 486;
+            }
+        return;
+    }
+    // distinct observations: position i keeps the id of its current run; a new run starts where the observation changed
+    __shared__ int s_uid[128], s_flag[128];
+    int upart = 0;
+    for (int k = tid; k < b; k += 256) upart += p.ucnt[k];
+    s_red[tid] = upart;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (tid < d) s_red[tid] += s_red[tid + d];
+        __syncthreads();
+    }
+    int next = s_red[0];  // first distinct row of this window (identical in every thread)
+    for (int t = 0; t < T; ++t) {
+        const int na = s_nact[t];
+        if (tid < 128) s_flag[tid] = (tid < na) && !(t > 0 && p.dup[((size_t)t * B + b) * N + s_ord[tid]] != 0);
+        __syncthreads();
+        if (tid < na) {
+            if (s_flag[tid]) {
+                int before = 0;
+                for (int k = 0; k < tid; ++k) before += s_flag[k];
+                s_uid[tid] = next + before;
+                p.row_src[next + before] = (long long)b * p.o_sB + (long long)t * p.o_sT + (long long)s_ord[tid] * 486;
+            }
+            p.umap[offset + s_base[t] + tid] = s_uid[tid];
         }
+        int tot = 0;
+        for (int k = 0; k < na; ++k) tot += s_flag[k];
+        next += tot;
+        __syncthreads();
+    }
+}
+
+// d_u[u][:] = sum over the entries r with umap[r] == u of d_rows[r][:] (fp32 sum, one bf16 rounding): the gradient of a distinct
+// observation's row is the sum over the run of consecutive steps that share it.  One wavefront per row; the run's FIRST entry does
+// the sum, walking forward through gidx (the same position at later steps), the others return.
+struct DedupSumArgs {
+    int T, B, Nc, W8;  // W8: row width in 8-element (16-byte) chunks
+    long long rows;
+    const int32_t *gidx, *umap;
+    const int32_t *row_tbp;  // [rows] (t << 24) | (position << 16) | window
+    const uint4 *d_rows;
+    uint4 *d_u;
+};
+
+__global__ void __launch_bounds__(256) dedup_sum_kernel(DedupSumArgs p) {
+    const int lane = threadIdx.x & 63;
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < p.rows; r += (long long)gridDim.x * 4) {
+        const int tbp = p.row_tbp[r], t = tbp >> 24, pos = (tbp >> 16) & 255, b = tbp & 0xFFFF, u = p.umap[r];
+        if (t > 0 && p.umap[p.gidx[((size_t)(t - 1) * p.B + b) * p.Nc + pos]] == u) continue;  // not the head of its run
+        for (int c = lane; c < p.W8; c += 64) {
+            float acc[8];
+            {
+                const uint4 v = p.d_rows[r * p.W8 + c];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    acc[2 * k] = bf16_to_f32(w[k] & 0xFFFFu);
+                    acc[2 * k + 1] = bf16_to_f32(w[k] >> 16);
+                }
+            }
+            for (int t2 = t + 1; t2 < p.T; ++t2) {
+                const int r2 = p.gidx[((size_t)t2 * p.B + b) * p.Nc + pos];
+                if (r2 < 0 || p.umap[r2] != u) break;
+                const uint4 v = p.d_rows[(long long)r2 * p.W8 + c];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    acc[2 * k] += bf16_to_f32(w[k] & 0xFFFFu);
+                    acc[2 * k + 1] += bf16_to_f32(w[k] >> 16);
+                }
+            }
+            p.d_u[(long long)u * p.W8 + c] = make_uint4(f32_to_bf16(acc[0]) | (f32_to_bf16(acc[1]) << 16), f32_to_bf16(acc[2]) | (f32_to_bf16(acc[3]) << 16),
+                                                      f32_to_bf16(acc[4]) | (f32_to_bf16(acc[5]) << 16), f32_to_bf16(acc[6]) | (f32_to_bf16(acc[7]) << 16));
+        }
+    }
 }
 
 // obs_rows[r][:] = obs[row_src[r] ..+486] (bf16): one wavefront per row, 243 dwords
@@ -531,14 +676,15 @@ __global__ void __launch_bounds__(256) to_bf16_kernel(const float *__restrict__ 
 extern "C" {
 
 int mapf_plan_mark(const uint8_t *comm_dev, int64_t stride_b, int64_t stride_t, const int64_t *steps_dev, const float *extra_steps_dev, int T, int B,
-                   int N, int mark_all, uint8_t *rel_dev, int16_t *slot_dev, int16_t *order_dev, int32_t *nact_dev, int32_t *cnt_dev, int32_t *nag_dev, void *stream) {
+                   int N, int mark_all, uint8_t *rel_dev, int16_t *slot_dev, int16_t *order_dev, int32_t *nact_dev, int32_t *cnt_dev, int32_t *nag_dev,
+                   int32_t *ucnt_dev, void *stream) {
     if (T < 1 || T > MAPF_PLAN_MAX_STEPS || B < 0 || N < 1 || N > 128 || !comm_dev || !steps_dev || !slot_dev || !order_dev || !nact_dev || !cnt_dev ||
         !nag_dev || stride_b < 0 || stride_t < 0)
         return MAPF_ERR_INVALID_ARG;
     if (reinterpret_cast<uintptr_t>(steps_dev) & 7) return MAPF_ERR_INVALID_ARG;
     if (B == 0) return MAPF_OK;
     PlanMarkArgs p{comm_dev, stride_b, stride_t, reinterpret_cast<const long long *>(steps_dev), extra_steps_dev, T, B, N, mark_all != 0, rel_dev, slot_dev, order_dev, nact_dev,
-                   cnt_dev, nag_dev};
+                   cnt_dev, nag_dev, ucnt_dev};
     hipLaunchKernelGGL(plan_mark_kernel, dim3(B), dim3(128), 0, static_cast<hipStream_t>(stream), p);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
@@ -547,7 +693,8 @@ int mapf_plan_mark(const uint8_t *comm_dev, int64_t stride_b, int64_t stride_t, 
 int mapf_plan_rows(int T, int B, int N, int Nc, const int16_t *order_dev, const int32_t *nact_dev, const int32_t *cnt_dev, const int32_t *nag_dev,
                    const uint8_t *comm_dev, int64_t comm_stride_b, int64_t comm_stride_t, const uint16_t *hidden_dev, int hidden_is_bf16,
                    const uint16_t *obs_bf16_dev, int64_t obs_stride_b, int64_t obs_stride_t, int32_t *gidx_dev, uint8_t *comm_c_dev, uint16_t *h0_c_dev,
-                   int64_t num_rows, int64_t *row_src_dev, uint16_t *obs_rows_dev, void *stream) {
+                   int64_t num_rows, int64_t *row_src_dev, uint16_t *obs_rows_dev, const uint8_t *dup_dev, const int32_t *ucnt_dev, int32_t *umap_dev,
+                   int32_t *row_tbp_dev, void *stream) {
     if (T < 1 || T > MAPF_PLAN_MAX_STEPS || B < 0 || N < 1 || N > 128 || Nc < 16 || Nc > 128 || (Nc & 15) || !order_dev || !nact_dev || !cnt_dev || !nag_dev ||
         !comm_dev || !hidden_dev || !gidx_dev || !comm_c_dev || !h0_c_dev)
         return MAPF_ERR_INVALID_ARG;
@@ -555,9 +702,13 @@ int mapf_plan_rows(int T, int B, int N, int Nc, const int16_t *order_dev, const 
                          (reinterpret_cast<uintptr_t>(obs_bf16_dev) & 3) || (reinterpret_cast<uintptr_t>(obs_rows_dev) & 3)))
         return MAPF_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(hidden_dev) & 15) || (reinterpret_cast<uintptr_t>(h0_c_dev) & 15)) return MAPF_ERR_INVALID_ARG;
+    if (dup_dev && (!ucnt_dev || !umap_dev || !row_src_dev)) return MAPF_ERR_INVALID_ARG;
+    if (B > 65535) return MAPF_ERR_UNSUPPORTED;
     if (B == 0) return MAPF_OK;
     PlanRowsArgs p{T, B, N, Nc, order_dev, nact_dev, cnt_dev, nag_dev, comm_dev, comm_stride_b, comm_stride_t, hidden_dev, hidden_is_bf16 != 0, obs_bf16_dev,
-                   obs_stride_b, obs_stride_t, gidx_dev, comm_c_dev, h0_c_dev, reinterpret_cast<long long *>(row_src_dev)};
+                   obs_stride_b, obs_stride_t, gidx_dev, comm_c_dev, h0_c_dev, reinterpret_cast<long long *>(row_src_dev), dup_dev, ucnt_dev, umap_dev,
+                   row_tbp_dev};
+    hipLaunchKernelGGL(plan_masks_kernel, dim3(B, T + 1), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     hipLaunchKernelGGL(plan_rows_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     if (obs_rows_dev && num_rows > 0) {
         long long blocks = (num_rows + 3) / 4;
@@ -686,6 +837,37 @@ int mapf_adam_step(int64_t n, float *params_dev, float *grads_dev, float *exp_av
     long long blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+int mapf_obs_dup(int T, int To, int B, int N, const uint16_t *obs_bf16_dev, int64_t obs_stride_b, int64_t obs_stride_t, const int16_t *slot_online_dev,
+                 const int16_t *slot_target_dev, const int32_t *nact_online_dev, const int32_t *nact_target_dev, uint8_t *dup_dev, int32_t *ucnt_online_dev,
+                 int32_t *ucnt_target_dev, void *stream) {
+    if (T < 1 || To < 1 || To > T || B < 0 || N < 1 || N > 128 || !obs_bf16_dev || !slot_online_dev || !slot_target_dev || !nact_online_dev ||
+        !nact_target_dev || !dup_dev || !ucnt_online_dev || !ucnt_target_dev || (obs_stride_b % 2) || (obs_stride_t % 2) ||
+        (reinterpret_cast<uintptr_t>(obs_bf16_dev) & 3))
+        return MAPF_ERR_INVALID_ARG;
+    if (B == 0) return MAPF_OK;
+    ObsDupArgs p{T, To, B, N, obs_bf16_dev, obs_stride_b, obs_stride_t, slot_online_dev, slot_target_dev, nact_online_dev, nact_target_dev, dup_dev,
+                 ucnt_online_dev, ucnt_target_dev};
+    long long blocks = ((long long)T * B * N + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(obs_dup_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+int mapf_dedup_sum(int T, int B, int Nc, int64_t rows, int row_bytes, const int32_t *gidx_dev, const int32_t *umap_dev, const int32_t *row_tbp_dev,
+                   const void *d_rows_dev, void *d_unique_dev, void *stream) {
+    if (T < 1 || B < 1 || Nc < 16 || rows < 0 || row_bytes < 16 || (row_bytes & 15) || !gidx_dev || !umap_dev || !row_tbp_dev || !d_rows_dev || !d_unique_dev)
+        return MAPF_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(d_rows_dev) & 15) || (reinterpret_cast<uintptr_t>(d_unique_dev) & 15)) return MAPF_ERR_INVALID_ARG;
+    if (rows == 0) return MAPF_OK;
+    DedupSumArgs p{T, B, Nc, row_bytes / 16, (long long)rows, gidx_dev, umap_dev, row_tbp_dev, static_cast<const uint4 *>(d_rows_dev), static_cast<uint4 *>(d_unique_dev)};
+    long long blocks = (rows + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(dedup_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }

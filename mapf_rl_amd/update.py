@@ -211,16 +211,24 @@ class FusedUpdate:
         B, T, N, dev = v["B"], v["T"], v["N"], self.dev
         st = _stream(dev)
         po, pt = WindowPlan(T - FORWARD_STEPS, B, N, dev), WindowPlan(T, B, N, dev)
-        counts = torch.empty((4, B), dtype=torch.int32, device=dev)  # cnt online, nag online, cnt target, nag target
+        counts = torch.empty((6, B), dtype=torch.int32, device=dev)  # cnt online, nag online, cnt target, nag target, distinct online, distinct target
         cm = v["comm"]
         from .model import Network
 
         mark_all = 0 if Network.PRUNE_UNREACHABLE else 1  # 1: encode every observation up to the window's last step, like the reference
         for k, (p, extra) in enumerate(((po, None), (pt, v["steps"]))):
             check(lib.mapf_plan_mark(_ptr(cm), cm.stride(0), cm.stride(1), _ptr(v["bt"]), _ptr(extra), p.T, B, N, mark_all, None, _ptr(p.slot), _ptr(p.order),
-                                     _ptr(p.nact), _ptr(counts[2 * k]), _ptr(counts[2 * k + 1]), st), "mapf_plan_mark")
-            p.cnt, p.nag = counts[2 * k], counts[2 * k + 1]
-        host = torch.empty((4, B), dtype=torch.int32, pin_memory=True)
+                                     _ptr(p.nact), _ptr(counts[2 * k]), _ptr(counts[2 * k + 1]), _ptr(counts[4 + k]), st), "mapf_plan_mark")
+            p.cnt, p.nag, p.ucnt = counts[2 * k], counts[2 * k + 1], counts[4 + k]
+        dup = None
+        if self.DEDUP:
+            # which entries repeat the observation of the same agent one step earlier (exact reuse: one encoder pass per run)
+            obs = v["obs"]
+            dup = torch.empty((T, B, N), dtype=torch.uint8, device=dev)
+            check(lib.mapf_obs_dup(T, po.T, B, N, _ptr(obs), obs.stride(0), obs.stride(1), _ptr(po.slot), _ptr(pt.slot), _ptr(po.nact), _ptr(pt.nact),
+                                   _ptr(dup), _ptr(po.ucnt), _ptr(pt.ucnt), st), "mapf_obs_dup")
+        po.dup = pt.dup = dup
+        host = torch.empty((6, B), dtype=torch.int32, pin_memory=True)
         host.copy_(counts, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
@@ -240,12 +248,17 @@ class FusedUpdate:
             p.gidx = torch.empty((T, B, Nc), dtype=torch.int32, device=dev)
             p.comm_c = torch.empty((T, B, Nc, Nc), dtype=torch.uint8, device=dev)
             p.h0_c = torch.empty((B, Nc, 256), dtype=torch.bfloat16, device=dev)
-            p.obs_rows = torch.empty((max(p.rows, 1), 6, 9, 9), dtype=torch.bfloat16, device=dev)
-            row_src = torch.empty(max(p.rows, 1), dtype=torch.int64, device=dev)
+            # the observations to encode: every row, or -- with the duplicate flags -- the distinct ones (umap: entry -> distinct row)
+            p.urows = int(h[4 + k].sum()) if p.dup is not None else p.rows
+            p.obs_rows = torch.empty((max(p.urows, 1), 6, 9, 9), dtype=torch.bfloat16, device=dev)
+            row_src = torch.empty(max(p.urows, 1), dtype=torch.int64, device=dev)
+            p.umap = torch.empty(max(p.rows, 1), dtype=torch.int32, device=dev) if p.dup is not None else None
+            p.row_tbp = torch.empty(max(p.rows, 1), dtype=torch.int32, device=dev) if p.dup is not None else None
             cm, obs, hid = v["comm"], v["obs"], v["hidden"]
             check(lib.mapf_plan_rows(T, B, N, Nc, _ptr(p.order), _ptr(p.nact), _ptr(p.cnt), _ptr(p.nag), _ptr(cm), cm.stride(0), cm.stride(1),
                                      _ptr(hid), int(hid.dtype == torch.bfloat16), _ptr(obs), obs.stride(0), obs.stride(1), _ptr(p.gidx),
-                                     _ptr(p.comm_c), _ptr(p.h0_c), p.rows, _ptr(row_src), _ptr(p.obs_rows), st), "mapf_plan_rows")
+                                     _ptr(p.comm_c), _ptr(p.h0_c), p.urows, _ptr(row_src), _ptr(p.obs_rows), _ptr(p.dup), _ptr(p.ucnt), _ptr(p.umap),
+                                     _ptr(p.row_tbp), st), "mapf_plan_rows")
         return pl
 
     # ------------------------------------------------------------------ pieces
@@ -267,9 +280,9 @@ class FusedUpdate:
         st = _stream(dev)
         wp, bp = penc.get(net.obs_encoder, net.weights_epoch)
         w, b = prec.get(net)
-        lat = torch.empty((p.rows, 784), dtype=torch.bfloat16, device=dev)
-        check(lib.mapf_encoder_forward(_ptr(p.obs_rows), 1, p.rows, _ptr(wp), _ptr(bp), _ptr(lat), st), "mapf_encoder_forward")
-        gi = mm_rows(lat, self._w_ih(net, own))  # [rows, 768]
+        lat = torch.empty((p.urows, 784), dtype=torch.bfloat16, device=dev)
+        check(lib.mapf_encoder_forward(_ptr(p.obs_rows), 1, p.urows, _ptr(wp), _ptr(bp), _ptr(lat), st), "mapf_encoder_forward")
+        gi = self._expand(mm_rows(lat, self._w_ih(net, own)), p)  # [rows, 768]
         compact = Nc <= RECUR_NARROW_AGENTS  # the <= 48-agent kernels read / write the rows that exist (gidx); the wide ones are dense
         if not compact:
             gi_rows, gi = gi, torch.empty((T, B, Nc, 768), dtype=torch.bfloat16, device=dev)
@@ -279,6 +292,17 @@ class FusedUpdate:
         check(lib.mapf_recurrent_infer(_ptr(gi), _ptr(p.h0_c), _ptr(p.comm_c), _ptr(w), _ptr(b), T, B, Nc, _ptr(h_out), _ptr(a0),
                                        _ptr(p.gidx) if compact else None, p.rows if compact else 0, st), "mapf_recurrent_infer")
         return a0
+
+    def _expand(self, x_u, p):
+        """Rows of the distinct observations [urows, w] -> one row per entry [rows, w] (umap); the identity without duplicate flags."""
+        if p.umap is None:
+            return x_u
+        out = torch.empty((p.rows, x_u.shape[1]), dtype=x_u.dtype, device=x_u.device)
+        check(lib.mapf_rows_scatter(_ptr(x_u), _ptr(p.umap), _ptr(out), p.rows, x_u.shape[1] * x_u.element_size(), 1, _stream(self.dev)),
+              "mapf_rows_scatter")
+        return out
+
+    DEDUP = True  # encode the distinct observations of a batch only (mapf_obs_dup: same agent, consecutive steps, same 486 values)
 
     # ------------------------------------------------------------------ the update
     def usable(self, batch):
@@ -325,15 +349,15 @@ class FusedUpdate:
             if lr.double_q:
                 a0_on2 = self._infer_a0(model, self.packed_on_enc, self.packed_on_recur, pt, True)
         # ---- online network forward, saving what the backward needs ----
-        M = po.rows
+        M, Mu = po.rows, po.urows  # entries of the window set / distinct observations among them
         bf = torch.bfloat16
-        acts = torch.empty((7, M, 7, 7, 128), dtype=bf, device=dev)
-        lat = torch.empty((M, 784), dtype=bf, device=dev)
-        bits = torch.empty((7, M, 49, 4), dtype=torch.int32, device=dev)
-        check(lib.mapf_encoder_forward_save(_ptr(po.obs_rows), 1, M, _ptr(wp), _ptr(bp), _ptr(lat), _ptr(acts), _ptr(bits), st),
+        acts = torch.empty((7, Mu, 7, 7, 128), dtype=bf, device=dev)
+        lat = torch.empty((Mu, 784), dtype=bf, device=dev)
+        bits = torch.empty((7, Mu, 49, 4), dtype=torch.int32, device=dev)
+        check(lib.mapf_encoder_forward_save(_ptr(po.obs_rows), 1, Mu, _ptr(wp), _ptr(bp), _ptr(lat), _ptr(acts), _ptr(bits), st),
               "mapf_encoder_forward_save")
         w_ih = self._w_ih(model, True)
-        gi_rows = mm_rows(lat, w_ih)
+        gi_rows = self._expand(mm_rows(lat, w_ih), po)
         compact = Nc <= RECUR_NARROW_AGENTS
         # rows of the recurrence's saved tensors / gradient outputs: the M rows that exist (compact: the <= 48-agent kernels address
         # them through gidx) or all To x B x Nc (step, window, position) entries (the wide kernels)
@@ -361,7 +385,9 @@ class FusedUpdate:
             for t in (a0_tg, a0_on2):  # allocated on the side stream, consumed on this one
                 if t is not None:
                     t.record_stream(cur)
-            for t in (pt.obs_rows, pt.gidx, pt.comm_c, pt.h0_c):  # allocated on this stream, read on the side stream
+            for t in (pt.obs_rows, pt.gidx, pt.comm_c, pt.h0_c, pt.umap):  # allocated on this stream, read on the side stream
+                if t is None:
+                    continue
                 t.record_stream(side)
         flat.grads.zero_()
         outs = torch.empty((3, B), dtype=torch.float32, device=dev)  # q, q_next, td
@@ -381,8 +407,18 @@ class FusedUpdate:
         idxes, old_ptr = batch[8], batch[10]
         if lr.buffer is not None and idxes is not None:
             lr.buffer.update_priorities(idxes, prio, old_ptr)                                     # worker.py:331 (values known here)
+        pre_ready = None
         if lr.prefetch and own_batch:
-            lr._launch_prefetch()
+            # the next batch is sampled and planned NOW (its priorities are in), on the second stream: ~0.5 ms of small kernels that
+            # fit beside the backward-through-time kernel (192 workgroups on 256 CUs) instead of in front of it
+            if lr._side is not None:
+                lr._side.wait_stream(cur)
+                with torch.cuda.stream(lr._side):
+                    lr._launch_prefetch()
+                    pre_ready = torch.cuda.Event()
+                    pre_ready.record(lr._side)
+            else:
+                lr._launch_prefetch()
         # ---- backward through time ----
         outs_b = [torch.empty((R, 768), dtype=bf, device=dev), torch.empty((R, 768), dtype=bf, device=dev),
                   torch.empty((2, R, 768), dtype=bf, device=dev), torch.empty((2, R, 768), dtype=bf, device=dev),
@@ -413,15 +449,25 @@ class FusedUpdate:
         else:
             d_gi_rows = torch.empty((M, 768), dtype=bf, device=dev)
             check(lib.mapf_rows_scatter(_ptr(d_gi_rows), _ptr(po.gidx), _ptr(d_gi1), R, 1536, 0, st), "mapf_rows_scatter")
+        if po.umap is not None:  # gradient of a shared row = the sum over the entries that use it
+            d_gi_u = torch.empty((Mu, 768), dtype=bf, device=dev)
+            check(lib.mapf_dedup_sum(To, B, Nc, M, 1536, _ptr(po.gidx), _ptr(po.umap), _ptr(po.row_tbp), _ptr(d_gi_rows), _ptr(d_gi_u), st),
+                  "mapf_dedup_sum")
+            d_gi_rows = d_gi_u
         g_lat = mm_rows(d_gi_rows, w_ih, transpose_w=False)
         _tall_tn_into(flat.mem(G, "recurrent.weight_ih"), d_gi_rows, lat, rows=4096)
         # ---- encoder: backward-data chain in one kernel, then the weight-gradient kernels ----
-        self._encoder_backward(po.obs_rows, M, acts, lat, bits, g_lat, wpt)
+        self._encoder_backward(po.obs_rows, Mu, acts, lat, bits, g_lat, wpt)
         # ---- the only collective, clip, Adam ----
         lr.bucket.all_reduce_mean()
         if lr.grad_hook is not None:
             lr.grad_hook(lr)
         grad_norm = flat.adam_step(lr.current_lr())
+        if pre_ready is not None:
+            # everything the caller enqueues from here on (the next update; an actor step that appends to the replay) is ordered behind
+            # the sample.  Memory: the prefetched tensors come from the second stream's pool and are consumed on this one -- safe without
+            # record_stream because every use of the second stream starts with wait_stream(this one)
+            cur.wait_event(pre_ready)
         return dict(loss=loss[0], td=outs[2].view(B, 1), priorities=prio, grad_norm=grad_norm, q=outs[0].view(B, 1), q_next=outs[1].view(B, 1))
 
     def _encoder_backward(self, obs_rows, M, acts, lat, bits, g_lat, wpt):

@@ -32,7 +32,7 @@ def _plan_mark(comm, steps, extra=None, mark_all=0, want_rel=True):
     cnt = torch.empty(B, dtype=torch.int32, device="cuda")
     nag = torch.empty(B, dtype=torch.int32, device="cuda")
     check(lib.mapf_plan_mark(_p(cm), cm.stride(0), cm.stride(1), _p(steps), _p(extra), T, B, N, mark_all, _p(rel), _p(slot), _p(order), _p(nact),
-                             _p(cnt), _p(nag), None), "mapf_plan_mark")
+                             _p(cnt), _p(nag), None, None), "mapf_plan_mark")
     torch.cuda.synchronize()
     return rel, slot, order, nact, cnt, nag
 
@@ -100,7 +100,7 @@ def test_plan_rows_compact_layout(B, T, N, p, tm):
     row_src = torch.empty(rows, dtype=torch.int64, device="cuda")
     cm = comm.view(torch.uint8)
     check(lib.mapf_plan_rows(T, B, N, Nc, _p(order), _p(nact), _p(cnt), _p(nag), _p(cm), cm.stride(0), cm.stride(1), _p(hidden), 0, _p(obs),
-                             obs.stride(0), obs.stride(1), _p(gidx), _p(comm_c), _p(h0_c), rows, _p(row_src), _p(obs_rows), None), "mapf_plan_rows")
+                             obs.stride(0), obs.stride(1), _p(gidx), _p(comm_c), _p(h0_c), rows, _p(row_src), _p(obs_rows), None, None, None, None, None), "mapf_plan_rows")
     torch.cuda.synchronize()
     G, O, NA = gidx.cpu().numpy(), order.cpu().numpy().astype(np.int64), nact.cpu().numpy()
     flat = [G[t, b, i] for b in range(B) for t in range(T) for i in range(NA[t, b])]
@@ -380,7 +380,7 @@ def test_recurrence_kernels_compact_rows_equal_dense_rows(B, T, N, p):
     hidden = (torch.randn((B * N, 256), device="cuda", generator=g) * 0.3).to(torch.float16)
     cm = comm.view(torch.uint8)
     check(lib.mapf_plan_rows(T, B, N, Nc, _p(order), _p(nact), _p(cnt), _p(nag), _p(cm), cm.stride(0), cm.stride(1), _p(hidden), 0, None, 0, 0,
-                             _p(gidx), _p(comm_c), _p(h0_c), 0, None, None, None), "mapf_plan_rows")
+                             _p(gidx), _p(comm_c), _p(h0_c), 0, None, None, None, None, None, None, None), "mapf_plan_rows")
     gi_rows = (torch.randn((rows, 768), device="cuda", generator=g) * 0.5).to(torch.bfloat16)
     gi_dense = torch.empty((T, B, Nc, 768), dtype=torch.bfloat16, device="cuda")
     check(lib.mapf_rows_scatter(_p(gi_rows), _p(gidx), _p(gi_dense), T * B * Nc, 1536, 1, None), "mapf_rows_scatter")
@@ -425,3 +425,104 @@ def test_recurrence_kernels_compact_rows_equal_dense_rows(B, T, N, p):
     mask[sel] = False
     for d in out_d[:6]:
         assert not d[:, mask].float().abs().any()
+
+
+@pytest.mark.parametrize("B,T,N,p", [(24, 18, 40, 0.05), (4, 18, 128, 0.02), (7, 5, 3, 0.5)])
+def test_repeated_observations_are_found_numbered_and_summed(B, T, N, p):
+    """mapf_obs_dup / mapf_plan_rows(dup) / mapf_dedup_sum: an entry that carries the same 486 values as the same agent one step earlier
+    shares its row of distinct observations -- obs_rows[umap[r]] is entry r's observation for EVERY entry --, the distinct rows are
+    counted per window for both closures, and the gradient of a shared row is the sum over its entries."""
+    from mapf_rl_amd._lib import check, lib
+
+    comm, steps, g = _random_windows(B, T, N, p, 21 + N, True)
+    To = T - 2
+    bt = torch.clamp(steps, max=To)
+    extra = torch.randint(1, 3, (B,), device="cuda", generator=g).float()
+    cm = comm.view(torch.uint8)
+    plans = []
+    ucnt = torch.full((2, B), 77, dtype=torch.int32, device="cuda")  # (zeroed by plan_mark)
+    for k, (Tk, ex) in enumerate(((To, None), (T, extra))):
+        slot = torch.empty((B, N), dtype=torch.int16, device="cuda")
+        order = torch.empty((B, N), dtype=torch.int16, device="cuda")
+        nact = torch.empty((Tk, B), dtype=torch.int32, device="cuda")
+        cnt = torch.empty(B, dtype=torch.int32, device="cuda")
+        nag = torch.empty(B, dtype=torch.int32, device="cuda")
+        rel = torch.empty((Tk, B, N), dtype=torch.uint8, device="cuda")
+        check(lib.mapf_plan_mark(_p(cm), cm.stride(0), cm.stride(1), _p(bt), _p(ex), Tk, B, N, 0, _p(rel), _p(slot), _p(order), _p(nact), _p(cnt), _p(nag),
+                                 _p(ucnt[k]), None), "mapf_plan_mark")
+        plans.append((Tk, slot, order, nact, cnt, nag, rel))
+    obs = torch.rand((T, B, N, 486), device="cuda", generator=g).to(torch.bfloat16)
+    rep = torch.rand((T, B, N), device="cuda", generator=g) < 0.5
+    for t in range(1, T):  # runs of identical observations of the same agent
+        obs[t] = torch.where(rep[t].unsqueeze(-1), obs[t - 1], obs[t])
+    obs = obs.transpose(0, 1)  # [B, T, N, 486] view of time-major memory
+    dup = torch.empty((T, B, N), dtype=torch.uint8, device="cuda")
+    check(lib.mapf_obs_dup(T, To, B, N, _p(obs), obs.stride(0), obs.stride(1), _p(plans[0][1]), _p(plans[1][1]), _p(plans[0][3]), _p(plans[1][3]), _p(dup),
+                           _p(ucnt[0]), _p(ucnt[1]), None), "mapf_obs_dup")
+    torch.cuda.synchronize()
+    same = torch.zeros((T, B, N), dtype=torch.bool, device="cuda")
+    same[1:] = (obs.transpose(0, 1)[1:] == obs.transpose(0, 1)[:-1]).all(dim=-1)
+    rel_t = plans[1][6].bool()
+    assert torch.equal(dup.bool() & rel_t, same & rel_t) and not (dup.bool() & ~rel_t).any()
+    for k in range(2):
+        Tk, rel = plans[k][0], plans[k][6].bool()
+        assert torch.equal(ucnt[k].long(), (rel & ~same[:Tk]).sum(dim=(0, 2)))
+    hidden = torch.zeros((B * N, 256), dtype=torch.float16, device="cuda")
+    for k in range(2):
+        Tk, slot, order, nact, cnt, nag, rel = plans[k]
+        Nc = 16 * -(-int(nag.max()) // 16)
+        rows, urows = int(cnt.sum()), int(ucnt[k].sum())
+        gidx = torch.empty((Tk, B, Nc), dtype=torch.int32, device="cuda")
+        comm_c = torch.empty((Tk, B, Nc, Nc), dtype=torch.uint8, device="cuda")
+        h0_c = torch.empty((B, Nc, 256), dtype=torch.bfloat16, device="cuda")
+        obs_u = torch.empty((urows, 486), dtype=torch.bfloat16, device="cuda")
+        row_src = torch.empty(urows, dtype=torch.int64, device="cuda")
+        umap = torch.empty(rows, dtype=torch.int32, device="cuda")
+        tbp = torch.empty(rows, dtype=torch.int32, device="cuda")
+        check(lib.mapf_plan_rows(Tk, B, N, Nc, _p(order), _p(nact), _p(cnt), _p(nag), _p(cm), cm.stride(0), cm.stride(1), _p(hidden), 0, _p(obs),
+                                 obs.stride(0), obs.stride(1), _p(gidx), _p(comm_c), _p(h0_c), urows, _p(row_src), _p(obs_u), _p(dup), _p(ucnt[k]), _p(umap),
+                                 _p(tbp), None), "mapf_plan_rows")
+        torch.cuda.synchronize()
+        # every entry finds its own observation in the distinct rows, and the distinct rows are all used, in order of first use
+        G, O = gidx.cpu().numpy(), order.cpu().numpy().astype(np.int64)
+        um, tb = umap.cpu().numpy(), tbp.cpu().numpy()
+        ob, ou = obs.float().cpu().numpy(), obs_u.float().cpu().numpy()
+        assert um.min() == 0 and um.max() == urows - 1 and len(np.unique(um)) == urows
+        first = np.sort(np.unique(um, return_index=True)[1])
+        assert np.array_equal(um[first], np.arange(urows))
+        for r in range(0, rows, max(1, rows // 400)):
+            t, i, b = tb[r] >> 24, (tb[r] >> 16) & 255, tb[r] & 0xFFFF
+            assert G[t, b, i] == r and np.array_equal(ou[um[r]], ob[b, t, O[b, i]])
+        # gradient of a shared row
+        d_rows = (torch.randn((rows, 768), device="cuda", generator=g) * 0.3).to(torch.bfloat16)
+        d_u = torch.empty((urows, 768), dtype=torch.bfloat16, device="cuda")
+        check(lib.mapf_dedup_sum(Tk, B, Nc, rows, 1536, _p(gidx), _p(umap), _p(tbp), _p(d_rows), _p(d_u), None), "mapf_dedup_sum")
+        want = torch.zeros((urows, 768), device="cuda").index_add_(0, umap.long(), d_rows.float())
+        assert torch.allclose(d_u.float(), want, rtol=1e-2, atol=1e-2) and float((d_u.float() - want).abs().max()) <= 0.02 * float(want.abs().max())
+
+
+def test_fused_update_with_and_without_observation_reuse():
+    """update.FusedUpdate.DEDUP: encoding every entry or the distinct observations only gives the same forward bits (the latent of a
+    repeated observation is a copy) and the same gradients up to the order of sums."""
+    from mapf_rl_amd.update import FusedUpdate
+
+    z = H.load_npz("dqn_big.npz")
+    res = {}
+    try:
+        for dedup in (False, True):
+            FusedUpdate.DEDUP = dedup
+            lr = _models("cuda")
+            grads = _grads_of(lr)
+            b = BG.batch(z, "b40", "cuda", torch.bfloat16)
+            obs = b[0].clone()
+            obs[:, 5:9] = obs[:, 4:5]   # steps 4..8 of every window: nobody's observation changes -> runs of 5
+            out = lr.update((obs,) + b[1:])
+            torch.cuda.synchronize()
+            res[dedup] = (out, grads, lr._fused)
+    finally:
+        FusedUpdate.DEDUP = True
+    (o0, g0, _), (o1, g1, _) = res[False], res[True]
+    assert torch.equal(o0["td"], o1["td"]) and torch.equal(o0["q"], o1["q"]) and float(o0["loss"]) == float(o1["loss"])
+    tot = float(torch.sqrt(sum((v ** 2).sum() for v in g0.values())))
+    for k in g0:
+        assert float((g0[k] - g1[k]).norm()) <= 1e-2 * float(g0[k].norm()) + 1e-3 * tot, k
