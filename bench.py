@@ -65,7 +65,7 @@ def parse_args(argv=None):
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) on real multi-GPU runs; gloo only to "
                     "exercise the multi-rank code path on a single GPU (set MAPF_BENCH_SHARE_GPU=1)")
     ap.add_argument("--dqn-updates", type=int, default=20)
-    ap.add_argument("--dqn-actor-iters", type=int, default=5)
+    ap.add_argument("--dqn-actor-iters", type=int, default=12)
     ap.add_argument("--train-iters", type=int, default=10, help="interleaved actor-step + learner-update iterations")
     return ap.parse_args(argv)
 
@@ -387,15 +387,42 @@ def main():
             cap = 1 << (2 * E - 1).bit_length()
             buf = GlobalBuffer(cap, max_agents=max(N, 6), device=dev, init_set=(N, args.map), fixed_level=True)
             learner = Learner(buf, device=dev, batch_size=192)
-            actor = VecActor(env, learner.model, buf, seed=rank, density=args.density)
+            import config as ref_config
+
+            # the actor acts on a snapshot of the learner's weights pulled every config.actor_update_steps = 400 iterations, as the
+            # reference's actors do (worker.py:416-420) and as train.py runs it
+            actor = VecActor(env, learner.model, buf, seed=rank, density=args.density, weights_period=ref_config.actor_update_steps)
             for _ in range(260):
                 actor.step(actions_override=heuristic_actions(actor.obs, gen).long())
             torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.dqn_actor_iters):
-                actor.step()
-            torch.cuda.synchronize()
-            dt_act = (time.perf_counter() - t1) / args.dqn_actor_iters
+
+            def timed_actor(tape, iters):
+                """ms per actor iteration + share of agent rows the encoder saw (an unchanged observation keeps its latent)."""
+                enc = 0
+                for _ in range(24):  # untimed: let the population of moving / standing agents settle under this policy
+                    actor.step(actions_override=heuristic_actions(actor.obs, gen).long() if tape else None)
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                for _ in range(iters):
+                    actor.step(actions_override=heuristic_actions(actor.obs, gen).long() if tape else None)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t_) / iters
+                if actor.latents is not None:  # (a second, untimed pass for the statistic: reading the device counter synchronises)
+                    for _ in range(4):
+                        actor.step(actions_override=heuristic_actions(actor.obs, gen).long() if tape else None)
+                        enc += actor.latents.last_encoded()
+                    return dt, enc / (4.0 * E * N)
+                return dt, 1.0
+
+            # moving agents (the tape policy's actions are executed; the network's forward runs all the same), then the loop as
+            # worker.py:376-414 runs it: the network's own greedy actions -- under random-init weights most agents stand still
+            dt_act_tape, enc_tape = timed_actor(True, args.dqn_actor_iters)
+            dt_act, enc_greedy = timed_actor(False, args.dqn_actor_iters)
+            cache, actor.latents = actor.latents, None  # the same loop encoding every agent row every step
+            dt_act_all, _ = timed_actor(False, args.dqn_actor_iters)
+            actor.latents = cache
+            if cache is not None:
+                cache.key = None
             assert len(buf) >= 192 * 18, "the actor loop did not fill the replay"
 
             def timed_updates():
@@ -412,15 +439,23 @@ def main():
                     dist.barrier()
                 return (time.perf_counter() - t_) / args.dqn_updates
 
+            from mapf_rl_amd.update import FusedUpdate
+
             dt_upd = timed_updates()
-            Network.PRUNE_UNREACHABLE = False  # the same update with every observation of the window encoded (as the reference does)
+            # the same update with EVERY observation of the window through the encoder, as the reference does: no pruning of the
+            # entries that cannot reach agent 0's Q-value, no reuse of repeated observations
+            Network.PRUNE_UNREACHABLE, FusedUpdate.DEDUP = False, False
             learner._drop_prefetch()
             dt_upd_all = timed_updates()
-            Network.PRUNE_UNREACHABLE = True
+            Network.PRUNE_UNREACHABLE, FusedUpdate.DEDUP = True, True
             learner._drop_prefetch()
             probe = buf.sample_batch(192)
             reach = float(relevance(probe[7][:, :-2], probe[5]).float().mean())
             reach_min = reach_max = reach
+            distinct = 1.0
+            if learner._fused is not None:
+                pl = learner._fused._finish_plan(learner._fused.plan(probe))
+                distinct = pl["online"].urows / max(1, pl["online"].rows)
             # interleaved: the loop train.py runs (one update per actor iteration)
             actor.step()
             learner.update()
@@ -437,9 +472,9 @@ def main():
             dt_train = (time.perf_counter() - t1) / args.train_iters
             env.check_status()
             if world > 1:
-                tt = torch.tensor([dt_upd, dt_act, dt_train, dt_upd_all], dtype=torch.float64, device=dev)
+                tt = torch.tensor([dt_upd, dt_act, dt_train, dt_upd_all, dt_act_tape, dt_act_all], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dt_upd, dt_act, dt_train, dt_upd_all = [float(v) for v in tt.tolist()]
+                dt_upd, dt_act, dt_train, dt_upd_all, dt_act_tape, dt_act_all = [float(v) for v in tt.tolist()]
                 # the pruned update's encoder batch is data-dependent, hence per rank: make the spread visible
                 rmm = torch.tensor([reach, -reach], dtype=torch.float64, device=dev)
                 dist.all_reduce(rmm, op=dist.ReduceOp.MAX)
@@ -462,14 +497,27 @@ def main():
                 "learner_ms_per_update_all_observations": dt_upd_all * 1e3,
                 "learner_reachable_fraction": reach, "learner_reachable_fraction_min": reach_min,
                 "learner_reachable_fraction_max": reach_max,
+                "learner_distinct_fraction": distinct,
                 "learner_note": "only agent 0's Q-value is learned from (reference model.py:248): an update encodes the observations that can "
-                                "reach it through the communication masks (same Q-values bit for bit, tests/test_relevance_gpu.py); "
-                                "learner_ms_per_update_all_observations = the same update encoding every observation of the window",
+                                "reach it through the communication masks (learner_reachable_fraction of the window; same Q-values, "
+                                "tests/test_relevance_gpu.py), and of those only the DISTINCT ones (learner_distinct_fraction: an agent that "
+                                "stands still in an unchanged neighbourhood repeats its observation; same forward bits, tests/test_update_gpu.py); "
+                                "learner_ms_per_update_all_observations = the same update with every observation of the window through the "
+                                "encoder, as the reference does",
                 "learner_config": "B=192 x T=18 x A=%d windows per rank from the device replay (episodes of the actor loop under the tape policy), bf16 autocast, Adam, %s" % (
                     N, "flat-bucket RCCL all-reduce x%d (synchronous data parallel: this is the job's update rate, global batch %d)" % (
                         world, 192 * world) if world > 1 else "1 GPU"),
                 "actor_loop_env_steps_per_sec": world * E / dt_act, "actor_loop_ms_per_iter": dt_act * 1e3,
-                "actor_loop_config": "Network.step_batch (bf16) + mapf_step + local-buffer recording + episode flush into the device replay, %d envs x %d agents per GPU" % (E, N),
+                "actor_loop_rows_encoded_fraction": enc_greedy,
+                "actor_loop_tape_policy_env_steps_per_sec": world * E / dt_act_tape, "actor_loop_tape_policy_ms_per_iter": dt_act_tape * 1e3,
+                "actor_loop_tape_policy_rows_encoded_fraction": enc_tape,
+                "actor_loop_every_row_ms_per_iter": dt_act_all * 1e3, "actor_loop_every_row_env_steps_per_sec": world * E / dt_act_all,
+                "actor_loop_note": "an agent whose 6x9x9 observation did not change since the previous step keeps its latent (the encoder is "
+                                   "a deterministic per-observation function: same bits, tests/test_actor_gpu.py), so the rate depends on how many "
+                                   "agents move: actor_loop_* = the network's own greedy actions (random-init weights: most agents stand), "
+                                   "actor_loop_tape_policy_* = the bench tape's 80 %% heuristic-following actions executed instead, "
+                                   "actor_loop_every_row_* = every agent row through the encoder every step (round 2's loop)",
+                "actor_loop_config": "Network.step_batch (bf16) + mapf_step + local-buffer recording + episode flush into the device replay, %d envs x %d agents per GPU; weights snapshot pulled every %d iterations (config.actor_update_steps)" % (E, N, ref_config.actor_update_steps),
                 "train_loop_updates_per_sec": 1.0 / dt_train, "train_loop_env_steps_per_sec": world * E / dt_train,
                 "train_loop_ms_per_iter": dt_train * 1e3,
                 "train_loop_config": "one actor iteration (%d envs/GPU) + one learner update per iteration, same stream order as train.py" % E,

@@ -55,6 +55,15 @@ int mapf_encoder_pack(const float *const *w_dev, const float *const *b_dev, int 
 int mapf_encoder_forward(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev,
                          const float *bias_dev, uint16_t *latent_dev, void *stream);
 
+/*
+ * The same for LISTED rows only: observation i (i < *row_count_dev <= max_rows; the count is read on the device) of obs_dev
+ * u8 [*row_count][486] is encoded into row row_index[i] of latent_dev; every other row of latent_dev is left as it is.  For the
+ * actor loop: an agent whose observation did not change since the previous step keeps its latent (the encoder is a deterministic
+ * per-observation function), and the host never learns how many changed (include/mapf_replay.h: mapf_obs_changed).
+ */
+int mapf_encoder_forward_rows(const uint8_t *obs_dev, int64_t max_rows, const int32_t *row_index_dev, const int32_t *row_count_dev,
+                              const uint16_t *packed_dev, const float *bias_dev, uint16_t *latent_dev, void *stream);
+
 /* Training forward: the same kernel, additionally storing what the backward pass needs:
  *   acts_dev bf16 [7][M][7][7][128] (NHWC) the 7 post-ReLU layer outputs, in order conv0, res1.block1, res1,
  *            res2.block1, res2, res3.block1, res3 -- the inputs of the weight gradients (16-byte aligned);

@@ -57,6 +57,7 @@ SYMBOLS = [
     ("mapf_actor_record", _i, [_i] * 6 + [_vp] * 16),
     ("mapf_actor_rewind", _i, [_i] * 5 + [_vp] * 6),
     ("mapf_actor_log", _i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    ("mapf_obs_changed", _i, [_vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     ("mapf_replay_sample", _i, [_vp, _vp, _i, _i] + [_vp] * 12),
     ("mapf_replay_update_priorities", _i, [_vp, _vp, _vp, _i, _vp, _vp]),
     # include/mapf_dqn.h
@@ -69,6 +70,7 @@ SYMBOLS = [
     ("mapf_window_relevance", _i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     ("mapf_encoder_pack", _i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _vp, _vp, _vp]),
     ("mapf_encoder_forward", _i, [_vp, _i, ctypes.c_int64, _vp, _vp, _vp, _vp]),
+    ("mapf_encoder_forward_rows", _i, [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_encoder_pack_bwd", _i, [ctypes.POINTER(_vp), _i, _vp, _vp]),
     ("mapf_encoder_backward_data", _i, [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_encoder_wgrad0", _i, [_vp, _vp, _i, ctypes.c_int64, _vp, _vp]),

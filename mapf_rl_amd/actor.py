@@ -56,9 +56,27 @@ def pack_comm_device(comm, cw):
 
 
 class VecActor:
+    REUSE_LATENTS = True  # encode only the agents whose observation changed since the previous step (fused.LatentCache: exact)
+
     def __init__(self, env: VecEnvironment, model, buffer, epsilons=None, max_steps=MAX_STEPS, seed=0, density=-1.0,
-                 keep_flushed=False, on_device_reset=True):
-        self.env, self.model, self.buffer = env, model, buffer
+                 keep_flushed=False, on_device_reset=True, weights_period=None):
+        """weights_period (reference config.actor_update_steps = 400, worker.py:416-420: an actor pulls the learner's weights every
+        400 steps and acts on that snapshot in between): None = act on `model` itself (always the newest weights); an integer =
+        keep an own copy of the network, refreshed from `model` every that many steps -- the reference's semantics, and what keeps
+        the latents of unchanged observations reusable from step to step while the learner updates `model`."""
+        self.env, self.buffer = env, buffer
+        self.source_model, self.weights_period = model, weights_period
+        if weights_period is not None:
+            from copy import deepcopy
+
+            model = deepcopy(model)
+            for p in model.parameters():
+                p.requires_grad_(False)
+        self.model = model
+        self._since_pull = 0
+        from .fused import LatentCache
+
+        self.latents = LatentCache() if (self.REUSE_LATENTS and env.device.type == "cuda") else None
         E, N = env.num_envs, env.num_agents
         d = env.device
         self.E, self.N, self.device, self.max_steps, self.density = E, N, d, max_steps, density
@@ -109,14 +127,32 @@ class VecActor:
     def step(self, actions_override=None):
         """One lock-step iteration.  `actions_override` (int tensor [E, N], tests only): the joint action to execute instead of
         the policy's (teacher forcing along a recorded trajectory); the policy's own greedy actions stay in `last_policy_actions`."""
-        E, N, d = self.E, self.N, self.device
-        if self.pos.dtype == torch.int16 and N <= 128:  # mask + the replay's packed comm row from one kernel
+        comm, comm_packed = self.policy_inputs()
+        self.pull_weights()
+        actions, q, hidden, comm = self.model.step_batch(self.obs, self.pos, self.hidden, comm, cache=self.latents)
+        return self.act(actions, q, hidden, comm, comm_packed, actions_override)
+
+    def pull_weights(self):
+        """worker.py:416-420: with `weights_period` the actor acts on its own snapshot, refreshed every that many steps."""
+        if self.weights_period is not None:
+            if self._since_pull >= self.weights_period:
+                self.model.load_state_dict(self.source_model.state_dict())
+                self._since_pull = 0
+            self._since_pull += 1
+
+    def policy_inputs(self):
+        """(comm mask bool [E, N, N], the replay's packed comm rows) of the current positions (reference model.py:195-208)."""
+        if self.pos.dtype == torch.int16 and self.N <= 128:  # mask + the replay's packed comm row from one kernel
             from .fused import comm_mask
 
-            comm, comm_packed = comm_mask(self.pos, packed_words=self.CW)
-        else:
-            comm, comm_packed = None, None
-        actions, q, hidden, comm = self.model.step_batch(self.obs, self.pos, self.hidden, comm)
+            return comm_mask(self.pos, packed_words=self.CW)
+        return None, None
+
+    @torch.no_grad()
+    def act(self, actions, q, hidden, comm, comm_packed, actions_override=None):
+        """Everything of an iteration behind the policy's forward (worker.py:380-414): exploration, environment step, recording,
+        episode flush.  actions int64 [E, N], q f32 [E, N, 5], hidden bf16 [E*N, 256] as Network.step_batch returns them."""
+        E, N, d = self.E, self.N, self.device
         self.last_policy_actions = actions.clone()
         # worker.py:380-382: only agent 0 of an environment explores
         explore = torch.rand(E, device=d, generator=self.gen, dtype=torch.float64) < self.eps

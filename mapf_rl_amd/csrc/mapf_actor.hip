@@ -123,6 +123,65 @@ __global__ void __launch_bounds__(1024) actor_log_kernel(int E, const uint8_t *f
     }
 }
 
+// Which agents see something new: a row (486-byte observation) that differs from the copy of the step before is appended to the
+// list (order does not matter: every row is encoded independently) and the copy is refreshed.  One wavefront per PAIR of rows: two
+// rows are 972 bytes = 243 dwords starting on a 4-byte boundary (a single row of odd index does not), dword 121 straddles them.
+__global__ void __launch_bounds__(256) obs_changed_kernel(const uint32_t *__restrict__ obs, uint32_t *__restrict__ prev, long long rows,
+                                                          int32_t *__restrict__ list, int32_t *__restrict__ count, uint16_t *__restrict__ packed) {
+    const int lane = threadIdx.x & 63;
+    const long long pairs = (rows + 1) >> 1;
+    for (long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); q < pairs; q += (long long)gridDim.x * 4) {
+        const bool two = 2 * q + 1 < rows;
+        const int nd = two ? 243 : 122;  // a last single row: 121.5 dwords (its buffer ends on a 2-byte boundary: handled below)
+        const uint32_t *cur = obs + q * 243;
+        uint32_t *old = prev + q * 243;
+        uint32_t v[4], o[4];
+        bool d0 = false, d1 = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int d = lane + 64 * k;
+            v[k] = o[k] = 0u;
+            if (d < nd) {
+                if (!two && d == 121) {  // only the low half exists
+                    v[k] = reinterpret_cast<const uint16_t *>(cur)[242];
+                    o[k] = reinterpret_cast<const uint16_t *>(old)[242];
+                } else {
+                    v[k] = cur[d];
+                    o[k] = old[d];
+                }
+                const uint32_t x = v[k] ^ o[k];
+                d0 |= d < 121 ? x != 0u : (d == 121 && (x & 0xFFFFu) != 0u);
+                d1 |= d > 121 ? x != 0u : (d == 121 && (x >> 16) != 0u);
+            }
+        }
+        const bool c0 = __ballot(d0) != 0ull, c1 = two && __ballot(d1) != 0ull;
+        if (c0 | c1) {
+            int base = 0;
+            if (lane == 0) {
+                base = atomicAdd(count, (int)c0 + (int)c1);
+                if (c0) list[base] = (int32_t)(2 * q);
+                if (c1) list[base + (int)c0] = (int32_t)(2 * q + 1);
+            }
+            if (packed) {  // the changed rows back to back, in list order: what mapf_encoder_forward_rows reads
+                base = __shfl(base, 0, 64);
+                const uint16_t *c16 = reinterpret_cast<const uint16_t *>(cur);
+                for (int k = lane; k < 243; k += 64) {
+                    if (c0) packed[(long long)base * 243 + k] = c16[k];
+                    if (c1) packed[(long long)(base + (int)c0) * 243 + k] = c16[243 + k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int d = lane + 64 * k;
+                if (d < nd && v[k] != o[k]) {
+                    if (!two && d == 121) reinterpret_cast<uint16_t *>(old)[242] = (uint16_t)v[k];
+                    else old[d] = v[k];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -151,6 +210,20 @@ int mapf_actor_rewind(int num_envs, int num_agents, int local_steps, int env_row
         return MAPF_ERR_INVALID_ARG;
     RewindParams p{num_envs, num_agents, local_steps, env_row_dwords, row_dwords, finished_dev, obs_bits_dev, t_dev, lb_obs_dev, hidden_dev};
     hipLaunchKernelGGL(actor_rewind_kernel, dim3(num_envs), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
+}
+
+int mapf_obs_changed(const uint8_t *obs_dev, uint8_t *prev_dev, int64_t rows, int32_t *list_dev, int32_t *count_dev, uint8_t *packed_dev, void *stream) {
+    if (rows < 0 || !obs_dev || !prev_dev || !list_dev || !count_dev || (reinterpret_cast<uintptr_t>(obs_dev) & 3) || (reinterpret_cast<uintptr_t>(prev_dev) & 3) ||
+        (reinterpret_cast<uintptr_t>(packed_dev) & 3))
+        return MAPF_ERR_INVALID_ARG;
+    if (rows == 0) return MAPF_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(count_dev, 0, 4, s) != hipSuccess) return MAPF_ERR_HIP;
+    long long blocks = ((rows + 1) / 2 + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(obs_changed_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(obs_dev),
+                       reinterpret_cast<uint32_t *>(prev_dev), (long long)rows, list_dev, count_dev, reinterpret_cast<uint16_t *>(packed_dev));
     return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
 }
 

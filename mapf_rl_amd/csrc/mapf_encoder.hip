@@ -179,11 +179,20 @@ __device__ __forceinline__ void save_rows(const unsigned char *act, uint16_t *__
     }
 }
 
-template <typename InT, bool SAVE>
+template <typename InT, bool SAVE, bool IDX = false>
 __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__restrict__ obs, long long M,
                                                           const uint16_t *__restrict__ wp, const float *__restrict__ bias,
                                                           uint16_t *__restrict__ out, uint16_t *__restrict__ save,
-                                                          uint32_t *__restrict__ relu_bits) {
+                                                          uint32_t *__restrict__ relu_bits, const int32_t *__restrict__ row_index,
+                                                          const int32_t *__restrict__ row_count) {
+    // IDX (inference only): `obs` holds *row_count <= M observations back to back (the count is read from device memory) and the
+    // latent of observation i goes to row row_index[i] of `out` -- the actor loop re-encodes only the agents whose observation
+    // changed since the previous step (mapf_obs_changed packs them), without the host knowing how many.
+    // The grid is a fixed number of workgroups that WALK the list (a grid of max_rows / 4 workgroups that mostly return at once cost
+    // 2 ms at 163,840 rows: every one of them is a 76-KB-LDS workgroup to place).
+    if constexpr (IDX) M = min(M, (long long)*row_count);
+    if constexpr (IDX)
+        if ((long long)blockIdx.x * G >= M) return;
     __shared__ __attribute__((aligned(16))) unsigned char smem[ACT_BYTES + RAW_BYTES];
     unsigned char *const act = smem;
     const InT *const raw = reinterpret_cast<const InT *>(smem + ACT_BYTES);
@@ -191,7 +200,14 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int cb = w;
     const int lr = lane & 15, lh = lane >> 4;
-    const long long obs0 = (long long)blockIdx.x * G;
+  for (long long wg = blockIdx.x;; wg += gridDim.x) {  // (one pass unless IDX)
+    // IDX: an opaque zero (the row count is never negative) added to the weight / bias bases -- otherwise every layer's per-lane
+    // weight address is loop-invariant, gets hoisted in front of the walk and spilled (44 registers in scratch)
+    int z = 0;
+    if constexpr (IDX) z = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int32_t *>(row_count) >> 31);
+    const uint16_t *const wpz = wp + z;
+    const float *const biasz = bias + z;
+    const long long obs0 = wg * G;
     const long long left = M - obs0;
     const int nobs = left < G ? (int)left : G;  // >= 1 by the grid size
 
@@ -233,7 +249,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
 
     f32x4 acc[2][NT];
     uint32_t nib[NT];  // training forward: this lane's ReLU sign nibbles of the layer being finished
-    const float *bl = bias;
+    const float *bl = biasz;
     const int co_lane = cb * 32 + 4 * lh;  // + 16*a: first of this lane's 4 output channels
 
     // =========================== conv0: 6 -> 128, 3x3 valid on 9x9 (K = 54 -> 64) ===========================
@@ -242,7 +258,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const bf16x8 *wv = reinterpret_cast<const bf16x8 *>(wp + WP_L0) + (2 * cb) * 64 + lane;
+        const bf16x8 *wv = reinterpret_cast<const bf16x8 *>(wpz + WP_L0) + (2 * cb) * 64 + lane;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const bf16x8 a0 = wv[(s * 8 + 0) * 64];
@@ -288,7 +304,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
 
     // =========================== 3 residual blocks ===========================
     for (int blk = 0; blk < 3; ++blk) {
-        const bf16x8 *wv1 = reinterpret_cast<const bf16x8 *>(wp + WP_RES + (2 * blk) * WP_RES_SIZE) + (2 * cb) * 64 + lane;
+        const bf16x8 *wv1 = reinterpret_cast<const bf16x8 *>(wpz + WP_RES + (2 * blk) * WP_RES_SIZE) + (2 * cb) * 64 + lane;
         const bf16x8 *wv2 = wv1 + WP_RES_SIZE / 8;
         // ---- block1: t = relu(conv(x) + b1) ----
 #pragma unroll
@@ -340,7 +356,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
 
     // =========================== conv 1x1: 128 -> 16, ReLU, NCHW flatten ===========================
     {
-        const bf16x8 *wv = reinterpret_cast<const bf16x8 *>(wp + WP_L7) + lane;
+        const bf16x8 *wv = reinterpret_cast<const bf16x8 *>(wpz + WP_L7) + lane;
         bf16x8 a7[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) a7[s] = wv[s * 64];
@@ -355,7 +371,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
             for (int s = 0; s < 4; ++s)
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a7[s], *reinterpret_cast<const bf16x8 *>(rowp + s * 64), c, 0, 0, 0);
             if (v) {
-                uint16_t *dst = out + (obs0 + o) * 784 + (4 * lh) * 49 + q;  // latent[obs][co*49 + y*7 + x]
+                const long long orow = IDX ? (long long)row_index[obs0 + o] : obs0 + o;
+                uint16_t *dst = out + orow * 784 + (4 * lh) * 49 + q;  // latent[obs][co*49 + y*7 + x]
                 dst[0] = (uint16_t)f32_to_bf16_bits(fmaxf(c[0] + b4.x, 0.f));
                 dst[49] = (uint16_t)f32_to_bf16_bits(fmaxf(c[1] + b4.y, 0.f));
                 dst[98] = (uint16_t)f32_to_bf16_bits(fmaxf(c[2] + b4.z, 0.f));
@@ -363,6 +380,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
             }
         }
     }
+    if constexpr (!IDX) break;
+    if ((wg + gridDim.x) * G >= M) break;
+    __syncthreads();  // every wave is done with the activation image before the next pass zeroes it
+  }
 }
 
 // ---- weight packing: fp32 [co][ci][kh][kw] (contiguous) -> bf16 MFMA A fragments, biases concatenated ----
@@ -694,13 +715,13 @@ static int encoder_launch(const void *obs_dev, int obs_dtype, int64_t M, const u
     const uint8_t *o8 = static_cast<const uint8_t *>(obs_dev);
     const uint16_t *o16 = static_cast<const uint16_t *>(obs_dev);
     if (obs_dtype == MAPF_ENC_OBS_U8 && !save)
-        hipLaunchKernelGGL((encoder_fwd_kernel<uint8_t, false>), grid, block, 0, st, o8, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev);
+        hipLaunchKernelGGL((encoder_fwd_kernel<uint8_t, false>), grid, block, 0, st, o8, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev, (const int32_t *)nullptr, (const int32_t *)nullptr);
     else if (obs_dtype == MAPF_ENC_OBS_U8)
-        hipLaunchKernelGGL((encoder_fwd_kernel<uint8_t, true>), grid, block, 0, st, o8, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev);
+        hipLaunchKernelGGL((encoder_fwd_kernel<uint8_t, true>), grid, block, 0, st, o8, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev, (const int32_t *)nullptr, (const int32_t *)nullptr);
     else if (!save)
-        hipLaunchKernelGGL((encoder_fwd_kernel<uint16_t, false>), grid, block, 0, st, o16, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev);
+        hipLaunchKernelGGL((encoder_fwd_kernel<uint16_t, false>), grid, block, 0, st, o16, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev, (const int32_t *)nullptr, (const int32_t *)nullptr);
     else
-        hipLaunchKernelGGL((encoder_fwd_kernel<uint16_t, true>), grid, block, 0, st, o16, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev);
+        hipLaunchKernelGGL((encoder_fwd_kernel<uint16_t, true>), grid, block, 0, st, o16, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev, (const int32_t *)nullptr, (const int32_t *)nullptr);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }
@@ -708,6 +729,22 @@ static int encoder_launch(const void *obs_dev, int obs_dtype, int64_t M, const u
 int mapf_encoder_forward(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev, const float *bias_dev,
                          uint16_t *latent_dev, void *stream) {
     return encoder_launch(obs_dev, obs_dtype, M, packed_dev, bias_dev, latent_dev, nullptr, nullptr, false, stream);
+}
+
+int mapf_encoder_forward_rows(const uint8_t *obs_dev, int64_t max_rows, const int32_t *row_index_dev, const int32_t *row_count_dev,
+                              const uint16_t *packed_dev, const float *bias_dev, uint16_t *latent_dev, void *stream) {
+    if (max_rows < 0 || !packed_dev || !bias_dev || !row_index_dev || !row_count_dev || (max_rows > 0 && (!obs_dev || !latent_dev)))
+        return MAPF_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(obs_dev) & 1) || (reinterpret_cast<uintptr_t>(packed_dev) & 15) || (reinterpret_cast<uintptr_t>(bias_dev) & 15) ||
+        (reinterpret_cast<uintptr_t>(latent_dev) & 1))
+        return MAPF_ERR_INVALID_ARG;
+    if (max_rows == 0) return MAPF_OK;
+    long long blocks = (max_rows + G - 1) / G;
+    if (blocks > 2048) blocks = 2048;  // 2 workgroups per CU x 256 CUs x 4: they walk the list (see the kernel)
+    hipLaunchKernelGGL((encoder_fwd_kernel<uint8_t, false, true>), dim3((unsigned)blocks), dim3(NTHREADS), 0, static_cast<hipStream_t>(stream), obs_dev,
+                       (long long)max_rows, packed_dev, bias_dev, latent_dev, (uint16_t *)nullptr, (uint32_t *)nullptr, row_index_dev, row_count_dev);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
 }
 
 int mapf_encoder_forward_save(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev, const float *bias_dev,

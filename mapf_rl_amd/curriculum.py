@@ -94,12 +94,30 @@ class LevelTable:
 
 
 class CurriculumActors:
-    def __init__(self, model, buffer, envs_per_level=256, device=None, seed=0, max_steps=256, reward_fn=None):
-        self.model, self.buffer = model, buffer
+    """One vectorised actor per active level, stepped TOGETHER: the levels' observations live back to back in one buffer, so an
+    iteration is one change detection + one encoder launch + one input-projection GEMM + one Q head for all levels
+    (`Network.step_levels`), and per level only what depends on its shape: comm mask, recurrence, environment step, recording,
+    episode flush.  (Round 2 stepped the levels one after the other: ~31 launches x up to 13 levels on small batches.)
+    `weights_period` (reference config.actor_update_steps = 400, worker.py:416-420): the actors act on a snapshot of `model`
+    refreshed every that many iterations; None = on `model` itself."""
+
+    BATCHED = True
+
+    def __init__(self, model, buffer, envs_per_level=256, device=None, seed=0, max_steps=256, reward_fn=None, weights_period=None):
+        self.source_model, self.buffer, self.weights_period = model, buffer, weights_period
+        if weights_period is not None:
+            from copy import deepcopy
+
+            model = deepcopy(model)
+            for p in model.parameters():
+                p.requires_grad_(False)
+        self.model = model
+        self._since_pull = 0
         self.envs_per_level, self.seed, self.max_steps, self.reward_fn = envs_per_level, seed, max_steps, reward_fn
         self.device = buffer.device if device is None else torch.device(device)
         self.actors = {}
         self.retired_env_steps = 0
+        self.obs_all = self.latents = None
         self.sync_levels()
 
     def _make(self, key):
@@ -113,18 +131,52 @@ class CurriculumActors:
     def sync_levels(self):
         """Create actors for new levels, drop actors of levels no longer in GlobalBuffer.level (worker.py:224)."""
         want = [tuple(k) for k in self.buffer.get_level()]
+        changed = False
         for key in want:
             if key not in self.actors:
                 self.actors[key] = self._make(key)
+                changed = True
         for key in list(self.actors):
             if key not in want:
                 self.retired_env_steps += self.actors[key].env_steps
                 del self.actors[key]
+                changed = True
+        if changed:
+            self._layout()
         return want
 
+    def _layout(self):
+        """The levels' observation buffers back to back in ONE tensor (every environment handle then writes its observations
+        straight into its slice) + one latent cache over it."""
+        from .fused import LatentCache
+
+        acts = list(self.actors.values())
+        total = sum(a.E * a.N for a in acts)
+        self.obs_all = torch.empty((max(total, 1), 6, 9, 9), dtype=torch.uint8, device=self.device)
+        off = 0
+        for a in acts:
+            view = self.obs_all[off:off + a.E * a.N].view(a.E, a.N, 6, 9, 9)
+            view.copy_(a.obs)              # (the current observation: the environments' state does not change here)
+            a.env.obs = a.obs = view
+            a.latents = None               # the shared cache below takes over
+            off += a.E * a.N
+        self.latents = LatentCache() if (VecActor.REUSE_LATENTS and self.device.type == "cuda") else None
+
     def step(self):
-        for actor in self.actors.values():
-            actor.step()
+        acts = list(self.actors.values())
+        if self.weights_period is not None:  # worker.py:416-420
+            if self._since_pull >= self.weights_period:
+                self.model.load_state_dict(self.source_model.state_dict())
+                self._since_pull = 0
+            self._since_pull += 1
+        if not self.BATCHED:
+            for a in acts:
+                a.step()
+            return
+        inputs = [a.policy_inputs() for a in acts]
+        outs = self.model.step_levels([(a.E, a.N, a.pos, a.hidden, cm) for a, (cm, _) in zip(acts, inputs)], self.obs_all, self.latents)
+        for a, (cm, packed), (actions, q, hidden, _) in zip(acts, inputs, outs):
+            a.act(actions, q, hidden, cm, packed)
 
     @property
     def env_steps(self):

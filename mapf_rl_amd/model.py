@@ -450,13 +450,22 @@ class Network(nn.Module):
 
     # ------------------------------------------------------------------ actor side
     @torch.no_grad()
-    def step_batch(self, obs, pos, hidden: Optional[torch.Tensor], comm_mask: Optional[torch.Tensor] = None):
+    def step_batch(self, obs, pos, hidden: Optional[torch.Tensor], comm_mask: Optional[torch.Tensor] = None, cache=None):
         """One actor step for E environments at once.
         obs [E, N, 6, 9, 9], pos [E, N, 2], hidden [E*N, 256] or None (episode start, model.py:186-189).
-        Returns (actions int64 [E, N], q float32 [E, N, 5], hidden [E*N, 256] (compute dtype), comm_mask bool [E, N, N])."""
+        Returns (actions int64 [E, N], q float32 [E, N, 5], hidden [E*N, 256] (compute dtype), comm_mask bool [E, N, N]).
+        `cache` (fused.LatentCache, HIP device, uint8 observations in a persistent buffer): only the agents whose observation changed
+        since the previous call are encoded again -- same latents, bit for bit."""
         E, N = obs.shape[:2]
         with self._autocast(obs.device):
-            latent = self.encode(obs.reshape(E * N, *OBS_SHAPE))
+            if cache is not None and obs.is_cuda and obs.dtype == torch.uint8 and obs.is_contiguous() and self.FUSED_INFERENCE:
+                from .fused import PackedEncoder
+
+                if self._packed is None:
+                    self._packed = PackedEncoder()
+                latent = cache.encode(obs.view(E * N, *OBS_SHAPE), self._packed, self.obs_encoder, self.weights_epoch)
+            else:
+                latent = self.encode(obs.reshape(E * N, *OBS_SHAPE))
             if comm_mask is None:
                 comm_mask = comm_mask_from_pos(pos)
             if self.FUSED_RECURRENCE and latent.is_cuda and latent.dtype == torch.bfloat16 and N <= RECUR_MAX_AGENTS:
@@ -468,6 +477,48 @@ class Network(nn.Module):
                 hidden = self.comm(hidden.view(E, N, self.latent_dim), comm_mask).reshape(E * N, self.latent_dim)
             q = self.q_head(hidden).float().view(E, N, 5)
         return q.argmax(-1), q, hidden, comm_mask
+
+    @torch.no_grad()
+    def step_levels(self, levels, obs_all, cache=None):
+        """One actor step for SEVERAL groups of environments of different shapes at once -- the reference draws a (num_agents, map)
+        level per episode inside one actor (environment.py:148-151, worker.py:422-428); here every active level is a group of E_l
+        lock-step environments of N_l agents.  The encoder and the GRU input projection are per observation and do not care about
+        the shape: ONE encoder launch and ONE GEMM over the concatenated observations; the recurrence (attention mixes the agents of
+        one environment) runs per level; ONE Q head over the concatenated hidden states.
+        levels: list of (E, N, pos [E, N, 2], hidden [E*N, 256] or None, comm bool [E, N, N]); obs_all uint8 [sum E_l N_l, 6, 9, 9],
+        the levels' observations back to back (every level's `obs` is a view of it).  Returns per level what step_batch returns."""
+        dev = obs_all.device
+        if not (self.FUSED_RECURRENCE and self.FUSED_INFERENCE and dev.type == "cuda" and all(lv[1] <= RECUR_MAX_AGENTS for lv in levels)):
+            outs, off = [], 0
+            for E, N, pos, hidden, comm in levels:
+                outs.append(self.step_batch(obs_all[off:off + E * N].view(E, N, *OBS_SHAPE), pos, hidden, comm))
+                off += E * N
+            return outs
+        from .fused import PackedEncoder, PackedRecurrence, mm_rows, recurrent_infer
+
+        with self._autocast(dev):
+            if self._packed is None:
+                self._packed = PackedEncoder()
+            if self._packed_recur is None:
+                self._packed_recur = PackedRecurrence()
+            if cache is not None and obs_all.dtype == torch.uint8 and obs_all.is_contiguous():
+                latent = cache.encode(obs_all, self._packed, self.obs_encoder, self.weights_epoch)
+            else:
+                latent = self.encode(obs_all)
+            w, b = self._packed_recur.get(self)
+            gi_all = mm_rows(latent, self.recurrent.weight_ih.detach().to(torch.bfloat16))
+            hs, off = [], 0
+            for E, N, pos, hidden, comm in levels:
+                h0 = None if hidden is None else hidden.reshape(E, N, self.latent_dim)
+                hs.append(recurrent_infer(gi_all[off:off + E * N].view(1, E, N, 768), h0, comm.unsqueeze(0), w, b, False)[0].view(E * N, self.latent_dim))
+                off += E * N
+            q_all = self.q_head(torch.cat(hs) if len(hs) > 1 else hs[0]).float()
+        outs, off = [], 0
+        for (E, N, pos, hidden, comm), h in zip(levels, hs):
+            q = q_all[off:off + E * N].view(E, N, 5)
+            outs.append((q.argmax(-1), q.contiguous(), h, comm))
+            off += E * N
+        return outs
 
     @torch.no_grad()
     def step(self, obs, pos, comm_mask=None):

@@ -169,3 +169,87 @@ def test_actor_tape_matches_reference(tag):
     # and the reference's own numbers through the same formula reproduce its td (the recording logic, fp-exact)
     ref_td = RO.local_finish(np.concatenate([z[pre + "q0"], np.zeros((1, 5), np.float32)]), z[pre + "act_buf"], z[pre + "rew_buf"].astype(np.float16), size, capacity=ms)
     assert np.allclose(ref_td[:size], z[pre + "td"][:size], rtol=0, atol=1e-12)
+
+
+def test_latent_cache_encodes_only_changed_rows_and_is_exact():
+    """fused.LatentCache (mapf_obs_changed + mapf_encoder_forward_rows): with some agents' observations unchanged from call to call,
+    the cached latents are the same bits as encoding every row; the changed rows are counted on the device; a weight change or a
+    different observation buffer invalidates the cache."""
+    from mapf_rl_amd.fused import LatentCache, PackedEncoder, encoder_forward
+    from mapf_rl_amd.model import Network
+
+    torch.manual_seed(0)
+    net = Network().cuda()
+    packed, cache = PackedEncoder(), LatentCache()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    R = 1003  # odd: rows at every 2-byte alignment, a ragged last workgroup
+    obs = (torch.rand((R, 6, 9, 9), device="cuda", generator=g) < 0.3).to(torch.uint8)
+    for k in range(6):
+        if k:
+            change = torch.rand(R, device="cuda", generator=g) < (0.0, 0.3, 1.0, 0.05, 0.0, 0.5)[k]
+            new = (torch.rand((R, 6, 9, 9), device="cuda", generator=g) < 0.3).to(torch.uint8)
+            new[:, 0, 0, 0] = 1 - obs[:, 0, 0, 0]  # a changed row really differs
+            obs.copy_(torch.where(change.view(R, 1, 1, 1), new, obs))
+        lat = cache.encode(obs, packed, net.obs_encoder)
+        wp, bp = packed.get(net.obs_encoder)
+        assert torch.equal(lat, encoder_forward(obs, wp, bp)), k
+        assert cache.last_encoded() == (R if k == 0 else int(change.sum())), k
+    assert cache.full == 1 and cache.calls == 6
+    with torch.no_grad():
+        net.obs_encoder[0].bias.add_(0.1)  # new weights: everything is encoded again
+    lat = cache.encode(obs, packed, net.obs_encoder)
+    wp, bp = packed.get(net.obs_encoder)
+    assert cache.full == 2 and cache.last_encoded() == R and torch.equal(lat, encoder_forward(obs, wp, bp))
+    other = obs.clone()
+    cache.encode(other, packed, net.obs_encoder)
+    assert cache.full == 3
+
+
+def test_actor_with_latent_reuse_records_the_same_episodes():
+    """VecActor.REUSE_LATENTS on / off from the same seeds: identical actions, Q-values, hidden states and replay contents (the
+    encoder is per observation; an unchanged observation has an unchanged latent).  Also the reference's actor semantics
+    (worker.py:416-420): with weights_period the actor acts on its own snapshot until the next pull."""
+    import mapf_rl_amd as M
+    from mapf_rl_amd.actor import VecActor
+    from mapf_rl_amd.model import Network
+    from mapf_rl_amd.replay import GlobalBuffer
+
+    E, L, N, K = 64, 16, 10, 40
+    out = {}
+    try:
+        for reuse in (True, False):
+            VecActor.REUSE_LATENTS = reuse
+            torch.manual_seed(3)
+            net = Network().cuda()
+            env = M.VecEnvironment(E, L, N)
+            maps, agents, goals, _ = M.generate_scenarios(E, L, N, 0.2, seed=8)
+            env.load(maps, agents, goals)
+            buf = GlobalBuffer(256, max_agents=N, init_set=(N, L), fixed_level=True)
+            actor = VecActor(env, net, buf, seed=5, density=0.2, max_steps=16)
+            assert (actor.latents is not None) == reuse
+            acts, enc = [], []
+            for _ in range(K):
+                actor.step()
+                acts.append(actor.last_policy_actions.clone())
+                if reuse:
+                    enc.append(actor.latents.last_encoded())
+            torch.cuda.synchronize()
+            out[reuse] = (torch.stack(acts), actor.hidden.clone(), buf.priority_tree.tree().clone(), buf.state(), enc)
+    finally:
+        VecActor.REUSE_LATENTS = True
+    a, b = out[True], out[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3]
+    assert a[4][0] == E * N and min(a[4][1:]) < E * N  # standing agents are not encoded again
+    # weight snapshots: the actor keeps acting on the old weights until the pull
+    net = Network().cuda()
+    env = M.VecEnvironment(8, 12, 4)
+    env.reset_envs(None, 0.2, seed=1)
+    actor = VecActor(env, net, None, seed=0, density=0.2, weights_period=3)
+    assert actor.model is not net
+    with torch.no_grad():
+        net.adv.bias.add_(5.0)
+    before = actor.model.adv.bias.detach().clone()
+    for k in range(1, 8):
+        actor.step()
+        pulled = k > 3
+        assert torch.equal(actor.model.adv.bias, net.adv.bias if pulled else before), k

@@ -49,3 +49,42 @@ def test_level_promotion_and_mixed_levels():
     assert obs.shape == (32, 18, 6, 6, 9, 9)
     assert float(obs[:, :, 2:].abs().sum()) == 0.0          # no level had more than 2 agents
     assert float(obs[:, :, 0].abs().sum()) > 0
+
+
+def test_level_batched_step_equals_serial_steps():
+    """CurriculumActors.step with all active levels through ONE change detection / encoder launch / projection GEMM / Q head
+    (Network.step_levels) against the levels stepped one after the other (BATCHED = False), from the same seeds: every recorded
+    row -- observations, actions, rewards, comm rows, episode sizes, the replay's ring state and sum tree -- is identical; Q-values
+    and hidden states agree to bf16 rounding (the GEMM runs on another row count)."""
+    from mapf_rl_amd.curriculum import CurriculumActors
+    from mapf_rl_amd.model import Network
+    from mapf_rl_amd.replay import GlobalBuffer
+
+    levels = [(1, 10), (2, 10), (3, 15), (6, 20), (4, 25), (5, 10)]
+    runs = {}
+    try:
+        for batched in (True, False):
+            CurriculumActors.BATCHED = batched
+            torch.manual_seed(0)
+            net = Network().cuda().eval()
+            buf = GlobalBuffer(1024, max_agents=6, init_set=(1, 10), max_map_length=40, pass_rate=0.9)
+            buf.stat_dict = {k: [] for k in levels}
+            cur = CurriculumActors(net, buf, envs_per_level=32, seed=3, max_steps=12)
+            assert sorted(cur.actors) == sorted(levels)
+            for _ in range(30):
+                cur.step()
+            torch.cuda.synchronize()
+            rec = {k: dict(obs=a.lb_obs.clone(), act=a.lb_act.clone(), rew=a.lb_rew.clone(), comm=a.lb_comm.clone(), t=a.t.clone(), q=a.lb_q.clone(),
+                           hid=a.lb_hid.clone(), pos=a.pos.clone(), eps=a.episodes) for k, a in cur.actors.items()}
+            runs[batched] = (rec, buf.state(), buf.priority_tree.tree().clone(), cur.latents)
+    finally:
+        CurriculumActors.BATCHED = True
+    (ra, sa, ta, lat), (rb, sb, tb, _) = runs[True], runs[False]
+    assert lat is not None and lat.calls == 30 and lat.full == 1  # one cache over all levels; re-encoded in full only at the start
+    assert sa == sb
+    for k in levels:
+        for f in ("obs", "act", "rew", "comm", "t", "pos"):
+            assert torch.equal(ra[k][f], rb[k][f]), (k, f)
+        assert ra[k]["eps"] == rb[k]["eps"]
+        assert torch.allclose(ra[k]["q"], rb[k]["q"], rtol=2e-2, atol=2e-2) and torch.allclose(ra[k]["hid"].float(), rb[k]["hid"].float(), rtol=2e-2, atol=2e-2)
+    assert torch.allclose(ta, tb, rtol=1e-2, atol=1e-6)  # priorities are |td| of those Q-values

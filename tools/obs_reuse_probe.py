@@ -61,6 +61,8 @@ def run(policy, label, model):
         same = same & ~fin.view(E, 1)                                       # a reset environment starts over
         same_tot += int(same.sum())
         tot += E * N
+        if k % 50 == 49 and actor.latents is not None:
+            print("  step %d: LatentCache re-encoded %.3f of the rows at this step's start" % (k, actor.latents.last_encoded() / (E * N)))
         if k % 50 == 49:
             by_phase.append(float(same.float().mean()))
         prev = cur.clone()

@@ -62,6 +62,8 @@ def main(argv=None):
     ap.add_argument("--dist-backend", default="nccl", help="nccl = RCCL; gloo only for the CPU-side multi-rank tests")
     ap.add_argument("--double-q", action="store_true", default=bool(getattr(config, "double_q", False)),
                     help="double-DQN target (online argmax, target value); config.double_q is dead in the reference (worker.py:300-303)")
+    ap.add_argument("--actor-update-steps", type=int, default=config.actor_update_steps,
+                    help="actor iterations between two pulls of the learner's weights (config.actor_update_steps, worker.py:416-420)")
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args(argv)
     fixed = a.agents is not None or a.map is not None
@@ -112,10 +114,12 @@ def main(argv=None):
         for p in learner.model.parameters():
             dist.broadcast(p.data, src=0)
         learner.sync_target()
+    # the actors act on a snapshot of the learner's weights, pulled every config.actor_update_steps iterations (worker.py:416-420)
     if fixed:
-        actor = VecActor(env, learner.model, buffer, seed=seed)
+        actor = VecActor(env, learner.model, buffer, seed=seed, weights_period=a.actor_update_steps)
     else:
-        actor = CurriculumActors(learner.model, buffer, envs_per_level=a.envs, device=dev, seed=seed, reward_fn=config.reward_fn)
+        actor = CurriculumActors(learner.model, buffer, envs_per_level=a.envs, device=dev, seed=seed, reward_fn=config.reward_fn,
+                                 weights_period=a.actor_update_steps)
 
     t_start = t_last = time.time()
     debt = 0.0
