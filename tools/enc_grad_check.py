@@ -14,24 +14,22 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "b40"
 
 
 def run(fused_training, fp32=False):
+    from mapf_rl_amd.learner import Learner
+
     Network.FUSED_TRAINING = fused_training
-    lr = _models("cuda")
-    b = BG.batch(z, tag, "cuda", torch.float32 if fp32 else torch.bfloat16)
-    grads = {}
-    orig = torch.nn.utils.clip_grad_norm_
-    def grab(params, m):
-        for k, p in lr.model.named_parameters():
-            grads[k] = p.grad.detach().float().cpu().numpy()
-        return orig(lr.model.parameters(), m)
-    torch.nn.utils.clip_grad_norm_ = grab
+    Learner.FUSED_UPDATE = fused_training and not fp32  # (a): update.FusedUpdate; (b), (c): autograd over Network.bootstrap
     try:
+        lr = _models("cuda")
+        b = BG.batch(z, tag, "cuda", torch.float32 if fp32 else torch.bfloat16)
+        grads = {}
+        lr.grad_hook = lambda l: grads.update({k: p.grad.detach().float().cpu().numpy() for k, p in l.model.named_parameters()})
         if fp32:
             lr.model._autocast = lambda dev: torch.autocast("cuda", enabled=False)
             lr.tar_model._autocast = lr.model._autocast
         out = lr.update(b)
     finally:
-        torch.nn.utils.clip_grad_norm_ = orig
         Network.FUSED_TRAINING = True
+        Learner.FUSED_UPDATE = True
     return BG.grad_errors(z, tag, grads, floor=1e-3), grads, out
 
 ea, ga, oa = run(True)

@@ -32,3 +32,10 @@ for k in range(6):
     col = b[:, k] - t0
     print("stamp %d %-28s mean %9.1f  min %9.1f  max %9.1f   phase mean %8.1f" % (
         k, names[k], col.mean(), col.min(), col.max(), (b[:, k] - b[:, k - 1]).mean() if k else 0))
+
+# how the blocks' start / end times spread over the launch (dispatch rate vs per-block latency)
+st, en = np.sort(b[:, 0] - t0), np.sort(b[:, 5] - t0)
+q = [0, 10, 25, 50, 75, 90, 100]
+print("block START percentiles (cycles):", " ".join("%d%%:%d" % (k, np.percentile(st, k)) for k in q))
+print("block END   percentiles (cycles):", " ".join("%d%%:%d" % (k, np.percentile(en, k)) for k in q))
+print("per-block duration (cycles): mean %.0f  min %.0f  max %.0f" % ((b[:, 5] - b[:, 0]).mean(), (b[:, 5] - b[:, 0]).min(), (b[:, 5] - b[:, 0]).max()))
