@@ -29,16 +29,18 @@ int mapf_bias_res_relu_bwd(const uint16_t *g_dev, const uint16_t *y_dev, uint16_
  * Fused observation encoder, inference only (no autograd): replaces the reference's
  * `self.obs_encoder(obs)` in `Network.step` (model.py:184) and in the target network's `bootstrap`
  * (model.py:237, called without gradients at worker.py:300-303) by ONE kernel that keeps the activations of
- * 4 observations per workgroup in LDS across all 8 convolutions (csrc/mapf_encoder.hip).  bf16 MFMA, fp32
- * accumulation, one rounding to bf16 per layer output.
+ * 4 observations per workgroup in LDS across all 8 convolutions (csrc/mapf_encoder.hip).  f16 MFMA, fp32
+ * accumulation, one rounding to f16 per layer output (clamped to +-65504) -- the arithmetic of the reference's fp16
+ * autocast (worker.py:283); the OUTPUT is bf16 like the rest of the network's activations.  ("Element" below = IEEE half,
+ * 16 bits, carried in uint16_t.)
  *
  * Packed weights (produced by mapf_encoder_pack from the 8 convolutions of `Network.obs_encoder`, in module
  * order: [0], [2].block1, [2].block2, [3].block1, [3].block2, [4].block1, [4].block2, [5]; each weight fp32
- * contiguous [co][ci][kh][kw], each bias fp32 [co]): bf16 A-operand fragments of v_mfma_f32_16x16x32_bf16,
+ * contiguous [co][ci][kh][kw], each bias fp32 [co]): f16 A-operand fragments of v_mfma_f32_16x16x32_f16,
  *   conv0   [s=2 ][c=8][lane=64][j=8]   k = 32 s + 8 (lane>>4) + j = ci*9 + kh*3 + kw  (k >= 54 -> 0)
  *   3x3 x6  [s=36][c=8][lane=64][j=8]   s = (kh*3+kw)*4 + chunk, ci = 32 chunk + 8 (lane>>4) + j
  *   1x1     [s=4 ]     [lane=64][j=8]   ci = 32 s + 8 (lane>>4) + j
- * with co = 16 c + (lane & 15); MAPF_ENC_PACKED_ELEMS bf16 in total.  Biases: MAPF_ENC_BIAS_ELEMS fp32,
+ * with co = 16 c + (lane & 15); MAPF_ENC_PACKED_ELEMS f16 in total.  Biases: MAPF_ENC_BIAS_ELEMS fp32,
  * concatenated in the same order.  Both buffers must be 16-byte aligned.
  */
 #define MAPF_ENC_OBS_PER_BLOCK 4
@@ -65,7 +67,7 @@ int mapf_encoder_forward_rows(const uint8_t *obs_dev, int64_t max_rows, const in
                               const uint16_t *packed_dev, const float *bias_dev, uint16_t *latent_dev, void *stream);
 
 /* Training forward: the same kernel, additionally storing what the backward pass needs:
- *   acts_dev bf16 [7][M][7][7][128] (NHWC) the 7 post-ReLU layer outputs, in order conv0, res1.block1, res1,
+ *   acts_dev f16 [7][M][7][7][128] (NHWC) the 7 post-ReLU layer outputs, in order conv0, res1.block1, res1,
  *            res2.block1, res2, res3.block1, res3 -- the inputs of the weight gradients (16-byte aligned);
  *   relu_bits_dev uint32 [7][M][49][4] their sign bits -- the ReLU masks of the backward-data chain (16 bytes per
  *            position instead of 256): channel c = 32 w + 16 a + 4 h + r (w < 4, a < 2, h < 4, r < 4) of a position is > 0
@@ -78,10 +80,11 @@ int mapf_encoder_forward_save(const void *obs_dev, int obs_dtype, int64_t M, con
 /*
  * Backward-data chain of the encoder in one kernel (the mirror image of the forward: the transposed convolutions are
  * the same LDS-resident implicit GEMMs on weights packed by mapf_encoder_pack_bwd -- channels swapped, taps
- * flipped; MAPF_ENC_PACKED_BWD_ELEMS bf16).
- *   gz7_dev  bf16 [M][7][7][16]   gradient w.r.t. the 1x1 convolution's pre-activation (ReLU mask already applied)
+ * flipped; MAPF_ENC_PACKED_BWD_ELEMS f16).
+ *   gz7_dev  f16 [M][7][7][16]    gradient w.r.t. the 1x1 convolution's pre-activation (ReLU mask already applied), in whatever
+ *            units the caller chose (f16 has 5 exponent bits: scale small gradients up); every output is in the same units
  *   relu_bits_dev uint32 [7][M][49][4] the ReLU sign bits written by mapf_encoder_forward_save
- *   gz_dev   bf16 [7][M][7][7][128] OUT: gradient w.r.t. each 128-channel layer's pre-activation (ReLU-masked), same
+ *   gz_dev   f16 [7][M][7][7][128] OUT: gradient w.r.t. each 128-channel layer's pre-activation (ReLU-masked), same
  *            layer order; conv_k's weight gradient is the correlation of gz_dev[k] with the layer's input
  *            (acts_dev[k-1] of the forward, or the observation for k = 0).
  *   gbias_partial_dev f32 [7][ceil(M / MAPF_ENC_OBS_PER_BLOCK)][128] OUT: per-workgroup sums of gz over its
@@ -96,34 +99,44 @@ int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint32_
  * Weight gradient of conv0 (6 -> 128, 3x3 valid on the 9x9 observation; csrc/mapf_wgrad0.hip):
  *   partial_dev f32 [MAPF_ENC_WGRAD0_PARTS][128][64]: per-partition partial sums of
  *   dW0[co][j = ci*9 + ky*3 + kx] = sum_{m,y,x} gz0[m][y][x][co] * obs[m][ci][y+ky][x+kx]   (columns 54..63 are zero);
- *   gz0_dev bf16 [M][49][128] = layer 0 of mapf_encoder_backward's gz; obs_dev / obs_dtype as in mapf_encoder_forward.
+ *   gz0_dev f16 [M][49][128] = layer 0 of mapf_encoder_backward's gz; obs_dev / obs_dtype as in mapf_encoder_forward;
+ *   grad_scale_dev = mapf_encoder_backward's (the partial sums are multiplied by grad_scale_dev[1]), or NULL: gz0 as it is.
  * The caller adds the partitions (deterministic) and keeps the first 54 columns = the weight's own [co][ci][ky][kx] order.
  */
 #define MAPF_ENC_WGRAD0_PARTS 512
-int mapf_encoder_wgrad0(const uint16_t *gz0_dev, const void *obs_dev, int obs_dtype, int64_t M, float *partial_dev, void *stream);
+int mapf_encoder_wgrad0(const uint16_t *gz0_dev, const void *obs_dev, int obs_dtype, int64_t M, const uint32_t *grad_scale_dev,
+                        float *partial_dev, void *stream);
 
 /*
  * The same chain, starting one step earlier: `g_latent_dev` is the gradient w.r.t. the encoder's OUTPUT (bf16 [M][784],
  * the forward's flattened NCHW order: channel * 49 + position) and `latent_dev` that output; the kernel applies the 1x1
  * layer's ReLU mask itself while staging (three elementwise passes and a reduction less for the caller) and also writes
- * the masked gradient position-major, gz7_dev bf16 [M][49][16] (operand of the caller's 1x1 weight-gradient GEMM), and
+ * the masked gradient position-major, gz7_dev f16 [M][49][16] (operand of the caller's 1x1 weight-gradient GEMM), and
  * gb7_partial_dev f32 [4 * ceil(M/4)][16], per-wave partial bias gradients of the 1x1 layer (the caller adds the rows).
+ *
+ * Loss scale.  The chain's gradients are f16, so it works on S * gradient with S the power of two that puts max |g_latent| into
+ * (8, 16] (a reduction over g_latent launched by this call; the reference's GradScaler, worker.py:283,316-323, does the same job
+ * with a dynamic S and skipped steps).  grad_scale_dev, uint32 [2], OUT: [0] = max |g_latent| as bf16 bits, [1] = the bits of the
+ * float 1 / S.  gz_dev and gz7_dev are S * gradient; the bias partials are already divided by S; the weight-gradient kernels take
+ * grad_scale_dev and divide theirs; a caller that forms a weight gradient itself (the 1x1 layer's GEMM) multiplies by [1].
  */
 int mapf_encoder_backward(const uint16_t *g_latent_dev, const uint16_t *latent_dev, int64_t M, const uint32_t *relu_bits_dev,
                           const uint16_t *packed_bwd_dev, uint16_t *gz_dev, float *gbias_partial_dev, uint16_t *gz7_dev,
-                          float *gb7_partial_dev, void *stream);
+                          float *gb7_partial_dev, uint32_t *grad_scale_dev, void *stream);
 
 /*
  * Weight gradient of one 3x3 128->128 convolution of the encoder (csrc/mapf_wgrad.hip):
  *   dW[co][ky][kx][ci] = sum_m sum_(y,x) gz[m][y][x][co] * in[m][y+ky-1][x+kx-1][ci]
  * gz_dev = the layer's slice of mapf_encoder_backward_data's output, in_dev = the layer's input (the matching slice
- * of mapf_encoder_forward_save's acts), both bf16 [M][7][7][128].  The kernel writes MAPF_ENC_WGRAD_PARTS partial
+ * of mapf_encoder_forward_save's acts), both f16 [M][7][7][128]; grad_scale_dev = mapf_encoder_backward's (the partial sums are
+ * multiplied by grad_scale_dev[1]) or NULL (gz as it is).  The kernel writes MAPF_ENC_WGRAD_PARTS partial
  * sums, fp32 [MAPF_ENC_WGRAD_PARTS][128][3][3][128] (co, ky, kx, ci -- the channels_last order of a [co][ci][3][3]
  * weight); the weight gradient is their sum over the first axis (deterministic, no atomics).
  */
 #define MAPF_ENC_WGRAD_PARTS 128
 #define MAPF_ENC_WGRAD_SLABS 2 /* internal: input-channel halves of the output, one workgroup each per partition */
-int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M, float *partial_dev, void *stream);
+int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M, const uint32_t *grad_scale_dev, float *partial_dev,
+                       void *stream);
 
 /*
  * Inference recurrence behind the encoder (csrc/mapf_recur.hip): for T steps and E environments of N <= 48 agents

@@ -73,9 +73,9 @@ SYMBOLS = [
     ("mapf_encoder_forward_rows", _i, [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_encoder_pack_bwd", _i, [ctypes.POINTER(_vp), _i, _vp, _vp]),
     ("mapf_encoder_backward_data", _i, [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp]),
-    ("mapf_encoder_wgrad0", _i, [_vp, _vp, _i, ctypes.c_int64, _vp, _vp]),
-    ("mapf_encoder_backward", _i, [_vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    ("mapf_encoder_wgrad", _i, [_vp, _vp, ctypes.c_int64, _vp, _vp]),
+    ("mapf_encoder_wgrad0", _i, [_vp, _vp, _i, ctypes.c_int64, _vp, _vp, _vp]),
+    ("mapf_encoder_backward", _i, [_vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("mapf_encoder_wgrad", _i, [_vp, _vp, ctypes.c_int64, _vp, _vp, _vp]),
     ("mapf_encoder_forward_save", _i, [_vp, _i, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_plan_mark", _i, [_vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_obs_dup", _i, [_i, _i, _i, _i, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

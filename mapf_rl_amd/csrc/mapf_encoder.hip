@@ -2,7 +2,7 @@
 // 3 x ResBlock(128) (model.py:30-42, two 3x3 pad-1 convolutions + identity skip, no normalisation),
 // Conv(128->16,1x1)+ReLU, Flatten) as ONE inference kernel for gfx950 (see include/mapf_dqn.h).
 //
-// Why one kernel: per observation the encoder is 87.6 MFLOP over activations of only 7x7x128 bf16 = 12.5 KB.
+// Why one kernel: per observation the encoder is 87.6 MFLOP over activations of only 7x7x128 f16 = 12.5 KB.
 // Layer-by-layer (MIOpen implicit GEMM + an epilogue pass per layer) every layer round-trips that activation
 // through HBM and pays a launch; here a workgroup keeps the activations of G = 4 observations resident in LDS for
 // all 8 layers and only the packed weights (1.8 MB, L2-resident) stream in.  MFMA-bound.
@@ -10,7 +10,7 @@
 // Mapping (256 threads = 4 waves, <= 256 VGPR each; 76 KB LDS -> TWO independent workgroups per CU, 2 waves per
 // SIMD: while one workgroup is in a layer epilogue / at a barrier the other one keeps the MFMA pipe busy):
 //  * Each 3x3 layer is the GEMM  out[co][p] = sum_{tap,ci} W[co][ci][tap] * act[p + tap][ci]  with M = 128 output
-//    channels, N = 49*G positions, K = 9*128, on v_mfma_f32_16x16x32_bf16: A = weights, B = activations, so a lane's
+//    channels, N = 49*G positions, K = 9*128, on v_mfma_f32_16x16x32_f16: A = weights, B = activations, so a lane's
 //    4 accumulator registers are 4 consecutive output channels of one position -> one 8-byte LDS store.
 //  * Wave w owns output channels [32*w, +32) (two 16-row A tiles) and all 13 position tiles (16 positions each,
 //    208 >= 196): 104 accumulator registers.
@@ -22,7 +22,7 @@
 //  * The A operand is pre-packed in exact fragment order (mapf_encoder_pack): one k-step of one 16-channel tile is a
 //    contiguous 1 KiB, read straight into registers with global_load_dwordx4 (no LDS round trip; each weight byte
 //    is used by exactly one wave of the workgroup).
-//  * ResBlock: the skip input of this wave's own (co, position) elements is read from LDS as packed bf16 before
+//  * ResBlock: the skip input of this wave's own (co, position) elements is read from LDS as packed f16 before
 //    conv1's output overwrites it and becomes the initial accumulator of conv2 -> a single activation buffer.
 //  * conv0 (K = 54, padded to 64) builds its B fragments directly from the raw observation bytes staged in LDS.
 #include <hip/hip_runtime.h>
@@ -35,14 +35,13 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #ifndef MAPF_ENC_ABLATE  // diagnostic builds only (tools/micro/enc_ablate.py): 1 = no saved-activation copies, 2 = no ReLU sign words
 #define MAPF_ENC_ABLATE 0
 #endif
 constexpr int G = MAPF_ENC_OBS_PER_BLOCK;  // observations per workgroup
-constexpr int ROWB = 272;                  // bytes per activation row (128 bf16 + 16 B pad)
+constexpr int ROWB = 272;                  // bytes per activation row (128 f16 + 16 B pad)
 constexpr int ACT_ROWS = 64 * G + 9;
 constexpr int ACT_BYTES = ACT_ROWS * ROWB;  // 141,712
 constexpr int OBS_ELEMS = 6 * 9 * 9;        // 486
@@ -54,7 +53,7 @@ static_assert(NT * 16 >= NPOS, "tiles must cover all positions");
 static_assert(ACT_BYTES % 16 == 0, "");
 static_assert(2 * (ACT_BYTES + RAW_BYTES) <= 160 * 1024, "LDS budget: two workgroups per CU");
 
-// packed-weight element offsets (bf16 elements), see mapf_dqn.h
+// packed-weight element offsets (f16 elements), see mapf_dqn.h
 constexpr int WP_L0 = 0;
 constexpr int WP_L0_SIZE = 2 * 8 * 512;
 constexpr int WP_RES = WP_L0 + WP_L0_SIZE;
@@ -72,21 +71,40 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {  // round to nea
 }
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
 
-__device__ __forceinline__ uint16_t raw_to_bf16(uint8_t v) { return (uint16_t)f32_to_bf16_bits((float)v); }  // exact for 0..255
-__device__ __forceinline__ uint16_t raw_to_bf16(uint16_t v) { return v; }                                   // already bf16 bits
-
-// relu(acc + bias) for the 4 consecutive channels of one lane, packed to 4 bf16 (v_cvt_pk_bf16_f32: RNE)
+// ---- the element type of everything the encoder kernels keep between layers: IEEE half (f16) ----
+// Activations (LDS and the saved copies), packed weights and pre-activation gradients are f16, accumulated in fp32 by
+// v_mfma_f32_16x16x32_f16 -- the arithmetic the reference trains in (fp16 autocast, worker.py:283,316-323).  Rounds 1-2 kept
+// them in bf16: same speed, but 3 fewer mantissa bits on every layer output put the weight gradients 7-10 % off the fp32
+// direction (profiles/r03_encoder_grad_error_fp16.txt: f16 activations + weights bring that to 2-3 %, the format of the
+// gradients themselves does not matter).  f16's range is the price: conversions clamp to +-65504 (no inf, hence no NaN from
+// inf * 0), and the backward chain works on gradients multiplied by a power-of-two loss scale (GradScale below).  The encoder's
+// OUTPUT (the latent the projection GEMM reads) and the gradient arriving for it stay bf16 like the rest of the network.
+typedef __attribute__((ext_vector_type(8))) _Float16 el8;  // one MFMA A/B fragment
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+constexpr float EL_MAX = 65504.f;
+__device__ __forceinline__ f32x4 el_mfma(const el8 &a, const el8 &b, const f32x4 &c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ uint32_t el_pack2(float lo, float hi) {  // round to nearest even; callers clamp
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));
+}
+__device__ __forceinline__ float el_to_f32(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
+__device__ __forceinline__ float el_lo(uint32_t w) { return el_to_f32(w & 0xFFFFu); }
+__device__ __forceinline__ float el_hi(uint32_t w) { return el_to_f32(w >> 16); }
+__device__ __forceinline__ uint16_t f32_to_el_bits(float f) {
+    return __builtin_bit_cast(uint16_t, (_Float16)__builtin_amdgcn_fmed3f(f, -EL_MAX, EL_MAX));
+}
+__device__ __forceinline__ uint16_t raw_to_el(uint8_t v) { return __builtin_bit_cast(uint16_t, (_Float16)(float)v); }  // exact for 0..255
+__device__ __forceinline__ uint16_t raw_to_el(uint16_t v) { return f32_to_el_bits(bf16_bits_to_f32(v)); }            // bf16 input
+
+// relu(acc + bias) for the 4 consecutive channels of one lane, packed to 4 elements (v_med3_f32 = ReLU and range clamp in one)
 __device__ __forceinline__ uint2 pack_relu(const f32x4 &a, const float4 &b) {
-    return make_uint2(pack2_bf16(fmaxf(a[0] + b.x, 0.f), fmaxf(a[1] + b.y, 0.f)),
-                      pack2_bf16(fmaxf(a[2] + b.z, 0.f), fmaxf(a[3] + b.w, 0.f)));
+    return make_uint2(el_pack2(__builtin_amdgcn_fmed3f(a[0] + b.x, 0.f, EL_MAX), __builtin_amdgcn_fmed3f(a[1] + b.y, 0.f, EL_MAX)),
+                      el_pack2(__builtin_amdgcn_fmed3f(a[2] + b.z, 0.f, EL_MAX), __builtin_amdgcn_fmed3f(a[3] + b.w, 0.f, EL_MAX)));
 }
 
-// bit r of the result: the r-th of the 4 bf16 values in `y` (a ReLU output) is > 0
+// bit r of the result: the r-th of the 4 f16 values in `y` (a ReLU output) is > 0
 __device__ __forceinline__ uint32_t positive4(const uint2 y) {
     // y holds max(., 0) results: the sign bit can only belong to a -0, so "> 0" is "magnitude bits non-zero"
     return ((y.x & 0x7FFFu) ? 1u : 0u) | ((y.x & 0x7FFF0000u) ? 2u : 0u) | ((y.y & 0x7FFFu) ? 4u : 0u) | ((y.y & 0x7FFF0000u) ? 8u : 0u);
@@ -126,9 +144,9 @@ __device__ __forceinline__ int tap_off(int s) {
 // step 4, the store at step 22 of each group.  As a separate pass between the barrier and the convolution the same copy
 // cost 3.3 us per layer and workgroup (1.3 of the training forward's 8.5 ms).
 template <bool COPY = false>
-__device__ __forceinline__ void conv3x3(const unsigned char *act, const bf16x8 *__restrict__ wv, const int (&addr)[NT],
+__device__ __forceinline__ void conv3x3(const unsigned char *act, const el8 *__restrict__ wv, const int (&addr)[NT],
                                         f32x4 (&acc)[2][NT], uint16_t *__restrict__ cdst = nullptr, int ctotal = 0, int tid = 0) {
-    bf16x8 ar[RA][2], br[RB];
+    el8 ar[RA][2], br[RB];
     uint4 cv = make_uint4(0, 0, 0, 0);
     int cc = 0;
 #pragma unroll
@@ -137,13 +155,13 @@ __device__ __forceinline__ void conv3x3(const unsigned char *act, const bf16x8 *
         ar[s][1] = wv[(s * 8 + 1) * 64];
     }
 #pragma unroll
-    for (int t = 0; t < PB; ++t) br[t] = *reinterpret_cast<const bf16x8 *>(act + addr[t % NT] + tap_off(t / NT));
+    for (int t = 0; t < PB; ++t) br[t] = *reinterpret_cast<const el8 *>(act + addr[t % NT] + tap_off(t / NT));
 #pragma unroll
     for (int s = 0; s < 36; ++s) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int t = s * NT + n, tn = t + PB;
-            if (tn < 36 * NT) br[tn % RB] = *reinterpret_cast<const bf16x8 *>(act + addr[tn % NT] + tap_off(tn / NT));
+            if (tn < 36 * NT) br[tn % RB] = *reinterpret_cast<const el8 *>(act + addr[tn % NT] + tap_off(tn / NT));
             if (n == 0 && s + PA < 36) {
                 ar[(s + PA) % RA][0] = wv[((s + PA) * 8 + 0) * 64];
                 ar[(s + PA) % RA][1] = wv[((s + PA) * 8 + 1) * 64];
@@ -160,8 +178,8 @@ __device__ __forceinline__ void conv3x3(const unsigned char *act, const bf16x8 *
                 cv = *reinterpret_cast<const uint4 *>(act + (64 * o + 8 * y + x + 9) * ROWB + ch * 16);
             }
             if (COPY && !(MAPF_ENC_ABLATE & 1) && t % 36 == 22) reinterpret_cast<uint4 *>(cdst)[cc] = cv;
-            acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[s % RA][0], br[t % RB], acc[0][n], 0, 0, 0);
-            acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[s % RA][1], br[t % RB], acc[1][n], 0, 0, 0);
+            acc[0][n] = el_mfma(ar[s % RA][0], br[t % RB], acc[0][n]);
+            acc[1][n] = el_mfma(ar[s % RA][1], br[t % RB], acc[1][n]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -258,11 +276,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[a][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const bf16x8 *wv = reinterpret_cast<const bf16x8 *>(wpz + WP_L0) + (2 * cb) * 64 + lane;
+        const el8 *wv = reinterpret_cast<const el8 *>(wpz + WP_L0) + (2 * cb) * 64 + lane;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const bf16x8 a0 = wv[(s * 8 + 0) * 64];
-            const bf16x8 a1 = wv[(s * 8 + 1) * 64];
+            const el8 a0 = wv[(s * 8 + 0) * 64];
+            const el8 a1 = wv[(s * 8 + 1) * 64];
             int koff[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -277,13 +295,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
                 const int o = p / 49, q = p - 49 * o, y = q / 7, x = q - 7 * y;
                 const int rb = v ? o * OBS_ELEMS + y * 9 + x : 0;
                 union {
-                    bf16x8 v8;
+                    el8 v8;
                     uint16_t u[8];
                 } b;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) b.u[j] = koff[j] >= 0 ? raw_to_bf16(raw[rb + koff[j]]) : (uint16_t)0;
-                acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b.v8, acc[0][n], 0, 0, 0);
-                acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b.v8, acc[1][n], 0, 0, 0);
+                for (int j = 0; j < 8; ++j) b.u[j] = koff[j] >= 0 ? raw_to_el(raw[rb + koff[j]]) : (uint16_t)0;
+                acc[0][n] = el_mfma(a0, b.v8, acc[0][n]);
+                acc[1][n] = el_mfma(a1, b.v8, acc[1][n]);
             }
         }
 #pragma unroll
@@ -304,8 +322,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
 
     // =========================== 3 residual blocks ===========================
     for (int blk = 0; blk < 3; ++blk) {
-        const bf16x8 *wv1 = reinterpret_cast<const bf16x8 *>(wpz + WP_RES + (2 * blk) * WP_RES_SIZE) + (2 * cb) * 64 + lane;
-        const bf16x8 *wv2 = wv1 + WP_RES_SIZE / 8;
+        const el8 *wv1 = reinterpret_cast<const el8 *>(wpz + WP_RES + (2 * blk) * WP_RES_SIZE) + (2 * cb) * 64 + lane;
+        const el8 *wv2 = wv1 + WP_RES_SIZE / 8;
         // ---- block1: t = relu(conv(x) + b1) ----
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -334,8 +352,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
-                acc[a][n] = f32x4{bf16_bits_to_f32(xres[a][n].x & 0xFFFFu), bf16_bits_to_f32(xres[a][n].x >> 16),
-                                  bf16_bits_to_f32(xres[a][n].y & 0xFFFFu), bf16_bits_to_f32(xres[a][n].y >> 16)};
+                acc[a][n] = f32x4{el_lo(xres[a][n].x), el_hi(xres[a][n].x), el_lo(xres[a][n].y), el_hi(xres[a][n].y)};
         conv3x3<SAVE>(act, wv2, addr, acc, save + ((1 + 2 * blk) * M + obs0) * 6272, ctotal, tid);  // t = saved layer 1 + 2 blk
         __syncthreads();
 #pragma unroll
@@ -356,8 +373,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
 
     // =========================== conv 1x1: 128 -> 16, ReLU, NCHW flatten ===========================
     {
-        const bf16x8 *wv = reinterpret_cast<const bf16x8 *>(wpz + WP_L7) + lane;
-        bf16x8 a7[4];
+        const el8 *wv = reinterpret_cast<const el8 *>(wpz + WP_L7) + lane;
+        el8 a7[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) a7[s] = wv[s * 64];
         const float4 b4 = *reinterpret_cast<const float4 *>(bl + 4 * lh);
@@ -369,7 +386,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
             f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a7[s], *reinterpret_cast<const bf16x8 *>(rowp + s * 64), c, 0, 0, 0);
+                c = el_mfma(a7[s], *reinterpret_cast<const el8 *>(rowp + s * 64), c);
             if (v) {
                 const long long orow = IDX ? (long long)row_index[obs0 + o] : obs0 + o;
                 uint16_t *dst = out + orow * 784 + (4 * lh) * 49 + q;  // latent[obs][co*49 + y*7 + x]
@@ -386,7 +403,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
   }
 }
 
-// ---- weight packing: fp32 [co][ci][kh][kw] (contiguous) -> bf16 MFMA A fragments, biases concatenated ----
+// ---- weight packing: fp32 [co][ci][kh][kw] (contiguous) -> f16 MFMA A fragments, biases concatenated ----
 struct PackArgs {
     const float *w[8];
     const float *b[8];
@@ -422,7 +439,7 @@ __global__ void __launch_bounds__(256) encoder_pack_kernel(PackArgs pa, uint16_t
         const int f = i - WP_L7, s = f >> 9;
         v = pa.w[7][r * 128 + 32 * s + 8 * h + j];
     }
-    wp[i] = (uint16_t)f32_to_bf16_bits(v);
+    wp[i] = f32_to_el_bits(v);
 }
 
 // =====================================================================================================
@@ -446,14 +463,40 @@ constexpr int WPT_L7 = 6 * WP_RES_SIZE;
 constexpr int WPT_TOTAL = WPT_L7 + 8 * 512;
 static_assert(WPT_TOTAL == MAPF_ENC_PACKED_BWD_ELEMS, "header constant out of date");
 
-// masked gradient of 4 channels, packed to bf16; `bs` accumulates this lane's share of the bias gradient
+// Loss scale of the backward chain: the power of two that puts the largest magnitude of the gradient arriving at the encoder's
+// output into (8, 16] -- 12 binary orders of headroom below f16's 65504 for growth inside the chain (conversions clamp beyond
+// that), the small end of the distribution as far above f16's subnormal range as it can be.  `max_bits`: that largest magnitude
+// as bf16 bits (grad_absmax_kernel).  Exact: scaling by 2^k and back changes no mantissa.
+__device__ __forceinline__ float grad_scale_from_max(uint32_t max_bits) {
+    int k = 130 - (int)((max_bits >> 7) & 0xFFu);  // the maximum lies in [2^(e-127), 2^(e-126)): times 2^(130-e) -> [8, 16)
+    k = k < -24 ? -24 : (k > 60 ? 60 : k);
+    return __uint_as_float((uint32_t)(k + 127) << 23);
+}
+__global__ void __launch_bounds__(256) grad_absmax_kernel(const uint4 *__restrict__ g, long long chunks, uint32_t *__restrict__ out) {
+    uint32_t m = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long long)gridDim.x * 256) {
+        const uint4 v = g[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = w[k] & 0x7FFFu, hi = (w[k] >> 16) & 0x7FFFu;
+            m = max(m, max(lo < 0x7F80u ? lo : 0u, hi < 0x7F80u ? hi : 0u));  // (inf / NaN do not set the scale)
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+__device__ __forceinline__ float clamp_el(float v) { return __builtin_amdgcn_fmed3f(v, -EL_MAX, EL_MAX); }
+
+// masked gradient of 4 channels, packed to f16 (still multiplied by the loss scale); `bs` accumulates this lane's share of the bias gradient
 __device__ __forceinline__ uint2 pack_masked(const f32x4 &a, uint32_t m, float (&bs)[4]) {
     const float v0 = (m & 1u) ? a[0] : 0.f, v1 = (m & 2u) ? a[1] : 0.f, v2 = (m & 4u) ? a[2] : 0.f, v3 = (m & 8u) ? a[3] : 0.f;
     bs[0] += v0;
     bs[1] += v1;
     bs[2] += v2;
     bs[3] += v3;
-    return make_uint2(pack2_bf16(v0, v1), pack2_bf16(v2, v3));
+    return make_uint2(el_pack2(clamp_el(v0), clamp_el(v1)), el_pack2(clamp_el(v2), clamp_el(v3)));
 }
 // Sum over the 16 lanes of a DPP row (every lane ends up with the total): row rotations by 8 and 4, then the two quad
 // permutations.  VALU-only: __shfl_xor compiles to ds_bpermute_b32, an LDS-pipe instruction with LDS latency.
@@ -469,12 +512,12 @@ __device__ __forceinline__ float row_sum16(float v) {
 }
 // Sum the per-lane bias shares over the 16 lanes that hold the same channels (different positions) and store this
 // workgroup's partial bias gradient of one layer: dst[co] for co = co_lane + 16 a + r (each written by one lane).
-__device__ __forceinline__ void store_bias_partial(float (&bs)[2][4], float *__restrict__ dst, int co_lane, int lr) {
+__device__ __forceinline__ void store_bias_partial(float (&bs)[2][4], float *__restrict__ dst, int co_lane, int lr, float inv_scale) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float v = row_sum16(bs[a][r]);
+            const float v = row_sum16(bs[a][r]) * inv_scale;
             if (lr == 0) dst[co_lane + 16 * a + r] = v;
             bs[a][r] = 0.f;
         }
@@ -489,7 +532,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
                                                                   const uint32_t *__restrict__ relu_bits,
                                                                   const uint16_t *__restrict__ wpt, uint16_t *__restrict__ gz,
                                                                   float *__restrict__ gb_part, const uint16_t *__restrict__ latent,
-                                                                  uint16_t *__restrict__ gz7_out, float *__restrict__ gb7_part) {
+                                                                  uint16_t *__restrict__ gz7_out, float *__restrict__ gb7_part,
+                                                                  uint32_t *__restrict__ grad_scale) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[ACT_BYTES + GZ7_BYTES];
     unsigned char *const act = smem;
     const unsigned char *const raw = smem + ACT_BYTES;
@@ -500,8 +544,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
     const long long left = M - obs0;
     const int nobs = left < G ? (int)left : G;
 
+    // HEAD: the chain runs on gradients times `scale`; bias partials are divided by it again here, the weight-gradient kernels
+    // divide theirs (they read 1/scale from grad_scale[1]).  Without HEAD the caller's gz7 is taken as it is.
+    const float scale = HEAD ? grad_scale_from_max(grad_scale[0]) : 1.f, inv_scale = 1.f / scale;
+    if (HEAD && blockIdx.x == 0 && tid == 0) grad_scale[1] = __float_as_uint(inv_scale);
     for (int i = tid; i < ACT_BYTES / 16; i += NTHREADS) reinterpret_cast<uint4 *>(act)[i] = make_uint4(0, 0, 0, 0);
-    if (HEAD) {  // mask with (latent > 0) and transpose [obs][c][p] -> [obs][p][c] on the way into LDS
+    if (HEAD) {  // mask with (latent > 0), scale, convert bf16 -> f16 and transpose [obs][c][p] -> [obs][p][c] on the way into LDS
         // (16-byte loads of both tensors issued together; one observation is 98 chunks, so a chunk is all-valid or all-padding)
         const uint4 *gsrc = reinterpret_cast<const uint4 *>(gz7 + obs0 * 784), *lsrc = reinterpret_cast<const uint4 *>(latent + obs0 * 784);
         uint16_t *dst = reinterpret_cast<uint16_t *>(smem + ACT_BYTES);
@@ -525,7 +573,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
             for (int k = 0; k < 8; ++k) {
                 const int i = ch * 8 + k, o = i / 784, rem = i - 784 * o, c = rem / 49, p = rem - 49 * c;
                 const uint32_t y = (lw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, gq = (gw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-                dst[(o * 49 + p) * 16 + c] = (uint16_t)(((y & 0x7FFFu) != 0u && !(y & 0x8000u)) ? gq : 0u);
+                dst[(o * 49 + p) * 16 + c] = ((y & 0x7FFFu) != 0u && !(y & 0x8000u)) ? f32_to_el_bits(bf16_bits_to_f32(gq) * scale) : (uint16_t)0;
             }
         }
     } else {  // gz7 rows of this block: contiguous, 32 B per position
@@ -554,10 +602,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
             float v = 0.f;
 #pragma unroll
             for (int j = 0; j < 13; ++j)
-                if (lh + 4 * j < 49) v += bf16_bits_to_f32(rows[(lh + 4 * j) * 16]);
+                if (lh + 4 * j < 49) v += el_to_f32(rows[(lh + 4 * j) * 16]);
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if (lane < 16) gb7_part[((long long)blockIdx.x * 4 + cb) * 16 + lane] = v;
+            if (lane < 16) gb7_part[((long long)blockIdx.x * 4 + cb) * 16 + lane] = v * inv_scale;
         }
     }
 
@@ -582,21 +630,21 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
     f32x4 acc[2][NT];
     // ---- 1x1^T: g_y3[ci][p] = sum_co W7[co][ci] gz7[co][p]  (K = 16, zero-padded to 32) ----
     {
-        const bf16x8 *wv = reinterpret_cast<const bf16x8 *>(wpt + WPT_L7) + (2 * cb) * 64 + lane;
-        const bf16x8 a0 = wv[0], a1 = wv[64];
+        const el8 *wv = reinterpret_cast<const el8 *>(wpt + WPT_L7) + (2 * cb) * 64 + lane;
+        const el8 a0 = wv[0], a1 = wv[64];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int p = n * 16 + lr;
-            bf16x8 b = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (((vmask >> n) & 1u) && lh < 2) b = *reinterpret_cast<const bf16x8 *>(raw + p * 32 + lh * 16);
-            acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            el8 b = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (((vmask >> n) & 1u) && lh < 2) b = *reinterpret_cast<const el8 *>(raw + p * 32 + lh * 16);
+            acc[0][n] = el_mfma(a0, b, f32x4{0.f, 0.f, 0.f, 0.f});
+            acc[1][n] = el_mfma(a1, b, f32x4{0.f, 0.f, 0.f, 0.f});
         }
     }
 
     for (int blk = 2; blk >= 0; --blk) {
-        const bf16x8 *wv1 = reinterpret_cast<const bf16x8 *>(wpt + (2 * blk) * WP_RES_SIZE) + (2 * cb) * 64 + lane;
-        const bf16x8 *wv2 = wv1 + WP_RES_SIZE / 8;
+        const el8 *wv1 = reinterpret_cast<const el8 *>(wpt + (2 * blk) * WP_RES_SIZE) + (2 * cb) * 64 + lane;
+        const el8 *wv2 = wv1 + WP_RES_SIZE / 8;
         // ---- gz2 = g_y * (y > 0) -> LDS (input of conv2^T) ----
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -605,7 +653,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
                 if ((vmask >> n) & 1u)
                     *reinterpret_cast<uint2 *>(act + addr[n] - lh * 16 + 9 * ROWB + (co_lane + 16 * a) * 2) =
                         pack_masked(acc[a][n], (mk[n] >> (4 * a)) & 0xFu, bs[a]);
-        store_bias_partial(bs, gb_dst(2 + 2 * blk), co_lane, lr);
+        store_bias_partial(bs, gb_dst(2 + 2 * blk), co_lane, lr, inv_scale);
         load_masks(1 + 2 * blk);
         __syncthreads();
         // ---- g_t = conv2^T(gz2) ----
@@ -625,7 +673,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
                 skip[a][n] = *cell;
                 if ((vmask >> n) & 1u) *cell = pack_masked(acc[a][n], (mk[n] >> (4 * a)) & 0xFu, bs[a]);
             }
-        store_bias_partial(bs, gb_dst(1 + 2 * blk), co_lane, lr);
+        store_bias_partial(bs, gb_dst(1 + 2 * blk), co_lane, lr, inv_scale);
         load_masks(2 * blk);  // y of the previous block, or conv0's output for blk = 0
         __syncthreads();
         // ---- g_x = conv1^T(gz1) + gz2 ----
@@ -633,8 +681,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
-                acc[a][n] = f32x4{bf16_bits_to_f32(skip[a][n].x & 0xFFFFu), bf16_bits_to_f32(skip[a][n].x >> 16),
-                                  bf16_bits_to_f32(skip[a][n].y & 0xFFFFu), bf16_bits_to_f32(skip[a][n].y >> 16)};
+                acc[a][n] = f32x4{el_lo(skip[a][n].x), el_hi(skip[a][n].x), el_lo(skip[a][n].y), el_hi(skip[a][n].y)};
         conv3x3<true>(act, wv1, addr, acc, gz + (1 + 2 * blk) * LSTRIDE + obs0 * 6272, nobs * 49 * 16, tid);
         __syncthreads();
     }
@@ -647,7 +694,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
             for (int n = 0; n < NT; ++n)
                 if ((vmask >> n) & 1u)
                     *reinterpret_cast<uint2 *>(g0 + cell_off(a, n)) = pack_masked(acc[a][n], (mk[n] >> (4 * a)) & 0xFu, bs[a]);
-        store_bias_partial(bs, gb_dst(0), co_lane, lr);
+        store_bias_partial(bs, gb_dst(0), co_lane, lr, inv_scale);
     }
 }
 
@@ -668,7 +715,7 @@ __global__ void __launch_bounds__(256) encoder_pack_bwd_kernel(PackArgs pa, uint
         const int c = ((idx - WPT_L7) >> 9) & 7, k = 8 * h + j, o = 16 * c + r;
         if (k < 16) v = pa.w[7][k * 128 + o];
     }
-    wpt[idx] = (uint16_t)f32_to_bf16_bits(v);
+    wpt[idx] = f32_to_el_bits(v);
 }
 
 #define HIP_TRY(expr)                                                                          \
@@ -777,15 +824,15 @@ int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint32_
     const long long blocks = (M + G - 1) / G;
     if (blocks > 0x7FFFFFFFLL) return MAPF_ERR_INVALID_ARG;
     hipLaunchKernelGGL(encoder_bwd_kernel<false>, dim3((unsigned)blocks), dim3(NTHREADS), 0, static_cast<hipStream_t>(stream), gz7_dev,
-                       (long long)M, relu_bits_dev, packed_bwd_dev, gz_dev, gbias_partial_dev, nullptr, nullptr, nullptr);
+                       (long long)M, relu_bits_dev, packed_bwd_dev, gz_dev, gbias_partial_dev, nullptr, nullptr, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }
 
 int mapf_encoder_backward(const uint16_t *g_latent_dev, const uint16_t *latent_dev, int64_t M, const uint32_t *relu_bits_dev,
                           const uint16_t *packed_bwd_dev, uint16_t *gz_dev, float *gbias_partial_dev, uint16_t *gz7_dev,
-                          float *gb7_partial_dev, void *stream) {
-    if (M < 0 || !packed_bwd_dev ||
+                          float *gb7_partial_dev, uint32_t *grad_scale_dev, void *stream) {
+    if (M < 0 || !packed_bwd_dev || !grad_scale_dev || (reinterpret_cast<uintptr_t>(grad_scale_dev) & 3) ||
         (M > 0 && (!g_latent_dev || !latent_dev || !relu_bits_dev || !gz_dev || !gbias_partial_dev || !gz7_dev || !gb7_partial_dev)))
         return MAPF_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(g_latent_dev) & 15) || (reinterpret_cast<uintptr_t>(latent_dev) & 15) ||
@@ -795,8 +842,15 @@ int mapf_encoder_backward(const uint16_t *g_latent_dev, const uint16_t *latent_d
     if (M == 0) return MAPF_OK;
     const long long blocks = (M + G - 1) / G;
     if (blocks > 0x7FFFFFFFLL) return MAPF_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(encoder_bwd_kernel<true>, dim3((unsigned)blocks), dim3(NTHREADS), 0, static_cast<hipStream_t>(stream), g_latent_dev,
-                       (long long)M, relu_bits_dev, packed_bwd_dev, gz_dev, gbias_partial_dev, latent_dev, gz7_dev, gb7_partial_dev);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // the loss scale: largest |g_latent| -> grad_scale_dev[0]; the chain below derives the power of two from it and leaves its
+    // inverse in grad_scale_dev[1] for the weight-gradient kernels
+    HIP_TRY(hipMemsetAsync(grad_scale_dev, 0, 8, st));
+    const long long chunks = M * 98;  // 784 bf16 = 98 x 16 bytes per observation
+    hipLaunchKernelGGL(grad_absmax_kernel, dim3((unsigned)(chunks < 256 * 1024 ? (chunks + 255) / 256 : 1024)), dim3(256), 0, st,
+                       reinterpret_cast<const uint4 *>(g_latent_dev), chunks, grad_scale_dev);
+    hipLaunchKernelGGL(encoder_bwd_kernel<true>, dim3((unsigned)blocks), dim3(NTHREADS), 0, st, g_latent_dev,
+                       (long long)M, relu_bits_dev, packed_bwd_dev, gz_dev, gbias_partial_dev, latent_dev, gz7_dev, gb7_partial_dev, grad_scale_dev);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }

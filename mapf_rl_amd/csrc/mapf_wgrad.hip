@@ -6,7 +6,7 @@
 //                          gz[m][y][x][co] * a[m][y+ky-1][x+kx-1][ci]            (zero outside the 7x7 image)
 //
 // gz = ReLU-masked pre-activation gradient of the layer (mapf_encoder_backward_data), a = the layer's input
-// (mapf_encoder_forward_save), both bf16 [M][49][128].  As a GEMM: 128 (co) x 1152 (tap, ci) outputs, K = all
+// (mapf_encoder_forward_save), both f16 [M][49][128] (gz times the chain's loss scale).  As a GEMM: 128 (co) x 1152 (tap, ci) outputs, K = all
 // positions of all observations -- tiny output, enormous K, so the output is held in registers and the
 // operands stream through LDS:
 //  * A workgroup (512 threads = 8 waves, two per SIMD) owns one of TWO slabs of the output -- all 128 co x 9 taps x
@@ -58,7 +58,7 @@ __device__ __attribute__((aligned(16))) unsigned int g_wgrad_zero[4];  // what t
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 el8;  // the encoder kernels' element type is f16 (mapf_encoder.hip)
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 template <int V>
@@ -85,14 +85,14 @@ constexpr int LPW = 3;                       // loads per wave and block: gz chu
 static_assert((2 * NTAP * NBUF) % RB == 0 && LDS_BYTES <= 160 * 1024, "");
 static_assert(MAPF_ENC_WGRAD_PARTS % 8 == 0, "");
 
-__device__ __forceinline__ bf16x8 tr_read2(const unsigned char *p0, const unsigned char *p1) {
+__device__ __forceinline__ el8 tr_read2(const unsigned char *p0, const unsigned char *p1) {
     // two transposed 4-row blocks -> the 8 k-elements of one MFMA fragment
     typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p0));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p1));
     union {
         s16x4 h[2];
-        bf16x8 v;
+        el8 v;
     } u;
     u.h[0] = lo;
     u.h[1] = hi;
@@ -100,7 +100,7 @@ __device__ __forceinline__ bf16x8 tr_read2(const unsigned char *p0, const unsign
 }
 
 __global__ void __launch_bounds__(NTHR) encoder_wgrad_kernel(const uint16_t *__restrict__ gz, const uint16_t *__restrict__ ain, long long M,
-                                                           float *__restrict__ ws) {
+                                                           float *__restrict__ ws, const uint32_t *__restrict__ grad_scale) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(NTHR) encoder_wgrad_kernel(const uint16_t *__r
     __syncthreads();
 
     // fragments: the CT gz (A) tiles of the current k-step and of the next one; the input (B) tiles pass through a ring of RB
-    bf16x8 af[2][CT], br[RB];
+    el8 af[2][CT], br[RB];
     auto read_a = [&](const unsigned char *gbuf, int ks, int c) {
         return tr_read2(gbuf + a_addr[c] + (32 * ks) * 256, gbuf + a_addr[c] + (32 * ks + 16) * 256);
     };
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(NTHR) encoder_wgrad_kernel(const uint16_t *__r
 #pragma unroll
                 for (int c = 0; c < CT; ++c)
                     // tied destination: hipcc does not tie the builtin's, and shuffles 4 registers per MFMA on the loop back-edge
-                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[c][t]) : "v"(af[cur][c]), "v"(br[gr % RB]));
+                    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[c][t]) : "v"(af[cur][c]), "v"(br[gr % RB]));
                 __builtin_amdgcn_sched_barrier(0);
             }
             bc = bn;
@@ -285,6 +285,8 @@ __global__ void __launch_bounds__(NTHR) encoder_wgrad_kernel(const uint16_t *__r
 
     // ---- partial sums of this partition: ws[part][co][tap = ky*3 + kx][ci] ----
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the asm MFMAs are opaque to hipcc's hazard padding: let the last ones retire
+    // (gz carries the backward chain's loss scale: taken out here, in fp32)
+    const float inv_scale = grad_scale ? __uint_as_float(grad_scale[1]) : 1.f;
     float *out = ws + (long long)part * (128 * 9 * 128);
 #pragma unroll
     for (int c = 0; c < CT; ++c)
@@ -294,7 +296,7 @@ __global__ void __launch_bounds__(NTHR) encoder_wgrad_kernel(const uint16_t *__r
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = 16 * (CT * chalf + c) + 4 * lh + r;
-                out[(co * 9 + t) * 128 + ci] = acc[c][t][r];
+                out[(co * 9 + t) * 128 + ci] = acc[c][t][r] * inv_scale;
             }
         }
 }
@@ -312,7 +314,8 @@ __global__ void __launch_bounds__(NTHR) encoder_wgrad_kernel(const uint16_t *__r
 
 extern "C" {
 
-int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M, float *partial_dev, void *stream) {
+int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M, const uint32_t *grad_scale_dev, float *partial_dev,
+                       void *stream) {
     if (M < 0 || !partial_dev || (M > 0 && (!gz_dev || !in_dev))) return MAPF_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(gz_dev) & 15) || (reinterpret_cast<uintptr_t>(in_dev) & 15) ||
         (reinterpret_cast<uintptr_t>(partial_dev) & 15))
@@ -320,7 +323,7 @@ int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M
     if ((M + MAPF_ENC_WGRAD_PARTS - 1) / MAPF_ENC_WGRAD_PARTS > (1 << 18)) return MAPF_ERR_INVALID_ARG;  // int element offsets inside a partition
     // every partition writes its slab (zeros when it has no observations), so the caller's sum is always defined
     hipLaunchKernelGGL(encoder_wgrad_kernel, dim3(SLABS * MAPF_ENC_WGRAD_PARTS), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gz_dev,
-                       in_dev, (long long)M, partial_dev);
+                       in_dev, (long long)M, partial_dev, grad_scale_dev);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }

@@ -4,7 +4,7 @@
 //     dW0[co][ci][ky][kx] = sum over observations m and output positions (y,x) in 7x7 of
 //                           gz0[m][y][x][co] * obs[m][ci][y+ky][x+kx]
 //
-// gz0 = ReLU-masked pre-activation gradient of the layer (mapf_encoder_backward, layer 0), bf16 [M][49][128]; obs the raw
+// gz0 = ReLU-masked pre-activation gradient of the layer (mapf_encoder_backward, layer 0), f16 [M][49][128]; obs the raw
 // observations (uint8 / bool bytes or bf16 [M][6][9][9]).  As a GEMM the output is 128 x 54 with K = 49 M: far too small
 // for a BLAS call per se, and the im2col matrix [49 M][54] a library GEMM wants is 0.65 GB written and read again (0.9 ms
 // per update at 122,880 observations).  Here a workgroup keeps its 128 x 64 slab of the output in registers and streams
@@ -15,7 +15,7 @@
 //    15-KB slots, the raw bytes three ahead through a ring of four (the patch matrix is built one step early), 67 KB in
 //    all: two workgroups per CU, one building patches or waiting at its barrier while the other multiplies.  Every wave
 //    issues exactly 5 loads per step, so `s_waitcnt vmcnt(5)` = "everything issued before this step has landed".
-//  * The patch matrix of an observation is built TRANSPOSED in LDS, PT[j = ci*9 + ky*3 + kx][k = 7y + x] (bf16, 64 x 64,
+//  * The patch matrix of an observation is built TRANSPOSED in LDS, PT[j = ci*9 + ky*3 + kx][k = 7y + x] (f16, 64 x 64,
 //    rows >= 54 and positions >= 49 zero; columns permuted inside each 32 to the k order of the transposed read), one step ahead of its use (double buffer), so that the B fragment of the MFMA
 //    (8 consecutive k of one column j) is a plain ds_read_b128; the A fragment (gz0^T: 8 consecutive k of one co) comes
 //    from the position-major gz0 image through ds_read_b64_tr_b16, padding k slots pointed at an all-zero row.
@@ -31,7 +31,7 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 el8;  // the encoder kernels' element type is f16 (mapf_encoder.hip)
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -49,26 +49,28 @@ constexpr int OFF_PT = OFF_RAW + NRAW * RAW_BYTES;
 constexpr int LDS_BYTES = OFF_PT + 2 * PT_BYTES;
 static_assert(2 * LDS_BYTES <= 160 * 1024, "LDS budget: two workgroups per CU");
 
-__device__ __forceinline__ bf16x8 tr_read2(const unsigned char *p0, const unsigned char *p1) {
+__device__ __forceinline__ el8 tr_read2(const unsigned char *p0, const unsigned char *p1) {
     typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p0));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p1));
     union {
         s16x4 h[2];
-        bf16x8 v;
+        el8 v;
     } u;
     u.h[0] = lo;
     u.h[1] = hi;
     return u.v;
 }
 
-__device__ __forceinline__ uint32_t u8_to_bf16_bits(uint32_t v) {  // exact for 0..255
-    return __float_as_uint((float)v) >> 16;
+__device__ __forceinline__ uint32_t f32_to_el_bits(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+__device__ __forceinline__ uint32_t u8_to_el_bits(uint32_t v) { return f32_to_el_bits((float)v); }  // exact for 0..255
+__device__ __forceinline__ uint32_t bf16_to_el_bits(uint32_t h) {  // observation given as bf16: clamped into f16's range
+    return f32_to_el_bits(__builtin_amdgcn_fmed3f(__uint_as_float(h << 16), -65504.f, 65504.f));
 }
 
 template <typename InT>
 __global__ void __launch_bounds__(NTHR, 2) conv0_wgrad_kernel(const uint16_t *__restrict__ gz, const InT *__restrict__ obs, long long M,
-                                                            float *__restrict__ ws) {
+                                                            float *__restrict__ ws, const uint32_t *__restrict__ grad_scale) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,10 +116,10 @@ __global__ void __launch_bounds__(NTHR, 2) conv0_wgrad_kernel(const uint16_t *__
                 asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, %2" ::"s"(rdst), "v"(roff), "s"(osrc) : "memory");
         }
     };
-    // element e (0..485) of the staged observation as bf16 bits
+    // element e (0..485) of the staged observation as f16 bits
     auto raw_elem = [&](const unsigned char *raw, int e) -> uint32_t {
-        if (sizeof(InT) == 1) return u8_to_bf16_bits(raw[(e >> 1) * 4 + (e & 1)]);
-        return *reinterpret_cast<const uint16_t *>(raw + 2 * e);
+        if (sizeof(InT) == 1) return u8_to_el_bits(raw[(e >> 1) * 4 + (e & 1)]);
+        return bf16_to_el_bits(*reinterpret_cast<const uint16_t *>(raw + 2 * e));
     };
     // PT[j][8 kc .. 8 kc + 8) for this thread's tasks (54 rows x 8 chunks = 432 tasks over 256 threads)
     auto build_pt = [&](int slot, int pb) __attribute__((always_inline)) {
@@ -182,15 +184,15 @@ __global__ void __launch_bounds__(NTHR, 2) conv0_wgrad_kernel(const uint16_t *__
         const unsigned char *gzb = smem + gs * GZ_BYTES, *ptb = smem + OFF_PT + pb * PT_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[2], b[4];
+            el8 a[2], b[4];
 #pragma unroll
             for (int c = 0; c < 2; ++c) a[c] = tr_read2(gzb + a_row[ks][0] + c * 32, gzb + a_row[ks][1] + c * 32);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const bf16x8 *>(ptb + b_off + t * 16 * PT_ROW + ks * 64);
+            for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const el8 *>(ptb + b_off + t * 16 * PT_ROW + ks * 64);
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[c], b[t], acc[c][t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[c], b[t], acc[c][t], 0, 0, 0);
         }
         if (full)
             asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // gz s + 1 and raw s + 2 (issued one step ago) have landed
@@ -201,13 +203,14 @@ __global__ void __launch_bounds__(NTHR, 2) conv0_wgrad_kernel(const uint16_t *__
     }
 
     // ---- partial sums of this partition: ws[part][co][j] ----
+    const float inv_scale = grad_scale ? __uint_as_float(grad_scale[1]) : 1.f;  // gz carries the backward chain's loss scale
     float *out = ws + (long long)part * (128 * 64);
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[(16 * (2 * w + c) + 4 * lh + r) * 64 + 16 * t + li] = acc[c][t][r];
+            for (int r = 0; r < 4; ++r) out[(16 * (2 * w + c) + 4 * lh + r) * 64 + 16 * t + li] = acc[c][t][r] * inv_scale;
 }
 
 #define HIP_TRY(expr)                                                                         \
@@ -223,7 +226,8 @@ __global__ void __launch_bounds__(NTHR, 2) conv0_wgrad_kernel(const uint16_t *__
 
 extern "C" {
 
-int mapf_encoder_wgrad0(const uint16_t *gz0_dev, const void *obs_dev, int obs_dtype, int64_t M, float *partial_dev, void *stream) {
+int mapf_encoder_wgrad0(const uint16_t *gz0_dev, const void *obs_dev, int obs_dtype, int64_t M, const uint32_t *grad_scale_dev,
+                        float *partial_dev, void *stream) {
     if (M < 0 || !partial_dev || (M > 0 && (!gz0_dev || !obs_dev))) return MAPF_ERR_INVALID_ARG;
     if (obs_dtype != MAPF_ENC_OBS_U8 && obs_dtype != MAPF_ENC_OBS_BF16) return MAPF_ERR_INVALID_ARG;
     // u8 observations are fetched two bytes at a time (486 bytes each: every observation starts on an even address iff the base does)
@@ -234,10 +238,10 @@ int mapf_encoder_wgrad0(const uint16_t *gz0_dev, const void *obs_dev, int obs_dt
     // every partition writes its slab (zeros when it has no observations), so the caller's sum is always defined
     if (obs_dtype == MAPF_ENC_OBS_U8)
         hipLaunchKernelGGL(conv0_wgrad_kernel<uint8_t>, dim3(PARTS), dim3(NTHR), 0, st, gz0_dev, static_cast<const uint8_t *>(obs_dev),
-                           (long long)M, partial_dev);
+                           (long long)M, partial_dev, grad_scale_dev);
     else
         hipLaunchKernelGGL(conv0_wgrad_kernel<uint16_t>, dim3(PARTS), dim3(NTHR), 0, st, gz0_dev, static_cast<const uint16_t *>(obs_dev),
-                           (long long)M, partial_dev);
+                           (long long)M, partial_dev, grad_scale_dev);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }

@@ -92,6 +92,22 @@ ENC_WGRAD0_PARTS = 512
 ENC_WGRAD_PARTS = 128
 ENC_OBS_PER_BLOCK = 4
 _ENC_OBS_U8, _ENC_OBS_BF16 = 0, 1
+# what the encoder kernels keep between layers and save for the backward pass: IEEE half (csrc/mapf_encoder.hip) -- activations,
+# packed weights, pre-activation gradients.  The latent they output and the gradient they receive for it are bf16.
+ENC_ELEMENT = torch.float16
+
+
+def tall_tn_f32(a, b, rows=8192):
+    """a^T b in fp32 for 16-bit a [K, m], b [K, n] with K in the 10^5..10^6 range (model._tall_tn: K split into batches so that the
+    library GEMM fills the chip) -- with fp32 partial products: f16 operands carry a loss scale, a 16-bit partial could overflow."""
+    K, m = a.shape
+    S = K // rows
+    if S > 1:
+        out = torch.bmm(a[:S * rows].view(S, rows, m).transpose(1, 2), b[:S * rows].view(S, rows, -1), out_dtype=torch.float32).sum(dim=0)
+        if K > S * rows:
+            out += torch.mm(a[S * rows:].t(), b[S * rows:], out_dtype=torch.float32)
+        return out
+    return torch.mm(a.t(), b, out_dtype=torch.float32)
 
 
 def encoder_convs(obs_encoder):
@@ -133,7 +149,7 @@ class PackedEncoder:
             bs = [c.bias.detach().to(torch.float32).contiguous() for c in convs]
             assert [tuple(w.shape) for w in ws] == [(128, 6, 3, 3)] + [(128, 128, 3, 3)] * 6 + [(16, 128, 1, 1)]
             if self.weights is None or self.weights.device != dev:
-                self.weights = torch.empty(ENC_PACKED_ELEMS, dtype=torch.bfloat16, device=dev)
+                self.weights = torch.empty(ENC_PACKED_ELEMS, dtype=ENC_ELEMENT, device=dev)
                 self.bias = torch.empty(ENC_BIAS_ELEMS, dtype=torch.float32, device=dev)
             bp = (ctypes.c_void_p * 8)(*[b.data_ptr() for b in bs])
             check(lib.mapf_encoder_pack(wp, bp, nhwc, _ptr(self.weights), _ptr(self.bias), _stream(dev)), "mapf_encoder_pack")
@@ -152,7 +168,7 @@ def pack_encoder_backward(obs_encoder_or_params):
         convs = encoder_convs(obs_encoder_or_params)
     ws, nhwc, wp = _conv_weight_ptrs(convs)
     dev = ws[0].device
-    wpt = torch.empty(ENC_PACKED_BWD_ELEMS, dtype=torch.bfloat16, device=dev)
+    wpt = torch.empty(ENC_PACKED_BWD_ELEMS, dtype=ENC_ELEMENT, device=dev)
     check(lib.mapf_encoder_pack_bwd(wp, nhwc, _ptr(wpt), _stream(dev)), "mapf_encoder_pack_bwd")
     return wpt
 
@@ -253,7 +269,7 @@ class _EncoderTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, obs, packed_w, packed_b, *params):
         M = obs.shape[0]
-        acts = torch.empty((7, M, 7, 7, 128), dtype=torch.bfloat16, device=obs.device)
+        acts = torch.empty((7, M, 7, 7, 128), dtype=ENC_ELEMENT, device=obs.device)
         out = torch.empty((M, 784), dtype=torch.bfloat16, device=obs.device)
         bits = torch.empty((7, M, 49, 4), dtype=torch.int32, device=obs.device)  # ReLU sign bits for the backward chain
         kind = _ENC_OBS_U8 if obs.dtype == torch.uint8 else _ENC_OBS_BF16
@@ -276,11 +292,13 @@ class _EncoderTrain(torch.autograd.Function):
         g = g.to(torch.bfloat16).contiguous()
         nblk = -(-M // ENC_OBS_PER_BLOCK)
         gz = torch.empty_like(acts)
-        gz7 = torch.empty((M * 49, 16), dtype=torch.bfloat16, device=dev)
+        gz7 = torch.empty((M * 49, 16), dtype=ENC_ELEMENT, device=dev)
         gb_part = torch.empty((7, nblk, 128), dtype=torch.float32, device=dev)
         gb7_part = torch.empty((4 * nblk, 16), dtype=torch.float32, device=dev)
+        # gz / gz7 come back multiplied by the chain's loss scale S (include/mapf_dqn.h); scale[1] = the bits of 1 / S
+        scale = torch.empty(2, dtype=torch.int32, device=dev)
         check(lib.mapf_encoder_backward(_ptr(g), _ptr(out), M, _ptr(bits), _ptr(wpt), _ptr(gz), _ptr(gb_part), _ptr(gz7), _ptr(gb7_part),
-                                        _stream(dev)), "mapf_encoder_backward")
+                                        _ptr(scale), _stream(dev)), "mapf_encoder_backward")
         # per-workgroup partial bias gradients -> [7][128]: in two stages (a reduction over the middle axis of [7, 30720, 128] in
         # one call runs at 0.4 TB/s; the 240-row inner stage is contiguous per output and the outer stage tiny)
         pad = (-nblk) % 256
@@ -290,19 +308,18 @@ class _EncoderTrain(torch.autograd.Function):
         # partial sums per observation partition, added here
         ws = torch.empty((ENC_WGRAD_PARTS, 128, 3, 3, 128), dtype=torch.float32, device=dev)
         for k in range(1, 7):
-            check(lib.mapf_encoder_wgrad(_ptr(gz[k]), _ptr(acts[k - 1]), M, _ptr(ws), _stream(dev)), "mapf_encoder_wgrad")
+            check(lib.mapf_encoder_wgrad(_ptr(gz[k]), _ptr(acts[k - 1]), M, _ptr(scale), _ptr(ws), _stream(dev)), "mapf_encoder_wgrad")
             gws[k] = ws.sum(dim=0).permute(0, 3, 1, 2)  # [co][ky][kx][ci] memory == channels_last [co, ci, 3, 3]
         # conv0 (6 -> 128 on the raw 9x9 observation): its own streaming kernel (csrc/mapf_wgrad0.hip) -- the im2col matrix a
         # library GEMM would need is 0.65 GB at the learner's shape; the 1x1 layer (16 outputs) is a plain split-K GEMM
         ws0 = torch.empty((ENC_WGRAD0_PARTS, 128, 64), dtype=torch.float32, device=dev)
         kind = _ENC_OBS_U8 if obs.dtype == torch.uint8 else _ENC_OBS_BF16
-        check(lib.mapf_encoder_wgrad0(_ptr(gz[0]), _ptr(obs), kind, M, _ptr(ws0), _stream(dev)), "mapf_encoder_wgrad0")
+        check(lib.mapf_encoder_wgrad0(_ptr(gz[0]), _ptr(obs), kind, M, _ptr(scale), _ptr(ws0), _stream(dev)), "mapf_encoder_wgrad0")
         gws[0] = ws0.sum(dim=0)[:, :54].reshape(128, 6, 3, 3)
-        from .model import _tall_tn  # split-K GEMM for [K, m]^T [K, n] with huge K
 
         # the 1x1 head (16 x 128 outputs over 6 M rows): the library's split-K GEMM streams its 1.7 GB of input at 5.3-5.9 TB/s
         # (0.33 ms at 40 agents); a hand-written vector-ALU streaming kernel tried in round 2 reached 3.2-3.8 TB/s and was dropped
-        gws[7] = _tall_tn(gz7, acts[6].reshape(M * 49, 128)).view(16, 128, 1, 1)
+        gws[7] = (tall_tn_f32(gz7, acts[6].reshape(M * 49, 128)) * scale.view(torch.float32)[1]).view(16, 128, 1, 1)
         grads = []
         for i in range(8):
             grads += [gws[i].to(params[2 * i].dtype), gbs[i].to(params[2 * i + 1].dtype)]

@@ -26,7 +26,7 @@ import torch
 
 from ._lib import check, lib
 from .fused import (ENC_OBS_PER_BLOCK, ENC_WGRAD0_PARTS, ENC_WGRAD_PARTS, RECUR_NARROW_AGENTS, RECUR_WEIGHT_ELEMS, PackedEncoder,
-                    PackedRecurrence, mm_rows, pack_encoder_backward, recurrence_params)
+                    PackedRecurrence, mm_rows, pack_encoder_backward, recurrence_params, ENC_ELEMENT)
 
 GAMMA = 0.99
 GRAD_CLIP = 40.0
@@ -351,7 +351,7 @@ class FusedUpdate:
         # ---- online network forward, saving what the backward needs ----
         M, Mu = po.rows, po.urows  # entries of the window set / distinct observations among them
         bf = torch.bfloat16
-        acts = torch.empty((7, Mu, 7, 7, 128), dtype=bf, device=dev)
+        acts = torch.empty((7, Mu, 7, 7, 128), dtype=ENC_ELEMENT, device=dev)
         lat = torch.empty((Mu, 784), dtype=bf, device=dev)
         bits = torch.empty((7, Mu, 49, 4), dtype=torch.int32, device=dev)
         check(lib.mapf_encoder_forward_save(_ptr(po.obs_rows), 1, Mu, _ptr(wp), _ptr(bp), _ptr(lat), _ptr(acts), _ptr(bits), st),
@@ -475,11 +475,14 @@ class FusedUpdate:
         G, st, bf = flat.grads, _stream(dev), torch.bfloat16
         nblk = -(-M // ENC_OBS_PER_BLOCK)
         gz = torch.empty_like(acts)
-        gz7 = torch.empty((M * 49, 16), dtype=bf, device=dev)
+        gz7 = torch.empty((M * 49, 16), dtype=ENC_ELEMENT, device=dev)
         gb_part = torch.empty((7, nblk, 128), dtype=torch.float32, device=dev)
         gb7_part = torch.empty((4 * nblk, 16), dtype=torch.float32, device=dev)
-        check(lib.mapf_encoder_backward(_ptr(g_lat), _ptr(lat), M, _ptr(bits), _ptr(wpt), _ptr(gz), _ptr(gb_part), _ptr(gz7), _ptr(gb7_part), st),
-              "mapf_encoder_backward")
+        # the chain's gradients are f16 times a power-of-two loss scale S picked from max |g_lat| (include/mapf_dqn.h);
+        # scale[1] = the bits of 1 / S, which the weight-gradient kernels multiply their partial sums by
+        scale = torch.empty(2, dtype=torch.int32, device=dev)
+        check(lib.mapf_encoder_backward(_ptr(g_lat), _ptr(lat), M, _ptr(bits), _ptr(wpt), _ptr(gz), _ptr(gb_part), _ptr(gz7), _ptr(gb7_part),
+                                        _ptr(scale), st), "mapf_encoder_backward")
         names = ["obs_encoder.0", "obs_encoder.2.block1", "obs_encoder.2.block2", "obs_encoder.3.block1", "obs_encoder.3.block2",
                  "obs_encoder.4.block1", "obs_encoder.4.block2", "obs_encoder.5"]
         # bias gradients: the kernel's per-workgroup partials, summed in two stages (see fused._EncoderTrain.backward)
@@ -489,24 +492,27 @@ class FusedUpdate:
         torch.sum(gb7_part, dim=0, out=flat.mem(G, names[7] + ".bias"))
         ws = torch.empty((ENC_WGRAD_PARTS, 128, 3, 3, 128), dtype=torch.float32, device=dev)
         for k in range(1, 7):
-            check(lib.mapf_encoder_wgrad(_ptr(gz[k]), _ptr(acts[k - 1]), M, _ptr(ws), st), "mapf_encoder_wgrad")
+            check(lib.mapf_encoder_wgrad(_ptr(gz[k]), _ptr(acts[k - 1]), M, _ptr(scale), _ptr(ws), st), "mapf_encoder_wgrad")
             torch.sum(ws, dim=0, out=flat.mem(G, names[k] + ".weight"))  # [co][ky][kx][ci] == the weight's channels_last memory
         ws0 = torch.empty((ENC_WGRAD0_PARTS, 128, 64), dtype=torch.float32, device=dev)
-        check(lib.mapf_encoder_wgrad0(_ptr(gz[0]), _ptr(obs_rows), 1, M, _ptr(ws0), st), "mapf_encoder_wgrad0")
+        check(lib.mapf_encoder_wgrad0(_ptr(gz[0]), _ptr(obs_rows), 1, M, _ptr(scale), _ptr(ws0), st), "mapf_encoder_wgrad0")
         # conv0: columns j = ci*9 + ky*3 + kx -> the weight's memory [co][ky][kx][ci]
         flat.mem(G, names[0] + ".weight").copy_(ws0.sum(dim=0)[:, :54].view(128, 6, 3, 3).permute(0, 2, 3, 1))
-        _tall_tn_into(flat.mem(G, names[7] + ".weight").view(16, 128), gz7, acts[6].reshape(M * 49, 128))
+        g7 = flat.mem(G, names[7] + ".weight").view(16, 128)
+        _tall_tn_into(g7, gz7, acts[6].reshape(M * 49, 128))
+        g7.mul_(scale.view(torch.float32)[1])
 
 
 def _tall_tn_into(out, a, b, rows=8192):
     """out[m, n] = a^T b for a [K, m], b [K, n] with K in the 10^5 .. 10^6 range (model._tall_tn), written in place: K is split into
-    batches of `rows` (bmm, bf16 in / fp32 accumulate inside a batch) that are summed in fp32 straight into `out`."""
+    batches of `rows` (bmm, 16-bit in / fp32 out) that are summed in fp32 straight into `out`.  (fp32 partial products: the
+    encoder's f16 operands carry a loss scale, and a 16-bit partial of 8192 rows also costs the gradient 2-3 digits.)"""
     K, m = a.shape
     S = K // rows
     if S > 1:
-        part = torch.bmm(a[:S * rows].view(S, rows, m).transpose(1, 2), b[:S * rows].view(S, rows, -1))
-        torch.sum(part, dim=0, dtype=torch.float32, out=out)
+        part = torch.bmm(a[:S * rows].view(S, rows, m).transpose(1, 2), b[:S * rows].view(S, rows, -1), out_dtype=torch.float32)
+        torch.sum(part, dim=0, out=out)
         if K > S * rows:
-            out += torch.mm(a[S * rows:].t(), b[S * rows:]).float()
+            out += torch.mm(a[S * rows:].t(), b[S * rows:], out_dtype=torch.float32)
     else:
-        out.copy_(torch.mm(a.t(), b))
+        out.copy_(torch.mm(a.t(), b, out_dtype=torch.float32))

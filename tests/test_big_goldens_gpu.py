@@ -1,4 +1,4 @@
-"""GPU (bf16 kernels): the product path against REFERENCE goldens at the BASELINE agent counts (tests/golden/dqn_big.npz,
+"""GPU (16-bit MFMA kernels): the product path against REFERENCE goldens at the BASELINE agent counts (tests/golden/dqn_big.npz,
 captured by tests/golden/make_dqn_goldens_big.py from the unmodified reference in fp32): Network.step on the reference's
 64-agent fixture, and one Learner.train body on replay-shaped batches of real observations at A = 40 (config 2), A = 6 (the
 reference's training shape) and A = 128 (config 5) -- Q-values, td error, loss, gradient norm and EVERY parameter's gradient
@@ -7,11 +7,12 @@ parameter tensor ||g - g_ref|| <= BOUND ||g_ref|| (estimated from 24 fixed +-1 p
 gradient norms below 1e-3 of the global norm measured against that floor (bf16 rounding noise of the other tensors):
   * BOUND = 2e-2 for every parameter of the recurrence and the Q head (GRU cells, attention, W_O, adv/state: the BPTT kernels;
     measured 1e-3 .. 8e-3);
-  * BOUND = 0.15 for the 16 encoder tensors: their gradient is a sum over ~10^6 positions through 8 layers of bf16 activations
-    and bf16 pre-activation gradients with strong cancellation, and bf16 rounding alone puts it 6-14 % off the fp32 direction --
-    the layer-by-layer MIOpen path under the same autocast measures 0.07-0.14 against this golden, the fused kernels 0.06-0.11, the
-    same module path in fp32 on the GPU 1e-6 (tools/enc_grad_check.py, gpurun_out/r02_b_encgrad.log); every tensor's NORM (and
-    every GRU gate block's) still agrees within 2e-2."""
+  * BOUND = 0.04 for the 16 encoder tensors: their gradient is a sum over ~10^6 positions through 8 layers of 16-bit activations
+    with strong cancellation.  The encoder kernels keep activations, weights and pre-activation gradients in f16 (the reference's own
+    AMP format, worker.py:283) and measure 0.009-0.037 against this golden; in bf16 (rounds 1-2; and the layer-by-layer MIOpen path
+    under bf16 autocast today) the same tensors sit 0.06-0.14 off -- the 3 mantissa bits of the ACTIVATIONS are what matters, the
+    format of the gradients does not (profiles/r03_encoder_grad_error_fp16.txt); the same module path in fp32 on the GPU measures
+    1e-6 (tools/enc_grad_check.py); every tensor's NORM (and every GRU gate block's) agrees within 2e-2."""
 import numpy as np
 import pytest
 import torch
@@ -83,5 +84,5 @@ def test_update_bf16_kernels_vs_reference(tag):
             # td tolerance (bf16 Q-values move small td errors by a few per cent), not a kernel's
             assert err <= 6e-2, (name, err)
             continue
-        assert err <= (0.15 if name.startswith("obs_encoder.") else 2e-2), (name, err)
+        assert err <= (0.04 if name.startswith("obs_encoder.") else 2e-2), (name, err)
         assert blk <= 2e-2, (name, blk)

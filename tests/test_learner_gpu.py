@@ -147,7 +147,9 @@ def test_double_q_update_on_gpu(tag):
     td = out["td"].float().cpu().numpy().astype(np.float64).reshape(-1)
     qn = out["q_next"].float().cpu().numpy().astype(np.float64).reshape(-1)
     check_q_next(qn)  # the update itself (update.FusedUpdate: third recurrence on the side stream, head in mapf_dqn_head_loss)
-    assert np.all(np.abs(qn - got) <= tol * np.maximum(1.0, np.abs(got)))
+    # (and it agrees with target_q wherever the online arg-max is not a near tie: there the two paths may pick differently)
+    clear = np.array([np.sum(q_on[i] >= q_on[i].max() - 2 * tol * max(1.0, abs(q_on[i].max()))) == 1 for i in range(len(qn))])
+    assert np.all(np.abs(qn - got)[clear] <= tol * np.maximum(1.0, np.abs(got))[clear])
     want = q_sel - (rew + 0.99 ** steps * qn)  # the learner's own q_next: the pick is checked above
     assert np.all(np.isfinite(td)) and np.all(np.abs(td - want) <= 4e-2 * np.maximum(1.0, np.abs(want))), np.abs(td - want).max()
     assert np.isfinite(float(out["loss"])) and np.isfinite(float(out["grad_norm"])) and lr.counter == 1
