@@ -40,10 +40,10 @@ def run():
     for lib in libs.values():
         lib.mapf_encoder_forward.argtypes = [vp, ctypes.c_int, ctypes.c_int64, vp, vp, vp, vp]
         lib.mapf_encoder_forward_save.argtypes = [vp, ctypes.c_int, ctypes.c_int64, vp, vp, vp, vp, vp, vp]
-        lib.mapf_encoder_backward.argtypes = [vp, vp, ctypes.c_int64, vp, vp, vp, vp, vp, vp, vp]
+        lib.mapf_encoder_backward.argtypes = [vp, vp, ctypes.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]  # (round-3 ABI: base revisions from d464af7 on)
     g = torch.Generator(device="cuda").manual_seed(1)
-    w = (torch.randn(894976, device="cuda", generator=g) * 0.03).to(torch.bfloat16)
-    wt = (torch.randn(888832, device="cuda", generator=g) * 0.03).to(torch.bfloat16)
+    w = (torch.randn(894976, device="cuda", generator=g) * 0.03).to(torch.float16)
+    wt = (torch.randn(888832, device="cuda", generator=g) * 0.03).to(torch.float16)
     b = torch.randn(912, dtype=torch.float32, device="cuda", generator=g) * 0.1
 
     def timed(fn, n=5):
@@ -65,17 +65,18 @@ def run():
         for name, lib in libs.items():
             lat = torch.zeros((M, 784), dtype=torch.bfloat16, device="cuda")
             lat2 = torch.zeros((M, 784), dtype=torch.bfloat16, device="cuda")
-            acts = torch.zeros((7, M, 49, 128), dtype=torch.bfloat16, device="cuda")
+            acts = torch.zeros((7, M, 49, 128), dtype=torch.float16, device="cuda")
             bits = torch.zeros((7, M, 49, 4), dtype=torch.int32, device="cuda")
-            gz = torch.zeros((7, M, 49, 128), dtype=torch.bfloat16, device="cuda")
-            gz7 = torch.zeros((M, 49, 16), dtype=torch.bfloat16, device="cuda")
+            gz = torch.zeros((7, M, 49, 128), dtype=torch.float16, device="cuda")
+            gz7 = torch.zeros((M, 49, 16), dtype=torch.float16, device="cuda")
+            sw = torch.zeros(2, dtype=torch.int32, device="cuda")
             nblk = (M + 3) // 4
             gbp = torch.zeros((7, nblk, 128), dtype=torch.float32, device="cuda")
             gb7 = torch.zeros((4 * nblk, 16), dtype=torch.float32, device="cuda")
             f = lambda: lib.mapf_encoder_forward(obs.data_ptr(), 0, M, w.data_ptr(), b.data_ptr(), lat.data_ptr(), None)
             fs = lambda: lib.mapf_encoder_forward_save(obs.data_ptr(), 0, M, w.data_ptr(), b.data_ptr(), lat2.data_ptr(), acts.data_ptr(), bits.data_ptr(), None)
             bw = lambda: lib.mapf_encoder_backward(gl.data_ptr(), lat2.data_ptr(), M, bits.data_ptr(), wt.data_ptr(), gz.data_ptr(), gbp.data_ptr(),
-                                                   gz7.data_ptr(), gb7.data_ptr(), None)
+                                                   gz7.data_ptr(), gb7.data_ptr(), sw.data_ptr(), None)
             tf, tfs, tb = timed(f), timed(fs), timed(bw)
             print("M=%6d %-5s forward %.3f ms   forward_save %.3f ms   backward %.3f ms" % (M, name, tf, tfs, tb), flush=True)
             out[name] = (lat, lat2, acts, bits, gz, gz7)
