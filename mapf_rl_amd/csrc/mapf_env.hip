@@ -880,7 +880,13 @@ int launch_step_nt(const mapf_env *h, const StepParams &p, hipStream_t s, size_t
     if constexpr (!DO_OBS) {
         hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, false, 16, 1, NT, 1>), g, b, smem, s, p);
     } else if constexpr (NT == 64) {
-        if (need <= 4)
+        // (the unrolled rounds all issue their loads and field deposits, predicated off when a round has no task: a round too many
+        // costs the one-wavefront blocks of the small shapes ~8 % -- 16 agents need 3 rounds)
+        if (need <= 2)
+            hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 2, NT, 1>), g, b, smem, s, p);
+        else if (need <= 3)
+            hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 3, NT, 1>), g, b, smem, s, p);
+        else if (need <= 4)
             hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 4, NT, 1>), g, b, smem, s, p);
         else if (need <= 7)
             hipLaunchKernelGGL((env_step_kernel<W, 4, DO_STEP, true, VEC, 7, NT, 1>), g, b, smem, s, p);
@@ -904,7 +910,11 @@ int launch_step_packed(const mapf_env *h, const StepParams &p, hipStream_t s, si
     if constexpr (!DO_OBS) {
         hipLaunchKernelGGL((env_step_kernel<uint32_t, 4, DO_STEP, false, 16, 1, 64, G>), g, b, smem, s, p);
     } else {
-        if (need <= 4)
+        if (need <= 2)
+            hipLaunchKernelGGL((env_step_kernel<uint32_t, 4, DO_STEP, true, 16, 2, 64, G>), g, b, smem, s, p);
+        else if (need <= 3)
+            hipLaunchKernelGGL((env_step_kernel<uint32_t, 4, DO_STEP, true, 16, 3, 64, G>), g, b, smem, s, p);
+        else if (need <= 4)
             hipLaunchKernelGGL((env_step_kernel<uint32_t, 4, DO_STEP, true, 16, 4, 64, G>), g, b, smem, s, p);
         else if (need <= 7)
             hipLaunchKernelGGL((env_step_kernel<uint32_t, 4, DO_STEP, true, 16, 7, 64, G>), g, b, smem, s, p);
