@@ -76,13 +76,22 @@ if args.ckpt:
     lr.load_state_dict(torch.load(args.ckpt, map_location="cpu"))
 buf = run("tape", "tape policy (80 % heuristic / 20 % uniform)", lr.model)
 run("greedy", "the network's greedy actions (%s)" % ("checkpoint " + args.ckpt if args.ckpt else "random init"), lr.model)
-# learner: duplicate rows among the rows an update encodes
+# learner: duplicate rows among the rows an update encodes -- what the built reuse catches (same agent, consecutive steps: the plan's
+# `urows` of `rows`) and the bound for any reuse scheme (distinct rows by value over the whole window set)
+from mapf_rl_amd.update import FusedUpdate  # noqa: E402
+
 learner = Learner(buf, device=dev, batch_size=192, model=lr.model)
 fu = learner._fused
 for _ in range(3):
     batch = buf.sample_batch(192)
-    pl = fu._finish_plan(fu.plan(batch))
-    rows = pl["online"].obs_rows.view(pl["online"].rows, -1)
+    FusedUpdate.DEDUP = True
+    po = fu._finish_plan(fu.plan(batch))["online"]
+    built = 1 - po.urows / po.rows
+    FusedUpdate.DEDUP = False
+    po = fu._finish_plan(fu.plan(batch))["online"]
+    FusedUpdate.DEDUP = True
+    rows = po.obs_rows[:po.rows].reshape(po.rows, -1)
     torch.cuda.synchronize()
     uniq = torch.unique(rows.view(torch.int16), dim=0).shape[0]
-    print("learner: %d rows to encode in the online window, %d distinct (%.3f duplicates)" % (rows.shape[0], uniq, 1 - uniq / rows.shape[0]), flush=True)
+    print("learner: %d rows to encode in the online window; the update's run-length reuse drops %.3f of them; %d distinct by value "
+          "(%.3f duplicates: the bound)" % (po.rows, built, uniq, 1 - uniq / po.rows), flush=True)

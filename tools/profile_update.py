@@ -14,6 +14,9 @@ N = int(os.environ.get("NAGENTS", 40))
 L = int(os.environ.get("MAPLEN", 64 if N > 64 else 32))
 E = int(os.environ.get("NENVS", 1024 if N > 64 else 2048))
 Network.PRUNE_UNREACHABLE = os.environ.get("PRUNE", "1") != "0"
+if not Network.PRUNE_UNREACHABLE:  # "every observation": no pruning and no reuse of repeated observations either (the reference's work)
+    from mapf_rl_amd.update import FusedUpdate
+    FusedUpdate.DEDUP = False
 dev = torch.device("cuda")
 torch.manual_seed(0)
 buf = GlobalBuffer(4096, max_agents=max(N, 6), device=dev, init_set=(N, L), fixed_level=True)
