@@ -26,7 +26,7 @@ import torch
 
 from ._lib import check, lib
 from .fused import (ENC_OBS_PER_BLOCK, ENC_WGRAD0_PARTS, ENC_WGRAD_PARTS, RECUR_NARROW_AGENTS, RECUR_WEIGHT_ELEMS, PackedEncoder,
-                    PackedRecurrence, mm_rows, pack_encoder_backward, recurrence_params, ENC_ELEMENT)
+                    PackedRecurrence, mm_rows, pack_encoder_backward, recurrence_params, rows_buffer, ENC_ELEMENT)
 
 GAMMA = 0.99
 GRAD_CLIP = 40.0
@@ -250,10 +250,10 @@ class FusedUpdate:
             p.h0_c = torch.empty((B, Nc, 256), dtype=torch.bfloat16, device=dev)
             # the observations to encode: every row, or -- with the duplicate flags -- the distinct ones (umap: entry -> distinct row)
             p.urows = int(h[4 + k].sum()) if p.dup is not None else p.rows
-            p.obs_rows = torch.empty((max(p.urows, 1), 6, 9, 9), dtype=torch.bfloat16, device=dev)
-            row_src = torch.empty(max(p.urows, 1), dtype=torch.int64, device=dev)
-            p.umap = torch.empty(max(p.rows, 1), dtype=torch.int32, device=dev) if p.dup is not None else None
-            p.row_tbp = torch.empty(max(p.rows, 1), dtype=torch.int32, device=dev) if p.dup is not None else None
+            p.obs_rows = rows_buffer((), max(p.urows, 1), (6, 9, 9), torch.bfloat16, dev)
+            row_src = rows_buffer((), max(p.urows, 1), (), torch.int64, dev)
+            p.umap = rows_buffer((), max(p.rows, 1), (), torch.int32, dev) if p.dup is not None else None
+            p.row_tbp = rows_buffer((), max(p.rows, 1), (), torch.int32, dev) if p.dup is not None else None
             cm, obs, hid = v["comm"], v["obs"], v["hidden"]
             check(lib.mapf_plan_rows(T, B, N, Nc, _ptr(p.order), _ptr(p.nact), _ptr(p.cnt), _ptr(p.nag), _ptr(cm), cm.stride(0), cm.stride(1),
                                      _ptr(hid), int(hid.dtype == torch.bfloat16), _ptr(obs), obs.stride(0), obs.stride(1), _ptr(p.gidx),
@@ -280,7 +280,7 @@ class FusedUpdate:
         st = _stream(dev)
         wp, bp = penc.get(net.obs_encoder, net.weights_epoch)
         w, b = prec.get(net)
-        lat = torch.empty((p.urows, 784), dtype=torch.bfloat16, device=dev)
+        lat = rows_buffer((), p.urows, (784,), torch.bfloat16, dev)
         check(lib.mapf_encoder_forward(_ptr(p.obs_rows), 1, p.urows, _ptr(wp), _ptr(bp), _ptr(lat), st), "mapf_encoder_forward")
         gi = self._expand(mm_rows(lat, self._w_ih(net, own)), p)  # [rows, 768]
         compact = Nc <= RECUR_NARROW_AGENTS  # the <= 48-agent kernels read / write the rows that exist (gidx); the wide ones are dense
@@ -297,7 +297,7 @@ class FusedUpdate:
         """Rows of the distinct observations [urows, w] -> one row per entry [rows, w] (umap); the identity without duplicate flags."""
         if p.umap is None:
             return x_u
-        out = torch.empty((p.rows, x_u.shape[1]), dtype=x_u.dtype, device=x_u.device)
+        out = rows_buffer((), p.rows, (x_u.shape[1],), x_u.dtype, x_u.device)
         check(lib.mapf_rows_scatter(_ptr(x_u), _ptr(p.umap), _ptr(out), p.rows, x_u.shape[1] * x_u.element_size(), 1, _stream(self.dev)),
               "mapf_rows_scatter")
         return out
@@ -351,9 +351,9 @@ class FusedUpdate:
         # ---- online network forward, saving what the backward needs ----
         M, Mu = po.rows, po.urows  # entries of the window set / distinct observations among them
         bf = torch.bfloat16
-        acts = torch.empty((7, Mu, 7, 7, 128), dtype=ENC_ELEMENT, device=dev)
-        lat = torch.empty((Mu, 784), dtype=bf, device=dev)
-        bits = torch.empty((7, Mu, 49, 4), dtype=torch.int32, device=dev)
+        acts = rows_buffer((7,), Mu, (7, 7, 128), ENC_ELEMENT, dev)
+        lat = rows_buffer((), Mu, (784,), bf, dev)
+        bits = rows_buffer((7,), Mu, (49, 4), torch.int32, dev)
         check(lib.mapf_encoder_forward_save(_ptr(po.obs_rows), 1, Mu, _ptr(wp), _ptr(bp), _ptr(lat), _ptr(acts), _ptr(bits), st),
               "mapf_encoder_forward_save")
         w_ih = self._w_ih(model, True)
@@ -369,10 +369,10 @@ class FusedUpdate:
         else:
             gi = torch.empty((To, B, Nc, 768), dtype=bf, device=dev)
             check(lib.mapf_rows_scatter(_ptr(gi_rows), _ptr(po.gidx), _ptr(gi), To * B * Nc, 1536, 1, st), "mapf_rows_scatter")
-        saves = [torch.empty((R, 256), dtype=bf, device=dev), torch.empty((R, 1024), dtype=bf, device=dev),
-                 torch.empty((2, R, 256), dtype=bf, device=dev), torch.empty((2, R, 384), dtype=bf, device=dev),
-                 torch.empty((2, R, 128), dtype=bf, device=dev), torch.empty((2, R, 64), dtype=bf, device=dev),
-                 torch.empty((2, R, 1024), dtype=bf, device=dev),
+        saves = [rows_buffer((), R, (256,), bf, dev), rows_buffer((), R, (1024,), bf, dev),
+                 rows_buffer((2,), R, (256,), bf, dev), rows_buffer((2,), R, (384,), bf, dev),
+                 rows_buffer((2,), R, (128,), bf, dev), rows_buffer((2,), R, (64,), bf, dev),
+                 rows_buffer((2,), R, (1024,), bf, dev),
                  torch.empty((2, To * B, 2, 48, 64) if Nc <= RECUR_NARROW_AGENTS else (8,), dtype=bf, device=dev)]
         h_out = torch.empty((B, Nc, 256), dtype=bf, device=dev)
         a0 = torch.empty((To, B, 256), dtype=bf, device=dev)
@@ -420,9 +420,9 @@ class FusedUpdate:
             else:
                 lr._launch_prefetch()
         # ---- backward through time ----
-        outs_b = [torch.empty((R, 768), dtype=bf, device=dev), torch.empty((R, 768), dtype=bf, device=dev),
-                  torch.empty((2, R, 768), dtype=bf, device=dev), torch.empty((2, R, 768), dtype=bf, device=dev),
-                  torch.empty((2, R, 64), dtype=bf, device=dev), torch.empty((2, R, 384), dtype=bf, device=dev),
+        outs_b = [rows_buffer((), R, (768,), bf, dev), rows_buffer((), R, (768,), bf, dev),
+                  rows_buffer((2,), R, (768,), bf, dev), rows_buffer((2,), R, (768,), bf, dev),
+                  rows_buffer((2,), R, (64,), bf, dev), rows_buffer((2,), R, (384,), bf, dev),
                   torch.empty((B, 2432), dtype=torch.float32, device=dev)]
         check(lib.mapf_recurrent_backward(sp, _ptr(po.comm_c), _ptr(d_a0), _ptr(wt), To, B, Nc, _ptr_array(outs_b), ridx, nrows, st),
               "mapf_recurrent_backward")
@@ -447,10 +447,10 @@ class FusedUpdate:
         if compact:
             d_gi_rows = d_gi1[:M]
         else:
-            d_gi_rows = torch.empty((M, 768), dtype=bf, device=dev)
+            d_gi_rows = rows_buffer((), M, (768,), bf, dev)
             check(lib.mapf_rows_scatter(_ptr(d_gi_rows), _ptr(po.gidx), _ptr(d_gi1), R, 1536, 0, st), "mapf_rows_scatter")
         if po.umap is not None:  # gradient of a shared row = the sum over the entries that use it
-            d_gi_u = torch.empty((Mu, 768), dtype=bf, device=dev)
+            d_gi_u = rows_buffer((), Mu, (768,), bf, dev)
             check(lib.mapf_dedup_sum(To, B, Nc, M, 1536, _ptr(po.gidx), _ptr(po.umap), _ptr(po.row_tbp), _ptr(d_gi_rows), _ptr(d_gi_u), st),
                   "mapf_dedup_sum")
             d_gi_rows = d_gi_u
@@ -474,10 +474,10 @@ class FusedUpdate:
         dev, flat = self.dev, self.flat
         G, st, bf = flat.grads, _stream(dev), torch.bfloat16
         nblk = -(-M // ENC_OBS_PER_BLOCK)
-        gz = torch.empty_like(acts)
-        gz7 = torch.empty((M * 49, 16), dtype=ENC_ELEMENT, device=dev)
-        gb_part = torch.empty((7, nblk, 128), dtype=torch.float32, device=dev)
-        gb7_part = torch.empty((4 * nblk, 16), dtype=torch.float32, device=dev)
+        gz = rows_buffer((7,), M, (7, 7, 128), ENC_ELEMENT, dev)
+        gz7 = rows_buffer((), M, (49, 16), ENC_ELEMENT, dev).view(M * 49, 16)
+        gb_part = rows_buffer((7,), nblk, (128,), torch.float32, dev)
+        gb7_part = rows_buffer((), 4 * nblk, (16,), torch.float32, dev)
         # the chain's gradients are f16 times a power-of-two loss scale S picked from max |g_lat| (include/mapf_dqn.h);
         # scale[1] = the bits of 1 / S, which the weight-gradient kernels multiply their partial sums by
         scale = torch.empty(2, dtype=torch.int32, device=dev)

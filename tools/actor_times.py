@@ -35,3 +35,15 @@ for reuse in (True, False):
             for _ in range(3): step()
             torch.cuda.synchronize()
         print(prof.key_averages().table(sort_by="device_time_total", row_limit=14, max_name_column_width=60))
+if os.environ.get("PROFILE_HOST"):
+    import cProfile, pstats
+    actor.latents = actor.latents or None
+    from mapf_rl_amd.fused import LatentCache
+    if actor.latents is None:
+        actor.latents = LatentCache()
+    for _ in range(5): step()
+    torch.cuda.synchronize()
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(40): step()
+    torch.cuda.synchronize(); pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(40)
