@@ -59,10 +59,12 @@ int mapf_encoder_forward(const void *obs_dev, int obs_dtype, int64_t M, const ui
 
 /*
  * The same for LISTED rows only: observation i (i < *row_count_dev <= max_rows; the count is read on the device) of obs_dev
- * u8 [*row_count][486] is encoded into row row_index[i] of latent_dev; every other row of latent_dev is left as it is.  For the
+ * u8 [*row_count][MAPF_ENC_PACKED_OBS_STRIDE] (486 bytes + 2 of padding: rows start on 4-byte boundaries, what mapf_obs_changed
+ * writes) is encoded into row row_index[i] of latent_dev; every other row of latent_dev is left as it is.  For the
  * actor loop: an agent whose observation did not change since the previous step keeps its latent (the encoder is a deterministic
  * per-observation function), and the host never learns how many changed (include/mapf_replay.h: mapf_obs_changed).
  */
+#define MAPF_ENC_PACKED_OBS_STRIDE 488
 int mapf_encoder_forward_rows(const uint8_t *obs_dev, int64_t max_rows, const int32_t *row_index_dev, const int32_t *row_count_dev,
                               const uint16_t *packed_dev, const float *bias_dev, uint16_t *latent_dev, void *stream);
 

@@ -122,7 +122,8 @@ int mapf_actor_rewind(int num_envs, int num_agents, int local_steps, int env_row
                       const uint8_t *finished_dev, const int32_t *obs_bits_dev, int64_t *t_dev, int32_t *lb_obs_dev,
                       uint16_t *hidden_dev, void *stream);
 /* Rows (486-byte observations) of obs_dev that differ from prev_dev: their indices are appended to list_dev (any order), their number
- * goes to count_dev [1] (zeroed here), the rows themselves go back to back, in list order, to packed_dev u8 [rows][486] (optional)
+ * goes to count_dev [1] (zeroed here), the rows themselves go, in list order, to packed_dev u8 [rows][488] (optional; 486 bytes + 2 of
+ * padding per row = MAPF_ENC_PACKED_OBS_STRIDE of mapf_dqn.h: dword stores, and what mapf_encoder_forward_rows reads)
  * and prev_dev is refreshed -- reference worker.py:378 calls the network on every agent every step; an unchanged observation has an
  * unchanged encoding. */
 int mapf_obs_changed(const uint8_t *obs_dev, uint8_t *prev_dev, int64_t rows, int32_t *list_dev, int32_t *count_dev, uint8_t *packed_dev,

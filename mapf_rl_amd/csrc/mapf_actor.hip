@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 
+#include "mapf_dqn.h"
 #include "mapf_env.h"
 #include "mapf_replay.h"
 
@@ -124,58 +125,81 @@ __global__ void __launch_bounds__(1024) actor_log_kernel(int E, const uint8_t *f
 }
 
 // Which agents see something new: a row (486-byte observation) that differs from the copy of the step before is appended to the
-// list (order does not matter: every row is encoded independently) and the copy is refreshed.  One wavefront per PAIR of rows: two
-// rows are 972 bytes = 243 dwords starting on a 4-byte boundary (a single row of odd index does not), dword 121 straddles them.
+// list (order does not matter: every row is encoded independently), copied to the packed buffer and the copy is refreshed.
+// One wavefront per CHUNK of 8 row pairs: two rows are 972 bytes = 243 dwords starting on a 4-byte boundary (a single row of odd
+// index does not), dword 121 straddles them.  The chunk's changed rows get their list slots with ONE atomic (first version: one per
+// pair -- 80 k atomics on one address per call when most agents move, ~0.8 ms), and the packed rows have a 488-byte stride
+// (MAPF_ENC_PACKED_OBS_STRIDE) so that they are written with dword stores whatever the slot's parity (first version: 486-byte stride,
+// 2-byte stores).
+constexpr int CH_PAIRS = 8;
 __global__ void __launch_bounds__(256) obs_changed_kernel(const uint32_t *__restrict__ obs, uint32_t *__restrict__ prev, long long rows,
-                                                          int32_t *__restrict__ list, int32_t *__restrict__ count, uint16_t *__restrict__ packed) {
+                                                          int32_t *__restrict__ list, int32_t *__restrict__ count, uint32_t *__restrict__ packed) {
     const int lane = threadIdx.x & 63;
     const long long pairs = (rows + 1) >> 1;
-    for (long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); q < pairs; q += (long long)gridDim.x * 4) {
-        const bool two = 2 * q + 1 < rows;
-        const int nd = two ? 243 : 122;  // a last single row: 121.5 dwords (its buffer ends on a 2-byte boundary: handled below)
-        const uint32_t *cur = obs + q * 243;
-        uint32_t *old = prev + q * 243;
-        uint32_t v[4], o[4];
-        bool d0 = false, d1 = false;
+    const long long chunks = (pairs + CH_PAIRS - 1) / CH_PAIRS;
+    for (long long c = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); c < chunks; c += (long long)gridDim.x * 4) {
+        uint32_t cm = 0;  // bit 2 i: first row of pair i changed, bit 2 i + 1: its second row
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int d = lane + 64 * k;
-            v[k] = o[k] = 0u;
-            if (d < nd) {
-                if (!two && d == 121) {  // only the low half exists
-                    v[k] = reinterpret_cast<const uint16_t *>(cur)[242];
-                    o[k] = reinterpret_cast<const uint16_t *>(old)[242];
-                } else {
-                    v[k] = cur[d];
-                    o[k] = old[d];
-                }
-                const uint32_t x = v[k] ^ o[k];
-                d0 |= d < 121 ? x != 0u : (d == 121 && (x & 0xFFFFu) != 0u);
-                d1 |= d > 121 ? x != 0u : (d == 121 && (x >> 16) != 0u);
-            }
-        }
-        const bool c0 = __ballot(d0) != 0ull, c1 = two && __ballot(d1) != 0ull;
-        if (c0 | c1) {
-            int base = 0;
-            if (lane == 0) {
-                base = atomicAdd(count, (int)c0 + (int)c1);
-                if (c0) list[base] = (int32_t)(2 * q);
-                if (c1) list[base + (int)c0] = (int32_t)(2 * q + 1);
-            }
-            if (packed) {  // the changed rows back to back, in list order: what mapf_encoder_forward_rows reads
-                base = __shfl(base, 0, 64);
-                const uint16_t *c16 = reinterpret_cast<const uint16_t *>(cur);
-                for (int k = lane; k < 243; k += 64) {
-                    if (c0) packed[(long long)base * 243 + k] = c16[k];
-                    if (c1) packed[(long long)(base + (int)c0) * 243 + k] = c16[243 + k];
-                }
-            }
+        for (int i = 0; i < CH_PAIRS; ++i) {
+            const long long q = c * CH_PAIRS + i;
+            if (q >= pairs) break;  // (wave-uniform)
+            const bool two = 2 * q + 1 < rows;
+            const int nd = two ? 243 : 122;  // a last single row: 121.5 dwords (its buffer ends on a 2-byte boundary: handled below)
+            const uint32_t *cur = obs + q * 243;
+            uint32_t *old = prev + q * 243;
+            uint32_t v[4], o[4];
+            bool d0 = false, d1 = false;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int d = lane + 64 * k;
-                if (d < nd && v[k] != o[k]) {
-                    if (!two && d == 121) reinterpret_cast<uint16_t *>(old)[242] = (uint16_t)v[k];
-                    else old[d] = v[k];
+                v[k] = o[k] = 0u;
+                if (d < nd) {
+                    if (!two && d == 121) {  // only the low half exists
+                        v[k] = reinterpret_cast<const uint16_t *>(cur)[242];
+                        o[k] = reinterpret_cast<const uint16_t *>(old)[242];
+                    } else {
+                        v[k] = cur[d];
+                        o[k] = old[d];
+                    }
+                    const uint32_t x = v[k] ^ o[k];
+                    d0 |= d < 121 ? x != 0u : (d == 121 && (x & 0xFFFFu) != 0u);
+                    d1 |= d > 121 ? x != 0u : (d == 121 && (x >> 16) != 0u);
+                }
+            }
+            const bool c0 = __ballot(d0) != 0ull, c1 = two && __ballot(d1) != 0ull;
+            cm |= ((uint32_t)c0 | ((uint32_t)c1 << 1)) << (2 * i);
+            if (c0 | c1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int d = lane + 64 * k;
+                    if (d < nd && v[k] != o[k]) {
+                        if (!two && d == 121) reinterpret_cast<uint16_t *>(old)[242] = (uint16_t)v[k];
+                        else old[d] = v[k];
+                    }
+                }
+            }
+        }
+        if (cm == 0u) continue;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(count, __popc(cm));
+        base = __shfl(base, 0, 64);
+        // list entries: lane r (< 16) owns row r of the chunk
+        if (lane < 2 * CH_PAIRS && ((cm >> lane) & 1u)) list[base + __popc(cm & ((1u << lane) - 1u))] = (int32_t)(2 * c * CH_PAIRS + lane);
+        if (packed) {  // the changed rows, in list order, 122 dwords each (the last 2 bytes are padding): what mapf_encoder_forward_rows reads
+            for (uint32_t m = cm; m != 0u; m &= m - 1u) {
+                const int r = __ffs((int)m) - 1;
+                const long long row = 2 * c * CH_PAIRS + r;
+                uint32_t *dst = packed + (long long)(base + __popc(cm & ((1u << r) - 1u))) * (MAPF_ENC_PACKED_OBS_STRIDE / 4);
+                const uint16_t *c16 = reinterpret_cast<const uint16_t *>(obs) + row * 243;  // (the row was just read: cache hits)
+                for (int j = lane; j < 122; j += 64) {
+                    uint32_t w;
+                    if (!(r & 1)) {
+                        w = j < 121 ? reinterpret_cast<const uint32_t *>(c16)[j] : (uint32_t)c16[242];
+                    } else {
+                        w = (uint32_t)c16[2 * j];
+                        if (j < 121) w |= (uint32_t)c16[2 * j + 1] << 16;
+                    }
+                    dst[j] = w;
                 }
             }
         }
@@ -220,10 +244,10 @@ int mapf_obs_changed(const uint8_t *obs_dev, uint8_t *prev_dev, int64_t rows, in
     if (rows == 0) return MAPF_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(count_dev, 0, 4, s) != hipSuccess) return MAPF_ERR_HIP;
-    long long blocks = ((rows + 1) / 2 + 3) / 4;
+    long long blocks = (((rows + 1) / 2 + CH_PAIRS - 1) / CH_PAIRS + 3) / 4;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(obs_changed_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(obs_dev),
-                       reinterpret_cast<uint32_t *>(prev_dev), (long long)rows, list_dev, count_dev, reinterpret_cast<uint16_t *>(packed_dev));
+                       reinterpret_cast<uint32_t *>(prev_dev), (long long)rows, list_dev, count_dev, reinterpret_cast<uint32_t *>(packed_dev));
     return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
 }
 

@@ -45,7 +45,7 @@ constexpr int ROWB = 272;                  // bytes per activation row (128 f16 
 constexpr int ACT_ROWS = 64 * G + 9;
 constexpr int ACT_BYTES = ACT_ROWS * ROWB;  // 141,712
 constexpr int OBS_ELEMS = 6 * 9 * 9;        // 486
-constexpr int RAW_BYTES = ((G * OBS_ELEMS * 2 + 15) / 16) * 16;  // sized for 2-byte inputs
+constexpr int RAW_BYTES = ((G * OBS_ELEMS * 2 + 15) / 16) * 16;  // sized for 2-byte inputs (>= G * MAPF_ENC_PACKED_OBS_STRIDE bytes too)
 constexpr int NT = 13;                      // position tiles (16 positions each)
 constexpr int NTHREADS = 256;
 constexpr int NPOS = 49 * G;
@@ -232,13 +232,16 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
     // ---- zero the activation image (its border rows must be zero; they are never written afterwards) ----
     for (int i = tid; i < ACT_BYTES / 16; i += NTHREADS) reinterpret_cast<uint4 *>(act)[i] = make_uint4(0, 0, 0, 0);
     // ---- stage the raw observations of this block (contiguous in global memory); missing ones read as zero ----
+    // (IDX: packed rows of RAW_STRIDE = 488 bytes, dword-aligned each; otherwise 486 * sizeof(InT) back to back)
+    constexpr int RAW_STRIDE = IDX ? MAPF_ENC_PACKED_OBS_STRIDE : OBS_ELEMS;  // elements (IDX is u8 only)
+    static_assert(!IDX || sizeof(InT) == 1, "");
     {
-        constexpr int DW = G * OBS_ELEMS * (int)sizeof(InT) / 4;
-        static_assert((G * OBS_ELEMS * sizeof(InT)) % 4 == 0, "block input must stay 4-byte aligned");
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(obs + obs0 * OBS_ELEMS);
+        constexpr int DW = G * RAW_STRIDE * (int)sizeof(InT) / 4;
+        static_assert((G * RAW_STRIDE * sizeof(InT)) % 4 == 0, "block input must stay 4-byte aligned");
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(obs + obs0 * RAW_STRIDE);
         uint32_t *dst = reinterpret_cast<uint32_t *>(smem + ACT_BYTES);
-        const int have = nobs * OBS_ELEMS * (int)sizeof(InT) / 4;  // 486*sizeof(InT) is a multiple of 4 only for even sizes...
-        const int have_bytes = nobs * OBS_ELEMS * (int)sizeof(InT);
+        const int have = nobs * RAW_STRIDE * (int)sizeof(InT) / 4;  // 486*sizeof(InT) is a multiple of 4 only for even sizes...
+        const int have_bytes = nobs * RAW_STRIDE * (int)sizeof(InT);
         for (int i = tid; i < DW; i += NTHREADS) {
             uint32_t v = 0;
             if (i < have) {
@@ -293,7 +296,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
                 const int p = n * 16 + lr;
                 const bool v = (vmask >> n) & 1u;
                 const int o = p / 49, q = p - 49 * o, y = q / 7, x = q - 7 * y;
-                const int rb = v ? o * OBS_ELEMS + y * 9 + x : 0;
+                const int rb = v ? o * RAW_STRIDE + y * 9 + x : 0;
                 union {
                     el8 v8;
                     uint16_t u[8];
@@ -782,7 +785,7 @@ int mapf_encoder_forward_rows(const uint8_t *obs_dev, int64_t max_rows, const in
                               const uint16_t *packed_dev, const float *bias_dev, uint16_t *latent_dev, void *stream) {
     if (max_rows < 0 || !packed_dev || !bias_dev || !row_index_dev || !row_count_dev || (max_rows > 0 && (!obs_dev || !latent_dev)))
         return MAPF_ERR_INVALID_ARG;
-    if ((reinterpret_cast<uintptr_t>(obs_dev) & 1) || (reinterpret_cast<uintptr_t>(packed_dev) & 15) || (reinterpret_cast<uintptr_t>(bias_dev) & 15) ||
+    if ((reinterpret_cast<uintptr_t>(obs_dev) & 3) || (reinterpret_cast<uintptr_t>(packed_dev) & 15) || (reinterpret_cast<uintptr_t>(bias_dev) & 15) ||
         (reinterpret_cast<uintptr_t>(latent_dev) & 1))
         return MAPF_ERR_INVALID_ARG;
     if (max_rows == 0) return MAPF_OK;

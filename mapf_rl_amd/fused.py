@@ -116,6 +116,7 @@ ENC_PACKED_BWD_ELEMS = 888832
 ENC_WGRAD0_PARTS = 512
 ENC_WGRAD_PARTS = 128
 ENC_OBS_PER_BLOCK = 4
+ENC_PACKED_OBS_STRIDE = 488  # include/mapf_dqn.h: MAPF_ENC_PACKED_OBS_STRIDE
 _ENC_OBS_U8, _ENC_OBS_BF16 = 0, 1
 # what the encoder kernels keep between layers and save for the backward pass: IEEE half (csrc/mapf_encoder.hip) -- activations,
 # packed weights, pre-activation gradients.  The latent they output and the gradient they receive for it are bf16.
@@ -240,7 +241,7 @@ class LatentCache:
             if self.lat is None or self.lat.shape[0] != R or self.lat.device != dev:
                 self.lat = torch.empty((R, 784), dtype=torch.bfloat16, device=dev)
                 self.prev = torch.empty_like(obs)
-                self.packed = torch.empty_like(obs)
+                self.packed = torch.empty((R, ENC_PACKED_OBS_STRIDE), dtype=torch.uint8, device=dev)  # rows padded to dwords
                 self.list = torch.empty(R, dtype=torch.int32, device=dev)
                 self.count = torch.zeros(1, dtype=torch.int32, device=dev)
             check(lib.mapf_encoder_forward(_ptr(obs), _ENC_OBS_U8, R, _ptr(wp), _ptr(bp), _ptr(self.lat), st), "mapf_encoder_forward")
