@@ -205,6 +205,33 @@ def test_latent_cache_encodes_only_changed_rows_and_is_exact():
     assert cache.full == 3
 
 
+@pytest.mark.parametrize("R", [1, 2, 3, 15, 16, 17, 33, 4099])
+def test_obs_changed_lists_exactly_the_changed_rows(R):
+    """mapf_obs_changed at row counts around its work units (2 rows per wavefront step, 16 per list-slot atomic): the list holds
+    exactly the changed rows (any order), the packed buffer their bytes in list order at the 488-byte stride, `prev` is refreshed."""
+    from mapf_rl_amd._lib import check, lib
+    from mapf_rl_amd.fused import ENC_PACKED_OBS_STRIDE
+
+    g = torch.Generator(device="cuda").manual_seed(R)
+    prev = (torch.rand((R, 486), device="cuda", generator=g) < 0.3).to(torch.uint8)
+    for frac in (0.0, 0.4, 1.0):
+        obs = prev.clone()
+        change = torch.rand(R, device="cuda", generator=g) < frac
+        col = torch.randint(0, 486, (R,), device="cuda", generator=g)  # one differing byte anywhere in the row is enough
+        rows = change.nonzero().view(-1)
+        obs[rows, col[rows]] ^= 1
+        lst = torch.full((R,), -1, dtype=torch.int32, device="cuda")
+        cnt = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+        packed = torch.full((R, ENC_PACKED_OBS_STRIDE), 255, dtype=torch.uint8, device="cuda")
+        check(lib.mapf_obs_changed(obs.data_ptr(), prev.data_ptr(), R, lst.data_ptr(), cnt.data_ptr(), packed.data_ptr(), None), "mapf_obs_changed")
+        n = int(cnt)
+        assert n == int(change.sum())
+        got = lst[:n].long()
+        assert torch.equal(got.sort().values, rows) and bool((lst[n:] == -1).all())
+        assert torch.equal(packed[:n, :486], obs[got]) and bool((packed[n:] == 255).all())
+        assert torch.equal(prev, obs)
+
+
 def test_actor_with_latent_reuse_records_the_same_episodes():
     """VecActor.REUSE_LATENTS on / off from the same seeds: identical actions, Q-values, hidden states and replay contents (the
     encoder is per observation; an unchanged observation has an unchanged latent).  Also the reference's actor semantics

@@ -132,6 +132,32 @@ def test_encoder_layout_is_position_and_channel_exact():
     assert torch.equal(out.float(), ref)
 
 
+def test_encoder_stays_finite_beyond_the_f16_range():
+    """The kernels keep activations in f16: a layer output beyond 65504 is clamped there instead of becoming inf (and NaN one
+    layer later through inf * 0 or inf - inf), in the inference and the training forward alike."""
+    from mapf_rl_amd._lib import check, lib
+    from mapf_rl_amd.fused import PackedEncoder, encoder_forward
+
+    net = _net(5)
+    with torch.no_grad():
+        for c in _convs(net)[:3]:
+            c.weight.mul_(60.0)  # conv0's outputs reach ~10^2, the first block's ~10^5-10^6
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M = 37
+    obs = (torch.rand((M, 6, 9, 9), device="cuda", generator=g) < 0.5).to(torch.uint8)
+    ref = ref_fp32(net, obs)
+    assert float(ref.max()) > 65504.0  # the fp32 network does leave the range
+    wp, bp = PackedEncoder().get(net.obs_encoder)
+    out = encoder_forward(obs, wp, bp)
+    assert torch.isfinite(out.float()).all()
+    lat = torch.empty((M, 784), dtype=torch.bfloat16, device="cuda")
+    acts = torch.empty((7, M, 49, 128), dtype=torch.float16, device="cuda")
+    bits = torch.empty((7, M, 49, 4), dtype=torch.int32, device="cuda")
+    check(lib.mapf_encoder_forward_save(obs.data_ptr(), 0, M, wp.data_ptr(), bp.data_ptr(), lat.data_ptr(), acts.data_ptr(), bits.data_ptr(), None),
+          "mapf_encoder_forward_save")
+    assert torch.isfinite(acts.float()).all() and float(acts.float().max()) == 65504.0 and torch.equal(lat, out)
+
+
 def test_encoder_bf16_input_and_model_path():
     """bf16 observations (the replay gather's output type) and the `Network.encode` switch: without autograd under
     bf16 autocast the fused kernel runs; with autograd the MIOpen path runs; both agree within bf16 tolerance."""

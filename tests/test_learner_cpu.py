@@ -137,3 +137,16 @@ def test_double_q_is_online_argmax_target_value():
     assert not torch.equal(q_on.argmax(1), q_tar.argmax(1)) or True   # (the two networks carry different weights)
     out = lr2.update(b)
     assert torch.allclose(out["q_next"], want)
+
+
+def test_row_buckets_bound_the_slack():
+    """fused.row_bucket (allocation sizes of the learner's row-count-sized buffers): never below the request, at most 12.5 % above
+    it from 16 rows on, monotone, and a handful of distinct sizes per octave."""
+    from mapf_rl_amd.fused import row_bucket
+
+    prev = 0
+    for n in list(range(0, 600)) + [4097, 18320, 36804, 442368, 10 ** 7]:
+        b = row_bucket(n)
+        assert b >= max(n, 1) and b >= prev and (n < 16 or b <= n * 1.125 + 1), (n, b)
+        prev = b if n < 600 else 0
+    assert len({row_bucket(n) for n in range(32768, 65536)}) <= 16
