@@ -229,6 +229,7 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
             rec[it] = navi[(size_t)(i * L + rowc) * navi_mul];
         }
     }
+    STAMP(6)  // (diagnostics: both load rounds issued -- round 2's addresses wait for round 1's positions)
     // ---- LDS init (needs only round 1) ----
 #pragma unroll
     for (int q = 0; q < ROW_ITERS; ++q) {
@@ -352,6 +353,10 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
     if constexpr (DO_OBS) {
         block_sync<NT>();
         STAMP(2)
+        if (p.dbg) {  // diagnostics: how long the navi records are still outstanding when the field phase wants them
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(7)
+        }
 
         // ---- fields of every prefetched record that lies inside the final window ----
 #pragma unroll

@@ -25,17 +25,15 @@ lib.mapf_debug_set_stamps(env._h, ctypes.c_void_p(buf.data_ptr()))
 env.step(tape[5])
 torch.cuda.synchronize()
 b = buf.cpu().numpy().astype(np.float64)
-t0 = b[:, 0].min()
 names = ["start", "loads+init->barrierA", "step logic", "fields (navi wait+deposit)", "expand+store issue", "store drain"]
-print("blocks", E, "kernel span (cycles, s_memtime 100MHz?)", b[:, 5].max() - t0)
-for k in range(6):
-    col = b[:, k] - t0
-    print("stamp %d %-28s mean %9.1f  min %9.1f  max %9.1f   phase mean %8.1f" % (
-        k, names[k], col.mean(), col.min(), col.max(), (b[:, k] - b[:, k - 1]).mean() if k else 0))
+G = max(1, E // max(1, int((b[:, 5] != 0).sum())))  # environments per workgroup: only the first E / G rows of the buffer are written
+b = b[: E // G]
+print("environments", E, "workgroups", b.shape[0])
+for k in range(1, 6):
+    print("phase %d %-28s mean %8.1f cycles" % (k, names[k], (b[:, k] - b[:, k - 1]).mean()))
 
-# how the blocks' start / end times spread over the launch (dispatch rate vs per-block latency)
-st, en = np.sort(b[:, 0] - t0), np.sort(b[:, 5] - t0)
-q = [0, 10, 25, 50, 75, 90, 100]
-print("block START percentiles (cycles):", " ".join("%d%%:%d" % (k, np.percentile(st, k)) for k in q))
-print("block END   percentiles (cycles):", " ".join("%d%%:%d" % (k, np.percentile(en, k)) for k in q))
+# (absolute times are not comparable between blocks: every XCD has its own counter; only differences inside a block are used)
 print("per-block duration (cycles): mean %.0f  min %.0f  max %.0f" % ((b[:, 5] - b[:, 0]).mean(), (b[:, 5] - b[:, 0]).min(), (b[:, 5] - b[:, 0]).max()))
+print("G = %d; start -> both load rounds issued: %.0f; issued -> LDS init done + barrier: %.0f; step logic: %.0f; navi still outstanding after the step logic: %.0f; "
+      "field deposit: %.0f; expand + store issue: %.0f; store drain: %.0f" % (G, (b[:, 6] - b[:, 0]).mean(), (b[:, 1] - b[:, 6]).mean(), (b[:, 2] - b[:, 1]).mean(),
+      (b[:, 7] - b[:, 2]).mean(), (b[:, 3] - b[:, 7]).mean(), (b[:, 4] - b[:, 3]).mean(), (b[:, 5] - b[:, 4]).mean()))
