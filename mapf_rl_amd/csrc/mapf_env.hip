@@ -78,6 +78,7 @@ struct StepParams {
     float rtab[5];
     const uint8_t *mask;  // observe only (optional): a workgroup none of whose environments is flagged returns at once
     int ablate;  // tuning only: bit0 skip navi loads, bit1 skip obs stores
+    int plane;   // observation fields assembled per (agent, channel) plane from navi records staged in LDS (see the kernel)
     unsigned long long *dbg;  // diagnostic builds only: per-block phase stamps [E][8]
 };
 
@@ -160,12 +161,33 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
     W *s_obst = reinterpret_cast<W *>(smem);                             // [G][LP]
     W *s_agent = s_obst + G * LP;                                        // [G][LP]
     unsigned char *base = smem + (((size_t)2 * G * LP * sizeof(W) + 15) & ~(size_t)15);
-    unsigned char *s_id = base;                                          // [G][grid_q*16]  0xFF = empty
-    unsigned *s_bits = reinterpret_cast<unsigned *>(s_id + (size_t)G * grid_q * 16);  // [bits_q*4]
-    unsigned short *s_cur = reinterpret_cast<unsigned short *>(s_bits + (size_t)bits_q * 4);  // [NP]
-    unsigned short *s_next = s_cur + NP;                                 // [NP]
-    unsigned short *s_mov = s_next + NP;                                 // [NP]
-    int *s_flag = reinterpret_cast<int *>(s_mov + NP);                   // [G]  G > 1: some agent of the environment is off its goal
+    // p.plane: the bit string and the per-agent arrays first, then ONE region used by the step phase (id grids, next / mover
+    // arrays) and afterwards by the navi records of the field phase (step_smem_bytes); otherwise the round-1 layout
+    unsigned char *s_id;
+    unsigned *s_bits;
+    unsigned short *s_cur, *s_next, *s_mov, *s_gr = nullptr;
+    short *s_base = nullptr;  // (signed: an agent in map row 0 that tries to leave the map has slot 0 = row -1 - R)
+    int *s_flag;
+    NaviRec<W> *s_navi = nullptr;
+    if (p.plane) {
+        s_bits = reinterpret_cast<unsigned *>(base);                                         // [bits_q*4]
+        s_cur = reinterpret_cast<unsigned short *>(s_bits + (size_t)bits_q * 4);             // [NP] position after the step
+        s_base = reinterpret_cast<short *>(s_cur + NP);                                      // [NP] map row of navi slot 0, + R
+        s_gr = s_cur + 2 * NP;                                                               // [NP] first LDS row of the agent's environment
+        s_flag = reinterpret_cast<int *>(s_gr + NP);                                         // [G] (NP is a multiple of 8: 4-byte aligned)
+        unsigned char *uni = reinterpret_cast<unsigned char *>(s_flag) + ((4 * G + 15) & ~15);
+        s_id = uni;                                                                          // [G][grid_q*16]
+        s_next = reinterpret_cast<unsigned short *>(s_id + (size_t)G * grid_q * 16);         // [NP]
+        s_mov = s_next + NP;                                                                 // [NP]
+        s_navi = reinterpret_cast<NaviRec<W> *>(uni);                                        // [N * SPAN], after the step phase
+    } else {
+        s_id = base;                                                      // [G][grid_q*16]  0xFF = empty
+        s_bits = reinterpret_cast<unsigned *>(s_id + (size_t)G * grid_q * 16);  // [bits_q*4]
+        s_cur = reinterpret_cast<unsigned short *>(s_bits + (size_t)bits_q * 4);  // [NP]
+        s_next = s_cur + NP;                                              // [NP]
+        s_mov = s_next + NP;                                              // [NP]
+        s_flag = reinterpret_cast<int *>(s_mov + NP);                     // [G]  G > 1: some agent of the environment is off its goal
+    }
 
 #define STAMP(k)                                                                       \
     if (p.dbg && t == 0) {                                                             \
@@ -248,6 +270,11 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
     if constexpr (DO_OBS) {
         const uint4 zz = make_uint4(0u, 0u, 0u, 0u);
         for (int k = t; k < bits_q; k += nt) reinterpret_cast<uint4 *>(s_bits)[k] = zz;
+        if (p.plane && agent) {  // navi slot s of this agent holds map row cx + min(dx, 0) - R + s (round 2 above)
+            const int dxo = DO_STEP ? (act == 2) - (act == 1) : 0;
+            s_base[t] = (short)(cpos.x + (dxo < 0 ? dxo : 0));
+            s_gr[t] = (unsigned short)ge_rows;
+        }
     }
     const int cx = cpos.x, cy = cpos.y, gx = gpos.x, gy = gpos.y;
     int nx = cx, ny = cy;
@@ -358,6 +385,62 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
             STAMP(7)
         }
 
+        if (p.plane) {
+            // ---- (agent, channel) planes.  A channel of an agent's observation is 9 rows x 9 bits = 81 CONTIGUOUS bits of the bit
+            // string (bit (i * 6 + ch) * 81 + 9 dy + column), so a lane that owns a plane assembles it in three registers with
+            // compile-time shifts and deposits it with 3-4 LDS atomics -- against 6 scattered 9-bit deposits (a dozen
+            // instructions and up to two atomics each) per (agent, row) task in the first version.  The vector ALU is what the
+            // field phase is bound by (profiles/r03_shape_sweep.md: 865 vector instructions per wave at config 2, 63 % pipe
+            // utilisation over the whole kernel, all waves of a SIMD in this phase together).  The navi records were fetched as
+            // 16-byte-per-lane gathers by (agent, row) lanes (narrow per-plane loads were measured slower in round 2): they are
+            // staged in LDS in task order, in the space the step phase's id grids no longer need. ----
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int k = t + it * nt;
+                if (k < N * SPAN) {
+                    NaviRec<W> r = rec[it];
+                    if (rrow[it] < 0) r.w[0] = r.w[1] = r.w[2] = r.w[3] = (W)0;  // row outside the map (or not fetched): reads as zeros
+                    s_navi[k] = r;
+                }
+            }
+            block_sync<NT>();
+            for (int q = t; q < N * 6; q += nt) {
+                const int i = q / 6, ch = q - 6 * i;
+                const unsigned key = s_cur[i];
+                const int x = key >> 8, y = key & 255;
+                // LDS byte offset of the word of window row 0 and the distance between rows
+                unsigned a0;
+                int stride;
+                if (ch < 2) {
+                    const int gr = G == 1 ? 0 : (int)s_gr[i];
+                    a0 = (unsigned)(reinterpret_cast<const unsigned char *>((ch ? s_obst : s_agent) + gr + x) - smem);
+                    stride = (int)sizeof(W);
+                } else {
+                    a0 = (unsigned)(reinterpret_cast<const unsigned char *>(&s_navi[i * SPAN + (x - (int)s_base[i])].w[ch - 2]) - smem);
+                    stride = (int)sizeof(NaviRec<W>);
+                }
+                // columns y - R .. y + R of a row word -> a 9-bit field; near the left border (y < R) the field is the word's low
+                // 9 - sl bits moved up by sl = R - y: the move is the same for all 9 rows, so it is applied once, to the plane's
+                // bit offset (a field of 9 - sl bits shifted by sl stays inside its 9-bit slot)
+                const int sr = y < R ? 0 : y - R, sl = y < R ? R - y : 0;
+                const unsigned wm = (1u << (WW - sl)) - 1u;
+                unsigned f[WW];
+#pragma unroll
+                for (int dy = 0; dy < WW; ++dy) f[dy] = (unsigned)(*reinterpret_cast<const W *>(smem + a0 + dy * stride) >> sr) & wm;
+                if (ch == 0) f[R] &= ~(1u << (y - sr));  // centre (column y) of channel 0 forced to 0 (environment.py:461)
+                static_assert(WW == 9, "the plane packing below is written for the 9 x 9 field of view");
+                const unsigned p0 = f[0] | (f[1] << 9) | (f[2] << 18) | (f[3] << 27);
+                const unsigned p1 = (f[3] >> 5) | (f[4] << 4) | (f[5] << 13) | (f[6] << 22) | (f[7] << 31);
+                const unsigned p2 = (f[7] >> 1) | (f[8] << 8);
+                const unsigned off = (unsigned)q * (WW * WW) + (unsigned)sl, d = off >> 5, sh = off & 31u;
+                const unsigned w0 = p0 << sh, w1 = (p1 << sh) | ((p0 >> 1) >> (31u - sh)), w2 = (p2 << sh) | ((p1 >> 1) >> (31u - sh)),
+                               w3 = (p2 >> 1) >> (31u - sh);
+                if (w0) atomicOr(&s_bits[d], w0);
+                if (w1) atomicOr(&s_bits[d + 1], w1);
+                if (w2) atomicOr(&s_bits[d + 2], w2);
+                if (w3) atomicOr(&s_bits[d + 3], w3);
+            }
+        } else {
         // ---- fields of every prefetched record that lies inside the final window ----
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
@@ -381,6 +464,7 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
                     deposit_field<WW>(s_bits, off + 5 * WW * WW, window_bits<W, R>(rec[it].w[3], y));
                 }
             }
+        }
         }
         block_sync<NT>();
         STAMP(3)
@@ -808,6 +892,7 @@ struct mapf_env {
     int tune_lds_pad;  // extra dynamic LDS bytes per block to cap residency; MAPF_STEP_LDS_PAD
     int tune_ablate;   // MAPF_STEP_ABLATE (timing-only builds; results are wrong)
     int tune_group;    // MAPF_STEP_GROUP: cap on environments per workgroup (1 = never pack)
+    int tune_plane;    // MAPF_STEP_PLANE: -1 = automatic (step_use_plane), 0 / 1 = force the field phase's version
     unsigned long long *dbg;  // phase-stamp buffer (diagnostics)
 };
 
@@ -835,13 +920,32 @@ struct DeviceGuard {
     }
 };
 
-size_t step_smem_bytes(const mapf_env *h, int G) {
+size_t step_smem_bytes(const mapf_env *h, int G, bool plane = false) {
     const int WW = 2 * h->R + 1;
     size_t LP = h->L + 2 * h->R, GP = h->L + 2, NP = ((size_t)G * h->N + 7) & ~7;
     size_t rows = (2 * G * LP * word_bytes(h) + 15) & ~(size_t)15;
     size_t grid_q = (GP * GP + 15) >> 4;
     size_t bits_q = (((size_t)G * h->N * 6 * WW * WW + 31) / 32 + 1 + 3) >> 2;
-    return rows + G * grid_q * 16 + bits_q * 16 + 3 * NP * 2 + 16 + 4 * G;
+    if (!plane) return rows + G * grid_q * 16 + bits_q * 16 + 3 * NP * 2 + 16 + 4 * G;
+    // the kernel's p.plane layout: bit string, three per-agent arrays, flags, then max(step-phase arrays, navi records)
+    const size_t step_part = G * grid_q * 16 + 2 * NP * 2;
+    const size_t navi_part = (size_t)G * h->N * (2 * h->R + 2) * 4 * word_bytes(h);
+    return rows + bits_q * 16 + 3 * NP * 2 + ((4 * (size_t)G + 15) & ~(size_t)15) + (step_part > navi_part ? step_part : navi_part) + 16;
+}
+
+// Field phase by (agent, channel) planes (StepParams::plane) costs LDS for the staged navi records (G * N * 10 records of 16 / 32
+// bytes, overlaid on the step phase's arrays).  It is used when that still lets as many workgroups onto a CU as the launch can put
+// there (wave slots: 8 per SIMD; the launch: ceil(workgroups / 256)); otherwise the first version's per-(agent, row) deposits.
+// MAPF_STEP_PLANE=0/1 overrides for tuning runs.
+bool step_use_plane(const mapf_env *h, int G, int threads) {
+    if (h->tune_plane >= 0) return h->tune_plane != 0;
+    if (h->R != 4) return false;  // (the plane packing is written for the 9 x 9 field of view)
+    const size_t smem = (step_smem_bytes(h, G, true) + (size_t)h->tune_lds_pad + 1023) & ~(size_t)1023;
+    if (smem > 60 * 1024) return false;  // (beyond the default dynamic-LDS limit of a launch)
+    const long long by_lds = (160 * 1024) / (long long)smem;
+    const long long by_waves = 32 / (threads / 64);
+    const long long blocks = (h->E / G + 255) / 256;
+    return by_lds >= (blocks < by_waves ? blocks : by_waves);
 }
 
 // Environments per workgroup (env_step_kernel's G): with few agents one environment leaves most of a wavefront idle behind a
@@ -938,22 +1042,25 @@ int launch_step_iters(const mapf_env *h, const StepParams &p, hipStream_t s, int
 }
 
 template <typename W, bool DO_STEP>
-int launch_step_vec(const mapf_env *h, const StepParams &p, hipStream_t s) {
+int launch_step_vec(const mapf_env *h, const StepParams &p_in, hipStream_t s) {
+    StepParams p = p_in;
     const int total = h->N * 6 * 81;
     const int threads = step_block_threads(h);
     const bool a16 = (total % 16 == 0) && ((reinterpret_cast<uintptr_t>(p.obs) & 15) == 0);
     const bool a4 = (total % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.obs) & 3) == 0);
+    const bool obs = p.obs != nullptr || p.obs_bits != nullptr;
     if constexpr (sizeof(W) == 4) {
         const int G = step_group(h, p.obs);
         if (G > 1) {
-            const size_t smem_g = step_smem_bytes(h, G) + (size_t)h->tune_lds_pad;
-            const bool obs = p.obs != nullptr || p.obs_bits != nullptr;
+            p.plane = obs && step_use_plane(h, G, 64);
+            const size_t smem_g = step_smem_bytes(h, G, p.plane != 0) + (size_t)h->tune_lds_pad;
             if (G == 8) return obs ? launch_step_packed<DO_STEP, true, 8>(h, p, s, smem_g) : launch_step_packed<DO_STEP, false, 8>(h, p, s, smem_g);
             if (G == 4) return obs ? launch_step_packed<DO_STEP, true, 4>(h, p, s, smem_g) : launch_step_packed<DO_STEP, false, 4>(h, p, s, smem_g);
             return obs ? launch_step_packed<DO_STEP, true, 2>(h, p, s, smem_g) : launch_step_packed<DO_STEP, false, 2>(h, p, s, smem_g);
         }
     }
-    const size_t smem = step_smem_bytes(h, 1) + (size_t)h->tune_lds_pad;
+    p.plane = obs && step_use_plane(h, 1, threads);
+    const size_t smem = step_smem_bytes(h, 1, p.plane != 0) + (size_t)h->tune_lds_pad;
     if (p.obs == nullptr && p.obs_bits == nullptr) return launch_step_iters<W, DO_STEP, false, 16>(h, p, s, threads, smem);
     if (p.obs == nullptr) return launch_step_iters<W, DO_STEP, true, 16>(h, p, s, threads, smem);
     if (a16) return launch_step_iters<W, DO_STEP, true, 16>(h, p, s, threads, smem);
@@ -1138,6 +1245,8 @@ int mapf_create(int num_envs, int map_len, int num_agents, int obs_radius, int d
     h->tune_ablate = tv ? std::atoi(tv) : 0;
     tv = std::getenv("MAPF_STEP_GROUP");
     h->tune_group = tv ? std::atoi(tv) : 0;
+    tv = std::getenv("MAPF_STEP_PLANE");
+    h->tune_plane = tv ? std::atoi(tv) : -1;
     const float def[5] = {-0.075f, 0.0f, -0.075f, -0.5f, 3.0f};
     std::memcpy(h->rtab, def, sizeof(def));
     DeviceGuard guard(device);
