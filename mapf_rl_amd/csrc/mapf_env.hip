@@ -936,6 +936,11 @@ size_t step_smem_bytes(const mapf_env *h, int G, bool plane = false) {
 // Field phase by (agent, channel) planes (StepParams::plane) costs LDS for the staged navi records (G * N * 10 records of 16 / 32
 // bytes, overlaid on the step phase's arrays).  It is used when that still lets as many workgroups onto a CU as the launch can put
 // there (wave slots: 8 per SIMD; the launch: ceil(workgroups / 256)); otherwise the first version's per-(agent, row) deposits.
+// Measured on MI355X (rocprofv3, us per launch, first version -> planes): 4096 x 32x32/40 21.0 -> 19.5; 4096 x 16x16/40 21.2 -> 19.7;
+// 262144 x 10x10/1 39.5 -> 34.7; 4096 x 40x40/16 13.0 -> 12.4; 8192 x 20x20/6 12.3 -> 11.6; forced on where the rule says no:
+// 4096 x 64x64/40 23.8 -> 30.3, 2048 x 64x64/128 37.1 -> 55.3 (LDS residency).  A variant for 64-bit rows that stages the four
+// 9-bit windows of a record (8 bytes) instead of its four words (32) fits those shapes but was slower everywhere (64x64/128: 53.9;
+// 40x40/16: 13.2): the 64-bit shifts move to the (agent, row) lanes, ten rounds of them.
 // MAPF_STEP_PLANE=0/1 overrides for tuning runs.
 bool step_use_plane(const mapf_env *h, int G, int threads) {
     if (h->tune_plane >= 0) return h->tune_plane != 0;
