@@ -984,6 +984,9 @@ int step_block_threads(const mapf_env *h) {
         if (h->tune_threads >= h->N) return h->tune_threads;
     }
     if (h->N <= 64 && (h->N <= 24 || h->L > 32)) return 64;
+    // launches of several residency rounds (round 3, 32x32 / 40 agents, us per launch @128 / @256: 8,192 envs 47.0 / 48.4;
+    // 12,288 76.0 / 71.9; 16,384 102.8 / 99.0; 32,768 198.6 / 195.2): four waves per environment keep more loads in flight
+    if (h->N > 24 && h->N <= 128 && h->L <= 32 && h->E >= 12288) return 256;
     return h->N <= 128 ? 128 : 256;
 }
 
