@@ -79,6 +79,7 @@ struct StepParams {
     const uint8_t *mask;  // observe only (optional): a workgroup none of whose environments is flagged returns at once
     int ablate;  // tuning only: bit0 skip navi loads, bit1 skip obs stores
     int plane;   // observation fields assembled per (agent, channel) plane from navi records staged in LDS (see the kernel)
+    int nt_store;  // observation bytes written with non-temporal stores
     unsigned long long *dbg;  // diagnostic builds only: per-block phase stamps [E][8]
 };
 
@@ -507,7 +508,12 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
                 v.z = expand4m((bits >> 8) & 15u);
                 v.w = expand4m(bits >> 12);
                 if ((p.ablate & 2) && v.x != 0x77u) continue;  // never true for real data: keeps the work, drops the store
-                reinterpret_cast<uint4 *>(out)[task] = v;
+                if (p.nt_store) {  // (host: the launch's observations exceed what the Infinity Cache can hold on to, see step_nt_store)
+                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(v4u{v.x, v.y, v.z, v.w}, reinterpret_cast<v4u *>(out) + task);
+                } else {
+                    reinterpret_cast<uint4 *>(out)[task] = v;
+                }
             }
         } else if constexpr (VEC == 4) {
             const int ntask = total >> 2;
@@ -893,6 +899,7 @@ struct mapf_env {
     int tune_ablate;   // MAPF_STEP_ABLATE (timing-only builds; results are wrong)
     int tune_group;    // MAPF_STEP_GROUP: cap on environments per workgroup (1 = never pack)
     int tune_plane;    // MAPF_STEP_PLANE: -1 = automatic (step_use_plane), 0 / 1 = force the field phase's version
+    int tune_nt;       // MAPF_STEP_NT: -1 = automatic (step_nt_store), 0 / 1 = force regular / non-temporal observation stores
     unsigned long long *dbg;  // phase-stamp buffer (diagnostics)
 };
 
@@ -931,6 +938,17 @@ size_t step_smem_bytes(const mapf_env *h, int G, bool plane = false) {
     const size_t step_part = G * grid_q * 16 + 2 * NP * 2;
     const size_t navi_part = (size_t)G * h->N * (2 * h->R + 2) * 4 * word_bytes(h);
     return rows + bits_q * 16 + 3 * NP * 2 + ((4 * (size_t)G + 15) & ~(size_t)15) + (step_part > navi_part ? step_part : navi_part) + 16;
+}
+
+// Non-temporal stores for the observation bytes: when one launch writes more observations than the 256 MiB Infinity Cache can keep
+// until somebody reads them, writing them THROUGH the cache only evicts the navi records the next launch wants.  Measured on MI355X
+// (rocprofv3, us per launch, regular -> non-temporal; observation MB per launch in front): 318 MB (16,384 x 32x32/40) 95.2 -> 78.7;
+// 637 MB 184.0 -> 159.3; 239 MB 67.8 -> 60.2; 191 MB (65,536 x 20x20/6) 59.3 -> 54.3; 159 MB 46.2 -> 46.6; 127 MB (262,144 x 10x10/1)
+// 35.7 -> 34.9, (2,048 x 64x64/128) 36.9 -> 39.0; 119 MB 31.2 -> 35.1; 96 MB 28.9 -> 32.2; 80 MB (config 2) 19.5 -> 27.1, (64x64/40)
+// 24.0 -> 27.9.  Hence from 176 MB of observations per launch on.  MAPF_STEP_NT=0/1 overrides for tuning runs.
+bool step_nt_store(const mapf_env *h) {
+    if (h->tune_nt >= 0) return h->tune_nt != 0;
+    return (size_t)h->E * h->N * 6 * (2 * h->R + 1) * (2 * h->R + 1) >= ((size_t)176 << 20);
 }
 
 // Field phase by (agent, channel) planes (StepParams::plane) costs LDS for the staged navi records (G * N * 10 records of 16 / 32
@@ -1057,6 +1075,7 @@ int launch_step_vec(const mapf_env *h, const StepParams &p_in, hipStream_t s) {
     const bool a16 = (total % 16 == 0) && ((reinterpret_cast<uintptr_t>(p.obs) & 15) == 0);
     const bool a4 = (total % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.obs) & 3) == 0);
     const bool obs = p.obs != nullptr || p.obs_bits != nullptr;
+    p.nt_store = p.obs != nullptr && step_nt_store(h);
     if constexpr (sizeof(W) == 4) {
         const int G = step_group(h, p.obs);
         if (G > 1) {
@@ -1255,6 +1274,8 @@ int mapf_create(int num_envs, int map_len, int num_agents, int obs_radius, int d
     h->tune_group = tv ? std::atoi(tv) : 0;
     tv = std::getenv("MAPF_STEP_PLANE");
     h->tune_plane = tv ? std::atoi(tv) : -1;
+    tv = std::getenv("MAPF_STEP_NT");
+    h->tune_nt = tv ? std::atoi(tv) : -1;
     const float def[5] = {-0.075f, 0.0f, -0.075f, -0.5f, 3.0f};
     std::memcpy(h->rtab, def, sizeof(def));
     DeviceGuard guard(device);
