@@ -945,7 +945,9 @@ size_t step_smem_bytes(const mapf_env *h, int G, bool plane = false) {
 // (rocprofv3, us per launch, regular -> non-temporal; observation MB per launch in front): 318 MB (16,384 x 32x32/40) 95.2 -> 78.7;
 // 637 MB 184.0 -> 159.3; 239 MB 67.8 -> 60.2; 191 MB (65,536 x 20x20/6) 59.3 -> 54.3; 159 MB 46.2 -> 46.6; 127 MB (262,144 x 10x10/1)
 // 35.7 -> 34.9, (2,048 x 64x64/128) 36.9 -> 39.0; 119 MB 31.2 -> 35.1; 96 MB 28.9 -> 32.2; 80 MB (config 2) 19.5 -> 27.1, (64x64/40)
-// 24.0 -> 27.9.  Hence from 176 MB of observations per launch on.  MAPF_STEP_NT=0/1 overrides for tuning runs.
+// 24.0 -> 27.9.  Hence from 176 MB of observations per launch on.  (Non-temporal LOADS of the navi records were slower at every size:
+// 16,384 x 32x32/40 78.9 -> 88.3, 262,144 x 10x10/1 37.0 -> 44.6 -- neighbouring records share cache lines.)  MAPF_STEP_NT=0/1 overrides
+// for tuning runs.
 bool step_nt_store(const mapf_env *h) {
     if (h->tune_nt >= 0) return h->tune_nt != 0;
     return (size_t)h->E * h->N * 6 * (2 * h->R + 1) * (2 * h->R + 1) >= ((size_t)176 << 20);
