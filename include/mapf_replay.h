@@ -128,6 +128,11 @@ int mapf_actor_rewind(int num_envs, int num_agents, int local_steps, int env_row
  * unchanged encoding. */
 int mapf_obs_changed(const uint8_t *obs_dev, uint8_t *prev_dev, int64_t rows, int32_t *list_dev, int32_t *count_dev, uint8_t *packed_dev,
                      void *stream);
+/* Exploration of one actor iteration (worker.py:380-382): actions_dev i64 [E][N] holds the policy's greedy actions; with probability
+ * eps_dev[e] (f64 [E]) agent 0's is replaced by a uniform action in [0, 5) (counter-based generator: same (seed, counter) -> same
+ * draws); act8_dev i8 [E][N] receives the joint action as the environment step reads it, policy_dev (optional) the greedy actions. */
+int mapf_actor_explore(int num_envs, int num_agents, int64_t *actions_dev, int64_t *policy_dev, int8_t *act8_dev,
+                       const double *eps_dev, uint64_t seed, uint64_t counter, void *stream);
 int mapf_actor_log(int num_envs, const uint8_t *finished_dev, const uint8_t *done_dev, const uint8_t *stat_mask_dev,
                    uint8_t *log_dev, int log_size, int64_t *counters_dev, void *stream);
 

@@ -56,6 +56,7 @@ SYMBOLS = [
     ("mapf_replay_add_many", _i, [_vp, _i, _i, _i] + [_vp] * 10),
     ("mapf_actor_record", _i, [_i] * 6 + [_vp] * 16),
     ("mapf_actor_rewind", _i, [_i] * 5 + [_vp] * 6),
+    ("mapf_actor_explore", _i, [_i, _i, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _vp]),
     ("mapf_actor_log", _i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     ("mapf_obs_changed", _i, [_vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     ("mapf_replay_sample", _i, [_vp, _vp, _i, _i] + [_vp] * 12),

@@ -83,8 +83,8 @@ class VecActor:
         assert buffer is None or buffer.max_agents >= N, "replay rows must hold at least the environment's agents"
         self.eps = (epsilon_ladder(E) if epsilons is None else torch.as_tensor(epsilons, dtype=torch.float64).expand(E)).to(d)
         self.actor_ids = (torch.arange(E) % 16).tolist()
-        self.gen = torch.Generator(device=d)
-        self.gen.manual_seed(seed)
+        self.explore_seed, self._explore_counter = (seed * 0x9E3779B1 + 12345) & 0xFFFFFFFFFFFFFFFF, 0
+        self.last_policy_actions = self._act8 = None
         self.scenario_seed = seed * 1000003 + 17
         self.RD = env.obs_bits_row_dwords
         # replay rows are laid out for A = buffer.max_agents >= N agents: the N-agent bit row is a prefix of the
@@ -153,14 +153,22 @@ class VecActor:
         """Everything of an iteration behind the policy's forward (worker.py:380-414): exploration, environment step, recording,
         episode flush.  actions int64 [E, N], q f32 [E, N, 5], hidden bf16 [E*N, 256] as Network.step_batch returns them."""
         E, N, d = self.E, self.N, self.device
-        self.last_policy_actions = actions.clone()
-        # worker.py:380-382: only agent 0 of an environment explores
-        explore = torch.rand(E, device=d, generator=self.gen, dtype=torch.float64) < self.eps
-        rnd = torch.randint(0, 5, (E,), device=d, generator=self.gen)
-        actions[:, 0] = torch.where(explore, rnd, actions[:, 0])
-        if actions_override is not None:
+        st = _stream(d)
+        if actions_override is None:
+            # worker.py:380-382: only agent 0 of an environment explores -- exploration, the greedy copy and the int8 joint action in
+            # one launch (csrc/mapf_actor.hip: actor_explore_kernel, counter-based generator)
+            actions = actions.contiguous()
+            if self._act8 is None or self.last_policy_actions is None or self.last_policy_actions.shape != actions.shape:
+                self.last_policy_actions = torch.empty_like(actions)
+                self._act8 = torch.empty((E, N), dtype=torch.int8, device=d)
+            act8 = self._act8
+            check(lib.mapf_actor_explore(E, N, _ptr(actions), _ptr(self.last_policy_actions), _ptr(act8), _ptr(self.eps), self.explore_seed,
+                                         self._explore_counter, st), "mapf_actor_explore")
+            self._explore_counter += 1
+        else:  # tests: teacher forcing along a recorded trajectory
+            self.last_policy_actions = actions.clone()
             actions = torch.as_tensor(actions_override).to(d, torch.int64).view(E, N)
-        act8 = actions.to(torch.int8).contiguous()
+            act8 = actions.to(torch.int8).contiguous()
         obs, pos, reward, done, _ = self.env.step(act8, obs_bits_out=self.bits)
         if comm_packed is None:
             comm_packed = pack_comm_device(comm, self.CW)

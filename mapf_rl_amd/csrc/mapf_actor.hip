@@ -206,9 +206,46 @@ __global__ void __launch_bounds__(256) obs_changed_kernel(const uint32_t *__rest
     }
 }
 
+// Exploration of one actor iteration (reference worker.py:380-382: with probability epsilon, agent 0 of an environment takes a uniform
+// random action; the other agents act greedily) + the int8 copy of the joint action the environment step reads + a copy of the greedy
+// actions: one launch for what was rand / randint / compare / where / index-assign / cast / clone.  Own counter-based generator
+// (splitmix64 of seed, iteration and environment): the reference's numpy stream is not reproducible here anyway, epsilon is.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void __launch_bounds__(256) actor_explore_kernel(long long total, int N, int64_t *__restrict__ actions, int64_t *__restrict__ policy,
+                                                            int8_t *__restrict__ act8, const double *__restrict__ eps, uint64_t seed, uint64_t counter) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const long long e = idx / N;
+    int64_t a = actions[idx];
+    if (policy) policy[idx] = a;
+    if (idx - e * N == 0) {
+        const uint64_t r0 = splitmix64(seed ^ splitmix64(counter * 0xD6E8FEB86659FD93ull + (uint64_t)e));
+        const double u = (double)(r0 >> 11) * (1.0 / 9007199254740992.0);  // [0, 1)
+        if (u < eps[e]) {
+            a = (int64_t)(splitmix64(r0) % 5ull);
+            actions[idx] = a;
+        }
+    }
+    act8[idx] = (int8_t)a;
+}
+
 }  // namespace
 
 extern "C" {
+
+int mapf_actor_explore(int num_envs, int num_agents, int64_t *actions_dev, int64_t *policy_dev, int8_t *act8_dev, const double *eps_dev,
+                       uint64_t seed, uint64_t counter, void *stream) {
+    if (num_envs < 1 || num_agents < 1 || !actions_dev || !act8_dev || !eps_dev) return MAPF_ERR_INVALID_ARG;
+    const long long total = (long long)num_envs * num_agents;
+    hipLaunchKernelGGL(actor_explore_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), total, num_agents,
+                       actions_dev, policy_dev, act8_dev, eps_dev, (uint64_t)seed, (uint64_t)counter);
+    return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
+}
 
 int mapf_actor_record(int num_envs, int num_agents, int local_steps, int env_row_dwords, int row_dwords, int max_agents, const float *q_dev,
                       const int64_t *actions_dev, const float *reward_dev, const uint16_t *hidden_dev, const int32_t *comm_dev,

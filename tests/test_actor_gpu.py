@@ -232,6 +232,33 @@ def test_obs_changed_lists_exactly_the_changed_rows(R):
         assert torch.equal(prev, obs)
 
 
+def test_explore_kernel_statistics_and_determinism():
+    """mapf_actor_explore (worker.py:380-382): agent 0 of environment e takes a uniform action with probability eps[e], everybody
+    else keeps the greedy action; the int8 copy equals the result, the greedy copy the input; draws depend on (seed, counter) only."""
+    from mapf_rl_amd._lib import check, lib
+
+    E, N = 40000, 3
+    g = torch.Generator(device="cuda").manual_seed(0)
+    greedy = torch.randint(0, 5, (E, N), device="cuda", generator=g)
+    eps = torch.full((E,), 0.25, dtype=torch.float64, device="cuda")
+    eps[: E // 2] = 0.0
+
+    def run(seed, counter):
+        a, pol, a8 = greedy.clone(), torch.full_like(greedy, -1), torch.full((E, N), -1, dtype=torch.int8, device="cuda")
+        check(lib.mapf_actor_explore(E, N, a.data_ptr(), pol.data_ptr(), a8.data_ptr(), eps.data_ptr(), seed, counter, None), "mapf_actor_explore")
+        assert torch.equal(pol, greedy) and torch.equal(a8.long(), a) and torch.equal(a[:, 1:], greedy[:, 1:])
+        assert int(a.min()) >= 0 and int(a.max()) <= 4
+        return a[:, 0]
+
+    a = run(7, 0)
+    assert torch.equal(a[: E // 2], greedy[: E // 2, 0])  # eps = 0: never
+    changed = float((a[E // 2:] != greedy[E // 2:, 0]).float().mean())  # a uniform draw equals the greedy action 1 time in 5
+    assert abs(changed - 0.25 * 0.8) < 0.015, changed
+    drawn = a[E // 2:][a[E // 2:] != greedy[E // 2:, 0]]
+    assert all(abs(float((drawn == k).float().mean()) - 0.2) < 0.03 for k in range(5))
+    assert torch.equal(a, run(7, 0)) and not torch.equal(a, run(7, 1)) and not torch.equal(a, run(8, 0))
+
+
 def test_actor_with_latent_reuse_records_the_same_episodes():
     """VecActor.REUSE_LATENTS on / off from the same seeds: identical actions, Q-values, hidden states and replay contents (the
     encoder is per observation; an unchanged observation has an unchanged latent).  Also the reference's actor semantics
