@@ -126,7 +126,9 @@ class VecActor:
     @torch.no_grad()
     def step(self, actions_override=None):
         """One lock-step iteration.  `actions_override` (int tensor [E, N], tests only): the joint action to execute instead of
-        the policy's (teacher forcing along a recorded trajectory); the policy's own greedy actions stay in `last_policy_actions`."""
+        the policy's (teacher forcing along a recorded trajectory); the policy's own greedy actions stay in `last_policy_actions`.
+        Returns `self.finished` (u8 [E]: the environments whose episode ended in this step -- the actor's own buffer, valid until the
+        next step)."""
         comm, comm_packed = self.policy_inputs()
         self.pull_weights()
         actions, q, hidden, comm = self.model.step_batch(self.obs, self.pos, self.hidden, comm, cache=self.latents)
@@ -183,9 +185,8 @@ class VecActor:
               "mapf_actor_record")
         self.hidden = hidden
         self.env_steps += E
-        finished = self.finished.bool()
-        self._flush(finished, done)
-        return finished
+        self._flush(done)
+        return self.finished
 
     # ------------------------------------------------------------------ episode end
     def _finish_priorities(self, ids, sizes):
@@ -206,14 +207,15 @@ class VecActor:
             td = torch.cat([td, torch.zeros((td.shape[0], 256 - S), dtype=td.dtype, device=td.device)], dim=1)
         return td.contiguous()
 
-    def _flush(self, finished, done):
-        """finished: bool [E] device mask (episode over); done: u8 [E] (all agents on their goals).  Nothing here reads the
-        device: every launch is unconditional and returns at once for environments that are still running."""
+    def _flush(self, done):
+        """self.finished: u8 [E] device mask (episode over, set by mapf_actor_record); done: u8 [E] (all agents on their goals).
+        Nothing here reads the device: every launch is unconditional and returns at once for environments that are still running."""
+        finished = self.finished
         E, N, d = self.E, self.N, self.device
         sizes = self.t
         st = _stream(d)
         if self.keep_flushed:  # tests: host-side copies of every finished episode (synchronises)
-            ids = finished.nonzero().view(-1)
+            ids = finished.bool().nonzero().view(-1)
             td = self._finish_priorities(ids, sizes[ids])
             for k, e in enumerate(ids.tolist()):
                 size = int(sizes[e])
@@ -231,7 +233,7 @@ class VecActor:
         if self.on_device_reset:   # mapf_reset_envs: generation + placement + navi in one launch, only where the mask is set
             self.env.reset_envs(self.finished, self.density, self.scenario_seed)
         else:                      # host generator + partial load (synchronises)
-            ids_h = finished.nonzero().view(-1).tolist()
+            ids_h = finished.bool().nonzero().view(-1).tolist()
             if ids_h:
                 maps, agents, goals, _ = generate_scenarios(len(ids_h), self.env.map_length, N, self.density, self.scenario_seed)
                 self.env.load_envs(ids_h, maps, agents, goals)

@@ -513,10 +513,10 @@ class Network(nn.Module):
                 hs.append(recurrent_infer(gi_all[off:off + E * N].view(1, E, N, 768), h0, comm.unsqueeze(0), w, b, False)[0].view(E * N, self.latent_dim))
                 off += E * N
             q_all = self.q_head(torch.cat(hs) if len(hs) > 1 else hs[0]).float()
+        act_all = q_all.argmax(-1)  # (one launch for all levels; the per-level results are views)
         outs, off = [], 0
         for (E, N, pos, hidden, comm), h in zip(levels, hs):
-            q = q_all[off:off + E * N].view(E, N, 5)
-            outs.append((q.argmax(-1), q.contiguous(), h, comm))
+            outs.append((act_all[off:off + E * N].view(E, N), q_all[off:off + E * N].view(E, N, 5), h, comm))
             off += E * N
         return outs
 

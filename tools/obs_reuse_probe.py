@@ -58,7 +58,7 @@ def run(policy, label, model):
             fin = actor.step()
         cur = actor.obs
         same = (cur.view(E, N, -1) == prev.view(E, N, -1)).all(dim=2)      # [E, N]
-        same = same & ~fin.view(E, 1)                                       # a reset environment starts over
+        same = same & ~fin.bool().view(E, 1)                                # a reset environment starts over
         same_tot += int(same.sum())
         tot += E * N
         if k % 50 == 49 and actor.latents is not None:
