@@ -67,9 +67,20 @@ def mm_rows(x, w, transpose_w=True):
     n = x.shape[0]
     if not x.is_cuda:
         return torch.mm(x, w.t() if transpose_w else w)
-    out = rows_buffer((), n, (w.shape[0] if transpose_w else w.shape[1],), x.dtype, x.device)
+    m = w.shape[0] if transpose_w else w.shape[1]
+    out = rows_buffer((), n, (m,), x.dtype, x.device)
     if n <= MM_ROW_CHUNK:
-        return torch.mm(x, w.t() if transpose_w else w, out=out) if n else out
+        if n == 0:
+            return out
+        # the learner's row counts differ from batch to batch, and every new GEMM shape costs a heuristic lookup in the library
+        # (~90 us of host time per call, measured at 6 agents where the update is host-bound): when `x` sits in a bucket-sized
+        # buffer (rows_buffer), multiply the whole bucket -- a handful of shapes; the rows past n hold garbage on both sides
+        nb = row_bucket(n)
+        if nb > n and x.is_contiguous() and nb <= MM_ROW_CHUNK and \
+                x.untyped_storage().nbytes() >= (x.storage_offset() + nb * x.shape[1]) * x.element_size():
+            torch.mm(torch.as_strided(x, (nb, x.shape[1]), (x.shape[1], 1)), w.t() if transpose_w else w, out=torch.as_strided(out, (nb, m), (m, 1)))
+            return out
+        return torch.mm(x, w.t() if transpose_w else w, out=out)
     parts = -(-n // MM_ROW_CHUNK)
     step = -(-n // parts)
     for i in range(0, n, step):
