@@ -140,6 +140,11 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
     constexpr int SPAN = WW + 1;
     const int e = blockIdx.x * G, t = threadIdx.x;  // first environment of the block
     constexpr int nt = NT;
+    // every kernel argument the first phases use, fetched NOW, together: the compiler otherwise loads each one in the basic block
+    // that uses it first and waits there -- three dependent scalar-load round trips (mask / layout, stamp pointer, the arrays) before
+    // the first vector load, each to a scalar cache that is invalidated at every launch
+    asm volatile("" ::"s"(p.L), "s"(p.N), "s"(p.map_rows), "s"(p.agents), "s"(p.goals), "s"(p.navi), "s"(p.actions), "s"(p.obs), "s"(p.obs_bits),
+                 "s"(p.mask), "s"(p.ablate), "s"(p.plane), "s"(p.dbg));
     if constexpr (!DO_STEP) {
         // masked observe (the actor loop's re-observation after an auto-reset): the outputs of environments that were not reset
         // already hold exactly what this block would write, so a block without a flagged environment has nothing to do
@@ -162,33 +167,20 @@ __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
     W *s_obst = reinterpret_cast<W *>(smem);                             // [G][LP]
     W *s_agent = s_obst + G * LP;                                        // [G][LP]
     unsigned char *base = smem + (((size_t)2 * G * LP * sizeof(W) + 15) & ~(size_t)15);
-    // p.plane: the bit string and the per-agent arrays first, then ONE region used by the step phase (id grids, next / mover
-    // arrays) and afterwards by the navi records of the field phase (step_smem_bytes); otherwise the round-1 layout
-    unsigned char *s_id;
-    unsigned *s_bits;
-    unsigned short *s_cur, *s_next, *s_mov, *s_gr = nullptr;
-    short *s_base = nullptr;  // (signed: an agent in map row 0 that tries to leave the map has slot 0 = row -1 - R)
-    int *s_flag;
-    NaviRec<W> *s_navi = nullptr;
-    if (p.plane) {
-        s_bits = reinterpret_cast<unsigned *>(base);                                         // [bits_q*4]
-        s_cur = reinterpret_cast<unsigned short *>(s_bits + (size_t)bits_q * 4);             // [NP] position after the step
-        s_base = reinterpret_cast<short *>(s_cur + NP);                                      // [NP] map row of navi slot 0, + R
-        s_gr = s_cur + 2 * NP;                                                               // [NP] first LDS row of the agent's environment
-        s_flag = reinterpret_cast<int *>(s_gr + NP);                                         // [G] (NP is a multiple of 8: 4-byte aligned)
-        unsigned char *uni = reinterpret_cast<unsigned char *>(s_flag) + ((4 * G + 15) & ~15);
-        s_id = uni;                                                                          // [G][grid_q*16]
-        s_next = reinterpret_cast<unsigned short *>(s_id + (size_t)G * grid_q * 16);         // [NP]
-        s_mov = s_next + NP;                                                                 // [NP]
-        s_navi = reinterpret_cast<NaviRec<W> *>(uni);                                        // [N * SPAN], after the step phase
-    } else {
-        s_id = base;                                                      // [G][grid_q*16]  0xFF = empty
-        s_bits = reinterpret_cast<unsigned *>(s_id + (size_t)G * grid_q * 16);  // [bits_q*4]
-        s_cur = reinterpret_cast<unsigned short *>(s_bits + (size_t)bits_q * 4);  // [NP]
-        s_next = s_cur + NP;                                              // [NP]
-        s_mov = s_next + NP;                                              // [NP]
-        s_flag = reinterpret_cast<int *>(s_mov + NP);                     // [G]  G > 1: some agent of the environment is off its goal
-    }
+    // the bit string and the per-agent arrays first, then ONE region used by the step phase (id grids, next / mover arrays) and,
+    // with p.plane, afterwards by the navi records of the field phase (step_smem_bytes).  (One layout for both versions of the field
+    // phase: a branch on p.plane here split the kernel's entry block, and every block of it that touches a kernel argument for the
+    // first time waits for its own scalar load -- three round trips to a cache that is invalidated at every launch.)
+    unsigned *s_bits = reinterpret_cast<unsigned *>(base);                                               // [bits_q*4]
+    unsigned short *s_cur = reinterpret_cast<unsigned short *>(s_bits + (size_t)bits_q * 4);             // [NP] position after the step
+    short *s_base = reinterpret_cast<short *>(s_cur + NP);   // [NP] map row of navi slot 0, + R (signed: row -1 - R for an agent leaving row 0)
+    unsigned short *s_gr = s_cur + 2 * NP;                                                               // [NP] first LDS row of the agent's environment
+    int *s_flag = reinterpret_cast<int *>(s_gr + NP);        // [G] some agent of the environment is off its goal (NP: multiple of 8)
+    unsigned char *uni = reinterpret_cast<unsigned char *>(s_flag) + ((4 * G + 15) & ~15);
+    unsigned char *s_id = uni;                                                                           // [G][grid_q*16]  0xFF = empty
+    unsigned short *s_next = reinterpret_cast<unsigned short *>(s_id + (size_t)G * grid_q * 16);         // [NP]
+    unsigned short *s_mov = s_next + NP;                                                                 // [NP]
+    NaviRec<W> *s_navi = reinterpret_cast<NaviRec<W> *>(uni);                                            // [N * SPAN], after the step phase
 
 #define STAMP(k)                                                                       \
     if (p.dbg && t == 0) {                                                             \
@@ -933,10 +925,9 @@ size_t step_smem_bytes(const mapf_env *h, int G, bool plane = false) {
     size_t rows = (2 * G * LP * word_bytes(h) + 15) & ~(size_t)15;
     size_t grid_q = (GP * GP + 15) >> 4;
     size_t bits_q = (((size_t)G * h->N * 6 * WW * WW + 31) / 32 + 1 + 3) >> 2;
-    if (!plane) return rows + G * grid_q * 16 + bits_q * 16 + 3 * NP * 2 + 16 + 4 * G;
-    // the kernel's p.plane layout: bit string, three per-agent arrays, flags, then max(step-phase arrays, navi records)
+    // the kernel's layout: bit string, three per-agent arrays, flags, then max(step-phase arrays, navi records of the plane field phase)
     const size_t step_part = G * grid_q * 16 + 2 * NP * 2;
-    const size_t navi_part = (size_t)G * h->N * (2 * h->R + 2) * 4 * word_bytes(h);
+    const size_t navi_part = plane ? (size_t)G * h->N * (2 * h->R + 2) * 4 * word_bytes(h) : 0;
     return rows + bits_q * 16 + 3 * NP * 2 + ((4 * (size_t)G + 15) & ~(size_t)15) + (step_part > navi_part ? step_part : navi_part) + 16;
 }
 

@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests/test_update_gpu.py tests/test_learner_gpu.py tests/test_big_goldens_gpu.py tests/test_relevance_gpu.py -q -m gpu -x 2>&1 | tail -3
-PROFILE_HOST=1 timeout -k 10 300 python tools/update_times.py 6 20 2048 2>&1 | grep -v amdgpu | grep "update\|torch.mm\|bmm\|synchronize" | head -8
-timeout -k 10 300 python tools/update_times.py 2>&1 | grep -v amdgpu | tail -2
+timeout -k 10 900 python -m pytest tests/test_env_gpu.py tests/test_reset_gpu.py tests/test_actor_gpu.py tests/test_flush_gpu.py -q -m gpu -x 2>&1 | tail -3
+MAPF_STEP_PLANE=0 timeout -k 10 900 python -m pytest tests/test_env_gpu.py -q -m gpu -x 2>&1 | tail -2
+bash tools/gpu_scripts/r03_k2.sh 2>&1 | grep "==\|G =\|per-block"
