@@ -40,6 +40,15 @@ MAX_STEPS = 256      # config.max_steps
 FORWARD_GAMMA = 0.99
 
 
+def _wait_for_default_stream(device):
+    """An actor stepped on its own stream (train.py --overlap-actors) copies the learner's weights: behind everything the learner's
+    stream (the default one) has queued, i.e. behind its last optimizer step."""
+    if torch.device(device).type == "cuda":
+        cur, src = torch.cuda.current_stream(device), torch.cuda.default_stream(device)
+        if cur != src:
+            cur.wait_stream(src)
+
+
 def epsilon_ladder(num_envs, num_actors=16, base=0.4, alpha=7.0):
     """train.py:25: eps_i = 0.4 ** (1 + 7 i / 15); environment e plays the role of actor e mod 16."""
     i = torch.arange(num_envs) % num_actors
@@ -138,6 +147,7 @@ class VecActor:
         """worker.py:416-420: with `weights_period` the actor acts on its own snapshot, refreshed every that many steps."""
         if self.weights_period is not None:
             if self._since_pull >= self.weights_period:
+                _wait_for_default_stream(self.device)
                 self.model.load_state_dict(self.source_model.state_dict())
                 self._since_pull = 0
             self._since_pull += 1

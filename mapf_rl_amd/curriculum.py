@@ -166,6 +166,9 @@ class CurriculumActors:
         acts = list(self.actors.values())
         if self.weights_period is not None:  # worker.py:416-420
             if self._since_pull >= self.weights_period:
+                from .actor import _wait_for_default_stream
+
+                _wait_for_default_stream(self.device)
                 self.model.load_state_dict(self.source_model.state_dict())
                 self._since_pull = 0
             self._since_pull += 1

@@ -99,6 +99,9 @@ class Learner:
             p.requires_grad_(False)
         self.base_lr, self.milestones = lr, tuple(milestones)
         self.grad_hook = None  # tests: called with the learner after backward (+ all-reduce), before the clip (worker.py:316-319)
+        # actors that write the replay from ANOTHER stream (train.py --overlap-actors): `replay_gate`, if set, is an event this update's
+        # replay operations (priority write-back, next prioritized sample) wait for; `replay_released` is recorded behind them
+        self.replay_gate = self.replay_released = None
         self._fused = None
         if self.device.type == "cuda" and self.FUSED_UPDATE:
             from .update import FusedUpdate
@@ -211,6 +214,8 @@ class Learner:
             batch, plan = self._pre
             self._pre = None
         elif own_batch:
+            if self.replay_gate is not None and self.device.type == "cuda":
+                torch.cuda.current_stream(self.device).wait_event(self.replay_gate)
             batch = self.buffer.sample_batch(self.batch_size)
         if self._fused is not None and self._fused.usable(batch):
             out = self._fused.run(batch, plan if isinstance(plan, dict) else None, own_batch)
@@ -255,10 +260,15 @@ class Learner:
         td, q, q_next = self.compute_td(batch, q_next, rows_o)
         priorities = td.detach().view(-1).abs().clamp(1e-6)                                      # worker.py:308
         loss = (weights * huber_loss(td)).mean()                                                 # worker.py:310
+        if self.replay_gate is not None and self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).wait_event(self.replay_gate)
         if self.buffer is not None and idxes is not None:
             self.buffer.update_priorities(idxes, priorities, old_ptr)                            # worker.py:331 (values known here)
         if self.prefetch and own_batch:
             self._launch_prefetch()
+        if self.device.type == "cuda":
+            self.replay_released = torch.cuda.Event()
+            self.replay_released.record(torch.cuda.current_stream(self.device))
         self.bucket.zero()
         loss.backward()
         self.bucket.all_reduce_mean()                                                            # the only collective

@@ -405,6 +405,8 @@ class FusedUpdate:
                                      _ptr(outs[1]), _ptr(outs[2]), _ptr(prio), _ptr(loss), _ptr(scratch), _ptr(d_a0), head_g, st),
               "mapf_dqn_head_loss")
         idxes, old_ptr = batch[8], batch[10]
+        if lr.replay_gate is not None:  # (actors on their own stream: their last episode flush precedes this update's replay operations)
+            cur.wait_event(lr.replay_gate)
         if lr.buffer is not None and idxes is not None:
             lr.buffer.update_priorities(idxes, prio, old_ptr)                                     # worker.py:331 (values known here)
         pre_ready = None
@@ -419,6 +421,11 @@ class FusedUpdate:
                     pre_ready.record(lr._side)
             else:
                 lr._launch_prefetch()
+        # this update's replay operations (priority write-back, next sample) are enqueued: whoever else writes the replay waits for this
+        lr.replay_released = pre_ready
+        if pre_ready is None:
+            lr.replay_released = torch.cuda.Event()
+            lr.replay_released.record(cur)
         # ---- backward through time ----
         outs_b = [rows_buffer((), R, (768,), bf, dev), rows_buffer((), R, (768,), bf, dev),
                   rows_buffer((2,), R, (768,), bf, dev), rows_buffer((2,), R, (768,), bf, dev),

@@ -153,3 +153,48 @@ def test_double_q_update_on_gpu(tag):
     want = q_sel - (rew + 0.99 ** steps * qn)  # the learner's own q_next: the pick is checked above
     assert np.all(np.isfinite(td)) and np.all(np.abs(td - want) <= 4e-2 * np.maximum(1.0, np.abs(want))), np.abs(td - want).max()
     assert np.isfinite(float(out["loss"])) and np.isfinite(float(out["grad_norm"])) and lr.counter == 1
+
+
+def test_actors_on_their_own_stream_leave_the_replay_consistent():
+    """train.py --overlap-actors: the actor iteration runs on its own stream beside the learner's update; its episode flush is
+    ordered between two updates' replay operations by the events Learner.replay_released / replay_gate.  After a run the replay is
+    what a serial run can produce: every sum-tree node is the sum of its children, priorities are finite and non-negative, the
+    ring state counts what the actors flushed, and the update kept learning from finite numbers."""
+    import mapf_rl_amd as M
+    from mapf_rl_amd.actor import VecActor
+    from mapf_rl_amd.learner import Learner
+    from mapf_rl_amd.replay import GlobalBuffer
+
+    torch.manual_seed(0)
+    dev = torch.device("cuda")
+    E, N, L = 96, 3, 12
+    buf = GlobalBuffer(256, max_agents=N, device=dev, init_set=(N, L), fixed_level=True)
+    lr = Learner(buf, device=dev, batch_size=32)
+    env = M.VecEnvironment(E, L, N, device=dev)
+    maps, agents, goals, _ = M.generate_scenarios(E, L, N, 0.2, seed=2)
+    env.load(maps, agents, goals)
+    actor = VecActor(env, lr.model, buf, seed=1, density=0.2, max_steps=12, weights_period=7)
+    astream = torch.cuda.Stream(device=dev)
+    for _ in range(30):  # fill
+        actor.step()
+    torch.cuda.synchronize()
+    losses = []
+    for it in range(60):
+        if lr.replay_released is not None:
+            astream.wait_event(lr.replay_released)
+        with torch.cuda.stream(astream):
+            actor.step()
+            ev = torch.cuda.Event()
+            ev.record(astream)
+        lr.replay_gate = ev
+        losses.append(lr.update()["loss"])
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(torch.as_tensor(v)).all()) for v in losses) and lr.counter == 60
+    tree = buf.priority_tree.tree().cpu().numpy()
+    cap = buf.priority_tree.capacity
+    assert np.all(np.isfinite(tree)) and np.all(tree >= 0) and tree[0] > 0
+    parents = tree[: cap - 1]
+    assert np.allclose(parents, tree[1:2 * cap - 1:2] + tree[2:2 * cap - 1:2], rtol=1e-12, atol=0)
+    ptr, size, counter, _ = buf.state()
+    assert actor.episodes > 0 and 0 < size <= 256 * 256 and counter >= size
+    assert all(bool(torch.isfinite(p).all()) for p in lr.model.parameters())

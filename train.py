@@ -64,6 +64,9 @@ def main(argv=None):
                     help="double-DQN target (online argmax, target value); config.double_q is dead in the reference (worker.py:300-303)")
     ap.add_argument("--actor-update-steps", type=int, default=config.actor_update_steps,
                     help="actor iterations between two pulls of the learner's weights (config.actor_update_steps, worker.py:416-420)")
+    ap.add_argument("--overlap-actors", type=int, default=-1, help="1: the actors' iteration runs on its own HIP stream beside the learner's "
+                    "update (their episode flush ordered between two updates' replay operations by events); 0: one stream, strictly "
+                    "alternating; -1 (default): 1 with the curriculum (small launches that leave most of the chip idle), 0 for a fixed level")
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args(argv)
     fixed = a.agents is not None or a.map is not None
@@ -121,14 +124,36 @@ def main(argv=None):
         actor = CurriculumActors(learner.model, buffer, envs_per_level=a.envs, device=dev, seed=seed, reward_fn=config.reward_fn,
                                  weights_period=a.actor_update_steps)
 
+    # Actors beside the learner.  The reference's actors and learner are separate processes around a shared replay (worker.py); here
+    # one process enqueues both, and with --overlap-actors the actor iteration goes to its own stream: at curriculum shapes an update
+    # is a 4 ms chain of latency-bound launches and an actor iteration 1 ms of small ones, neither fills the chip.  The replay is the
+    # only shared state: an actor iteration starts behind the previous update's replay operations (learner.replay_released) and the
+    # next update's replay operations wait for it (learner.replay_gate); weight pulls wait for the learner's stream (actor.py).
+    overlap = (not fixed) if a.overlap_actors < 0 else bool(a.overlap_actors)
+    astream = torch.cuda.Stream(device=dev) if overlap else None
+
+    def actor_step():
+        if astream is None:
+            actor.step()
+            return
+        if learner.replay_released is not None:
+            astream.wait_event(learner.replay_released)
+        with torch.cuda.stream(astream):
+            actor.step()
+            done_ev = torch.cuda.Event()
+            done_ev.record(astream)
+        learner.replay_gate = done_ev
+
     t_start = t_last = time.time()
     debt = 0.0
     started = False
     stop = False
     while learner.counter < a.max_updates and not stop:
-        actor.step()
+        actor_step()
         now = time.time()
         # ---- decisions every rank must take identically (see module docstring): one MAX all-reduce of 3 flags ----
+        if astream is not None and not started:
+            astream.synchronize()  # (nothing orders the actors' flush before the read below until updates run)
         not_ready = 0 if started else int(len(buffer) < a.learning_starts)  # (reads the device-side ring state)
         time_up = int(a.minutes > 0 and (now - t_start) > a.minutes * 60)
         stats_now = int(rank == 0 and now - t_last >= a.interval)
@@ -146,6 +171,8 @@ def main(argv=None):
                 learner.update()
                 debt -= 1.0
         if stats_now:
+            if astream is not None:
+                astream.synchronize()  # (the statistics below read what the actors wrote)
             pooled = buffer.pooled_counts(flag_dev) if dist is not None else None
             with contextlib.nullcontext() if rank == 0 else contextlib.redirect_stdout(io.StringIO()):
                 # per-rank buffers keep their own counters; only rank 0 prints (its own speed, the pooled level statistics)
@@ -155,6 +182,8 @@ def main(argv=None):
             if not fixed:
                 actor.sync_levels()
                 stop = buffer.check_done(pooled, world)  # worker.py:237-250, train.py:41-43
+            if astream is not None:
+                astream.wait_stream(torch.cuda.current_stream(dev))  # (new levels were set up on this stream)
             t_last = now
         stop = stop or bool(time_up)
     if rank == 0:
