@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+true
+mkdir -p gpurun_out/r03b; timeout -k 10 420 python train.py --envs 512 --minutes 5 --interval 20 --learning-starts 20000 2>&1 | grep -v amdgpu > gpurun_out/r03b/train_curriculum_5min_overlap.log; echo train=$?
+tail -24 gpurun_out/r03b/train_curriculum_5min_overlap.log
