@@ -456,17 +456,30 @@ def main():
             if learner._fused is not None:
                 pl = learner._fused._finish_plan(learner._fused.plan(probe))
                 distinct = pl["online"].urows / max(1, pl["online"].rows)
-            # interleaved: the loop train.py runs (one update per actor iteration)
-            actor.step()
-            learner.update()
+            # interleaved: the loop train.py runs (one update per actor iteration; the actor iteration on its own stream beside the
+            # update, the replay ordered by the learner's two events -- train.py --overlap-actors, its default)
+            astream = torch.cuda.Stream(device=dev)
+
+            def train_iteration():
+                if learner.replay_released is not None:
+                    astream.wait_event(learner.replay_released)
+                with torch.cuda.stream(astream):
+                    actor.step()
+                    ev = torch.cuda.Event()
+                    ev.record(astream)
+                learner.replay_gate = ev
+                learner.update()
+
+            astream.wait_stream(torch.cuda.current_stream(dev))
+            train_iteration()
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
             t1 = time.perf_counter()
             for _ in range(args.train_iters):
-                actor.step()
-                learner.update()
+                train_iteration()
             torch.cuda.synchronize()
+            learner.replay_gate = None
             if world > 1:
                 dist.barrier()
             dt_train = (time.perf_counter() - t1) / args.train_iters
@@ -520,7 +533,7 @@ def main():
                 "actor_loop_config": "Network.step_batch (bf16) + mapf_step + local-buffer recording + episode flush into the device replay, %d envs x %d agents per GPU; weights snapshot pulled every %d iterations (config.actor_update_steps)" % (E, N, ref_config.actor_update_steps),
                 "train_loop_updates_per_sec": 1.0 / dt_train, "train_loop_env_steps_per_sec": world * E / dt_train,
                 "train_loop_ms_per_iter": dt_train * 1e3,
-                "train_loop_config": "one actor iteration (%d envs/GPU) + one learner update per iteration, same stream order as train.py" % E,
+                "train_loop_config": "one actor iteration (%d envs/GPU) + one learner update per iteration, the actor iteration on its own stream beside the update as in train.py (--overlap-actors)" % E,
                 "encoder_roofline": {"bound": "mfma", "kernel": "encoder_fwd_kernel", "achieved": enc_flop / enc_s / 1e12,
                                      "peak": 2500.0, "unit": "TFLOP/s", "frac": enc_flop / enc_s / 1e12 / 2500.0,
                                      "flop_per_launch": enc_flop, "kernel_avg_ms": enc_s * 1e3, "observations": E * N},
