@@ -36,7 +36,10 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 #ifndef MAPF_RECUR_ABLATE  // diagnostic builds only (tools/micro/recur_ablate.py): 1 GRU, 2 QKV, 4 attention, 8 W_O, 16 update cell
 #define MAPF_RECUR_ABLATE 0
 #endif
-constexpr int NT = 3;            // agent tiles of 16: up to 48 agents per environment
+#ifndef MAPF_RECUR_NT  // agent tiles of 16 the kernels of this translation unit are built for: 3 (up to 48 agents per environment) in
+#define MAPF_RECUR_NT 3  // csrc/mapf_recur.hip itself, 1 (up to 16) in csrc/mapf_recur_nt1.hip, which includes this file
+#endif
+constexpr int NT = MAPF_RECUR_NT;
 constexpr int NA = 16 * NT;
 constexpr int D = 256;           // hidden size (config.latent_dim)
 constexpr int HD = 64;           // attention head dim (comm output_dim)
@@ -436,9 +439,14 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
 
 }  // namespace
 
+#if MAPF_RECUR_NT == 3
 extern "C" {
+#define RECUR_ENTRY(name) name
+#else  // the <= 16-agent build: internal symbols, reached from the entry points of the 48-agent build (mapf_recur_internal.h)
+#define RECUR_ENTRY(name) __attribute__((visibility("hidden"))) name##_nt1
+#endif
 
-int mapf_recurrent_infer(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
+int RECUR_ENTRY(mapf_recurrent_infer)(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
                          const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev, const int32_t *row_index_dev,
                          int64_t num_rows, void *stream) {
     if (T < 1 || E < 0 || N < 1 || N > MAPF_RECUR_MAX_AGENTS || !gi_dev || !comm_dev || !weights_dev || !bias_dev || !h_out_dev)
@@ -449,6 +457,10 @@ int mapf_recurrent_infer(const uint16_t *gi_dev, const uint16_t *h0_dev, const u
         return MAPF_ERR_INVALID_ARG;
     if (E == 0) return MAPF_OK;
     if (row_index_dev && (N > NA || num_rows < 1)) return MAPF_ERR_UNSUPPORTED;  // compact rows: the <= 48-agent kernels only
+#if MAPF_RECUR_NT == 3
+    if (N <= MAPF_RECUR_SMALL_AGENTS)  // one agent tile: the same kernel built for 16 agents (a third of the MFMA / LDS work per step)
+        return mapf_recurrent_infer_nt1(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, row_index_dev, num_rows, stream);
+#endif
     if (N > NA)  // 49..128 agents: csrc/mapf_recur_wide.hip
         return mapf_recur_wide_forward(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, nullptr,
                                        static_cast<hipStream_t>(stream));
@@ -458,7 +470,7 @@ int mapf_recurrent_infer(const uint16_t *gi_dev, const uint16_t *h0_dev, const u
     return MAPF_OK;
 }
 
-int mapf_recurrent_forward_save(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
+int RECUR_ENTRY(mapf_recurrent_forward_save)(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
                                 const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev,
                                 uint16_t *const *save_dev, const int32_t *row_index_dev, int64_t num_rows, void *stream) {
     if (T < 1 || E < 0 || N < 1 || N > MAPF_RECUR_MAX_AGENTS || !gi_dev || !comm_dev || !weights_dev || !bias_dev || !h_out_dev ||
@@ -469,6 +481,11 @@ int mapf_recurrent_forward_save(const uint16_t *gi_dev, const uint16_t *h0_dev, 
     if (E == 0) return MAPF_OK;
     const RecurSave sv{save_dev[0], save_dev[1], save_dev[2], save_dev[3], save_dev[4], save_dev[5], save_dev[6], save_dev[7]};
     if (row_index_dev && (N > NA || num_rows < 1)) return MAPF_ERR_UNSUPPORTED;
+#if MAPF_RECUR_NT == 3
+    if (N <= MAPF_RECUR_SMALL_AGENTS)
+        return mapf_recurrent_forward_save_nt1(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, save_dev, row_index_dev,
+                                               num_rows, stream);
+#endif
     if (N > NA)
         return mapf_recur_wide_forward(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, &sv,
                                        static_cast<hipStream_t>(stream));
@@ -478,4 +495,6 @@ int mapf_recurrent_forward_save(const uint16_t *gi_dev, const uint16_t *h0_dev, 
     return MAPF_OK;
 }
 
+#if MAPF_RECUR_NT == 3
 }  // extern "C"
+#endif

@@ -41,7 +41,10 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #ifndef MAPF_RBWD_ABLATE  // diagnostic builds only (tools/micro/recur_bwd_ablate.py): 1 update-cell elementwise, 2 its GEMMs, 4 W_O + attention,
 #define MAPF_RBWD_ABLATE 0  // 8 W_qkv GEMM, 16 recurrent cell; results are wrong, only the time matters
 #endif
-constexpr int NT = 3, NA = 48, D = 256, HD = 64, NTHR = 512;
+#ifndef MAPF_RECUR_NT  // as in csrc/mapf_recur.hip: 3 agent tiles here, 1 in csrc/mapf_recur_bwd_nt1.hip (which includes this file)
+#define MAPF_RECUR_NT 3
+#endif
+constexpr int NT = MAPF_RECUR_NT, NA = 16 * NT, D = 256, HD = 64, NTHR = 512;
 constexpr int H_ROW = D * 2 + 32;     // 544
 constexpr int INFO_ROW = 64 * 2 + 32;  // 160
 constexpr int CTX_ROW = 128 * 2 + 32;  // 288
@@ -463,9 +466,9 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
                         uint4 *pad = reinterpret_cast<uint4 *>(smem + OFF_DSI + i * IMG_ROW + 96);
                         pad[0] = pad[1] = make_uint4(0, 0, 0, 0);
                     }
-                } else if (tid < 4 * NA + 16 * 8) {
+                } else if (tid < 4 * NA + (64 - NA) * 8) {  // rows NA .. 63 of the image stay zero
                     const int k = tid - 4 * NA;
-                    *reinterpret_cast<uint4 *>(smem + OFF_DSI + (48 + (k >> 3)) * IMG_ROW + (k & 7) * 16) = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4 *>(smem + OFF_DSI + (NA + (k >> 3)) * IMG_ROW + (k & 7) * 16) = make_uint4(0, 0, 0, 0);
                 }
                 __syncthreads();
                 // dv, dq, dk: 3 products x 4 d-tiles x 3 agent tiles, each K = 64 (image rows / slots 48..63 are zero)
@@ -546,9 +549,14 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
 
 }  // namespace
 
+#if MAPF_RECUR_NT == 3
 extern "C" {
+#define RECUR_ENTRY(name) name
+#else  // the <= 16-agent build: an internal symbol, reached from the entry point of the 48-agent build (mapf_recur_internal.h)
+#define RECUR_ENTRY(name) __attribute__((visibility("hidden"))) name##_nt1
+#endif
 
-int mapf_recurrent_backward(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev,
+int RECUR_ENTRY(mapf_recurrent_backward)(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev,
                             const uint16_t *weights_t_dev, int T, int E, int N, void *const *out_dev, const int32_t *row_index_dev,
                             int64_t num_rows, void *stream) {
     if (T < 1 || E < 0 || N < 1 || N > MAPF_RECUR_MAX_AGENTS || !saved_dev || !comm_dev || !d_agent0_dev || !weights_t_dev || !out_dev)
@@ -559,6 +567,10 @@ int mapf_recurrent_backward(const uint16_t *const *saved_dev, const uint8_t *com
         if (!out_dev[i] || (reinterpret_cast<uintptr_t>(out_dev[i]) & 15)) return MAPF_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(d_agent0_dev) & 15) || (reinterpret_cast<uintptr_t>(weights_t_dev) & 15)) return MAPF_ERR_INVALID_ARG;
     if (E == 0) return MAPF_OK;
+#if MAPF_RECUR_NT == 3
+    if (N <= MAPF_RECUR_SMALL_AGENTS)  // one agent tile: the same kernel built for 16 agents (and what the forward of these shapes saved)
+        return mapf_recurrent_backward_nt1(saved_dev, comm_dev, d_agent0_dev, weights_t_dev, T, E, N, out_dev, row_index_dev, num_rows, stream);
+#endif
     BwdArgs a;
     a.hin0 = saved_dev[0];
     a.g1 = saved_dev[1];
@@ -597,4 +609,6 @@ int mapf_recurrent_backward(const uint16_t *const *saved_dev, const uint8_t *com
     return MAPF_OK;
 }
 
+#if MAPF_RECUR_NT == 3
 }  // extern "C"
+#endif

@@ -9,6 +9,7 @@
 #include <cstdint>
 
 #define MAPF_RECUR_NARROW_AGENTS 48  /* one workgroup keeps every image of <= 48 agents in LDS (mapf_recur.hip) */
+#define MAPF_RECUR_SMALL_AGENTS 16   /* up to here the same kernels built for ONE agent tile run (mapf_recur_nt1.hip, mapf_recur_bwd_nt1.hip) */
 #define MAPF_RECUR_MAX_AGENTS 128    /* widest environment the fused recurrence kernels accept */
 
 // what the training forward stores for the backward kernel; R = T*E*N rows, row = (t*E + e)*N + agent
@@ -37,6 +38,18 @@ struct RecurBwdArgs {
     float *bsum;              // [E][MAPF_RECUR_BSUM_ELEMS] per-environment column sums (bias gradients)
     int T, E, N;
 };
+
+// csrc/mapf_recur_nt1.hip / mapf_recur_bwd_nt1.hip: csrc/mapf_recur.hip / mapf_recur_bwd.hip compiled for one agent tile (N <= 16: the
+// reference's own training shapes and every curriculum level).  Same arguments as the C ABI entry points that dispatch to them; the
+// attention weights P of the saved state are laid out for 16 agent rows per (step, environment) by this pair.
+int mapf_recurrent_infer_nt1(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev, const float *bias_dev,
+                             int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev, const int32_t *row_index_dev, int64_t num_rows,
+                             void *stream);
+int mapf_recurrent_forward_save_nt1(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
+                                    const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev, uint16_t *const *save_dev,
+                                    const int32_t *row_index_dev, int64_t num_rows, void *stream);
+int mapf_recurrent_backward_nt1(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev, const uint16_t *weights_t_dev,
+                                int T, int E, int N, void *const *out_dev, const int32_t *row_index_dev, int64_t num_rows, void *stream);
 
 // csrc/mapf_recur_wide.hip: forward for 48 < N <= 128 (sv == nullptr: inference, nothing saved).  Returns a MAPF_* status.
 int mapf_recur_wide_forward(const uint16_t *gi, const uint16_t *h0, const uint8_t *comm, const uint16_t *W, const float *bias, int T, int E,
