@@ -92,6 +92,8 @@ class FlatParams:
         self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.step = 0
         self.shapes = {k: tuple(p.shape) for k, p in named.items()}
+        self._views = {}
+        self._plist = [named[k] for k in self.names]  # (the parameter objects, in buffer order: no module-tree walk per update)
         for k in self.names:
             p = named[k]
             v = self._as_param(self.params, k)
@@ -105,9 +107,16 @@ class FlatParams:
         return (s[0], s[2], s[3], s[1]) if len(s) == 4 else s
 
     def mem(self, buf, k):
-        """The slice of `buf` that belongs to parameter k, shaped like its MEMORY ([co, kh, kw, ci] for a convolution weight)."""
-        n = int(np.prod(self.shapes[k]))
-        return buf[self.offsets[k]:self.offsets[k] + n].view(self._mem_shape(k))
+        """The slice of `buf` that belongs to parameter k, shaped like its MEMORY ([co, kh, kw, ci] for a convolution weight).
+        (Views of the four persistent buffers: made once -- an update asks for ~30 of them and is host-bound at few agents.)"""
+        key = (id(buf), k)
+        v = self._views.get(key)
+        if v is None or v.data_ptr() != buf.data_ptr() + self.offsets[k] * buf.element_size():
+            n = int(np.prod(self.shapes[k]))
+            v = buf[self.offsets[k]:self.offsets[k] + n].view(self._mem_shape(k))
+            if buf is self.params or buf is self.grads or buf is self.exp_avg or buf is self.exp_avg_sq or buf is self.bf16:
+                self._views[key] = v
+        return v
 
     def _as_param(self, buf, k):
         v = self.mem(buf, k)
@@ -124,16 +133,15 @@ class FlatParams:
 
     def attached(self):
         """True while the module's parameters (and their .grad) still are the views made here (a `.to()` / `.float()` re-allocates)."""
-        named = dict(self.model.named_parameters())
-        k = self.names[0]
-        return named[k].data_ptr() == self.params.data_ptr() and named[k].grad is not None and named[k].grad.data_ptr() == self.grads.data_ptr()
+        p0 = self._plist[0]
+        return p0.data_ptr() == self.params.data_ptr() and p0.grad is not None and p0.grad.data_ptr() == self.grads.data_ptr()
 
     def refresh_bf16(self):
         check(lib.mapf_to_bf16(_ptr(self.params), _ptr(self.bf16), self.numel, _stream(self.device)), "mapf_to_bf16")
         self._versions = self._version_key()
 
     def _version_key(self):
-        return tuple(p._version for p in self.model.parameters())
+        return tuple(p._version for p in self._plist)
 
     def sync(self):
         """Before an update: the module's parameters must still be the views made here, and the bf16 copy must follow whatever
@@ -185,6 +193,7 @@ class FusedUpdate:
         self.packed_tar_enc = PackedEncoder()
         self.packed_on_recur = PackedRecurrence()
         self.packed_on_enc = PackedEncoder()
+        self._tar_head = None
 
     # ------------------------------------------------------------------ batch views
     def _views(self, batch):
@@ -397,8 +406,10 @@ class FusedUpdate:
         d_a0 = torch.empty((To, B, 256), dtype=bf, device=dev)
         head_names = ("adv.weight", "adv.bias", "state.weight", "state.bias")
         head_on = _ptr_array([flat.mem(flat.params, k) for k in head_names])
-        tnamed = dict(tar.named_parameters())
-        head_tg_t = [tnamed[k].detach().to(torch.float32).contiguous() for k in head_names]
+        if self._tar_head is None or self._tar_head[0] is not tar:
+            tnamed = dict(tar.named_parameters())
+            self._tar_head = (tar, [tnamed[k] for k in head_names])
+        head_tg_t = [t.detach().to(torch.float32).contiguous() for t in self._tar_head[1]]
         head_g = _ptr_array([flat.mem(G, k) for k in head_names])
         check(lib.mapf_dqn_head_loss(B, To, Tt, _ptr(a0), _ptr(a0_tg), _ptr(a0_on2), _ptr(v["bt"]), _ptr(v["steps"]), _ptr(v["action"]),
                                      _ptr(v["reward"]), _ptr(v["done"]), _ptr(v["weights"]), head_on, _ptr_array(head_tg_t), GAMMA, _ptr(outs[0]),

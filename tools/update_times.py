@@ -62,4 +62,4 @@ if os.environ.get("PROFILE_HOST"):
         lr.update()
     torch.cuda.synchronize()
     pr.disable()
-    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(55)
