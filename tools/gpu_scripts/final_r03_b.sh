@@ -18,5 +18,5 @@ timeout -k 10 300 python tools/obs_reuse_probe.py --steps 200 2>&1 | grep -v amd
 timeout -k 10 300 python tools/actor_times.py 2>&1 | grep -v amdgpu > $O/actor_times.txt; timeout -k 10 300 python tools/actor_times.py --tape 2>&1 | grep -v amdgpu >> $O/actor_times.txt; echo at=$?; grep "reuse=" $O/actor_times.txt
 MAPF_BENCH_SHARE_GPU=1 MAPF_BENCH_WATCHDOG=280 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 5 --dist-backend gloo > $O/bench_2rank.json 2> $O/bench_2rank.err; echo bench2=$?
 tail -c 1500 $O/bench_2rank.json
-timeout -k 10 420 python train.py --envs 512 --minutes 5 --interval 20 --learning-starts 20000 2>&1 | grep -v amdgpu > $O/train_curriculum_5min.log; echo train=$?
+if [ -z "$SKIP_TRAIN" ]; then timeout -k 10 420 python train.py --envs 512 --minutes 5 --interval 20 --learning-starts 20000 2>&1 | grep -v amdgpu > $O/train_curriculum_5min.log; echo train=$?; fi
 tail -24 $O/train_curriculum_5min.log
