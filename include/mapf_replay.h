@@ -133,6 +133,38 @@ int mapf_obs_changed(const uint8_t *obs_dev, uint8_t *prev_dev, int64_t rows, in
  * draws); act8_dev i8 [E][N] receives the joint action as the environment step reads it, policy_dev (optional) the greedy actions. */
 int mapf_actor_explore(int num_envs, int num_agents, int64_t *actions_dev, int64_t *policy_dev, int8_t *act8_dev,
                        const double *eps_dev, uint64_t seed, uint64_t counter, void *stream);
+/*
+ * Everything of one actor iteration behind the policy's forward (worker.py:380-428), as ONE call: mapf_actor_explore, mapf_step
+ * (include/mapf_env.h), mapf_actor_record, mapf_replay_add_many (replay may be NULL), mapf_actor_log, mapf_reset_envs +
+ * mapf_observe_masked of the environments whose episode ended, mapf_actor_rewind -- the same launches in the same order; what it
+ * saves is the caller's side of eight calls (the vectorised actor of mapf_rl_amd/actor.py is host-bound at curriculum shapes).
+ * `a`: the actor's persistent device buffers (shapes as documented at the calls above); per iteration: the policy's greedy actions
+ * (in: greedy, out: executed), its Q-values, the new hidden states and the packed comm rows.
+ */
+typedef struct mapf_actor_state {
+    int32_t num_envs, num_agents, local_steps, env_row_dwords, row_dwords, max_agents, log_size, reserved;
+    float *lb_q;
+    uint8_t *lb_act;
+    uint16_t *lb_rew, *lb_hid;
+    int32_t *lb_comm, *lb_obs;
+    int64_t *t;
+    uint8_t *finished;
+    int32_t *obs_bits;
+    const uint8_t *stat_mask;
+    uint8_t *stat_log;
+    int64_t *counters;
+    const double *eps;
+    int64_t *policy_actions;
+    int8_t *act8;
+    uint8_t *obs;      /* the environment handle's output buffers */
+    int16_t *pos;
+    int8_t *reward_class;
+    float *reward;
+    uint8_t *done;
+} mapf_actor_state;
+int mapf_actor_iteration_tail(const mapf_actor_state *a, void *env, mapf_replay_t *replay, int64_t *actions_dev, const float *q_dev,
+                              uint16_t *hidden_dev, const int32_t *comm_dev, uint64_t explore_seed, uint64_t explore_counter,
+                              float density, uint64_t scenario_seed, void *stream);
 int mapf_actor_log(int num_envs, const uint8_t *finished_dev, const uint8_t *done_dev, const uint8_t *stat_mask_dev,
                    uint8_t *log_dev, int log_size, int64_t *counters_dev, void *stream);
 

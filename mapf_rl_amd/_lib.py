@@ -57,6 +57,7 @@ SYMBOLS = [
     ("mapf_actor_record", _i, [_i] * 6 + [_vp] * 16),
     ("mapf_actor_rewind", _i, [_i] * 5 + [_vp] * 6),
     ("mapf_actor_explore", _i, [_i, _i, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _vp]),
+    ("mapf_actor_iteration_tail", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_float, ctypes.c_uint64, _vp]),
     ("mapf_actor_log", _i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     ("mapf_obs_changed", _i, [_vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     ("mapf_replay_sample", _i, [_vp, _vp, _i, _i] + [_vp] * 12),
@@ -126,3 +127,10 @@ lib = _load()
 def check(status, where=""):
     if status != OK:
         raise MapfError(status, where)
+
+
+class ActorState(ctypes.Structure):
+    """include/mapf_replay.h: mapf_actor_state (the persistent device buffers of one vectorised actor)."""
+    _fields_ = [(k, ctypes.c_int32) for k in ("num_envs", "num_agents", "local_steps", "env_row_dwords", "row_dwords", "max_agents", "log_size", "reserved")] + \
+               [(k, ctypes.c_void_p) for k in ("lb_q", "lb_act", "lb_rew", "lb_hid", "lb_comm", "lb_obs", "t", "finished", "obs_bits", "stat_mask", "stat_log",
+                                               "counters", "eps", "policy_actions", "act8", "obs", "pos", "reward_class", "reward", "done")]

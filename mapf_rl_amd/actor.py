@@ -19,6 +19,7 @@ No host synchronisation in `step()`: which environments finished stays a device 
 (`mapf_reset_envs` takes the mask) and the local-buffer rewind are all launched unconditionally and do nothing for
 environments that are still running.  Episode outcomes for the curriculum go through a small device log that is read
 when statistics are asked for (`drain_outcomes`)."""
+import contextlib
 import ctypes
 
 import numpy as np
@@ -66,6 +67,7 @@ def pack_comm_device(comm, cw):
 
 class VecActor:
     REUSE_LATENTS = True  # encode only the agents whose observation changed since the previous step (fused.LatentCache: exact)
+    FUSED_TAIL = True     # exploration .. episode flush of an iteration as one library call (mapf_actor_iteration_tail)
 
     def __init__(self, env: VecEnvironment, model, buffer, epsilons=None, max_steps=MAX_STEPS, seed=0, density=-1.0,
                  keep_flushed=False, on_device_reset=True, weights_period=None):
@@ -93,7 +95,7 @@ class VecActor:
         self.eps = (epsilon_ladder(E) if epsilons is None else torch.as_tensor(epsilons, dtype=torch.float64).expand(E)).to(d)
         self.actor_ids = (torch.arange(E) % 16).tolist()
         self.explore_seed, self._explore_counter = (seed * 0x9E3779B1 + 12345) & 0xFFFFFFFFFFFFFFFF, 0
-        self.last_policy_actions = self._act8 = None
+        self.last_policy_actions = self._act8 = self._state = self._state_key = None
         self.scenario_seed = seed * 1000003 + 17
         self.RD = env.obs_bits_row_dwords
         # replay rows are laid out for A = buffer.max_agents >= N agents: the N-agent bit row is a prefix of the
@@ -143,6 +145,28 @@ class VecActor:
         actions, q, hidden, comm = self.model.step_batch(self.obs, self.pos, self.hidden, comm, cache=self.latents)
         return self.act(actions, q, hidden, comm, comm_packed, actions_override)
 
+    def _tail_state(self, actions):
+        """The mapf_actor_state struct of this actor (built once; rebuilt when a buffer it names was replaced)."""
+        E, N = self.E, self.N
+        if self._act8 is None or self.last_policy_actions is None or self.last_policy_actions.shape != actions.shape:
+            self.last_policy_actions = torch.empty_like(actions)
+            self._act8 = torch.empty((E, N), dtype=torch.int8, device=self.device)
+            self._state = None
+        key = (self.env.obs.data_ptr(), self.env.pos.data_ptr(), self.last_policy_actions.data_ptr(), self._act8.data_ptr())
+        if self._state is None or self._state_key != key:
+            from ._lib import ActorState
+
+            e = self.env
+            st = ActorState(E, N, self.max_steps, self.RD, self.RDA, self.A, self.STAT_LOG, 0)
+            for k, t in (("lb_q", self.lb_q), ("lb_act", self.lb_act), ("lb_rew", self.lb_rew), ("lb_hid", self.lb_hid), ("lb_comm", self.lb_comm),
+                         ("lb_obs", self.lb_obs), ("t", self.t), ("finished", self.finished), ("obs_bits", self.bits), ("stat_mask", self.stat_mask),
+                         ("stat_log", self.stat_log), ("counters", self.counters), ("eps", self.eps), ("policy_actions", self.last_policy_actions),
+                         ("act8", self._act8), ("obs", e.obs), ("pos", e.pos), ("reward_class", e.reward_class), ("reward", e.reward), ("done", e.done)):
+                assert t.is_contiguous()
+                setattr(st, k, t.data_ptr())
+            self._state, self._state_key = st, key
+        return self._state
+
     def pull_weights(self):
         """worker.py:416-420: with `weights_period` the actor acts on its own snapshot, refreshed every that many steps."""
         if self.weights_period is not None:
@@ -166,6 +190,24 @@ class VecActor:
         episode flush.  actions int64 [E, N], q f32 [E, N, 5], hidden bf16 [E*N, 256] as Network.step_batch returns them."""
         E, N, d = self.E, self.N, self.device
         st = _stream(d)
+        if actions_override is None and not self.keep_flushed and self.on_device_reset and comm_packed is not None and self.FUSED_TAIL:
+            # the whole tail of the iteration as ONE call into the library (include/mapf_replay.h: mapf_actor_iteration_tail): the same
+            # eight launches as below, without eight trips through the interpreter and ctypes -- the loop is host-bound at
+            # curriculum shapes
+            assert hidden.dtype == torch.bfloat16 and hidden.is_contiguous() and q.is_contiguous() and q.dtype == torch.float32
+            actions = actions.contiguous()
+            state = self._tail_state(actions)
+            self.scenario_seed += 1
+            buf = self.buffer
+            with (buf.lock if buf is not None else contextlib.nullcontext()):
+                check(lib.mapf_actor_iteration_tail(ctypes.byref(state), self.env._h, None if buf is None else buf._h, _ptr(actions), _ptr(q), _ptr(hidden),
+                                                    _ptr(comm_packed), self.explore_seed, self._explore_counter, float(self.density),
+                                                    int(self.scenario_seed) & 0xFFFFFFFFFFFFFFFF, st), "mapf_actor_iteration_tail")
+            self._explore_counter += 1
+            self.obs, self.pos = self.env.obs, self.env.pos
+            self.hidden = hidden
+            self.env_steps += E
+            return self.finished
         if actions_override is None:
             # worker.py:380-382: only agent 0 of an environment explores -- exploration, the greedy copy and the int8 joint action in
             # one launch (csrc/mapf_actor.hip: actor_explore_kernel, counter-based generator)

@@ -296,4 +296,31 @@ int mapf_actor_log(int num_envs, const uint8_t *finished_dev, const uint8_t *don
     return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
 }
 
+int mapf_actor_iteration_tail(const mapf_actor_state *a, void *env_v, mapf_replay_t *replay, int64_t *actions_dev, const float *q_dev,
+                              uint16_t *hidden_dev, const int32_t *comm_dev, uint64_t explore_seed, uint64_t explore_counter, float density,
+                              uint64_t scenario_seed, void *stream) {
+    if (!a || !env_v || !actions_dev || !q_dev || !hidden_dev || !comm_dev) return MAPF_ERR_INVALID_ARG;
+    mapf_env_t *env = static_cast<mapf_env_t *>(env_v);
+    const int E = a->num_envs, N = a->num_agents, S = a->local_steps;
+    int rc = mapf_actor_explore(E, N, actions_dev, a->policy_actions, a->act8, a->eps, explore_seed, explore_counter, stream);
+    if (rc != MAPF_OK) return rc;
+    rc = mapf_step(env, a->act8, a->obs, reinterpret_cast<uint32_t *>(a->obs_bits), a->pos, a->reward_class, a->reward, a->done, stream);
+    if (rc != MAPF_OK) return rc;
+    rc = mapf_actor_record(E, N, S, a->env_row_dwords, a->row_dwords, a->max_agents, q_dev, actions_dev, a->reward, hidden_dev, comm_dev, a->obs_bits,
+                           a->done, a->t, a->lb_q, a->lb_act, a->lb_rew, a->lb_hid, a->lb_comm, a->lb_obs, a->finished, stream);
+    if (rc != MAPF_OK) return rc;
+    if (replay) {
+        rc = mapf_replay_add_many(replay, E, N, S, a->finished, a->t, a->done, reinterpret_cast<const uint32_t *>(a->lb_obs),
+                                  reinterpret_cast<const uint32_t *>(a->lb_comm), a->lb_act, a->lb_rew, a->lb_hid, a->lb_q, stream);
+        if (rc != MAPF_OK) return rc;
+    }
+    rc = mapf_actor_log(E, a->finished, a->done, a->stat_mask, a->stat_log, a->log_size, a->counters, stream);
+    if (rc != MAPF_OK) return rc;
+    rc = mapf_reset_envs(env, a->finished, density, scenario_seed, stream);
+    if (rc != MAPF_OK) return rc;
+    rc = mapf_observe_masked(env, a->finished, a->obs, reinterpret_cast<uint32_t *>(a->obs_bits), a->pos, stream);
+    if (rc != MAPF_OK) return rc;
+    return mapf_actor_rewind(E, N, S, a->env_row_dwords, a->row_dwords, a->finished, a->obs_bits, a->t, a->lb_obs, hidden_dev, stream);
+}
+
 }  // extern "C"

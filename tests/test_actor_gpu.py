@@ -232,6 +232,45 @@ def test_obs_changed_lists_exactly_the_changed_rows(R):
         assert torch.equal(prev, obs)
 
 
+def test_fused_iteration_tail_equals_the_separate_calls():
+    """VecActor.FUSED_TAIL (mapf_actor_iteration_tail: exploration .. episode flush as one library call) against the eight separate
+    calls from the same seeds, with exploration on: same executed and greedy actions, hidden states, local buffers, replay ring and
+    sum tree, episode counters, environment state -- bit for bit."""
+    import mapf_rl_amd as M
+    from mapf_rl_amd.actor import VecActor
+    from mapf_rl_amd.model import Network
+    from mapf_rl_amd.replay import GlobalBuffer
+
+    E, L, N, K = 96, 14, 5, 45
+    out = {}
+    try:
+        for fused in (True, False):
+            VecActor.FUSED_TAIL = fused
+            torch.manual_seed(4)
+            net = Network().cuda()
+            env = M.VecEnvironment(E, L, N)
+            maps, agents, goals, _ = M.generate_scenarios(E, L, N, 0.25, seed=9)
+            env.load(maps, agents, goals)
+            buf = GlobalBuffer(256, max_agents=N + 1, init_set=(N, L), fixed_level=True)  # (rows wider than the level: the padded layout)
+            actor = VecActor(env, net, buf, epsilons=0.4, seed=6, density=0.25, max_steps=10)
+            acts, fins = [], []
+            for _ in range(K):
+                fins.append(actor.step().clone())
+                acts.append(actor.last_policy_actions.clone())
+            torch.cuda.synchronize()
+            out[fused] = dict(acts=torch.stack(acts), fins=torch.stack(fins), hidden=actor.hidden.clone(), tree=buf.priority_tree.tree().clone(),
+                              state=buf.state(), t=actor.t.clone(), lb_obs=actor.lb_obs.clone(), lb_act=actor.lb_act.clone(), lb_q=actor.lb_q.clone(),
+                              lb_comm=actor.lb_comm.clone(), obs=actor.obs.clone(), pos=actor.pos.clone(), counters=actor.counters.clone(),
+                              log=actor.stat_log.clone(), steps=actor.env_steps)
+    finally:
+        VecActor.FUSED_TAIL = True
+    a, b = out[True], out[False]
+    assert a["state"] == b["state"] and a["steps"] == b["steps"] and int(a["counters"][0]) > E  # several episodes per environment
+    for k in a:
+        if torch.is_tensor(a[k]):
+            assert torch.equal(a[k], b[k]), k
+
+
 def test_explore_kernel_statistics_and_determinism():
     """mapf_actor_explore (worker.py:380-382): agent 0 of environment e takes a uniform action with probability eps[e], everybody
     else keeps the greedy action; the int8 copy equals the result, the greedy copy the input; draws depend on (seed, counter) only."""
