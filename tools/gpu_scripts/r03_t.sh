@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r03b; timeout -k 10 420 python train.py --envs 512 --minutes 5 --interval 20 --learning-starts 20000 2>&1 | grep -v amdgpu > gpurun_out/r03b/train_curriculum_5min_tail.log; echo train=$?
-tail -18 gpurun_out/r03b/train_curriculum_5min_tail.log
+timeout -k 10 1000 python -m pytest tests -q -m gpu -x 2>&1 | tail -4
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu | tail -2
