@@ -66,7 +66,8 @@ def main(argv=None):
                     help="actor iterations between two pulls of the learner's weights (config.actor_update_steps, worker.py:416-420)")
     ap.add_argument("--overlap-actors", type=int, default=-1, help="1: the actors' iteration runs on its own HIP stream beside the learner's "
                     "update (their episode flush ordered between two updates' replay operations by events); 0: one stream, strictly "
-                    "alternating; -1 (default) = 1 (curriculum, 5 minutes: 59 k -> 72.5 k updates; fixed 32x32 / 40-agent level: 63.6 -> 69.7 updates/s)")
+                    "alternating; -1 (default): 1 up to 48 agents per environment (curriculum, 5 minutes: 59 k -> 72.5 k updates; fixed 32x32 / "
+                    "40-agent level: 63.6 -> 69.7 updates/s), 0 beyond (40x40 / 64 agents: 106.7 -> 61.3 updates/s, 64x64 / 128 agents: no change)")
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args(argv)
     fixed = a.agents is not None or a.map is not None
@@ -129,7 +130,9 @@ def main(argv=None):
     # is a 4 ms chain of latency-bound launches and an actor iteration 1 ms of small ones, neither fills the chip.  The replay is the
     # only shared state: an actor iteration starts behind the previous update's replay operations (learner.replay_released) and the
     # next update's replay operations wait for it (learner.replay_gate); weight pulls wait for the learner's stream (actor.py).
-    overlap = True if a.overlap_actors < 0 else bool(a.overlap_actors)
+    # (beyond 48 agents the actors' recurrence runs in the wide kernels, whole-CU workgroups for milliseconds: beside them the update's
+    # chain of small launches starves -- measured, see --overlap-actors)
+    overlap = ((n_agents if fixed else config.max_num_agetns) <= 48) if a.overlap_actors < 0 else bool(a.overlap_actors)
     astream = torch.cuda.Stream(device=dev) if overlap else None
 
     def actor_step():
