@@ -442,8 +442,10 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
 #if MAPF_RECUR_NT == 3
 extern "C" {
 #define RECUR_ENTRY(name) name
-#else  // the <= 16-agent build: internal symbols, reached from the entry points of the 48-agent build (mapf_recur_internal.h)
-#define RECUR_ENTRY(name) __attribute__((visibility("hidden"))) name##_nt1
+#else  // the <= 16- / <= 32-agent builds: internal symbols, reached from the entry points of the 48-agent build (mapf_recur_internal.h)
+#define RECUR_PASTE2(a, b) a##b
+#define RECUR_PASTE(a, b) RECUR_PASTE2(a, b)
+#define RECUR_ENTRY(name) __attribute__((visibility("hidden"))) RECUR_PASTE(name, MAPF_RECUR_SUFFIX)
 #endif
 
 int RECUR_ENTRY(mapf_recurrent_infer)(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
@@ -460,6 +462,8 @@ int RECUR_ENTRY(mapf_recurrent_infer)(const uint16_t *gi_dev, const uint16_t *h0
 #if MAPF_RECUR_NT == 3
     if (N <= MAPF_RECUR_SMALL_AGENTS)  // one agent tile: the same kernel built for 16 agents (a third of the MFMA / LDS work per step)
         return mapf_recurrent_infer_nt1(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, row_index_dev, num_rows, stream);
+    if (N <= 2 * MAPF_RECUR_SMALL_AGENTS)  // two tiles
+        return mapf_recurrent_infer_nt2(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, row_index_dev, num_rows, stream);
 #endif
     if (N > NA)  // 49..128 agents: csrc/mapf_recur_wide.hip
         return mapf_recur_wide_forward(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, nullptr,
@@ -484,6 +488,9 @@ int RECUR_ENTRY(mapf_recurrent_forward_save)(const uint16_t *gi_dev, const uint1
 #if MAPF_RECUR_NT == 3
     if (N <= MAPF_RECUR_SMALL_AGENTS)
         return mapf_recurrent_forward_save_nt1(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, save_dev, row_index_dev,
+                                               num_rows, stream);
+    if (N <= 2 * MAPF_RECUR_SMALL_AGENTS)
+        return mapf_recurrent_forward_save_nt2(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, save_dev, row_index_dev,
                                                num_rows, stream);
 #endif
     if (N > NA)

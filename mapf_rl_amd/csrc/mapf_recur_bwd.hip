@@ -552,8 +552,10 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
 #if MAPF_RECUR_NT == 3
 extern "C" {
 #define RECUR_ENTRY(name) name
-#else  // the <= 16-agent build: an internal symbol, reached from the entry point of the 48-agent build (mapf_recur_internal.h)
-#define RECUR_ENTRY(name) __attribute__((visibility("hidden"))) name##_nt1
+#else  // the <= 16- / <= 32-agent builds: an internal symbol, reached from the entry point of the 48-agent build (mapf_recur_internal.h)
+#define RECUR_PASTE2(a, b) a##b
+#define RECUR_PASTE(a, b) RECUR_PASTE2(a, b)
+#define RECUR_ENTRY(name) __attribute__((visibility("hidden"))) RECUR_PASTE(name, MAPF_RECUR_SUFFIX)
 #endif
 
 int RECUR_ENTRY(mapf_recurrent_backward)(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev,
@@ -570,6 +572,8 @@ int RECUR_ENTRY(mapf_recurrent_backward)(const uint16_t *const *saved_dev, const
 #if MAPF_RECUR_NT == 3
     if (N <= MAPF_RECUR_SMALL_AGENTS)  // one agent tile: the same kernel built for 16 agents (and what the forward of these shapes saved)
         return mapf_recurrent_backward_nt1(saved_dev, comm_dev, d_agent0_dev, weights_t_dev, T, E, N, out_dev, row_index_dev, num_rows, stream);
+    if (N <= 2 * MAPF_RECUR_SMALL_AGENTS)  // two tiles
+        return mapf_recurrent_backward_nt2(saved_dev, comm_dev, d_agent0_dev, weights_t_dev, T, E, N, out_dev, row_index_dev, num_rows, stream);
 #endif
     BwdArgs a;
     a.hin0 = saved_dev[0];

@@ -117,7 +117,7 @@ def test_fast_recurrence_matches_module_path():
         assert float((a - b).norm()) <= 6e-2 * float(b.norm()) + 1e-4 * scale, (k, float((a - b).norm()), float(b.norm()))
 
 
-@pytest.mark.parametrize("E,N,T", [(5, 7, 1), (3, 40, 4), (2, 48, 2), (4, 1, 3), (3, 17, 2), (3, 16, 3), (2, 15, 2),  # <= 16: the one-tile build
+@pytest.mark.parametrize("E,N,T", [(5, 7, 1), (3, 40, 4), (2, 48, 2), (4, 1, 3), (3, 17, 2), (3, 16, 3), (2, 15, 2), (2, 32, 2), (3, 24, 3), (2, 33, 2),  # <= 16 / <= 32: the one- / two-tile builds
                                    (2, 64, 2), (3, 49, 3), (2, 100, 2), (3, 128, 3), (1, 65, 1)])  # > 48: csrc/mapf_recur_wide.hip
 def test_fused_recurrence_kernel_matches_module_path(E, N, T):
     """mapf_recurrent_infer (GRU cell + two communication rounds per step, all T steps in one launch) against the
@@ -157,7 +157,7 @@ def test_fused_recurrence_kernel_matches_module_path(E, N, T):
         assert torch.allclose(x, y, rtol=3e-2, atol=3e-2), float((x - y).abs().max())
 
 
-@pytest.mark.parametrize("B,T,N", [(6, 5, 7), (3, 16, 40), (4, 3, 48), (5, 2, 1), (4, 6, 16), (3, 4, 17),  # <= 16: csrc/mapf_recur*_nt1.hip
+@pytest.mark.parametrize("B,T,N", [(6, 5, 7), (3, 16, 40), (4, 3, 48), (5, 2, 1), (4, 6, 16), (3, 4, 17), (3, 5, 32), (2, 3, 33), (3, 4, 24),  # <= 16 / <= 32: csrc/mapf_recur*_nt1.hip / _nt2.hip
                                    (3, 4, 64), (2, 3, 100), (2, 5, 128), (3, 2, 49)])  # > 48: csrc/mapf_recur_wide*.hip
 def test_bptt_kernels_match_pytorch_recurrence(B, T, N):
     """mapf_recurrent_forward_save + mapf_recurrent_backward (the whole T-step GRU / CommBlock recurrence forward and
