@@ -26,7 +26,8 @@ sample: the K-step stretch is replayed R times back to back (one rewind launch o
 repetitions, inside the timed region and charged to it) until the region is >= ~12 ms; `steps` stays K, `timed_repeats` = R,
 `ms_per_step` = elapsed / (K R).  `roofline.frac` is the BASELINE configuration's number (4096 environments: the 84 MB of navi
 records + 80 MB of observations stay in the 256 MiB Infinity Cache between launches); `roofline.frac_out_of_cache` is the
-same kernel on 4x the environments (working set 654 MB: every launch streams from / to HBM proper).
+same kernel on 4x the environments (observation writes go to HBM, the per-step navi reads still fit the cache) and
+`roofline.frac_hbm_proper` on 8x (reads and writes both beyond the cache) -- see out_of_cache_leg.
 """
 import argparse
 import json
@@ -135,17 +136,12 @@ def heuristic_actions(obs, gen, p_follow=0.8):
     return torch.where(pick, follow, uni).to(torch.int8).contiguous()
 
 
-def out_of_cache_leg(M, dev, args, rank, steps=40, warmup=8):
-    """The same kernel on a working set that does not fit the 256 MiB Infinity Cache: 4x the environments (at config 2: 16,384,
-    navi 336 MB + observations 318 MB), own scenarios and tape, HIP events around `steps` back-to-back launches."""
+def _big_launch_point(M, dev, args, rank, E2, steps, warmup):
+    """env_step_kernel on E2 environments of the bench's shape: own scenarios and tape, HIP events around `steps` back-to-back launches
+    (second pass measured); the replay must reproduce the recording pass (positions) and its last observation block."""
     import torch
 
     L, N = args.map, args.agents
-    wb = 4 if L <= 32 else 8
-    per_env = N * L * 4 * wb + N * 486  # navi records + observation bytes
-    E2 = 4 * args.envs
-    while E2 * per_env < 2 * MALL_BYTES:
-        E2 *= 2
     maps, agents, goals, _ = M.generate_scenarios(E2, L, N, args.density, seed=5000 + rank)
     env = M.VecEnvironment(E2, L, N, device=dev)
     env.load(maps, agents, goals)
@@ -158,6 +154,7 @@ def out_of_cache_leg(M, dev, args, rank, steps=40, warmup=8):
         tape[t] = heuristic_actions(obs, gen)
         obs, pos, *_ = env.step(tape[t])
     first = pos.clone()
+    first_obs = obs.clone()
     a0 = torch.from_numpy(agents).to(dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for rep in range(2):  # the second pass is the measured one
@@ -166,17 +163,53 @@ def out_of_cache_leg(M, dev, args, rank, steps=40, warmup=8):
             env.step(tape[t])
         e0.record()
         for t in range(warmup, T):
-            env.step(tape[t])
+            obs, *_ = env.step(tape[t])
         e1.record()
     torch.cuda.synchronize()
     env.check_status()
-    assert torch.equal(env.pos, first), "out-of-cache replay diverged from its recording pass"
+    assert torch.equal(env.pos, first), "large-launch replay diverged from its recording pass"
+    assert torch.equal(obs, first_obs), "large-launch replay: observation bytes differ from the recording pass"
     us = e0.elapsed_time(e1) * 1e3 / steps
-    alg = (L * L + 821 * N + 1) * E2
-    ach = alg / (us * 1e-6) / 1e9
-    del env
-    return {"envs_out_of_cache": E2, "working_set_out_of_cache_bytes": E2 * per_env, "kernel_avg_us_out_of_cache": us,
-            "achieved_out_of_cache": ach, "frac_out_of_cache": ach / HBM_PEAK_GBS}
+    del env, tape, first_obs
+    return us
+
+
+def out_of_cache_leg(M, dev, args, rank, steps=40, warmup=8):
+    """The same kernel beyond the 256 MiB Infinity Cache (MALL), at two sizes, because "out of cache" has two thresholds:
+
+    * `*_out_of_cache` -- 4x the environments (config 2: 16,384).  The observation bytes one launch WRITES (318 MB) exceed the MALL and
+      go to HBM (non-temporal stores, step_nt_store); the navi records one step READS -- about 10 of an agent's 32 rows, ~180 MB by
+      FETCH_SIZE -- still fit it, so this point is HBM writes + largely MALL-served reads.  (Rounds 2-3 called it "nothing stays
+      cached": wrong for the reads.)
+    * `*_hbm_proper` -- the smallest power-of-two multiple whose per-step READ set also exceeds the MALL (config 2: 32,768
+      environments, ~360 MB read + 637 MB written per launch): both directions stream from / to HBM.  This is the fraction to hold
+      against the 8 TB/s spec; the chip's plain-copy rate is 6.29 TB/s = 0.79 (MI355X_MICROARCH.md).
+    * `*_hbm_proper_2x` -- twice that again (65,536): the read set is 3x the MALL; whatever residual hits the 32,768 point still had
+      are gone (measured 0.84 -> 0.79).
+    `read_set_bytes_*` = what one step fetches, estimated per environment as map rows + N x (10 navi records at 128-byte line
+    granularity) + positions / goals / actions; the measured FETCH_SIZE of the points is in profiles/r04_shape_sweep.md."""
+    L, N = args.map, args.agents
+    wb = 4 if L <= 32 else 8
+    per_env = N * L * 4 * wb + N * 486  # resident navi records + observation bytes
+    # one step's fetches at cache-line granularity: an agent's ~10 consecutive navi records (16 / 32 B each) straddle 128-byte lines
+    # (config 2: 12.0 KB per environment against 11.0 KB by FETCH_SIZE at 16,384 environments, profiles/r04_shape_sweep.md)
+    read_env = L * wb + N * (10 * 4 * wb + 128) + 9 * N
+    alg_env = L * L + 821 * N + 1
+    E_w = 4 * args.envs
+    while E_w * per_env < 2 * MALL_BYTES:
+        E_w *= 2
+    E_h = E_w
+    while E_h * read_env < 1.25 * MALL_BYTES:
+        E_h *= 2
+    out = {}
+    for tag, E2 in (("out_of_cache", E_w), ("hbm_proper", E_h), ("hbm_proper_2x", 2 * E_h)):
+        us = _big_launch_point(M, dev, args, rank, E2, steps, warmup)
+        ach = alg_env * E2 / (us * 1e-6) / 1e9
+        out.update({"envs_" + tag: E2, "working_set_%s_bytes" % tag: E2 * per_env, "read_set_bytes_" + tag: E2 * read_env,
+                    "kernel_avg_us_" + tag: us, "achieved_" + tag: ach, "frac_" + tag: ach / HBM_PEAK_GBS})
+    out["out_of_cache_note"] = ("frac_out_of_cache: observation writes exceed the 256 MiB Infinity Cache, the per-step navi reads do not; "
+                                "frac_hbm_proper: reads and writes both exceed it; frac_hbm_proper_2x: twice the environments again")
+    return out
 
 
 def cpu_baseline(args, maps, agents, goals, tape, final_pos, E, T):

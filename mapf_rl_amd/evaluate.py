@@ -36,6 +36,17 @@ def load_tests(path):
     return tests
 
 
+def load_fixture_npz(path, num_agents):
+    """The reference's shipped fixtures as committed bit-packed data (tests/golden/fixture_scenarios.npz, written by
+    tests/golden/make_fixture_scenarios.py from test{16,32,64}_40_0.3.pkl) back in the pkl schema `evaluate` takes."""
+    z = np.load(path)
+    L = int(z["side%d" % num_agents])
+    packed = z["maps%d" % num_agents]
+    maps = np.unpackbits(packed, axis=1, bitorder="little")[:, :L * L].reshape(-1, L, L)
+    return {"maps": [m.astype(np.float32) for m in maps], "agents": [a.astype(np.int64) for a in z["agents%d" % num_agents]],
+            "goals": [g.astype(np.int64) for g in z["goals%d" % num_agents]]}
+
+
 def save_tests(path, maps, agents, goals, extra=None):
     tests = {"maps": [np.asarray(m) for m in maps], "agents": [np.asarray(a, dtype=np.int64) for a in agents],
              "goals": [np.asarray(g, dtype=np.int64) for g in goals]}
@@ -73,9 +84,11 @@ def create_test(agent_range, map_range, test_num=TEST_NUM, density=-1.0, seed=1,
 
 
 @torch.no_grad()
-def evaluate(network, tests, device=None, max_steps=MAX_STEPS, num_cases=TEST_NUM):
+def evaluate(network, tests, device=None, max_steps=MAX_STEPS, num_cases=TEST_NUM, with_arrivals=False):
     """One checkpoint over the cases of a fixture (reference test.py:105-143): returns (finish_rate, mean_steps,
-    per-case steps, per-case success).  All cases share one shape and are stepped together."""
+    per-case steps, per-case success).  All cases share one shape and are stepped together.
+    with_arrivals=True appends the per-case share of agents standing on their goal when the episode ended or timed out (a finer
+    signal than the all-or-nothing finish rate; not a reference statistic)."""
     device = torch.device(device) if device is not None else torch.device("cuda")
     K = min(num_cases, len(tests["maps"]))
     maps = np.stack([np.asarray(m) != 0 for m in tests["maps"][:K]]).astype(np.int8)
@@ -100,8 +113,10 @@ def evaluate(network, tests, device=None, max_steps=MAX_STEPS, num_cases=TEST_NU
         if bool(finished.all()):
             break
     env.check_status()
-    ok = (env.agents_pos() == env.goals_pos()).all(-1).all(-1)   # test.py:130
-    return float(ok.float().mean()), float(steps.float().mean()), steps.cpu().numpy(), ok.cpu().numpy()
+    at_goal = (env.agents_pos() == env.goals_pos()).all(-1)
+    ok = at_goal.all(-1)   # test.py:130
+    out = (float(ok.float().mean()), float(steps.float().mean()), steps.cpu().numpy(), ok.cpu().numpy())
+    return out + (at_goal.float().mean(-1).cpu().numpy(),) if with_arrivals else out
 
 
 def test_model(test_case="test32_40_0.3.pkl", model_dir="./models", start=190000, device=None):

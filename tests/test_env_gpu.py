@@ -123,8 +123,37 @@ def _heuristic_tape_step(obs, rng, p_follow):
     (4, 24, 200, 0.1, 16),     # N > 128
 ])
 def test_differential_vs_oracle(M, E, L, N, rho, T):
+    _differential_vs_oracle(M, E, L, N, rho, T)
+
+
+# The launch shapes the automatic rules pick only at sizes no oracle comparison reaches in seconds (csrc/mapf_env.hip:
+# step_nt_store -- non-temporal observation stores from 176 MB of observations per launch on; step_block_threads -- four waves per
+# environment from 12,288 environments on; step_use_plane) -- forced through the handle's tuning overrides, which are read at
+# creation time, so that EVERY step, position, reward class, done flag and the final observation goes against the sequential oracle.
+@pytest.mark.parametrize("tune", [
+    {"MAPF_STEP_NT": "1"},
+    {"MAPF_STEP_THREADS": "256"},
+    {"MAPF_STEP_NT": "1", "MAPF_STEP_THREADS": "256"},      # what frac_out_of_cache runs (bench.py)
+    {"MAPF_STEP_NT": "1", "MAPF_STEP_THREADS": "256", "MAPF_STEP_PLANE": "0"},
+    {"MAPF_STEP_PLANE": "0"},
+    {"MAPF_STEP_PLANE": "1"},
+    {"MAPF_STEP_THREADS": "64"},
+], ids=lambda d: ",".join("%s=%s" % (k[10:], v) for k, v in d.items()))
+@pytest.mark.parametrize("E,L,N,rho,T", [(128, 32, 40, 0.3, 64), (48, 20, 6, 0.2, 40), (16, 64, 40, 0.3, 24)])
+def test_forced_launch_families_vs_oracle(M, tune, E, L, N, rho, T):
+    _differential_vs_oracle(M, E, L, N, rho, T, tune=tune, every_obs=True)
+
+
+def _differential_vs_oracle(M, E, L, N, rho, T, tune=None, every_obs=False):
+    import os
+
     maps, agents, goals = H.random_scenarios(E, L, N, rho, seed=E * 1000 + L * 10 + N)
-    env = M.VecEnvironment(E, L, N)
+    os.environ.update(tune or {})
+    try:
+        env = M.VecEnvironment(E, L, N)
+    finally:
+        for k in (tune or {}):
+            del os.environ[k]
     env.load(maps, agents, goals)
     nv = oracle.navi_batch(maps, goals)
     assert np.array_equal(_np(env.navi_map()), nv)
@@ -145,6 +174,9 @@ def test_differential_vs_oracle(M, E, L, N, rho, T):
         obs, pos, rew, done, rc = env.step(torch.from_numpy(tape[t]).cuda())
         got_pos[t], got_rc[t], got_done[t] = _np(pos), _np(rc), _np(done)
         assert np.array_equal(_np(rew), H.REWARD_VALUES.astype(np.float32)[got_rc[t]])
+        if every_obs:  # the observation of EVERY step (the stores are what the forced variants change), two environments each
+            for e in (0, E - 1):
+                assert np.array_equal(_np(obs[e]), oracle.observe(maps[e], got_pos[t, e], nv[e])), (t, e)
     env.check_status()
     ref = oracle.rollout(maps, agents, goals, nv, tape, want_obs_last=True)
     assert ref["status"] == 0
@@ -203,12 +235,15 @@ def test_packed_blocks_equal_one_block_per_environment(M, E, L, N):
     assert np.array_equal(_np(envs[0].steps()), np.full(E, T, np.int32))
 
 
-@pytest.mark.parametrize("E,L,N,T,stride", [(4096, 32, 40, 24, 64), (4096, 64, 40, 16, 128), (2048, 64, 128, 10, 128)],
-                         ids=["config2", "config3", "config5"])
+@pytest.mark.parametrize("E,L,N,T,stride", [(4096, 32, 40, 24, 64), (4096, 64, 40, 16, 128), (2048, 64, 128, 10, 128),
+                                            (16384, 32, 40, 12, 256), (32768, 32, 40, 8, 512)],
+                         ids=["config2", "config3", "config5", "config2_x4_nt_stores_4_waves", "config2_x8_hbm_proper"])
 def test_full_size_config_properties(M, E, L, N, T, stride):
     """BASELINE configs 2, 3 and 5 (per GPU) at FULL size -- 4096 x 32x32 x 40 agents, 4096 x 64x64 x 40, 2048 x 64x64 x 128:
     size-independent invariants on every environment (reference environment.py:424-428 uniqueness; obstacles never entered;
-    observation channels consistent with the state) + exact oracle comparison on every `stride`-th environment."""
+    observation channels consistent with the state) + exact oracle comparison on every `stride`-th environment.
+    The two larger config-2 launches (16,384 / 32,768 environments) are the ones bench.py's out-of-cache legs time: there the
+    AUTOMATIC rules select non-temporal observation stores and four waves per environment (step_nt_store, step_block_threads)."""
     maps, agents, goals, _ = M.generate_scenarios(E, L, N, 0.3, seed=11)
     env = M.VecEnvironment(E, L, N)
     env.load(maps, agents, goals)

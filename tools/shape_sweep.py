@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-SHAPES = [(4096, 32, 40), (16384, 32, 40), (4096, 64, 40), (2048, 64, 128), (4096, 40, 16), (4096, 16, 40),
+SHAPES = [(4096, 32, 40), (16384, 32, 40), (32768, 32, 40), (4096, 64, 40), (2048, 64, 128), (4096, 40, 16), (4096, 16, 40),
           (8192, 20, 6), (65536, 20, 6), (16384, 10, 1), (262144, 10, 1), (65536, 15, 3)]
 T = 40
 
