@@ -255,7 +255,8 @@ int mapf_plan_rows(int T, int B, int N, int Nc, const int16_t *order_dev, const 
  * mapf_plan_rows numbers the distinct observations like the rows (duplicates skipped): umap int32 [rows] = the distinct row an entry
  * uses, row_src / obs_rows then hold the num_rows = sum(ucnt) DISTINCT observations only; row_tbp int32 [rows] (optional) =
  * (t << 24) | (position << 16) | window of every row.  mapf_dedup_sum: d_unique[u] = sum of d_rows[r] over the entries r with
- * umap[r] == u (fp32 sum, fixed order), the gradient of a shared row.
+ * umap[r] == u (fp32 sum, fixed order), the gradient of a shared row; entries with row_tbp[r] < 0 are skipped (padding of a
+ * bucket-sized launch).
  */
 int mapf_obs_dup(int T, int To, int B, int N, const uint16_t *obs_bf16_dev, int64_t obs_stride_b, int64_t obs_stride_t,
                  const int16_t *slot_online_dev, const int16_t *slot_target_dev, const int32_t *nact_online_dev,
@@ -304,6 +305,12 @@ int mapf_recurrent_bias_grads(const float *bsum_dev, int E, float *const *grads_
 int mapf_adam_step(int64_t n, float *params_dev, float *grads_dev, float *exp_avg_dev, float *exp_avg_sq_dev,
                    uint16_t *params_bf16_dev, float *scratch_dev, float *norm_out_dev, float lr, float beta1, float beta2, float eps,
                    int64_t step, float max_norm, void *stream);
+/* The same step with the 1-based step count in DEVICE memory (int64 [1], 8-byte aligned): the first of the two launches increments it, the
+ * second takes Adam's bias corrections 1 - beta^step from it -- no host scalar changes from call to call, so the launches can be
+ * replayed from a captured HIP graph (mapf_rl_amd/update.py). */
+int mapf_adam_step_dev(int64_t n, float *params_dev, float *grads_dev, float *exp_avg_dev, float *exp_avg_sq_dev,
+                       uint16_t *params_bf16_dev, float *scratch_dev, float *norm_out_dev, float lr, float beta1, float beta2, float eps,
+                       int64_t *step_dev, float max_norm, void *stream);
 int mapf_to_bf16(const float *src_dev, uint16_t *dst_dev, int64_t n, void *stream);
 /* rows [first_row, last_row) of n <= 16 row-major device buffers := 0; bufs_dev: HOST array of DEVICE pointers (16-byte aligned),
  * row_bytes: HOST array of row sizes (multiples of 16). */

@@ -90,6 +90,7 @@ SYMBOLS = [
     ("mapf_recurrent_pack", _i, [ctypes.POINTER(_vp), _vp, _vp, _vp, _vp]),
     ("mapf_recurrent_bias_grads", _i, [_vp, _i, ctypes.POINTER(_vp), _vp]),
     ("mapf_adam_step", _i, [ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, ctypes.c_int64, _f, _vp]),
+    ("mapf_adam_step_dev", _i, [ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _f, _vp]),
     ("mapf_to_bf16", _i, [_vp, _vp, ctypes.c_int64, _vp]),
     ("mapf_zero_rows", _i, [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, ctypes.c_int64, ctypes.c_int64, _vp]),
     # include/mapf_search.h

@@ -307,7 +307,9 @@ struct DedupSumArgs {
 __global__ void __launch_bounds__(256) dedup_sum_kernel(DedupSumArgs p) {
     const int lane = threadIdx.x & 63;
     for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < p.rows; r += (long long)gridDim.x * 4) {
-        const int tbp = p.row_tbp[r], t = tbp >> 24, pos = (tbp >> 16) & 255, b = tbp & 0xFFFF, u = p.umap[r];
+        const int tbp = p.row_tbp[r];
+        if (tbp < 0) continue;  // (a padding entry of a bucket-sized launch: the caller filled row_tbp with -1 behind the real rows)
+        const int t = tbp >> 24, pos = (tbp >> 16) & 255, b = tbp & 0xFFFF, u = p.umap[r];
         if (t > 0 && p.umap[p.gidx[((size_t)(t - 1) * p.B + b) * p.Nc + pos]] == u) continue;  // not the head of its run
         for (int c = lane; c < p.W8; c += 64) {
             float acc[8];
@@ -572,8 +574,9 @@ __global__ void __launch_bounds__(256) recur_bias_grads_kernel(BiasGradArgs p) {
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int SUMSQ_BLOCKS = 256;
 
-__global__ void __launch_bounds__(256) sumsq_kernel(const float *__restrict__ g, long long n, float *__restrict__ partial) {
+__global__ void __launch_bounds__(256) sumsq_kernel(const float *__restrict__ g, long long n, float *__restrict__ partial, long long *step_dev) {
     __shared__ float s_red[256];
+    if (step_dev && blockIdx.x == 0 && threadIdx.x == 0) step_dev[0] += 1;  // (the step adam_kernel, the next launch, takes its bias corrections from)
     float s = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)SUMSQ_BLOCKS * 256) s += g[i] * g[i];
     s_red[threadIdx.x] = s;
@@ -592,6 +595,7 @@ struct AdamArgs {
     const float *partial;  // [SUMSQ_BLOCKS] from sumsq_kernel
     float *norm_out;       // [1] the gradient norm before clipping
     float lr, b1, b2, eps, bc1, bc2, max_norm;
+    const long long *step_dev;  // optional: 1-based step count in device memory (bias corrections computed here instead of on the host)
 };
 
 __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
@@ -605,7 +609,13 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
     const float norm = sqrtf(s_red[0]);
     if (blockIdx.x == 0 && threadIdx.x == 0) a.norm_out[0] = norm;
     const float coef = fminf(a.max_norm / (norm + 1e-6f), 1.f);  // clip_grad_norm_: clamp(max_norm / (total_norm + 1e-6), max = 1)
-    const float step_size = a.lr / a.bc1, inv_sqrt_bc2 = 1.f / sqrtf(a.bc2);
+    float bc1 = a.bc1, bc2 = a.bc2;
+    if (a.step_dev) {
+        const double st = (double)a.step_dev[0];
+        bc1 = (float)(1.0 - pow((double)a.b1, st));
+        bc2 = (float)(1.0 - pow((double)a.b2, st));
+    }
+    const float step_size = a.lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += stride) {
         const float g = a.g[i] * coef;
@@ -731,6 +741,7 @@ int mapf_dqn_head_loss(int B, int To, int Tt, const uint16_t *a0_online_dev, con
         return MAPF_ERR_INVALID_ARG;
     for (int i = 0; i < 4; ++i)
         if (!head_online[i] || !head_target[i] || !head_grads[i]) return MAPF_ERR_INVALID_ARG;
+    if (B > 1536) return MAPF_ERR_UNSUPPORTED;  // head_grad keeps [B][9] floats in LDS (checked before anything is launched or written)
     HeadArgs p{};
     p.B = B, p.To = To, p.Tt = Tt;
     p.a0_on = a0_online_dev, p.a0_tg = a0_target_dev, p.a0_on2 = a0_online_next_dev;
@@ -746,7 +757,7 @@ int mapf_dqn_head_loss(int B, int To, int Tt, const uint16_t *a0_online_dev, con
     p.g_w_adv = head_grads[0], p.g_b_adv = head_grads[1], p.g_w_st = head_grads[2], p.g_b_st = head_grads[3];
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, s, p);
-    if (B > 1536) return MAPF_ERR_UNSUPPORTED;  // head_grad keeps [B][9] floats in LDS
+    HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(head_grad_kernel, dim3(1), dim3(256), (size_t)B * 9 * 4, s, p);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
@@ -820,25 +831,44 @@ int mapf_recurrent_bias_grads(const float *bsum_dev, int E, float *const *grads_
     return MAPF_OK;
 }
 
-int mapf_adam_step(int64_t n, float *params_dev, float *grads_dev, float *exp_avg_dev, float *exp_avg_sq_dev, uint16_t *params_bf16_dev,
-                   float *scratch_dev, float *norm_out_dev, float lr, float beta1, float beta2, float eps, int64_t step, float max_norm, void *stream) {
-    if (n < 1 || !params_dev || !grads_dev || !exp_avg_dev || !exp_avg_sq_dev || !scratch_dev || !norm_out_dev || step < 1 || !(max_norm > 0.f))
+static int adam_step_impl(int64_t n, float *params_dev, float *grads_dev, float *exp_avg_dev, float *exp_avg_sq_dev, uint16_t *params_bf16_dev,
+                          float *scratch_dev, float *norm_out_dev, float lr, float beta1, float beta2, float eps, int64_t step, int64_t *step_dev,
+                          float max_norm, void *stream) {
+    if (n < 1 || !params_dev || !grads_dev || !exp_avg_dev || !exp_avg_sq_dev || !scratch_dev || !norm_out_dev || (!step_dev && step < 1) || !(max_norm > 0.f))
         return MAPF_ERR_INVALID_ARG;
+    if (step_dev && (reinterpret_cast<uintptr_t>(step_dev) & 7)) return MAPF_ERR_INVALID_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, grads_dev, (long long)n, scratch_dev);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, grads_dev, (long long)n, scratch_dev, reinterpret_cast<long long *>(step_dev));
     AdamArgs a{};
     a.n = n;
     a.p = params_dev, a.g = grads_dev, a.m = exp_avg_dev, a.v = exp_avg_sq_dev, a.p_bf16 = params_bf16_dev;
     a.partial = scratch_dev;
     a.norm_out = norm_out_dev;
     a.lr = lr, a.b1 = beta1, a.b2 = beta2, a.eps = eps, a.max_norm = max_norm;
-    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-    a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+    a.step_dev = reinterpret_cast<const long long *>(step_dev);
+    if (!step_dev) {
+        a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+        a.bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+    }
     long long blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
+}
+
+int mapf_adam_step(int64_t n, float *params_dev, float *grads_dev, float *exp_avg_dev, float *exp_avg_sq_dev, uint16_t *params_bf16_dev,
+                   float *scratch_dev, float *norm_out_dev, float lr, float beta1, float beta2, float eps, int64_t step, float max_norm, void *stream) {
+    return adam_step_impl(n, params_dev, grads_dev, exp_avg_dev, exp_avg_sq_dev, params_bf16_dev, scratch_dev, norm_out_dev, lr, beta1, beta2, eps, step,
+                          nullptr, max_norm, stream);
+}
+
+int mapf_adam_step_dev(int64_t n, float *params_dev, float *grads_dev, float *exp_avg_dev, float *exp_avg_sq_dev, uint16_t *params_bf16_dev,
+                       float *scratch_dev, float *norm_out_dev, float lr, float beta1, float beta2, float eps, int64_t *step_dev, float max_norm,
+                       void *stream) {
+    if (!step_dev) return MAPF_ERR_INVALID_ARG;
+    return adam_step_impl(n, params_dev, grads_dev, exp_avg_dev, exp_avg_sq_dev, params_bf16_dev, scratch_dev, norm_out_dev, lr, beta1, beta2, eps, 0,
+                          step_dev, max_norm, stream);
 }
 
 int mapf_obs_dup(int T, int To, int B, int N, const uint16_t *obs_bf16_dev, int64_t obs_stride_b, int64_t obs_stride_t, const int16_t *slot_online_dev,

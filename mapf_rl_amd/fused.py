@@ -175,11 +175,12 @@ class PackedEncoder:
         self.weights = None
         self.bias = None
 
-    def get(self, obs_encoder, epoch=0):
+    def get(self, obs_encoder, epoch=0, force=False):
+        """force: pack even if the key says nothing changed (a launch sequence being captured into a graph must contain the pack)."""
         convs = encoder_convs(obs_encoder)
         params = [c.weight for c in convs] + [c.bias for c in convs]
         key = (epoch,) + tuple((p.data_ptr(), p._version) for p in params)
-        if key != self.key:
+        if key != self.key or force:
             dev = params[0].device
             assert dev.type == "cuda", "the fused encoder needs a HIP device"
             ws, nhwc, wp = _conv_weight_ptrs(convs)
@@ -397,15 +398,18 @@ class PackedRecurrence:
         self.weights = None
         self.bias = None
 
-    def get(self, net):
+    def get(self, net, inplace=False, force=False):
+        """inplace: re-pack into the buffers of the last pack (their address is held by a captured graph; the caller packs on the stream
+        that reads them).  force: pack even if the key says nothing changed (a launch sequence being captured must contain the pack)."""
         params = recurrence_params(net)
         key = (getattr(net, "weights_epoch", 0),) + tuple((p.data_ptr(), p._version) for p in params)
-        if key != self.key:
+        if key != self.key or force:
             dev = params[0].device
             ts, ptrs = _recurrence_param_ptrs(params)
-            # fresh buffers per pack: a launch of the stream that packed before may still be reading the old image
-            self.weights = torch.empty(RECUR_WEIGHT_ELEMS, dtype=torch.bfloat16, device=dev)
-            self.bias = torch.empty(RECUR_BIAS_ELEMS, dtype=torch.float32, device=dev)
+            if not (inplace and self.weights is not None and self.weights.device == dev):
+                # fresh buffers per pack: a launch of the stream that packed before may still be reading the old image
+                self.weights = torch.empty(RECUR_WEIGHT_ELEMS, dtype=torch.bfloat16, device=dev)
+                self.bias = torch.empty(RECUR_BIAS_ELEMS, dtype=torch.float32, device=dev)
             check(lib.mapf_recurrent_pack(ptrs, _ptr(self.weights), _ptr(self.bias), None, _stream(dev)), "mapf_recurrent_pack")
             self.key = key
         return self.weights, self.bias

@@ -203,8 +203,13 @@ class Learner:
         """One Learner.train iteration (worker.py:287-338).  `batch` defaults to a fresh prioritized sample."""
         return self._update(batch)
 
+    def _sample(self):
+        """A prioritized sample -- into the fused update's static batch buffers when it replays captured graphs (update.FusedUpdate)."""
+        slot = self._fused.batch_slot() if self._fused is not None else None
+        return self.buffer.sample_batch(self.batch_size, out=slot)
+
     def _launch_prefetch(self):
-        nxt = self.buffer.sample_batch(self.batch_size)
+        nxt = self._sample()
         self._pre = (nxt, self._plan(nxt))
 
     def _update(self, batch=None):
@@ -216,7 +221,7 @@ class Learner:
         elif own_batch:
             if self.replay_gate is not None and self.device.type == "cuda":
                 torch.cuda.current_stream(self.device).wait_event(self.replay_gate)
-            batch = self.buffer.sample_batch(self.batch_size)
+            batch = self._sample()
         if self._fused is not None and self._fused.usable(batch):
             out = self._fused.run(batch, plan if isinstance(plan, dict) else None, own_batch)
             self.counter += 1

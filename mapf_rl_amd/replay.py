@@ -179,34 +179,40 @@ class GlobalBuffer:
             self.add_episode(b[1], b[3], b[4], b[5], b[6], b[7], b[8], b[9], b[10])
 
     # ------------------------------------------------------------------ sample
-    def sample_batch(self, batch_size, uniforms=None):
+    def make_batch_slot(self, batch_size):
+        """Persistent output buffers for `sample_batch(..., out=slot)`: every sample lands at the same addresses (what a captured HIP
+        graph of the learner's update needs, update.FusedUpdate)."""
+        d, A, B = self.device, self.max_agents, batch_size
+        return dict(B=B, A=A, old_ptr=torch.empty(1, dtype=torch.int64, device=d), idx=torch.empty(B, dtype=torch.int64, device=d),
+                    pri=torch.empty(B, dtype=torch.float64, device=d), obs=torch.empty((18, B, A, 6, 9, 9), dtype=torch.bfloat16, device=d),
+                    comm=torch.empty((18, B, A, A), dtype=torch.uint8, device=d), hidden=torch.empty((B * A, 256), dtype=torch.float16, device=d),
+                    action=torch.empty(B, dtype=torch.int64, device=d), reward=torch.empty(B, dtype=torch.float32, device=d),
+                    done=torch.empty(B, dtype=torch.float32, device=d), steps=torch.empty(B, dtype=torch.float32, device=d),
+                    bt=torch.empty(B, dtype=torch.int64, device=d), weights=torch.empty(B, dtype=torch.float32, device=d))
+
+    def sample_batch(self, batch_size, uniforms=None, out=None):
         """Returns the reference's 11-tuple (worker.py:168-182) as device tensors:
         (obs bf16 [B,18,A,6,9,9], action i64 [B,1], reward f32 [B,1], done f32 [B,1], steps f32 [B,1],
          bt_steps i64 [B], hidden f16 [B*A,256], comm_mask bool [B,18,A,A], idxes i64 [B], weights f32 [B,1],
-         old_ptr 0-dim i64 device tensor)."""
+         old_ptr 0-dim i64 device tensor).  out: a `make_batch_slot` dict to write into (the tuple then consists of views of it)."""
         d, A, B = self.device, self.max_agents, batch_size
+        if out is None:
+            out = self.make_batch_slot(B)
+        assert out["B"] == B and out["A"] == A
         with self.lock:
             u, unit = self.priority_tree._uniforms(B, uniforms)
-            old_ptr = torch.empty(1, dtype=torch.int64, device=d)
-            idx = torch.empty(B, dtype=torch.int64, device=d)
-            pri = torch.empty(B, dtype=torch.float64, device=d)
             # time-major in memory (the learner's recurrence wants [T, B, ...] and would otherwise transpose 130 MB per network);
             # handed out as [B, 18, ...] views: the reference's shape
-            obs = torch.empty((18, B, A, 6, 9, 9), dtype=torch.bfloat16, device=d)
-            comm = torch.empty((18, B, A, A), dtype=torch.uint8, device=d)
-            hidden = torch.empty((B * A, 256), dtype=torch.float16, device=d)
-            action = torch.empty(B, dtype=torch.int64, device=d)
-            reward = torch.empty(B, dtype=torch.float32, device=d)
-            done = torch.empty(B, dtype=torch.float32, device=d)
-            steps = torch.empty(B, dtype=torch.float32, device=d)
-            bt = torch.empty(B, dtype=torch.int64, device=d)
+            old_ptr, idx, pri, obs, comm, hidden = out["old_ptr"], out["idx"], out["pri"], out["obs"], out["comm"], out["hidden"]
+            action, reward, done, steps, bt = out["action"], out["reward"], out["done"], out["steps"], out["bt"]
             check(lib.mapf_replay_sample(self._h, _ptr(u), B, unit, _ptr(idx), _ptr(pri), _ptr(obs), _ptr(comm), _ptr(hidden),
                                          _ptr(action), _ptr(reward), _ptr(done), _ptr(steps), _ptr(bt), _ptr(old_ptr), _stream(d)),
                   "mapf_replay_sample")
             old_ptr = old_ptr[0]  # 0-dim device tensor: the ring pointer at sample time (worker.py:182); int(old_ptr) reads it
-        weights = torch.pow(pri / pri.min(), -self.beta).to(torch.float32)  # worker.py:165-166
+        out["weights"].copy_(torch.pow(pri / pri.min(), -self.beta))  # worker.py:165-166
+        # (the gather kernel writes 0 / 1 bytes: the bool tensor is a view)
         return (obs.transpose(0, 1), action.unsqueeze(1), reward.unsqueeze(1), done.unsqueeze(1), steps.unsqueeze(1), bt, hidden,
-                comm.bool().transpose(0, 1), idx, weights.unsqueeze(1), old_ptr)
+                comm.view(torch.bool).transpose(0, 1), idx, out["weights"].unsqueeze(1), old_ptr)
 
     def update_priorities(self, idxes, priorities, old_ptr):
         """worker.py:186-203; idxes / priorities: device tensors (or array-likes)."""

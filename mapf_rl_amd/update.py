@@ -90,7 +90,10 @@ class FlatParams:
         self.bf16 = torch.empty(off, dtype=torch.bfloat16, device=dev)
         self.scratch = torch.empty(256, dtype=torch.float32, device=dev)
         self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.step = 0
+        # Adam's step count lives on the DEVICE (mapf_adam_step_dev increments it and derives the bias corrections from it: no host
+        # scalar changes from update to update, so the launches can be replayed from a captured graph); step_host mirrors it
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.step_host = 0
         self.shapes = {k: tuple(p.shape) for k, p in named.items()}
         self._views = {}
         self._plist = [named[k] for k in self.names]  # (the parameter objects, in buffer order: no module-tree walk per update)
@@ -101,6 +104,15 @@ class FlatParams:
             p.data = v
             p.grad = self._as_param(self.grads, k)
         self.refresh_bf16()
+
+    @property
+    def step(self):
+        return self.step_host
+
+    @step.setter
+    def step(self, value):
+        self.step_host = int(value)
+        self.step_dev.fill_(int(value))
 
     def _mem_shape(self, k):
         s = self.shapes[k]
@@ -154,10 +166,10 @@ class FlatParams:
 
     def adam_step(self, lr):
         """clip_grad_norm_(40) + Adam over the whole buffer in two launches; returns the pre-clip gradient norm (device scalar)."""
-        self.step += 1
-        check(lib.mapf_adam_step(self.numel, _ptr(self.params), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), _ptr(self.bf16),
-                                 _ptr(self.scratch), _ptr(self.norm), float(lr), BETAS[0], BETAS[1], EPS, self.step, GRAD_CLIP,
-                                 _stream(self.device)), "mapf_adam_step")
+        self.step_host += 1
+        check(lib.mapf_adam_step_dev(self.numel, _ptr(self.params), _ptr(self.grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), _ptr(self.bf16),
+                                     _ptr(self.scratch), _ptr(self.norm), float(lr), BETAS[0], BETAS[1], EPS, _ptr(self.step_dev), GRAD_CLIP,
+                                     _stream(self.device)), "mapf_adam_step_dev")
         self.model.weights_epoch += 1  # the packed weight images of the fused kernels are stale now (fused.PackedEncoder)
         return self.norm[0].clone()
 
@@ -184,7 +196,35 @@ def _inner_contiguous(t, inner_dims):
     return True
 
 
+class _Ctx:
+    """The tensors one update hands from stage to stage (online forward -> head -> backward)."""
+
+
+def _round_up(n, step):
+    return max(step, -(-int(n) // step) * step)
+
+
 class FusedUpdate:
+    # ---- replaying the update from captured HIP graphs (few-agent batches the learner samples itself) ----
+    # At <= 16 agents per window -- the reference's own training shape (6) and every curriculum level -- an update is ~85 launches of
+    # small kernels and was host-bound: 2.7-2.9 of its 3.55 ms were Python, ctypes and the caching allocator (round 3).  The sequence
+    # is fixed except for its row counts (how many observations can reach agent 0's Q-value, how many of those are distinct), which
+    # differ from batch to batch.  Graph mode rounds them UP to buckets and pads: the kernels run on bucket-sized buffers whose
+    # padding rows are harmless by construction (their gradient is exactly zero, see _plan_rows / _online_forward / _backward), so a
+    # handful of captured graphs covers every batch.  An update is five graph launches over static interface buffers:
+    #   target   (side stream)  mapf_plan_rows + the target network's forward on the target window     -> a0_tg        [key: target buckets]
+    #   online   (main stream)  weight packs + mapf_plan_rows + forward-save of the online network     -> a0, saved    [key: online buckets]
+    #   head     (main)         dueling heads, TD error, loss, priorities, priority write-back                          [one graph]
+    #   prefetch (side)         next prioritized sample + its plan (closure marks, duplicate flags, counts -> pinned)   [one graph]
+    #   backward (main)         BPTT, weight gradients, encoder backward, clip + Adam                                   [key: online buckets, lr]
+    # with ordinary events between them (the actors' replay gate in front of `head`, `replay_released` behind `prefetch`), so the
+    # overlap of actors and learner (train.py) is what it was.
+    GRAPH = True
+    GRAPH_MAX_AGENTS = 16       # replay rows wider than this are GPU-bound (no gain) and would need many more buckets
+    GRAPH_ROW_STEP = 2048       # bucket of the entry count (== WGRAD_SPLIT: the weight-gradient GEMMs' K is padded to it anyway)
+    GRAPH_UROW_STEP = 1024      # bucket of the distinct-observation count (the encoder kernels' batch)
+    GRAPH_CACHE = 24            # captured graphs kept per stage (an online entry holds ~0.1 MB per row of saved tensors); LRU beyond it
+
     def __init__(self, learner):
         self.lr = learner
         self.dev = learner.device
@@ -194,6 +234,15 @@ class FusedUpdate:
         self.packed_on_recur = PackedRecurrence()
         self.packed_on_enc = PackedEncoder()
         self._tar_head = None
+        self._slot = None       # static batch buffers (GlobalBuffer.sample_batch(out=...)), graph mode
+        self._splan = None      # static plan buffers for that batch
+        self._iface = {}        # static interface tensors between the stage graphs
+        self._graphs = {}       # (stage, key) -> [graph, ctx, last use]
+        self._pools = {}
+        self._capturing = False
+        self._tar_w_ih = None
+        self._tick = 0
+        self.graph_replays = self.graph_captures = 0
 
     # ------------------------------------------------------------------ batch views
     def _views(self, batch):
@@ -213,82 +262,165 @@ class FusedUpdate:
         return dict(B=B, T=T, N=N, obs=obs, comm=cm, hidden=hid, action=action.reshape(-1).to(torch.int64).contiguous(), reward=f32(reward),
                     done=f32(done), steps=f32(steps), bt=bt.reshape(-1).to(torch.int64).contiguous(), weights=f32(batch[9]))
 
+    # ------------------------------------------------------------------ graph mode: static buffers
+    def graph_mode(self):
+        """Graph replay applies to the batches the learner samples itself from a device replay of narrow rows, single rank."""
+        lr = self.lr
+        if not (self.GRAPH and lr.buffer is not None and lr.prefetch and lr.buffer.max_agents <= self.GRAPH_MAX_AGENTS and lr.grad_hook is None):
+            return False
+        import torch.distributed as dist
+
+        return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+    def batch_slot(self):
+        """The static buffers every prioritized sample of this learner is written into (graph mode), or None."""
+        if not self.graph_mode():
+            return None
+        lr = self.lr
+        key = (lr.batch_size, lr.buffer.max_agents)
+        if self._slot is None or self._slot["key"] != key:
+            self._slot = lr.buffer.make_batch_slot(lr.batch_size)
+            self._slot["key"] = key
+            self._splan = None
+            self._drop_graphs()
+        return self._slot
+
+    def _is_slot(self, batch):
+        return self._slot is not None and torch.is_tensor(batch[0]) and batch[0].data_ptr() == self._slot["obs"].data_ptr()
+
+    def _static(self, name, shape, dtype, pinned=False):
+        key = (name, tuple(shape), dtype)
+        t = self._iface.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, pin_memory=True) if pinned else torch.empty(shape, dtype=dtype, device=self.dev)
+            self._iface[key] = t
+        return t
+
+    def _out(self, c, name, shape, dtype):
+        """An interface tensor of the update: static in graph mode (the stage graphs of different buckets meet in it), fresh otherwise."""
+        return self._static(name, shape, dtype) if c.static else torch.empty(shape, dtype=dtype, device=self.dev)
+
+    def _drop_graphs(self):
+        self._graphs.clear()
+
+    def _prealloc(self, B, To, Tt):
+        """The interface tensors between the stage graphs, allocated outside any capture."""
+        bf = torch.bfloat16
+        for name, shape, dt in (("a0", (To, B, 256), bf), ("a0_tg", (Tt, B, 256), bf), ("a0_on2", (Tt, B, 256), bf), ("d_a0", (To, B, 256), bf),
+                                ("outs", (3, B), torch.float32), ("prio", (B,), torch.float64), ("loss", (1,), torch.float32)):
+            self._static(name, shape, dt)
+
     # ------------------------------------------------------------------ plan: at sample time, one update ahead
     def plan(self, batch):
         """Launches the two closure kernels and the asynchronous copy of the per-window counts to pinned host memory."""
         v = self._views(batch)
         B, T, N, dev = v["B"], v["T"], v["N"], self.dev
         st = _stream(dev)
-        po, pt = WindowPlan(T - FORWARD_STEPS, B, N, dev), WindowPlan(T, B, N, dev)
-        counts = torch.empty((6, B), dtype=torch.int32, device=dev)  # cnt online, nag online, cnt target, nag target, distinct online, distinct target
-        cm = v["comm"]
+        static = self._is_slot(batch)
         from .model import Network
 
-        mark_all = 0 if Network.PRUNE_UNREACHABLE else 1  # 1: encode every observation up to the window's last step, like the reference
+        flags = (bool(Network.PRUNE_UNREACHABLE), bool(self.DEDUP))
+        if static:
+            if self._splan is None or self._splan["shape"] != (T, B, N):
+                self._splan = dict(shape=(T, B, N), po=WindowPlan(T - FORWARD_STEPS, B, N, dev), pt=WindowPlan(T, B, N, dev),
+                                   counts=torch.empty((6, B), dtype=torch.int32, device=dev), dup=torch.empty((T, B, N), dtype=torch.uint8, device=dev),
+                                   host=torch.empty((6, B), dtype=torch.int32, pin_memory=True))
+            sp = self._splan
+            po, pt, counts, host = sp["po"], sp["pt"], sp["counts"], sp["host"]
+        else:
+            po, pt = WindowPlan(T - FORWARD_STEPS, B, N, dev), WindowPlan(T, B, N, dev)
+            counts = torch.empty((6, B), dtype=torch.int32, device=dev)  # cnt online, nag online, cnt target, nag target, distinct online, distinct target
+            host = torch.empty((6, B), dtype=torch.int32, pin_memory=True)
+        cm = v["comm"]
+        mark_all = 0 if flags[0] else 1  # 1: encode every observation up to the window's last step, like the reference
         for k, (p, extra) in enumerate(((po, None), (pt, v["steps"]))):
             check(lib.mapf_plan_mark(_ptr(cm), cm.stride(0), cm.stride(1), _ptr(v["bt"]), _ptr(extra), p.T, B, N, mark_all, None, _ptr(p.slot), _ptr(p.order),
                                      _ptr(p.nact), _ptr(counts[2 * k]), _ptr(counts[2 * k + 1]), _ptr(counts[4 + k]), st), "mapf_plan_mark")
             p.cnt, p.nag, p.ucnt = counts[2 * k], counts[2 * k + 1], counts[4 + k]
         dup = None
-        if self.DEDUP:
+        if flags[1]:
             # which entries repeat the observation of the same agent one step earlier (exact reuse: one encoder pass per run)
             obs = v["obs"]
-            dup = torch.empty((T, B, N), dtype=torch.uint8, device=dev)
+            dup = self._splan["dup"] if static else torch.empty((T, B, N), dtype=torch.uint8, device=dev)
             check(lib.mapf_obs_dup(T, po.T, B, N, _ptr(obs), obs.stride(0), obs.stride(1), _ptr(po.slot), _ptr(pt.slot), _ptr(po.nact), _ptr(pt.nact),
                                    _ptr(dup), _ptr(po.ucnt), _ptr(pt.ucnt), st), "mapf_obs_dup")
         po.dup = pt.dup = dup
-        host = torch.empty((6, B), dtype=torch.int32, pin_memory=True)
         host.copy_(counts, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
-        return dict(views=v, online=po, target=pt, counts=counts, host=host, event=ev)
+        ev = None
+        if not self._capturing:  # (inside a capture the event is recorded behind the graph's replay, _run_graphed)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+        return dict(views=v, online=po, target=pt, counts=counts, host=host, event=ev, static=static, flags=flags)
 
-    def _finish_plan(self, pl):
+    def _plan_sizes(self, pl, padded=False):
         """Host side of the plan: row totals and the compact width of both window sets (waits for the count copy -- long finished
-        when the batch was planned during the update before), then `mapf_plan_rows`."""
+        when the batch was planned during the update before).  padded (graph mode): the totals rounded up to their buckets."""
         pl["event"].synchronize()
         h = pl["host"].numpy()
-        v, dev = pl["views"], self.dev
-        st = _stream(dev)
         for k, p in enumerate((pl["online"], pl["target"])):
             p.rows = int(h[2 * k].sum())
             p.nc = 16 * max(1, -(-int(h[2 * k + 1].max()) // 16))
-            T, B, N, Nc = p.T, p.B, p.N, p.nc
-            p.gidx = torch.empty((T, B, Nc), dtype=torch.int32, device=dev)
-            p.comm_c = torch.empty((T, B, Nc, Nc), dtype=torch.uint8, device=dev)
-            p.h0_c = torch.empty((B, Nc, 256), dtype=torch.bfloat16, device=dev)
-            # the observations to encode: every row, or -- with the duplicate flags -- the distinct ones (umap: entry -> distinct row)
             p.urows = int(h[4 + k].sum()) if p.dup is not None else p.rows
-            p.obs_rows = rows_buffer((), max(p.urows, 1), (6, 9, 9), torch.bfloat16, dev)
-            row_src = rows_buffer((), max(p.urows, 1), (), torch.int64, dev)
-            p.umap = rows_buffer((), max(p.rows, 1), (), torch.int32, dev) if p.dup is not None else None
-            p.row_tbp = rows_buffer((), max(p.rows, 1), (), torch.int32, dev) if p.dup is not None else None
-            cm, obs, hid = v["comm"], v["obs"], v["hidden"]
-            check(lib.mapf_plan_rows(T, B, N, Nc, _ptr(p.order), _ptr(p.nact), _ptr(p.cnt), _ptr(p.nag), _ptr(cm), cm.stride(0), cm.stride(1),
-                                     _ptr(hid), int(hid.dtype == torch.bfloat16), _ptr(obs), obs.stride(0), obs.stride(1), _ptr(p.gidx),
-                                     _ptr(p.comm_c), _ptr(p.h0_c), p.urows, _ptr(row_src), _ptr(p.obs_rows), _ptr(p.dup), _ptr(p.ucnt), _ptr(p.umap),
-                                     _ptr(p.row_tbp), st), "mapf_plan_rows")
+            p.true_rows, p.true_urows = p.rows, p.urows
+            if padded:
+                p.nc = 16 * max(1, -(-p.N // 16))
+                p.rows = _round_up(p.rows, self.GRAPH_ROW_STEP)
+                p.urows = _round_up(p.urows, self.GRAPH_UROW_STEP) if p.dup is not None else p.rows
+        return pl
+
+    def _plan_rows(self, p, v, padded=False):
+        """`mapf_plan_rows` for one window set.  padded: the launch sizes are buckets >= the real counts; the index tables are
+        initialised so that every padding row is harmless -- its observation is a copy of observation 0 of the batch (row_src = 0: the
+        encoder sees finite values), its entry uses distinct row 0 (umap = 0) and is skipped by the gradient sum (row_tbp = -1)."""
+        dev = self.dev
+        st = _stream(dev)
+        T, B, N, Nc = p.T, p.B, p.N, p.nc
+        p.gidx = torch.empty((T, B, Nc), dtype=torch.int32, device=dev)
+        p.comm_c = torch.empty((T, B, Nc, Nc), dtype=torch.uint8, device=dev)
+        p.h0_c = torch.empty((B, Nc, 256), dtype=torch.bfloat16, device=dev)
+        # the observations to encode: every row, or -- with the duplicate flags -- the distinct ones (umap: entry -> distinct row)
+        p.obs_rows = rows_buffer((), max(p.urows, 1), (6, 9, 9), torch.bfloat16, dev)
+        row_src = rows_buffer((), max(p.urows, 1), (), torch.int64, dev)
+        p.umap = rows_buffer((), max(p.rows, 1), (), torch.int32, dev) if p.dup is not None else None
+        p.row_tbp = rows_buffer((), max(p.rows, 1), (), torch.int32, dev) if p.dup is not None else None
+        if padded:
+            row_src.zero_()
+            if p.umap is not None:
+                p.umap.zero_()
+                p.row_tbp.fill_(-1)
+        cm, obs, hid = v["comm"], v["obs"], v["hidden"]
+        check(lib.mapf_plan_rows(T, B, N, Nc, _ptr(p.order), _ptr(p.nact), _ptr(p.cnt), _ptr(p.nag), _ptr(cm), cm.stride(0), cm.stride(1),
+                                 _ptr(hid), int(hid.dtype == torch.bfloat16), _ptr(obs), obs.stride(0), obs.stride(1), _ptr(p.gidx),
+                                 _ptr(p.comm_c), _ptr(p.h0_c), p.urows, _ptr(row_src), _ptr(p.obs_rows), _ptr(p.dup), _ptr(p.ucnt), _ptr(p.umap),
+                                 _ptr(p.row_tbp), st), "mapf_plan_rows")
+
+    def _finish_plan(self, pl):
+        """Exact sizes + `mapf_plan_rows` for both window sets (the eager path; tools and bench.py read `urows` / `rows` off it)."""
+        self._plan_sizes(pl)
+        for p in (pl["online"], pl["target"]):
+            self._plan_rows(p, pl["views"])
         return pl
 
     # ------------------------------------------------------------------ pieces
     def _w_ih(self, net, own):
-        """bf16 [768, 784] input-projection weight: a view of the flat bf16 copy for the online network, a cast for the target."""
+        """bf16 [768, 784] input-projection weight: a view of the flat bf16 copy for the online network, a cast for the target (kept in
+        ONE buffer, refreshed in place when the target's weights changed: captured graphs hold its address)."""
         if own:
             return self.flat.mem(self.flat.bf16, "recurrent.weight_ih")
-        c = getattr(net, "_w_ih_bf16", None)
         w = net.recurrent.weight_ih
-        key = (net.weights_epoch, w.data_ptr(), w._version)
-        if c is None or c[0] != key:
-            c = (key, w.detach().to(torch.bfloat16))
-            net._w_ih_bf16 = c
-        return c[1]
+        key = (id(net), net.weights_epoch, w.data_ptr(), w._version)
+        if self._tar_w_ih is None or self._tar_w_ih[0] != key:
+            buf = self._tar_w_ih[1] if self._tar_w_ih is not None else torch.empty(tuple(w.shape), dtype=torch.bfloat16, device=w.device)
+            buf.copy_(w.detach())
+            self._tar_w_ih = (key, buf)
+        return self._tar_w_ih[1]
 
-    def _infer_a0(self, net, penc, prec, p, own):
-        """agent-0 states bf16 [T, B, 256] of `net` on the window set `p`, no gradients (target network; double-DQN's arg-max)."""
+    def _infer_a0(self, net, images, p, own, a0):
+        """agent-0 states bf16 [T, B, 256] of `net` on the window set `p` into `a0`, no gradients (target network; double-DQN's arg-max).
+        images: the network's packed (encoder weights, encoder bias, recurrence weights, recurrence bias)."""
         dev, T, B, Nc = self.dev, p.T, p.B, p.nc
         st = _stream(dev)
-        wp, bp = penc.get(net.obs_encoder, net.weights_epoch)
-        w, b = prec.get(net)
+        wp, bp, w, b = images
         lat = rows_buffer((), p.urows, (784,), torch.bfloat16, dev)
         check(lib.mapf_encoder_forward(_ptr(p.obs_rows), 1, p.urows, _ptr(wp), _ptr(bp), _ptr(lat), st), "mapf_encoder_forward")
         gi = self._expand(mm_rows(lat, self._w_ih(net, own)), p)  # [rows, 768]
@@ -297,7 +429,6 @@ class FusedUpdate:
             gi_rows, gi = gi, torch.empty((T, B, Nc, 768), dtype=torch.bfloat16, device=dev)
             check(lib.mapf_rows_scatter(_ptr(gi_rows), _ptr(p.gidx), _ptr(gi), T * B * Nc, 1536, 1, st), "mapf_rows_scatter")
         h_out = torch.empty((B, Nc, 256), dtype=torch.bfloat16, device=dev)
-        a0 = torch.empty((T, B, 256), dtype=torch.bfloat16, device=dev)
         check(lib.mapf_recurrent_infer(_ptr(gi), _ptr(p.h0_c), _ptr(p.comm_c), _ptr(w), _ptr(b), T, B, Nc, _ptr(h_out), _ptr(a0),
                                        _ptr(p.gidx) if compact else None, p.rows if compact else 0, st), "mapf_recurrent_infer")
         return a0
@@ -322,88 +453,88 @@ class FusedUpdate:
         return (obs.is_cuda and obs.dim() == 6 and obs.shape[2] <= 128 and FORWARD_STEPS < obs.shape[1] <= 20 and Network.FUSED_TRAINING and
                 Network.FUSED_INFERENCE and Network.FUSED_BPTT and Network.FUSED_RECURRENCE and Network.FAST_RECURRENCE)
 
-    def run(self, batch, pl=None, own_batch=False):
-        lr, dev, flat = self.lr, self.dev, self.flat
-        model, tar = lr.model, lr.tar_model
-        flat.sync()
-        if pl is None:
-            pl = self.plan(batch)
-        pl = self._finish_plan(pl)
-        v, po, pt = pl["views"], pl["online"], pl["target"]
-        B, To, Tt, Nc = v["B"], po.T, pt.T, po.nc
-        cur = torch.cuda.current_stream(dev)
+    # ---- stages (each is a fixed launch sequence for given sizes: issued one after the other, or captured once per bucket) ----
+    def _target_images(self):
+        """Packed weight images of the target network (re-packed when its parameters changed; in place: captured graphs hold them)."""
+        tar = self.lr.tar_model
+        return self.packed_tar_enc.get(tar.obs_encoder, tar.weights_epoch) + self.packed_tar_recur.get(tar, inplace=True)
+
+    def _target_forward(self, c, pt, online_images):
+        """Target network (and double-DQN's online arg-max) on the target window -> c.a0_tg (c.a0_on2)."""
+        lr = self.lr
+        c.a0_tg = self._infer_a0(lr.tar_model, self._target_images(), pt, False, self._out(c, "a0_tg", (pt.T, pt.B, 256), torch.bfloat16))
+        c.a0_on2 = None
+        if lr.double_q:
+            c.a0_on2 = self._infer_a0(lr.model, online_images, pt, True, self._out(c, "a0_on2", (pt.T, pt.B, 256), torch.bfloat16))
+
+    def _pack_online(self, c):
+        """Weight images of the online network (its parameters changed with the last optimizer step)."""
+        model, dev = self.lr.model, self.dev
+        c.wp, c.bp = self.packed_on_enc.get(model.obs_encoder, model.weights_epoch, force=self._capturing)
+        c.w_rec, c.b_rec = self.packed_on_recur.get(model, force=self._capturing)
+        c.wt = torch.empty(RECUR_WEIGHT_ELEMS, dtype=torch.bfloat16, device=dev)  # the backward kernel's transposed image
+        check(lib.mapf_recurrent_pack(_ptr_array([p.detach() for p in recurrence_params(model)]), None, None, _ptr(c.wt), _stream(dev)), "mapf_recurrent_pack")
+        c.wpt = pack_encoder_backward(model.obs_encoder)
+
+    def _online_forward(self, c, po):
+        """Online network forward on the online window, saving what the backward needs -> c.a0 and the saved tensors.
+        c.padded: every tensor that enters a weight-gradient GEMM is zeroed first -- the kernels only write the rows that exist."""
+        dev = self.dev
         st = _stream(dev)
-        G = flat.grads
-        # ---- weight images of the online network, on THIS stream before the side stream may read them (double-DQN) ----
-        wp, bp = self.packed_on_enc.get(model.obs_encoder, model.weights_epoch)
-        w_rec, b_rec = self.packed_on_recur.get(model)
-        wt = torch.empty(RECUR_WEIGHT_ELEMS, dtype=torch.bfloat16, device=dev)  # the backward kernel's transposed image
-        check(lib.mapf_recurrent_pack(_ptr_array([p.detach() for p in recurrence_params(model)]), None, None, _ptr(wt), st), "mapf_recurrent_pack")
-        wpt = pack_encoder_backward(model.obs_encoder)
-        # ---- target network (and double-DQN's online arg-max) on the second stream ----
-        # (beyond ~260 k rows -- every observation of 128-agent windows -- either network's kernels fill the chip for tens of
-        # milliseconds: a second stream buys nothing there and doubles the transient allocations)
-        side = lr._side if max(po.rows, pt.rows) <= SIDE_STREAM_MAX_ROWS else None
-        a0_on2 = None
-        if side is not None:
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                a0_tg = self._infer_a0(tar, self.packed_tar_enc, self.packed_tar_recur, pt, False)
-                if lr.double_q:
-                    a0_on2 = self._infer_a0(model, self.packed_on_enc, self.packed_on_recur, pt, True)
-                ready = torch.cuda.Event()
-                ready.record(side)
-        else:
-            a0_tg = self._infer_a0(tar, self.packed_tar_enc, self.packed_tar_recur, pt, False)
-            if lr.double_q:
-                a0_on2 = self._infer_a0(model, self.packed_on_enc, self.packed_on_recur, pt, True)
-        # ---- online network forward, saving what the backward needs ----
+        B, To, Nc = po.B, po.T, po.nc
         M, Mu = po.rows, po.urows  # entries of the window set / distinct observations among them
         bf = torch.bfloat16
-        acts = rows_buffer((7,), Mu, (7, 7, 128), ENC_ELEMENT, dev)
-        lat = rows_buffer((), Mu, (784,), bf, dev)
-        bits = rows_buffer((7,), Mu, (49, 4), torch.int32, dev)
-        check(lib.mapf_encoder_forward_save(_ptr(po.obs_rows), 1, Mu, _ptr(wp), _ptr(bp), _ptr(lat), _ptr(acts), _ptr(bits), st),
+        c.acts = rows_buffer((7,), Mu, (7, 7, 128), ENC_ELEMENT, dev)
+        c.lat = rows_buffer((), Mu, (784,), bf, dev)
+        c.bits = rows_buffer((7,), Mu, (49, 4), torch.int32, dev)
+        check(lib.mapf_encoder_forward_save(_ptr(po.obs_rows), 1, Mu, _ptr(c.wp), _ptr(c.bp), _ptr(c.lat), _ptr(c.acts), _ptr(c.bits), st),
               "mapf_encoder_forward_save")
-        w_ih = self._w_ih(model, True)
-        gi_rows = self._expand(mm_rows(lat, w_ih), po)
-        compact = Nc <= RECUR_NARROW_AGENTS
+        c.w_ih = self._w_ih(self.lr.model, True)
+        gi_rows = self._expand(mm_rows(c.lat, c.w_ih), po)
+        c.compact = compact = Nc <= RECUR_NARROW_AGENTS
         # rows of the recurrence's saved tensors / gradient outputs: the M rows that exist (compact: the <= 48-agent kernels address
         # them through gidx) or all To x B x Nc (step, window, position) entries (the wide kernels)
         # (compact: padded to a multiple of the weight-gradient GEMMs' split size, the padding rows zeroed below)
-        R = -(-M // WGRAD_SPLIT) * WGRAD_SPLIT if compact else To * B * Nc
-        ridx, nrows = (_ptr(po.gidx), R) if compact else (None, 0)
+        c.R = R = -(-M // WGRAD_SPLIT) * WGRAD_SPLIT if compact else To * B * Nc
+        c.ridx, c.nrows = (_ptr(po.gidx), R) if compact else (None, 0)
         if compact:
             gi = gi_rows
         else:
             gi = torch.empty((To, B, Nc, 768), dtype=bf, device=dev)
             check(lib.mapf_rows_scatter(_ptr(gi_rows), _ptr(po.gidx), _ptr(gi), To * B * Nc, 1536, 1, st), "mapf_rows_scatter")
-        saves = [rows_buffer((), R, (256,), bf, dev), rows_buffer((), R, (1024,), bf, dev),
-                 rows_buffer((2,), R, (256,), bf, dev), rows_buffer((2,), R, (384,), bf, dev),
-                 rows_buffer((2,), R, (128,), bf, dev), rows_buffer((2,), R, (64,), bf, dev),
-                 rows_buffer((2,), R, (1024,), bf, dev),
-                 torch.empty((2, To * B, 2, 48, 64) if Nc <= RECUR_NARROW_AGENTS else (8,), dtype=bf, device=dev)]
+        if c.padded:
+            # one allocation for everything the tall GEMMs read, one memset: [saves 0, 2, 4, 5 | outputs of the backward 0..5]
+            widths = [256, 2 * 256, 2 * 128, 2 * 64, 768, 768, 2 * 768, 2 * 768, 2 * 64, 2 * 384]
+            zero = torch.zeros(R * sum(widths), dtype=bf, device=dev)
+            parts, off = [], 0
+            for w in widths:
+                parts.append(zero[off:off + R * w])
+                off += R * w
+            s0, s2, s4, s5 = parts[0].view(R, 256), parts[1].view(2, R, 256), parts[2].view(2, R, 128), parts[3].view(2, R, 64)
+            c.outs_b = [parts[4].view(R, 768), parts[5].view(R, 768), parts[6].view(2, R, 768), parts[7].view(2, R, 768), parts[8].view(2, R, 64),
+                        parts[9].view(2, R, 384), torch.empty((B, 2432), dtype=torch.float32, device=dev)]
+        else:
+            s0, s2, s4, s5 = (rows_buffer((), R, (256,), bf, dev), rows_buffer((2,), R, (256,), bf, dev), rows_buffer((2,), R, (128,), bf, dev),
+                              rows_buffer((2,), R, (64,), bf, dev))
+            c.outs_b = None
+        c.saves = [s0, rows_buffer((), R, (1024,), bf, dev), s2, rows_buffer((2,), R, (384,), bf, dev), s4, s5, rows_buffer((2,), R, (1024,), bf, dev),
+                   torch.empty((2, To * B, 2, 48, 64) if Nc <= RECUR_NARROW_AGENTS else (8,), dtype=bf, device=dev)]
         h_out = torch.empty((B, Nc, 256), dtype=bf, device=dev)
-        a0 = torch.empty((To, B, 256), dtype=bf, device=dev)
-        sp = _ptr_array(saves)
-        check(lib.mapf_recurrent_forward_save(_ptr(gi), _ptr(po.h0_c), _ptr(po.comm_c), _ptr(w_rec), _ptr(b_rec), To, B, Nc, _ptr(h_out), _ptr(a0), sp,
-                                              ridx, nrows, st), "mapf_recurrent_forward_save")
-        # ---- dueling heads, TD error, priorities, loss and their gradients ----
-        if side is not None:
-            cur.wait_event(ready)
-            for t in (a0_tg, a0_on2):  # allocated on the side stream, consumed on this one
-                if t is not None:
-                    t.record_stream(cur)
-            for t in (pt.obs_rows, pt.gidx, pt.comm_c, pt.h0_c, pt.umap):  # allocated on this stream, read on the side stream
-                if t is None:
-                    continue
-                t.record_stream(side)
+        c.a0 = self._out(c, "a0", (To, B, 256), bf)
+        c.sp = _ptr_array(c.saves)
+        check(lib.mapf_recurrent_forward_save(_ptr(gi), _ptr(po.h0_c), _ptr(po.comm_c), _ptr(c.w_rec), _ptr(c.b_rec), To, B, Nc, _ptr(h_out), _ptr(c.a0), c.sp,
+                                              c.ridx, c.nrows, st), "mapf_recurrent_forward_save")
+
+    def _head(self, c, v, To, Tt, batch):
+        """Dueling heads, TD error, priorities, loss and their gradients; then the priority write-back."""
+        lr, dev, flat = self.lr, self.dev, self.flat
+        tar, G, B = lr.tar_model, flat.grads, v["B"]
         flat.grads.zero_()
-        outs = torch.empty((3, B), dtype=torch.float32, device=dev)  # q, q_next, td
-        prio = torch.empty(B, dtype=torch.float64, device=dev)
-        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        c.outs = self._out(c, "outs", (3, B), torch.float32)  # q, q_next, td
+        c.prio = self._out(c, "prio", (B,), torch.float64)
+        c.loss = self._out(c, "loss", (1,), torch.float32)
         scratch = torch.empty(9 * B, dtype=torch.float32, device=dev)
-        d_a0 = torch.empty((To, B, 256), dtype=bf, device=dev)
+        c.d_a0 = self._out(c, "d_a0", (To, B, 256), torch.bfloat16)
         head_names = ("adv.weight", "adv.bias", "state.weight", "state.bias")
         head_on = _ptr_array([flat.mem(flat.params, k) for k in head_names])
         if self._tar_head is None or self._tar_head[0] is not tar:
@@ -411,40 +542,32 @@ class FusedUpdate:
             self._tar_head = (tar, [tnamed[k] for k in head_names])
         head_tg_t = [t.detach().to(torch.float32).contiguous() for t in self._tar_head[1]]
         head_g = _ptr_array([flat.mem(G, k) for k in head_names])
-        check(lib.mapf_dqn_head_loss(B, To, Tt, _ptr(a0), _ptr(a0_tg), _ptr(a0_on2), _ptr(v["bt"]), _ptr(v["steps"]), _ptr(v["action"]),
-                                     _ptr(v["reward"]), _ptr(v["done"]), _ptr(v["weights"]), head_on, _ptr_array(head_tg_t), GAMMA, _ptr(outs[0]),
-                                     _ptr(outs[1]), _ptr(outs[2]), _ptr(prio), _ptr(loss), _ptr(scratch), _ptr(d_a0), head_g, st),
+        check(lib.mapf_dqn_head_loss(B, To, Tt, _ptr(c.a0), _ptr(c.a0_tg), _ptr(c.a0_on2), _ptr(v["bt"]), _ptr(v["steps"]), _ptr(v["action"]),
+                                     _ptr(v["reward"]), _ptr(v["done"]), _ptr(v["weights"]), head_on, _ptr_array(head_tg_t), GAMMA, _ptr(c.outs[0]),
+                                     _ptr(c.outs[1]), _ptr(c.outs[2]), _ptr(c.prio), _ptr(c.loss), _ptr(scratch), _ptr(c.d_a0), head_g, _stream(dev)),
               "mapf_dqn_head_loss")
+
+    def _write_priorities(self, c, batch):
+        lr = self.lr
         idxes, old_ptr = batch[8], batch[10]
-        if lr.replay_gate is not None:  # (actors on their own stream: their last episode flush precedes this update's replay operations)
-            cur.wait_event(lr.replay_gate)
         if lr.buffer is not None and idxes is not None:
-            lr.buffer.update_priorities(idxes, prio, old_ptr)                                     # worker.py:331 (values known here)
-        pre_ready = None
-        if lr.prefetch and own_batch:
-            # the next batch is sampled and planned NOW (its priorities are in), on the second stream: ~0.5 ms of small kernels that
-            # fit beside the backward-through-time kernel (192 workgroups on 256 CUs) instead of in front of it
-            if lr._side is not None:
-                lr._side.wait_stream(cur)
-                with torch.cuda.stream(lr._side):
-                    lr._launch_prefetch()
-                    pre_ready = torch.cuda.Event()
-                    pre_ready.record(lr._side)
-            else:
-                lr._launch_prefetch()
-        # this update's replay operations (priority write-back, next sample) are enqueued: whoever else writes the replay waits for this
-        lr.replay_released = pre_ready
-        if pre_ready is None:
-            lr.replay_released = torch.cuda.Event()
-            lr.replay_released.record(cur)
-        # ---- backward through time ----
-        outs_b = [rows_buffer((), R, (768,), bf, dev), rows_buffer((), R, (768,), bf, dev),
-                  rows_buffer((2,), R, (768,), bf, dev), rows_buffer((2,), R, (768,), bf, dev),
-                  rows_buffer((2,), R, (64,), bf, dev), rows_buffer((2,), R, (384,), bf, dev),
-                  torch.empty((B, 2432), dtype=torch.float32, device=dev)]
-        check(lib.mapf_recurrent_backward(sp, _ptr(po.comm_c), _ptr(d_a0), _ptr(wt), To, B, Nc, _ptr_array(outs_b), ridx, nrows, st),
+            lr.buffer.update_priorities(idxes, c.prio, old_ptr)                                   # worker.py:331 (values known here)
+
+    def _backward(self, c, po, lr_value):
+        """Backward through time, weight gradients, encoder backward, the only collective, clip + Adam.  Returns the gradient norm."""
+        lr, dev, flat = self.lr, self.dev, self.flat
+        st, bf, G = _stream(dev), torch.bfloat16, flat.grads
+        B, To, Nc, R, M, Mu, compact = po.B, po.T, po.nc, c.R, po.rows, po.urows, c.compact
+        saves = c.saves
+        outs_b = c.outs_b
+        if outs_b is None:
+            outs_b = [rows_buffer((), R, (768,), bf, dev), rows_buffer((), R, (768,), bf, dev),
+                      rows_buffer((2,), R, (768,), bf, dev), rows_buffer((2,), R, (768,), bf, dev),
+                      rows_buffer((2,), R, (64,), bf, dev), rows_buffer((2,), R, (384,), bf, dev),
+                      torch.empty((B, 2432), dtype=torch.float32, device=dev)]
+        check(lib.mapf_recurrent_backward(c.sp, _ptr(po.comm_c), _ptr(c.d_a0), _ptr(c.wt), To, B, Nc, _ptr_array(outs_b), c.ridx, c.nrows, st),
               "mapf_recurrent_backward")
-        if compact and R > M:  # rows M..R of every GEMM operand (both rounds of the [2, R, w] tensors)
+        if compact and R > M and not c.padded:  # rows M..R of every GEMM operand (both rounds of the [2, R, w] tensors)
             ops = [saves[0], saves[2][0], saves[2][1], saves[4][0], saves[4][1], saves[5][0], saves[5][1], outs_b[1], outs_b[2][0], outs_b[2][1],
                    outs_b[3][0], outs_b[3][1], outs_b[4][0], outs_b[4][1], outs_b[5][0], outs_b[5][1]]
             rb = (ctypes.c_int * len(ops))(*[t.shape[-1] * 2 for t in ops])
@@ -469,24 +592,221 @@ class FusedUpdate:
             check(lib.mapf_rows_scatter(_ptr(d_gi_rows), _ptr(po.gidx), _ptr(d_gi1), R, 1536, 0, st), "mapf_rows_scatter")
         if po.umap is not None:  # gradient of a shared row = the sum over the entries that use it
             d_gi_u = rows_buffer((), Mu, (768,), bf, dev)
+            if c.padded:
+                d_gi_u.zero_()  # (distinct rows behind the real ones have no entry: their gradient must read zero)
             check(lib.mapf_dedup_sum(To, B, Nc, M, 1536, _ptr(po.gidx), _ptr(po.umap), _ptr(po.row_tbp), _ptr(d_gi_rows), _ptr(d_gi_u), st),
                   "mapf_dedup_sum")
             d_gi_rows = d_gi_u
-        g_lat = mm_rows(d_gi_rows, w_ih, transpose_w=False)
-        _tall_tn_into(flat.mem(G, "recurrent.weight_ih"), d_gi_rows, lat, rows=4096)
+        g_lat = mm_rows(d_gi_rows, c.w_ih, transpose_w=False)
+        _tall_tn_into(flat.mem(G, "recurrent.weight_ih"), d_gi_rows, c.lat, rows=4096)
         # ---- encoder: backward-data chain in one kernel, then the weight-gradient kernels ----
-        self._encoder_backward(po.obs_rows, Mu, acts, lat, bits, g_lat, wpt)
+        self._encoder_backward(po.obs_rows, Mu, c.acts, c.lat, c.bits, g_lat, c.wpt)
         # ---- the only collective, clip, Adam ----
         lr.bucket.all_reduce_mean()
         if lr.grad_hook is not None:
             lr.grad_hook(lr)
-        grad_norm = flat.adam_step(lr.current_lr())
+        return flat.adam_step(lr_value)
+
+    def run(self, batch, pl=None, own_batch=False):
+        lr, dev, flat = self.lr, self.dev, self.flat
+        flat.sync()
+        if pl is None:
+            pl = self.plan(batch)
+        if own_batch and pl.get("static") and self.graph_mode() and lr.prefetch and lr._side is not None:
+            return self._run_graphed(batch, pl)
+        pl = self._finish_plan(pl)
+        v, po, pt = pl["views"], pl["online"], pl["target"]
+        B, To, Tt = v["B"], po.T, pt.T
+        cur = torch.cuda.current_stream(dev)
+        c = _Ctx()
+        c.static = c.padded = False
+        # ---- weight images of the online network, on THIS stream before the side stream may read them (double-DQN) ----
+        self._pack_online(c)
+        # ---- target network (and double-DQN's online arg-max) on the second stream ----
+        # (beyond ~260 k rows -- every observation of 128-agent windows -- either network's kernels fill the chip for tens of
+        # milliseconds: a second stream buys nothing there and doubles the transient allocations)
+        side = lr._side if max(po.rows, pt.rows) <= SIDE_STREAM_MAX_ROWS else None
+        if side is not None:
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self._target_forward(c, pt, (c.wp, c.bp, c.w_rec, c.b_rec))
+                ready = torch.cuda.Event()
+                ready.record(side)
+        else:
+            self._target_forward(c, pt, (c.wp, c.bp, c.w_rec, c.b_rec))
+        # ---- online network forward, saving what the backward needs ----
+        self._online_forward(c, po)
+        # ---- dueling heads, TD error, priorities, loss and their gradients ----
+        if side is not None:
+            cur.wait_event(ready)
+            for t in (c.a0_tg, c.a0_on2):  # allocated on the side stream, consumed on this one
+                if t is not None:
+                    t.record_stream(cur)
+            for t in (pt.obs_rows, pt.gidx, pt.comm_c, pt.h0_c, pt.umap):  # allocated on this stream, read on the side stream
+                if t is None:
+                    continue
+                t.record_stream(side)
+        self._head(c, v, To, Tt, batch)
+        if lr.replay_gate is not None:  # (actors on their own stream: their last episode flush precedes this update's replay operations)
+            cur.wait_event(lr.replay_gate)
+        self._write_priorities(c, batch)
+        pre_ready = None
+        if lr.prefetch and own_batch:
+            # the next batch is sampled and planned NOW (its priorities are in), on the second stream: ~0.5 ms of small kernels that
+            # fit beside the backward-through-time kernel (192 workgroups on 256 CUs) instead of in front of it
+            if lr._side is not None:
+                lr._side.wait_stream(cur)
+                with torch.cuda.stream(lr._side):
+                    lr._launch_prefetch()
+                    pre_ready = torch.cuda.Event()
+                    pre_ready.record(lr._side)
+            else:
+                lr._launch_prefetch()
+        # this update's replay operations (priority write-back, next sample) are enqueued: whoever else writes the replay waits for this
+        lr.replay_released = pre_ready
+        if pre_ready is None:
+            lr.replay_released = torch.cuda.Event()
+            lr.replay_released.record(cur)
+        grad_norm = self._backward(c, po, lr.current_lr())
         if pre_ready is not None:
             # everything the caller enqueues from here on (the next update; an actor step that appends to the replay) is ordered behind
             # the sample.  Memory: the prefetched tensors come from the second stream's pool and are consumed on this one -- safe without
             # record_stream because every use of the second stream starts with wait_stream(this one)
             cur.wait_event(pre_ready)
-        return dict(loss=loss[0], td=outs[2].view(B, 1), priorities=prio, grad_norm=grad_norm, q=outs[0].view(B, 1), q_next=outs[1].view(B, 1))
+        return dict(loss=c.loss[0], td=c.outs[2].view(B, 1), priorities=c.prio, grad_norm=grad_norm, q=c.outs[0].view(B, 1), q_next=c.outs[1].view(B, 1))
+
+    # ------------------------------------------------------------------ graph mode
+    def _graph(self, stage, key, pool, fn):
+        """The captured graph of `stage` for `key` (captured now if new).  Returns (graph, what fn returned at capture time)."""
+        self._tick += 1
+        ent = self._graphs.get((stage, key))
+        if ent is None:
+            same = [k for k in self._graphs if k[0] == stage]
+            if len(same) >= self.GRAPH_CACHE:
+                del self._graphs[min(same, key=lambda k: self._graphs[k][2])]
+            g = torch.cuda.CUDAGraph()
+            self._capturing = True
+            try:
+                with torch.cuda.graph(g, pool=self._pools.get(pool)):
+                    out = fn()
+            finally:
+                self._capturing = False
+            self._pools.setdefault(pool, g.pool())
+            ent = [g, out, self._tick]
+            self._graphs[(stage, key)] = ent
+            self.graph_captures += 1
+        ent[2] = self._tick
+        return ent[0], ent[1]
+
+    def _run_graphed(self, batch, pl):
+        """One update as five graph replays (see the class comment).  `batch` / `pl` are the static slot and its static plan."""
+        lr, dev, flat = self.lr, self.dev, self.flat
+        self._plan_sizes(pl, padded=True)
+        v, po, pt = pl["views"], pl["online"], pl["target"]
+        B, To, Tt = v["B"], po.T, pt.T
+        cur, side = torch.cuda.current_stream(dev), lr._side
+        flags = pl["flags"] + (bool(lr.double_q),)
+        shape = (B, To, Tt, po.N)
+        key_t = shape + flags + (pt.nc, pt.rows, pt.urows)
+        key_o = shape + flags + (po.nc, po.rows, po.urows)
+        lr_value = lr.current_lr()
+        tar = lr.tar_model
+        # the target network's weight images follow its parameters OUTSIDE the graphs (they change every 2,500 updates), in place, on
+        # the stream that reads them
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self._target_images()
+            self._w_ih(tar, False)
+        cur.wait_stream(side)  # (captures below synchronise the device anyway; replays of the target graph run on `side` behind the packs)
+
+        def cap_target():
+            c = _Ctx()
+            c.static, c.padded = True, True
+            self._plan_rows(pt, v, padded=True)
+            self._target_forward(c, pt, (c_p.wp, c_p.bp, c_p.w_rec, c_p.b_rec))
+            return c
+
+        def cap_pack():
+            c = _Ctx()
+            self._pack_online(c)
+            return c
+
+        def cap_online():
+            c = _Ctx()
+            c.static, c.padded = True, True
+            c.wp, c.bp, c.w_rec, c.b_rec, c.wt, c.wpt = c_p.wp, c_p.bp, c_p.w_rec, c_p.b_rec, c_p.wt, c_p.wpt
+            c.backward = {}
+            self._plan_rows(po, v, padded=True)
+            self._online_forward(c, po)
+            c.po = (po.gidx, po.comm_c, po.h0_c, po.obs_rows, po.umap, po.row_tbp)  # (kept alive: the backward graph reads them)
+            return c
+
+        self._prealloc(B, To, Tt)
+        # the online network's weight images first, on this stream, before the side stream may read them (double-DQN's arg-max)
+        g_k, c_p = self._graph("pack", (), "main", cap_pack)
+        g_k.replay()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            g_t, c_t = self._graph("target", key_t, "side", cap_target)
+            g_t.replay()
+        g_o, c_o = self._graph("online", key_o, "main", cap_online)
+        g_o.replay()
+        cur.wait_stream(side)
+
+        def cap_head():
+            c = _Ctx()
+            c.static, c.padded = True, True
+            c.a0, c.a0_tg, c.a0_on2 = c_o.a0, c_t.a0_tg, c_t.a0_on2
+            self._head(c, v, To, Tt, batch)
+            self._write_priorities(c, batch)
+            return c
+
+        g_h, c_h = self._graph("head", shape + flags, "main", cap_head)
+        if lr.replay_gate is not None:  # (actors on their own stream: their last episode flush precedes this update's replay operations)
+            cur.wait_event(lr.replay_gate)
+        g_h.replay()
+
+        def cap_prefetch():
+            lr._launch_prefetch()
+            return lr._pre
+
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            g_p, pre = self._graph("prefetch", shape + flags, "side", cap_prefetch)
+            g_p.replay()
+            pre_ready = torch.cuda.Event()
+            pre_ready.record(side)
+        pre[1]["event"] = pre_ready
+        lr._pre = pre
+        lr.replay_released = pre_ready
+
+        def cap_backward():
+            (po.gidx, po.comm_c, po.h0_c, po.obs_rows, po.umap, po.row_tbp) = c_o.po
+            c_o.d_a0 = c_h.d_a0
+            norm = self._backward(c_o, po, lr_value)
+            return norm
+
+        ent = c_o.backward.get(lr_value)  # (kept with the online graph whose saved tensors it reads: evicted together)
+        if ent is None:
+            saved_step, saved_epoch = flat.step_host, lr.model.weights_epoch
+            g_b = torch.cuda.CUDAGraph()
+            self._capturing = True
+            try:
+                with torch.cuda.graph(g_b, pool=self._pools.get("main")):
+                    norm = cap_backward()
+            finally:
+                self._capturing = False
+            flat.step_host, lr.model.weights_epoch = saved_step, saved_epoch  # (a capture runs adam_step's Python without executing it)
+            ent = c_o.backward[lr_value] = (g_b, norm)
+            self.graph_captures += 1
+        g_b, norm = ent
+        g_b.replay()
+        flat.step_host += 1
+        lr.model.weights_epoch += 1
+        cur.wait_event(pre_ready)
+        self.graph_replays += 1
+        outs, prio, loss = c_h.outs.clone(), c_h.prio.clone(), c_h.loss.clone()
+        return dict(loss=loss[0], td=outs[2].view(B, 1), priorities=prio, grad_norm=norm.clone(), q=outs[0].view(B, 1), q_next=outs[1].view(B, 1))
 
     def _encoder_backward(self, obs_rows, M, acts, lat, bits, g_lat, wpt):
         dev, flat = self.dev, self.flat
