@@ -219,6 +219,11 @@ class FusedUpdate:
     #   backward (main)         BPTT, weight gradients, encoder backward, clip + Adam                                   [key: online buckets, lr]
     # with ordinary events between them (the actors' replay gate in front of `head`, `replay_released` behind `prefetch`), so the
     # overlap of actors and learner (train.py) is what it was.
+    # Memory.  Captures allocate from private pools, and a capture may reuse whatever an EARLIER capture of its pool has freed -- its
+    # temporaries.  That is only sound if no graph that still writes such a temporary is replayed between the producer and the
+    # consumer of a tensor a later capture placed there.  Hence three pools: "main" (pack, online, backward: the saved tensors of an
+    # online graph live until its backward graph has run, and only `head` runs in between), "head", and "side" (target, prefetch:
+    # nothing of theirs outlives its graph; their results land in buffers allocated outside any capture).
     GRAPH = True
     GRAPH_MAX_AGENTS = 16       # replay rows wider than this are GPU-bound (no gain) and would need many more buckets
     GRAPH_ROW_STEP = 2048       # bucket of the entry count (== WGRAD_SPLIT: the weight-gradient GEMMs' K is padded to it anyway)
@@ -761,7 +766,9 @@ class FusedUpdate:
             self._write_priorities(c, batch)
             return c
 
-        g_h, c_h = self._graph("head", shape + flags, "main", cap_head)
+        # (its own memory pool: this graph runs BETWEEN the online graph and its backward graph, whose saved tensors live in pool "main" --
+        # a temporary of this capture may not alias what a later capture keeps there across graphs)
+        g_h, c_h = self._graph("head", shape + flags, "head", cap_head)
         if lr.replay_gate is not None:  # (actors on their own stream: their last episode flush precedes this update's replay operations)
             cur.wait_event(lr.replay_gate)
         g_h.replay()
@@ -770,9 +777,12 @@ class FusedUpdate:
             lr._launch_prefetch()
             return lr._pre
 
+        from .model import Network
+
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            g_p, pre = self._graph("prefetch", shape + flags, "side", cap_prefetch)
+            # (keyed by what the NEXT batch's plan bakes in: the switches as they are now)
+            g_p, pre = self._graph("prefetch", shape + (bool(Network.PRUNE_UNREACHABLE), bool(self.DEDUP)), "side", cap_prefetch)
             g_p.replay()
             pre_ready = torch.cuda.Event()
             pre_ready.record(side)

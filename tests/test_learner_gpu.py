@@ -56,6 +56,8 @@ def test_pipelined_target_forward_equals_sequential_order(double_q):
     from mapf_rl_amd.model import Network
     from mapf_rl_amd.replay import GlobalBuffer
 
+    from mapf_rl_amd.update import FusedUpdate
+
     def run(prefetch):
         torch.manual_seed(0)
         rng = np.random.RandomState(1)
@@ -76,7 +78,11 @@ def test_pipelined_target_forward_equals_sequential_order(double_q):
         torch.cuda.synchronize()
         return outs, [p.detach().clone() for p in lr.model.parameters()], buf.priority_tree.tree().clone()
 
-    (o_seq, p_seq, t_seq), (o_pre, p_pre, t_pre) = run(False), run(True)
+    graph, FusedUpdate.GRAPH = FusedUpdate.GRAPH, False  # (bit-for-bit: the graph replay pads its launches, test below)
+    try:
+        (o_seq, p_seq, t_seq), (o_pre, p_pre, t_pre) = run(False), run(True)
+    finally:
+        FusedUpdate.GRAPH = graph
     for a, b in zip(o_seq, o_pre):
         assert torch.equal(a["q_next"], b["q_next"]) and torch.equal(a["td"], b["td"])
         assert float(a["loss"]) == float(b["loss"])
@@ -198,3 +204,82 @@ def test_actors_on_their_own_stream_leave_the_replay_consistent():
     ptr, size, counter, _ = buf.state()
     assert actor.episodes > 0 and 0 < size <= 256 * 256 and counter >= size
     assert all(bool(torch.isfinite(p).all()) for p in lr.model.parameters())
+
+
+def _filled_replay(A=6, episodes=24, seed=1):
+    from mapf_rl_amd.replay import GlobalBuffer
+
+    rng = np.random.RandomState(seed)
+    buf = GlobalBuffer(32, max_agents=A)
+    for k in range(episodes):
+        size = int(rng.randint(30, 120))
+        na = 1 + k % A                                     # levels of 1..A agents in one replay, like the curriculum
+        td = np.zeros(256)
+        td[:size] = rng.random_sample(size) + 0.1
+        obs = rng.random_sample((size + 1, na, 6, 9, 9)) < 0.3
+        obs[1::3] = obs[0:-1:3][:obs[1::3].shape[0]]       # repeated observations: the duplicate flags have something to find
+        comm = rng.random_sample((size + 1, na, na)) < 0.4
+        comm |= np.eye(na, dtype=bool)[None]
+        buf.add_episode(na, obs, rng.randint(0, 5, size).astype(np.uint8), rng.choice([-0.075, -0.5, 3.0], size).astype(np.float16),
+                        (rng.standard_normal((size, 256)) * 0.3).astype(np.float16), td, bool(k % 2), size, comm)
+    return buf
+
+
+@pytest.mark.parametrize("double_q", [False, True])
+def test_graph_replayed_update_follows_the_eager_update(double_q):
+    """update.FusedUpdate.GRAPH: at few agents the update is replayed from captured HIP graphs over bucket-sized (padded) launches.
+    Same state, same samples (identical RNG, identical priorities to within the first update's rounding): the first update's
+    Q-values / TD errors / loss / gradient norm and the parameters after it agree with the eager launch sequence to the tolerance of a
+    different GEMM tiling (the padded rows contribute exact zeros); then a run of updates goes through replays of several buckets
+    and stays close to the eager run."""
+    from mapf_rl_amd.learner import Learner
+    from mapf_rl_amd.model import Network
+    from mapf_rl_amd.update import FusedUpdate
+
+    def run(graph, n):
+        saved, FusedUpdate.GRAPH = FusedUpdate.GRAPH, graph
+        try:
+            buf = _filled_replay()
+            torch.manual_seed(7)
+            torch.cuda.manual_seed(7)
+            lr = Learner(buf, device="cuda", batch_size=48, model=Network(), double_q=double_q)
+            outs = []
+            for _ in range(n):
+                o = lr.update()
+                outs.append({k: v.detach().clone() for k, v in o.items()})
+            torch.cuda.synchronize()
+            fu = lr._fused
+            return (outs, [p.detach().clone() for p in lr.model.parameters()], buf.priority_tree.tree().clone(), (fu.graph_replays, fu.graph_captures),
+                    fu.flat.step, {k: fu.flat.mem(fu.flat.grads, k).clone() for k in fu.flat.names})
+        finally:
+            FusedUpdate.GRAPH = saved
+
+    # one update: every parameter tensor's (clipped) gradient
+    g_e, g_g = run(False, 1)[5], run(True, 1)[5]
+    for k in g_e:
+        err, ref = float((g_e[k] - g_g[k]).norm()), float(g_e[k].norm())
+        assert err <= 2e-2 * ref + 1e-7, (k, err, ref)
+    n = 14
+    o_e, p_e, t_e, (rep_e, _), step_e, _ = run(False, n)
+    o_g, p_g, t_g, (rep_g, cap_g), step_g, _ = run(True, n)
+    assert rep_e == 0 and rep_g == n and 5 <= cap_g <= 6 * n and step_e == step_g == n
+    a, b = o_e[0], o_g[0]
+    for k in ("q", "q_next", "td"):
+        assert torch.allclose(a[k], b[k], atol=2e-2, rtol=2e-2), (k, (a[k] - b[k]).abs().max())
+    assert abs(float(a["loss"]) - float(b["loss"])) <= 2e-2 * max(1.0, abs(float(a["loss"])))
+    assert abs(float(a["grad_norm"]) - float(b["grad_norm"])) <= 3e-2 * float(a["grad_norm"])
+    assert torch.allclose(a["priorities"], b["priorities"], atol=2e-2, rtol=2e-2)
+    # the whole run: same sampling stream, nearly the same priorities -> nearly the same batches; Adam steps are +-lr per element
+    num = sum(float((x - y).pow(2).sum()) for x, y in zip(p_e, p_g))
+    den = sum(float((x - p0).pow(2).sum()) for x, p0 in zip(p_e, run(False, 0)[1]))
+    # the two runs moved the parameters the same way: difference << distance travelled (Adam turns every sign flip of a near-zero
+    # gradient into +-lr, so this is a coarse bound; the per-tensor gradient check above is the sharp one)
+    assert num <= 0.1 * den, (num, den)
+    for o in o_g:
+        assert all(bool(torch.isfinite(v).all()) for v in o.values())
+    leaves = t_g[-buf_leaves(t_g):]
+    assert abs(float(t_g[0]) - float(leaves.sum())) < 1e-6 * float(t_g[0])
+
+
+def buf_leaves(tree):
+    return (tree.numel() + 1) // 2

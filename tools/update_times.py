@@ -39,18 +39,27 @@ print("%d agents, %dx%d: %.3f of the online window's (step, agent) entries can r
 print("windows by agents that matter: <=16: %d, 17..32: %d, 33..48: %d, >48: %d of %d" % (
     int((per_window <= 16).sum()), int(((per_window > 16) & (per_window <= 32)).sum()), int(((per_window > 32) & (per_window <= 48)).sum()),
     int((per_window > 48).sum()), per_window.numel()), flush=True)
-for prune in (False, True):
-    Network.PRUNE_UNREACHABLE = prune
-    for _ in range(3):
-        lr.update()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(20):
-        lr.update()
-    t1 = time.perf_counter()
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    print("prune=%-5s update %.2f ms wall (host enqueue %.2f ms)" % (prune, (t2 - t0) / 20 * 1e3, (t1 - t0) / 20 * 1e3), flush=True)
+from mapf_rl_amd.update import FusedUpdate  # noqa: E402
+
+ITERS = int(os.environ.get("ITERS", "100"))
+for graph in (False, True):
+    FusedUpdate.GRAPH = graph
+    for prune in (False, True):
+        Network.PRUNE_UNREACHABLE = prune
+        lr._drop_prefetch()
+        for _ in range(40 if graph else 3):  # (graph mode: the buckets this replay produces get captured)
+            lr.update()
+        torch.cuda.synchronize()
+        c0 = lr._fused.graph_captures
+        t0 = time.perf_counter()
+        for _ in range(ITERS):
+            lr.update()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print("graph=%-5s prune=%-5s update %.2f ms wall (host enqueue %.2f ms)   graph replays so far %d, captures %d (%d in the timed stretch)" % (
+            graph, prune, (t2 - t0) / ITERS * 1e3, (t1 - t0) / ITERS * 1e3, lr._fused.graph_replays, lr._fused.graph_captures,
+            lr._fused.graph_captures - c0), flush=True)
 if os.environ.get("PROFILE_HOST"):
     import cProfile
     import pstats
