@@ -130,6 +130,32 @@ int mapf_observe(mapf_env_t *env, uint8_t *obs_dev, uint32_t *obs_bits_dev, int1
 int mapf_observe_masked(mapf_env_t *env, const uint8_t *mask_dev, uint8_t *obs_dev, uint32_t *obs_bits_dev, int16_t *pos_dev,
                         void *stream);
 
+/*
+ * Several handles of DIFFERENT shapes stepped by one launch.  The reference draws a (num_agents, map side) level per episode inside
+ * one actor (environment.py:148-151, worker.py:422-428: Environment.reset(level)); here every active level is a handle of a few
+ * hundred lock-step environments, and a set binds up to 16 of them (one device; shapes whose workgroup is one wavefront: at most 25
+ * agents) together with the buffers their step reads and writes -- per handle i the arguments of mapf_step (actions, obs, obs_bits,
+ * pos, reward_class, reward, done) and the u8 [E_i] mask of mapf_observe_masked / mapf_reset_envs (the actor's end-of-episode flags).
+ * All pointers are device pointers that must stay valid while the set lives; the arrays of pointers themselves are host arrays read
+ * at creation.  MAPF_ERR_UNSUPPORTED for a shape outside the limits (callers then step the handles one by one).
+ *   mapf_multi_step             = mapf_step of every handle, ONE launch (same outputs, bit for bit);
+ *   mapf_multi_reset            = mapf_reset_envs(mask_i, seed = reset_seeds[i] + *tick_dev) of every handle, ONE launch
+ *                                 (reset_seeds: host array given at creation, NULL = i * a constant; tick_dev: uint64 in device
+ *                                 memory, optional -- the caller's iteration counter);
+ *   mapf_multi_observe_masked   = mapf_observe_masked(mask_i) of every handle, ONE launch.
+ * No host scalar has to change from iteration to iteration: the three launches can be replayed from a captured HIP graph.
+ */
+typedef struct mapf_multi mapf_multi_t;
+int mapf_multi_create(int n, mapf_env_t *const *envs, const int8_t *const *actions_dev, uint8_t *const *obs_dev,
+                      uint32_t *const *obs_bits_dev, int16_t *const *pos_dev, int8_t *const *reward_class_dev,
+                      float *const *reward_dev, uint8_t *const *done_dev, const uint8_t *const *mask_dev,
+                      const uint64_t *reset_seeds, mapf_multi_t **out);
+int mapf_multi_destroy(mapf_multi_t *set);
+int mapf_multi_num_workgroups(const mapf_multi_t *set);
+int mapf_multi_step(mapf_multi_t *set, void *stream);
+int mapf_multi_reset(mapf_multi_t *set, float density, const uint64_t *tick_dev, void *stream);
+int mapf_multi_observe_masked(mapf_multi_t *set, void *stream);
+
 /* Dwords per bit-packed observation row: ceil(N*486/32) rounded up to a multiple of 4. */
 int mapf_obs_bits_row_dwords(const mapf_env_t *env);
 

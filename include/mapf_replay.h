@@ -133,6 +133,10 @@ int mapf_obs_changed(const uint8_t *obs_dev, uint8_t *prev_dev, int64_t rows, in
  * draws); act8_dev i8 [E][N] receives the joint action as the environment step reads it, policy_dev (optional) the greedy actions. */
 int mapf_actor_explore(int num_envs, int num_agents, int64_t *actions_dev, int64_t *policy_dev, int8_t *act8_dev,
                        const double *eps_dev, uint64_t seed, uint64_t counter, void *stream);
+/* The same with the iteration counter in device memory: draws as for counter + *tick_dev (uint64 [1], 8-byte aligned) -- the launch can
+ * be replayed from a captured HIP graph while the caller advances the counter on the device. */
+int mapf_actor_explore_dev(int num_envs, int num_agents, int64_t *actions_dev, int64_t *policy_dev, int8_t *act8_dev,
+                           const double *eps_dev, uint64_t seed, uint64_t counter, const uint64_t *tick_dev, void *stream);
 /*
  * Everything of one actor iteration behind the policy's forward (worker.py:380-428), as ONE call: mapf_actor_explore, mapf_step
  * (include/mapf_env.h), mapf_actor_record, mapf_replay_add_many (replay may be NULL), mapf_actor_log, mapf_reset_envs +

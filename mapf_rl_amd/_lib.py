@@ -28,6 +28,12 @@ SYMBOLS = [
     ("mapf_observe", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("mapf_observe_masked", _i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_obs_bits_row_dwords", _i, [_vp]),
+    ("mapf_multi_create", _i, [_i] + [ctypes.POINTER(_vp)] * 9 + [ctypes.POINTER(_u64), ctypes.POINTER(_vp)]),
+    ("mapf_multi_destroy", _i, [_vp]),
+    ("mapf_multi_num_workgroups", _i, [_vp]),
+    ("mapf_multi_step", _i, [_vp, _vp]),
+    ("mapf_multi_reset", _i, [_vp, _f, _vp, _vp]),
+    ("mapf_multi_observe_masked", _i, [_vp, _vp]),
     ("mapf_load_envs", _i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     ("mapf_get_navi", _i, [_vp, _vp, _vp]),
     ("mapf_get_agents", _i, [_vp, _vp, _vp]),
@@ -57,6 +63,7 @@ SYMBOLS = [
     ("mapf_actor_record", _i, [_i] * 6 + [_vp] * 16),
     ("mapf_actor_rewind", _i, [_i] * 5 + [_vp] * 6),
     ("mapf_actor_explore", _i, [_i, _i, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _vp]),
+    ("mapf_actor_explore_dev", _i, [_i, _i, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _vp, _vp]),
     ("mapf_actor_iteration_tail", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_float, ctypes.c_uint64, _vp]),
     ("mapf_actor_log", _i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     ("mapf_obs_changed", _i, [_vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp]),

@@ -217,9 +217,11 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 __global__ void __launch_bounds__(256) actor_explore_kernel(long long total, int N, int64_t *__restrict__ actions, int64_t *__restrict__ policy,
-                                                            int8_t *__restrict__ act8, const double *__restrict__ eps, uint64_t seed, uint64_t counter) {
+                                                            int8_t *__restrict__ act8, const double *__restrict__ eps, uint64_t seed, uint64_t counter,
+                                                            const unsigned long long *__restrict__ tick) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
+    if (tick) counter += (uint64_t)tick[0];  // (the iteration counter in device memory: nothing changes on the host from launch to launch)
     const long long e = idx / N;
     int64_t a = actions[idx];
     if (policy) policy[idx] = a;
@@ -243,7 +245,18 @@ int mapf_actor_explore(int num_envs, int num_agents, int64_t *actions_dev, int64
     if (num_envs < 1 || num_agents < 1 || !actions_dev || !act8_dev || !eps_dev) return MAPF_ERR_INVALID_ARG;
     const long long total = (long long)num_envs * num_agents;
     hipLaunchKernelGGL(actor_explore_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), total, num_agents,
-                       actions_dev, policy_dev, act8_dev, eps_dev, (uint64_t)seed, (uint64_t)counter);
+                       actions_dev, policy_dev, act8_dev, eps_dev, (uint64_t)seed, (uint64_t)counter, (const unsigned long long *)nullptr);
+    return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
+}
+
+int mapf_actor_explore_dev(int num_envs, int num_agents, int64_t *actions_dev, int64_t *policy_dev, int8_t *act8_dev, const double *eps_dev,
+                           uint64_t seed, uint64_t counter, const uint64_t *tick_dev, void *stream) {
+    if (num_envs < 1 || num_agents < 1 || !actions_dev || !act8_dev || !eps_dev || !tick_dev || (reinterpret_cast<uintptr_t>(tick_dev) & 7))
+        return MAPF_ERR_INVALID_ARG;
+    const long long total = (long long)num_envs * num_agents;
+    hipLaunchKernelGGL(actor_explore_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), total, num_agents,
+                       actions_dev, policy_dev, act8_dev, eps_dev, (uint64_t)seed, (uint64_t)counter,
+                       reinterpret_cast<const unsigned long long *>(tick_dev));
     return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
 }
 

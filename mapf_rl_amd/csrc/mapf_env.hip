@@ -136,415 +136,75 @@ __device__ __forceinline__ int block_and(int pred) {
 // 16-byte aligned: 4-byte stores; with 1 agent byte stores).
 template <typename W, int R, bool DO_STEP, bool DO_OBS, int VEC, int ITERS, int NT, int G>
 __global__ void __launch_bounds__(NT) env_step_kernel(StepParams p) {
-    constexpr int WW = 2 * R + 1;
-    constexpr int SPAN = WW + 1;
-    const int e = blockIdx.x * G, t = threadIdx.x;  // first environment of the block
-    constexpr int nt = NT;
-    // every kernel argument the first phases use, fetched NOW, together: the compiler otherwise loads each one in the basic block
-    // that uses it first and waits there -- three dependent scalar-load round trips (mask / layout, stamp pointer, the arrays) before
-    // the first vector load, each to a scalar cache that is invalidated at every launch
-    asm volatile("" ::"s"(p.L), "s"(p.N), "s"(p.map_rows), "s"(p.agents), "s"(p.goals), "s"(p.navi), "s"(p.actions), "s"(p.obs), "s"(p.obs_bits),
-                 "s"(p.mask), "s"(p.ablate), "s"(p.plane), "s"(p.dbg));
-    if constexpr (!DO_STEP) {
-        // masked observe (the actor loop's re-observation after an auto-reset): the outputs of environments that were not reset
-        // already hold exactly what this block would write, so a block without a flagged environment has nothing to do
-        if (p.mask != nullptr) {
-            bool any = false;
-#pragma unroll
-            for (int g = 0; g < G; ++g) any |= p.mask[e + g] != 0;
-            if (!any) return;
-        }
-    }
-    const int L = p.L, N1 = p.N;
-    const int N = G * N1;  // (virtual) agents of the block
-    const int LP = L + 2 * R;
-    const int GP = L + 2;  // id grid pitch (1-cell border)
-    const int NP = (N + 7) & ~7;
-    const int grid_q = (GP * GP + 15) >> 4;          // uint4 count of one id grid
-    const int bits_q = ((N * 6 * WW * WW + 31) / 32 + 1 + 3) >> 2;  // uint4 count of the bit string (+1 spill dword)
+    const unsigned blk = blockIdx.x;  // the workgroup's index among the workgroups of the handle
+#include "mapf_env_step_body.inc"
+}
 
-    extern __shared__ __align__(16) unsigned char smem[];
-    W *s_obst = reinterpret_cast<W *>(smem);                             // [G][LP]
-    W *s_agent = s_obst + G * LP;                                        // [G][LP]
-    unsigned char *base = smem + (((size_t)2 * G * LP * sizeof(W) + 15) & ~(size_t)15);
-    // the bit string and the per-agent arrays first, then ONE region used by the step phase (id grids, next / mover arrays) and,
-    // with p.plane, afterwards by the navi records of the field phase (step_smem_bytes).  (One layout for both versions of the field
-    // phase: a branch on p.plane here split the kernel's entry block, and every block of it that touches a kernel argument for the
-    // first time waits for its own scalar load -- three round trips to a cache that is invalidated at every launch.)
-    unsigned *s_bits = reinterpret_cast<unsigned *>(base);                                               // [bits_q*4]
-    unsigned short *s_cur = reinterpret_cast<unsigned short *>(s_bits + (size_t)bits_q * 4);             // [NP] position after the step
-    short *s_base = reinterpret_cast<short *>(s_cur + NP);   // [NP] map row of navi slot 0, + R (signed: row -1 - R for an agent leaving row 0)
-    unsigned short *s_gr = s_cur + 2 * NP;                                                               // [NP] first LDS row of the agent's environment
-    int *s_flag = reinterpret_cast<int *>(s_gr + NP);        // [G] some agent of the environment is off its goal (NP: multiple of 8)
-    unsigned char *uni = reinterpret_cast<unsigned char *>(s_flag) + ((4 * G + 15) & ~15);
-    unsigned char *s_id = uni;                                                                           // [G][grid_q*16]  0xFF = empty
-    unsigned short *s_next = reinterpret_cast<unsigned short *>(s_id + (size_t)G * grid_q * 16);         // [NP]
-    unsigned short *s_mov = s_next + NP;                                                                 // [NP]
-    NaviRec<W> *s_navi = reinterpret_cast<NaviRec<W> *>(uni);                                            // [N * SPAN], after the step phase
+// the same body for a workgroup of a launch that covers several handles (env_step_multi_kernel): `p` = the handle's parameters in the
+// device-side table, `blk` = the workgroup's index among the workgroups of THAT handle
+template <typename W, int R, bool DO_STEP, bool DO_OBS, int VEC, int ITERS, int NT, int G>
+__device__ __forceinline__ void env_step_body(const StepParams &p, const unsigned blk) {
+#include "mapf_env_step_body.inc"
+}
 
-#define STAMP(k)                                                                       \
-    if (p.dbg && t == 0) {                                                             \
-        unsigned long long _ts;                                                        \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_ts)::"memory");   \
-        p.dbg[(size_t)blockIdx.x * 8 + (k)] = _ts;                                     \
-    }
-    STAMP(0)
-    // ---- round 1: every small load, unconditional (clamped indices) so that they all go out back to back ----
-    const bool agent = t < N;
-    const size_t own = (size_t)e * N1 + (agent ? t : N - 1);
-    const int ge = (G > 1 && agent) ? t / N1 : 0;  // this lane's environment within the block
-    const int ge_rows = ge * LP, ge_grid = ge * grid_q * 16;
-    const short2 cpos = *reinterpret_cast<const short2 *>(p.agents + own * 2);
-    short2 gpos = make_short2(0, 0);
-    int act = 0;
-    if constexpr (DO_STEP) {
-        gpos = *reinterpret_cast<const short2 *>(p.goals + own * 2);
-        act = p.actions[own];
-    }
-    const W *map_rows = reinterpret_cast<const W *>(p.map_rows) + (size_t)e * L;
-    constexpr int ROW_ITERS = G == 1 ? (64 + 2 * R + NT - 1) / NT : (G * (32 + 2 * R) + NT - 1) / NT;  // covers G * LP rows
-    W mrow[ROW_ITERS];
-#pragma unroll
-    for (int q = 0; q < ROW_ITERS; ++q) {
-        const int r = t + q * nt;
-        const int g = G == 1 ? 0 : min(r / LP, G - 1);
-        int rr = r - g * LP - R;
-        rr = rr < 0 ? 0 : (rr >= L ? L - 1 : rr);
-        mrow[q] = map_rows[g * L + rr];
-    }
-    int px[ITERS], pdx[ITERS];
-    if constexpr (DO_OBS) {
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            int k = t + it * nt;
-            k = k < N * SPAN ? k : N * SPAN - 1;
-            const size_t o = (size_t)e * N1 + k / SPAN;
-            px[it] = p.agents[o * 2];
-            pdx[it] = 0;
-            if constexpr (DO_STEP) pdx[it] = p.actions[o];
-        }
-    }
-    // ---- round 2: the navi records this env can need after the step (speculative, clamped, unconditional) ----
-    NaviRec<W> rec[ITERS];
-    int rrow[ITERS];
-    if constexpr (DO_OBS) {
-        const unsigned navi_mul = (p.ablate & 1) ? 0u : 1u;  // tuning: 0 = every lane reads record 0 (no traffic)
-        const NaviRec<W> *navi = reinterpret_cast<const NaviRec<W> *>(p.navi) + (size_t)e * N1 * L * navi_mul;
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            const int k = t + it * nt;
-            const int kc = k < N * SPAN ? k : N * SPAN - 1;
-            const int i = kc / SPAN, slot = kc - i * SPAN;
-            const int a = pdx[it];
-            const int dx = (a == 2) - (a == 1);
-            const int row = px[it] + (dx < 0 ? dx : 0) - R + slot;
-            const bool need = k < N * SPAN && slot < WW + (dx != 0) && row >= 0 && row < L;
-            const int rowc = row < 0 ? 0 : (row >= L ? L - 1 : row);
-            rrow[it] = need ? row : -1;
-            rec[it] = navi[(size_t)(i * L + rowc) * navi_mul];
-        }
-    }
-    STAMP(6)  // (diagnostics: both load rounds issued -- round 2's addresses wait for round 1's positions)
-    // ---- LDS init (needs only round 1) ----
-#pragma unroll
-    for (int q = 0; q < ROW_ITERS; ++q) {
-        const int r = t + q * nt;
-        if (r < G * LP) {
-            const int rr = (G == 1 ? r : r % LP) - R;
-            s_obst[r] = (rr >= 0 && rr < L) ? mrow[q] : (W)0;
-            s_agent[r] = (W)0;
-        }
-    }
-    if constexpr (DO_STEP) {
-        const uint4 ff = make_uint4(~0u, ~0u, ~0u, ~0u);
-        for (int k = t; k < G * grid_q; k += nt) reinterpret_cast<uint4 *>(s_id)[k] = ff;
-        if (G > 1 && t < G) s_flag[t] = 0;
-    }
-    if constexpr (DO_OBS) {
-        const uint4 zz = make_uint4(0u, 0u, 0u, 0u);
-        for (int k = t; k < bits_q; k += nt) reinterpret_cast<uint4 *>(s_bits)[k] = zz;
-        if (p.plane && agent) {  // navi slot s of this agent holds map row cx + min(dx, 0) - R + s (round 2 above)
-            const int dxo = DO_STEP ? (act == 2) - (act == 1) : 0;
-            s_base[t] = (short)(cpos.x + (dxo < 0 ? dxo : 0));
-            s_gr[t] = (unsigned short)ge_rows;
-        }
-    }
-    const int cx = cpos.x, cy = cpos.y, gx = gpos.x, gy = gpos.y;
-    int nx = cx, ny = cy;
-    int rc = MAPF_RC_STAY_ON_GOAL;
-    int all_done = 0;
-    block_sync<NT>();
-    STAMP(1)
 
-    if constexpr (DO_STEP) {
-        bool mover = false;
-        if (agent) {
-            if (act < 0 || act > 4) {  // reference: AssertionError (environment.py:290)
-                atomicOr(p.status, kStatusAction);
-                act = 0;
-            }
-            // S0 (environment.py:298-311)
-            mover = act != 0;
-            nx = cx + (act == 2) - (act == 1);  // action_list, environment.py:12
-            ny = cy + (act == 4) - (act == 3);
-            rc = mover ? MAPF_RC_MOVE : ((cx == gx && cy == gy) ? MAPF_RC_STAY_ON_GOAL : MAPF_RC_STAY_OFF_GOAL);
-            // S1 (environment.py:320-332)
-            if (mover) {
-                bool blocked = nx < 0 || ny < 0 || nx >= L || ny >= L;
-                if (!blocked) blocked = (s_obst[ge_rows + nx + R] >> ny) & 1;
-                if (blocked) {
-                    mover = false;
-                    rc = MAPF_RC_COLLISION;
-                    nx = cx;
-                    ny = cy;
-                }
-            }
-            s_id[ge_grid + (cx + 1) * GP + cy + 1] = (unsigned char)t;
-            s_next[t] = (unsigned short)((nx << 8) | ny);
-            s_mov[t] = mover;
-        }
-        block_sync<NT>();
+// ---------------------------------------------------------------------------------------------
+// Several handles in ONE launch (mapf_multi_*).  The reference draws a (num_agents, map side) level per episode inside one actor
+// (environment.py:148-151, worker.py:422-428); here every active level of the curriculum is a handle of a few hundred environments,
+// and one launch per level and step is a latency-bound launch of a few hundred one-wavefront workgroups each (0.24-0.6 of the
+// roofline, profiles/r03_shape_sweep.md).  The table below lives in DEVICE memory (built once per set of handles): a workgroup finds
+// its segment from the prefix of workgroup counts, loads that handle's parameters through the scalar unit and runs the body that was
+// instantiated for the handle's shape.  One-wavefront workgroups only (every shape the single-handle rules give 64 threads:
+// N <= 24, or 64-bit rows with N <= 64 -- here N <= 25 so that four load rounds suffice).
+// ---------------------------------------------------------------------------------------------
+constexpr int kMultiMax = 16;
+struct MultiTable {
+    int n;
+    int block_end[kMultiMax];  // workgroups of segments 0..i
+    int variant[kMultiMax];
+    StepParams seg[kMultiMax];
+    int env_end[kMultiMax];    // environments of segments 0..i (the reset launch: one wavefront per environment)
+    int32_t *epochs[kMultiMax];
+    unsigned long long reset_seed[kMultiMax];  // scenario stream of segment i at iteration k: reset_seed[i] + k
+};
 
-        // S2 swap (environment.py:335-365)
-        const unsigned my_cur = (unsigned)((cx << 8) | cy);
-        const unsigned my_next = (unsigned)((nx << 8) | ny);
-        int occ = 0xFF;
-        bool swap = false;
-        if (mover) {
-            occ = s_id[ge_grid + (nx + 1) * GP + ny + 1];
-            if (occ != 0xFF) swap = s_mov[occ] && s_next[occ] == my_cur;
-        }
-        block_sync<NT>();
-        if (swap) {
-            mover = false;
-            rc = MAPF_RC_COLLISION;
-            nx = cx;
-            ny = cy;
-            s_next[t] = (unsigned short)my_cur;
-            s_mov[t] = 0;
-        }
-        block_sync<NT>();
+// variant = instantiation of the body: (W, G, VEC, ITERS)
+enum : int {
+    MV_U32_G8_I2, MV_U32_G8_I4, MV_U32_G8_I7, MV_U32_G4_I4,
+    MV_U32_G1_V16_I2, MV_U32_G1_V16_I4, MV_U32_G1_V4_I2, MV_U32_G1_V4_I4, MV_U32_G1_V1_I2, MV_U32_G1_V1_I4,
+    MV_U64_G1_V16_I2, MV_U64_G1_V16_I4, MV_U64_G1_V4_I2, MV_U64_G1_V4_I4, MV_U64_G1_V1_I2, MV_U64_G1_V1_I4,
+    MV_COUNT
+};
 
-        // S3 vertex (environment.py:368-406), rule (b): a lower-id mover claims the same cell.  Rivals can
-        // only stand on the 4 neighbours of the target cell.
-        bool lose = false;
-        if (mover) {
-            const int c = ge_grid + (nx + 1) * GP + ny + 1;
-            const int nb[4] = {c - GP, c + GP, c - 1, c + 1};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = s_id[nb[q]];
-                if (j < t) lose |= (s_mov[j] && s_next[j] == my_next);
-            }
-        }
-        // rule (a) + cascade: target cell held by an agent that is (now) settled
-        for (int round = 0; round <= N1; ++round) {
-            bool revert = mover && (lose || (occ != 0xFF && !s_mov[occ]));
-            int any = block_or<NT>(revert);
-            if (revert) {
-                mover = false;
-                rc = MAPF_RC_COLLISION;
-                nx = cx;
-                ny = cy;
-                s_mov[t] = 0;
-            }
-            if (!any) break;
-            block_sync<NT>();
-        }
-
-        // S4 (environment.py:410-430); the result stores are issued at the very end of the kernel
-        if constexpr (G == 1) {
-            all_done = block_and<NT>(!agent || (nx == gx && ny == gy));
-        } else {  // per environment of the block
-            if (agent && !(nx == gx && ny == gy)) s_flag[ge] = 1;
-            block_sync<NT>();
-            all_done = !s_flag[ge];
-        }
-        if (all_done) rc = MAPF_RC_FINISH;
+template <bool DO_STEP>
+__global__ void __launch_bounds__(64) env_step_multi_kernel(const MultiTable *__restrict__ tab) {
+    int seg = 0;
+    const int n = tab->n;
+    while (seg < n - 1 && (int)blockIdx.x >= tab->block_end[seg]) ++seg;  // (wave-uniform: scalar loads)
+    const int blk = (int)blockIdx.x - (seg ? tab->block_end[seg - 1] : 0);
+    const StepParams &p = tab->seg[seg];
+    switch (tab->variant[seg]) {
+#define MV_CASE(id, W, G, VEC, ITERS) \
+    case id: env_step_body<W, 4, DO_STEP, true, VEC, ITERS, 64, G>(p, (unsigned)blk); break;
+        MV_CASE(MV_U32_G8_I2, uint32_t, 8, 16, 2)
+        MV_CASE(MV_U32_G8_I4, uint32_t, 8, 16, 4)
+        MV_CASE(MV_U32_G8_I7, uint32_t, 8, 16, 7)
+        MV_CASE(MV_U32_G4_I4, uint32_t, 4, 16, 4)
+        MV_CASE(MV_U32_G1_V16_I2, uint32_t, 1, 16, 2)
+        MV_CASE(MV_U32_G1_V16_I4, uint32_t, 1, 16, 4)
+        MV_CASE(MV_U32_G1_V4_I2, uint32_t, 1, 4, 2)
+        MV_CASE(MV_U32_G1_V4_I4, uint32_t, 1, 4, 4)
+        MV_CASE(MV_U32_G1_V1_I2, uint32_t, 1, 1, 2)
+        MV_CASE(MV_U32_G1_V1_I4, uint32_t, 1, 1, 4)
+        MV_CASE(MV_U64_G1_V16_I2, uint64_t, 1, 16, 2)
+        MV_CASE(MV_U64_G1_V16_I4, uint64_t, 1, 16, 4)
+        MV_CASE(MV_U64_G1_V4_I2, uint64_t, 1, 4, 2)
+        MV_CASE(MV_U64_G1_V4_I4, uint64_t, 1, 4, 4)
+        MV_CASE(MV_U64_G1_V1_I2, uint64_t, 1, 1, 2)
+        MV_CASE(MV_U64_G1_V1_I4, uint64_t, 1, 1, 4)
+#undef MV_CASE
+        default: break;
     }
-
-    // ---- agent occupancy rows after the step (+ the overlap invariant, environment.py:424-428) ----
-    if (agent) {
-        W bit = (W)1 << ny;
-        W old = lds_or(&s_agent[ge_rows + nx + R], bit);
-        if (DO_STEP && (old & bit)) atomicOr(p.status, kStatusOverlap);
-        s_cur[t] = (unsigned short)((nx << 8) | ny);
-    }
-    if constexpr (DO_OBS) {
-        block_sync<NT>();
-        STAMP(2)
-        if (p.dbg) {  // diagnostics: how long the navi records are still outstanding when the field phase wants them
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            STAMP(7)
-        }
-
-        if (p.plane) {
-            // ---- (agent, channel) planes.  A channel of an agent's observation is 9 rows x 9 bits = 81 CONTIGUOUS bits of the bit
-            // string (bit (i * 6 + ch) * 81 + 9 dy + column), so a lane that owns a plane assembles it in three registers with
-            // compile-time shifts and deposits it with 3-4 LDS atomics -- against 6 scattered 9-bit deposits (a dozen
-            // instructions and up to two atomics each) per (agent, row) task in the first version.  The vector ALU is what the
-            // field phase is bound by (profiles/r03_shape_sweep.md: 865 vector instructions per wave at config 2, 63 % pipe
-            // utilisation over the whole kernel, all waves of a SIMD in this phase together).  The navi records were fetched as
-            // 16-byte-per-lane gathers by (agent, row) lanes (narrow per-plane loads were measured slower in round 2): they are
-            // staged in LDS in task order, in the space the step phase's id grids no longer need. ----
-#pragma unroll
-            for (int it = 0; it < ITERS; ++it) {
-                const int k = t + it * nt;
-                if (k < N * SPAN) {
-                    NaviRec<W> r = rec[it];
-                    if (rrow[it] < 0) r.w[0] = r.w[1] = r.w[2] = r.w[3] = (W)0;  // row outside the map (or not fetched): reads as zeros
-                    s_navi[k] = r;
-                }
-            }
-            block_sync<NT>();
-            for (int q = t; q < N * 6; q += nt) {
-                const int i = q / 6, ch = q - 6 * i;
-                const unsigned key = s_cur[i];
-                const int x = key >> 8, y = key & 255;
-                // LDS byte offset of the word of window row 0 and the distance between rows
-                unsigned a0;
-                int stride;
-                if (ch < 2) {
-                    const int gr = G == 1 ? 0 : (int)s_gr[i];
-                    a0 = (unsigned)(reinterpret_cast<const unsigned char *>((ch ? s_obst : s_agent) + gr + x) - smem);
-                    stride = (int)sizeof(W);
-                } else {
-                    a0 = (unsigned)(reinterpret_cast<const unsigned char *>(&s_navi[i * SPAN + (x - (int)s_base[i])].w[ch - 2]) - smem);
-                    stride = (int)sizeof(NaviRec<W>);
-                }
-                // columns y - R .. y + R of a row word -> a 9-bit field; near the left border (y < R) the field is the word's low
-                // 9 - sl bits moved up by sl = R - y: the move is the same for all 9 rows, so it is applied once, to the plane's
-                // bit offset (a field of 9 - sl bits shifted by sl stays inside its 9-bit slot)
-                const int sr = y < R ? 0 : y - R, sl = y < R ? R - y : 0;
-                const unsigned wm = (1u << (WW - sl)) - 1u;
-                unsigned f[WW];
-#pragma unroll
-                for (int dy = 0; dy < WW; ++dy) f[dy] = (unsigned)(*reinterpret_cast<const W *>(smem + a0 + dy * stride) >> sr) & wm;
-                if (ch == 0) f[R] &= ~(1u << (y - sr));  // centre (column y) of channel 0 forced to 0 (environment.py:461)
-                static_assert(WW == 9, "the plane packing below is written for the 9 x 9 field of view");
-                const unsigned p0 = f[0] | (f[1] << 9) | (f[2] << 18) | (f[3] << 27);
-                const unsigned p1 = (f[3] >> 5) | (f[4] << 4) | (f[5] << 13) | (f[6] << 22) | (f[7] << 31);
-                const unsigned p2 = (f[7] >> 1) | (f[8] << 8);
-                const unsigned off = (unsigned)q * (WW * WW) + (unsigned)sl, d = off >> 5, sh = off & 31u;
-                const unsigned w0 = p0 << sh, w1 = (p1 << sh) | ((p0 >> 1) >> (31u - sh)), w2 = (p2 << sh) | ((p1 >> 1) >> (31u - sh)),
-                               w3 = (p2 >> 1) >> (31u - sh);
-                if (w0) atomicOr(&s_bits[d], w0);
-                if (w1) atomicOr(&s_bits[d + 1], w1);
-                if (w2) atomicOr(&s_bits[d + 2], w2);
-                if (w3) atomicOr(&s_bits[d + 3], w3);
-            }
-        } else {
-        // ---- fields of every prefetched record that lies inside the final window ----
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            if (rrow[it] >= 0) {
-                const int k = t + it * nt;
-                const int i = k / SPAN;
-                const unsigned key = s_cur[i];
-                const int x = key >> 8, y = key & 255;
-                const int dy = rrow[it] - (x - R);
-                if (dy >= 0 && dy < WW) {
-                    const int gr = G == 1 ? 0 : (i / N1) * LP;  // rows of the agent's environment
-                    unsigned f_ag = window_bits<W, R>(s_agent[gr + x + dy], y);
-                    if (dy == R) f_ag &= ~(1u << R);  // centre of channel 0 forced to 0 (environment.py:461)
-                    const unsigned f_ob = window_bits<W, R>(s_obst[gr + x + dy], y);
-                    const unsigned off = (unsigned)((i * 6 * WW + dy) * WW);
-                    deposit_field<WW>(s_bits, off, f_ag);
-                    deposit_field<WW>(s_bits, off + WW * WW, f_ob);
-                    deposit_field<WW>(s_bits, off + 2 * WW * WW, window_bits<W, R>(rec[it].w[0], y));
-                    deposit_field<WW>(s_bits, off + 3 * WW * WW, window_bits<W, R>(rec[it].w[1], y));
-                    deposit_field<WW>(s_bits, off + 4 * WW * WW, window_bits<W, R>(rec[it].w[2], y));
-                    deposit_field<WW>(s_bits, off + 5 * WW * WW, window_bits<W, R>(rec[it].w[3], y));
-                }
-            }
-        }
-        }
-        block_sync<NT>();
-        STAMP(3)
-
-        const int total = N * 6 * WW * WW;
-        // ---- optional: the bit string itself (bit-packed observation row for the replay) ----
-        if (p.obs_bits) {
-            uint32_t *ob = p.obs_bits + (size_t)e * p.obs_bits_rd;
-            if constexpr (G == 1) {
-                const int nd = (total + 31) >> 5;
-                for (int k = t; k < p.obs_bits_rd; k += nt) ob[k] = k < nd ? s_bits[k] : 0u;
-            } else {  // environment g's row = bits [g * total1, (g + 1) * total1) of the block's string
-                const int total1 = N1 * 6 * WW * WW;
-                for (int q = t; q < G * p.obs_bits_rd; q += nt) {
-                    const int g = q / p.obs_bits_rd, k = q - g * p.obs_bits_rd;
-                    const int left = total1 - 32 * k;  // bits of this row still to come
-                    unsigned v = 0u;
-                    if (left > 0) {
-                        const unsigned b0 = (unsigned)(g * total1 + 32 * k), d = b0 >> 5, sh = b0 & 31u;
-                        v = s_bits[d] >> sh;
-                        if (sh) v |= s_bits[d + 1] << (32u - sh);
-                        if (left < 32) v &= (1u << left) - 1u;
-                    }
-                    ob[q] = v;
-                }
-            }
-        }
-        // ---- expand the bit string: bit b -> byte b of this env's observation block ----
-        uint8_t *out = p.obs + (size_t)blockIdx.x * total;
-        if (p.obs == nullptr) {
-            // bit-packed output only
-        } else if constexpr (VEC == 16) {
-            const unsigned short *b16 = reinterpret_cast<const unsigned short *>(s_bits);
-            const int ntask = total >> 4;
-            for (int task = t; task < ntask; task += nt) {
-                const unsigned bits = b16[task];
-                uint4 v;
-                v.x = expand4m(bits & 15u);
-                v.y = expand4m((bits >> 4) & 15u);
-                v.z = expand4m((bits >> 8) & 15u);
-                v.w = expand4m(bits >> 12);
-                if ((p.ablate & 2) && v.x != 0x77u) continue;  // never true for real data: keeps the work, drops the store
-                if (p.nt_store) {  // (host: the launch's observations exceed what the Infinity Cache can hold on to, see step_nt_store)
-                    typedef unsigned v4u __attribute__((ext_vector_type(4)));
-                    __builtin_nontemporal_store(v4u{v.x, v.y, v.z, v.w}, reinterpret_cast<v4u *>(out) + task);
-                } else {
-                    reinterpret_cast<uint4 *>(out)[task] = v;
-                }
-            }
-        } else if constexpr (VEC == 4) {
-            const int ntask = total >> 2;
-            for (int task = t; task < ntask; task += nt) {
-                const unsigned bits = (s_bits[task >> 3] >> ((task & 7) * 4)) & 15u;
-                reinterpret_cast<unsigned *>(out)[task] = expand4m(bits);
-            }
-        } else {
-            for (int b = t; b < total; b += nt) out[b] = (uint8_t)((s_bits[b >> 5] >> (b & 31)) & 1u);
-        }
-        STAMP(4)
-    }
-
-    // ---- small result stores last (nothing waits on them) ----
-    if (agent) {
-        const size_t o = (size_t)e * N1 + t;
-        if constexpr (DO_STEP) {
-            *reinterpret_cast<short2 *>(p.agents + o * 2) = make_short2((short)nx, (short)ny);
-            if (p.rclass) p.rclass[o] = (int8_t)rc;
-            if (p.reward) p.reward[o] = p.rtab[rc];
-        }
-        if (p.pos_out) *reinterpret_cast<short2 *>(p.pos_out + o * 2) = make_short2((short)nx, (short)ny);
-    }
-    if constexpr (DO_STEP) {
-        if constexpr (G == 1) {
-            if (t == 0) {
-                if (p.done) p.done[e] = (uint8_t)(all_done != 0);
-                p.steps[e] += 1;
-            }
-        } else if (t < G) {
-            if (p.done) p.done[e + t] = (uint8_t)(s_flag[t] == 0);
-            p.steps[e + t] += 1;
-        }
-    }
-    if (p.dbg) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        STAMP(5)
-    }
-#undef STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -695,10 +355,10 @@ __device__ __forceinline__ int wave_sum(int v) {
 }
 
 template <typename W>
-__global__ void __launch_bounds__(64) reset_kernel(int E, int L, int N, const uint8_t *mask, float density, uint64_t seed,
-                                                   W *map_rows, int16_t *agents, int16_t *goals, NaviRec<W> *navi,
-                                                   int32_t *steps, int32_t *epochs, int32_t *status) {
-    const int e = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void reset_body(const int e, int E, int L, int N, const uint8_t *mask, float density, uint64_t seed,
+                                           W *map_rows, int16_t *agents, int16_t *goals, NaviRec<W> *navi,
+                                           int32_t *steps, int32_t *epochs, int32_t *status) {
+    const int lane = threadIdx.x;
     if (e >= E || (mask && !mask[e])) return;
     const int row = lane;
     const bool in_map = row < L;
@@ -789,6 +449,32 @@ __global__ void __launch_bounds__(64) reset_kernel(int E, int L, int N, const ui
         if (ok) steps[e] = 0;
         else atomicOr(status, kStatusRange);
     }
+}
+
+template <typename W>
+__global__ void __launch_bounds__(64) reset_kernel(int E, int L, int N, const uint8_t *mask, float density, uint64_t seed,
+                                                   W *map_rows, int16_t *agents, int16_t *goals, NaviRec<W> *navi,
+                                                   int32_t *steps, int32_t *epochs, int32_t *status) {
+    reset_body<W>((int)blockIdx.x, E, L, N, mask, density, seed, map_rows, agents, goals, navi, steps, epochs, status);
+}
+
+// mapf_reset_envs(mask) of every handle of a set in one launch: workgroup -> (segment, environment); the scenario stream of an
+// iteration is seed + the caller's iteration counter in DEVICE memory (the launch can be replayed from a captured graph)
+__global__ void __launch_bounds__(64) reset_multi_kernel(const MultiTable *tab, float density, const unsigned long long *tick) {
+    int seg = 0;
+    const int n = tab->n;
+    while (seg < n - 1 && (int)blockIdx.x >= tab->env_end[seg]) ++seg;
+    const int e = (int)blockIdx.x - (seg ? tab->env_end[seg - 1] : 0);
+    const StepParams &p = tab->seg[seg];
+    const uint64_t sd = (uint64_t)tab->reset_seed[seg] + (tick ? (uint64_t)tick[0] : 0ull);
+    if (p.L > 32)
+        reset_body<uint64_t>(e, p.E, p.L, p.N, p.mask, density, sd, const_cast<uint64_t *>(static_cast<const uint64_t *>(p.map_rows)), p.agents,
+                             const_cast<int16_t *>(p.goals), const_cast<NaviRec<uint64_t> *>(static_cast<const NaviRec<uint64_t> *>(p.navi)), p.steps,
+                             tab->epochs[seg], p.status);
+    else
+        reset_body<uint32_t>(e, p.E, p.L, p.N, p.mask, density, sd, const_cast<uint32_t *>(static_cast<const uint32_t *>(p.map_rows)), p.agents,
+                             const_cast<int16_t *>(p.goals), const_cast<NaviRec<uint32_t> *>(static_cast<const NaviRec<uint32_t> *>(p.navi)), p.steps,
+                             tab->epochs[seg], p.status);
 }
 
 // int8 map [E][L][L] -> bit rows; also range-checks agent/goal positions of a device-side load
@@ -1496,6 +1182,158 @@ int mapf_observe_masked(mapf_env_t *h, const uint8_t *mask_dev, uint8_t *obs_dev
     return launch_step<false>(h, p, static_cast<hipStream_t>(stream));
 }
 
+// ---- several handles in one launch -------------------------------------------------------------------------------------------
+struct mapf_multi {
+    int n, device;
+    int blocks, envs;
+    size_t smem;
+    MultiTable *table_dev;
+    mapf_env *env[kMultiMax];
+};
+
+namespace {
+// the body instantiation for one handle in a multi-handle launch (the single-handle rules of launch_step_vec, one-wavefront shapes)
+int multi_variant(const mapf_env *h, const void *obs, int *G_out) {
+    const int total = h->N * 6 * 81;
+    const int need1 = (h->N * 10 + 63) / 64;
+    if (h->R != 4 || step_block_threads(h) != 64 || h->N > 25) return -1;
+    if (!h->wide) {
+        const int G = step_group(h, obs);
+        if (G == 8 || G == 4) {
+            const int need = (G * h->N * 10 + 63) / 64;
+            *G_out = G;
+            if (G == 8) return need <= 2 ? MV_U32_G8_I2 : (need <= 4 ? MV_U32_G8_I4 : (need <= 7 ? MV_U32_G8_I7 : -1));
+            return need <= 4 ? MV_U32_G4_I4 : -1;
+        }
+    }
+    *G_out = 1;
+    const bool a16 = (total % 16 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15) == 0);
+    const bool a4 = (total % 4 == 0) && ((reinterpret_cast<uintptr_t>(obs) & 3) == 0);
+    const int base = h->wide ? MV_U64_G1_V16_I2 : MV_U32_G1_V16_I2;
+    const int vec = (obs == nullptr || a16) ? 0 : (a4 ? 2 : 4);
+    if (need1 > 4) return -1;
+    return base + vec + (need1 <= 2 ? 0 : 1);
+}
+}  // namespace
+
+int mapf_multi_create(int n, mapf_env_t *const *envs, const int8_t *const *actions_dev, uint8_t *const *obs_dev, uint32_t *const *obs_bits_dev,
+                      int16_t *const *pos_dev, int8_t *const *reward_class_dev, float *const *reward_dev, uint8_t *const *done_dev,
+                      const uint8_t *const *mask_dev, const uint64_t *reset_seeds, mapf_multi_t **out) {
+    if (!out) return MAPF_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (n < 1 || !envs || !actions_dev || !obs_dev || !obs_bits_dev || !pos_dev || !reward_class_dev || !reward_dev || !done_dev || !mask_dev)
+        return MAPF_ERR_INVALID_ARG;
+    if (n > kMultiMax) return MAPF_ERR_UNSUPPORTED;
+    MultiTable tab{};
+    mapf_multi *m = new (std::nothrow) mapf_multi();
+    if (!m) return MAPF_ERR_HIP;
+    tab.n = m->n = n;
+    m->device = envs[0] ? envs[0]->device : 0;
+    int blocks = 0, total_envs = 0;
+    size_t smem = 0;
+    for (int i = 0; i < n; ++i) {
+        mapf_env *h = envs[i];
+        if (!h || !actions_dev[i] || (!obs_dev[i] && !obs_bits_dev[i]) || h->device != m->device) {
+            delete m;
+            return MAPF_ERR_INVALID_ARG;
+        }
+        if (!h->loaded || !h->navi_ready) {
+            delete m;
+            return MAPF_ERR_NOT_READY;
+        }
+        int G = 1;
+        const int v = multi_variant(h, obs_dev[i], &G);
+        if (v < 0) {
+            delete m;
+            return MAPF_ERR_UNSUPPORTED;
+        }
+        StepParams p = make_params(h);
+        p.actions = actions_dev[i];
+        p.obs = obs_dev[i];
+        p.obs_bits = obs_bits_dev[i];
+        p.obs_bits_rd = mapf_obs_bits_row_dwords(h);
+        p.pos_out = pos_dev[i];
+        p.rclass = reward_class_dev[i];
+        p.reward = reward_dev[i];
+        p.done = done_dev[i];
+        p.mask = mask_dev[i];  // (read by the masked re-observation and the reset only: the step body ignores it)
+        p.nt_store = 0;
+        blocks += h->E / G;
+        total_envs += h->E;
+        m->env[i] = h;
+        tab.seg[i] = p;
+        tab.variant[i] = v;
+        tab.block_end[i] = blocks;
+        tab.env_end[i] = total_envs;
+        tab.epochs[i] = h->epochs;
+        tab.reset_seed[i] = reset_seeds ? reset_seeds[i] : (uint64_t)i * 0xD1B54A32D192ED03ull;
+    }
+    // the field phase by planes where every segment could take it next to the others (one dynamic-LDS size per launch)
+    for (int i = 0; i < n; ++i) {
+        const mapf_env *h = m->env[i];
+        const int G = (h->E + (tab.block_end[i] - (i ? tab.block_end[i - 1] : 0)) - 1) / (tab.block_end[i] - (i ? tab.block_end[i - 1] : 0));
+        bool plane = h->tune_plane >= 0 ? h->tune_plane != 0 : (h->R == 4);
+        if (plane) {
+            const size_t sm = (step_smem_bytes(h, G, true) + 1023) & ~(size_t)1023;
+            const long long by_lds = (160 * 1024) / (long long)sm, rounds = (blocks + 255) / 256;
+            if (sm > 60 * 1024 || by_lds < (rounds < 32 ? rounds : 32)) plane = false;
+        }
+        tab.seg[i].plane = plane;
+        const size_t sm = step_smem_bytes(h, G, plane);
+        if (sm > smem) smem = sm;
+    }
+    m->blocks = blocks;
+    m->envs = total_envs;
+    m->smem = smem;
+    DeviceGuard guard(m->device);
+    if (hipMalloc(reinterpret_cast<void **>(&m->table_dev), sizeof(MultiTable)) != hipSuccess) {
+        delete m;
+        return MAPF_ERR_HIP;
+    }
+    if (hipMemcpy(m->table_dev, &tab, sizeof(MultiTable), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(m->table_dev);
+        delete m;
+        return MAPF_ERR_HIP;
+    }
+    *out = m;
+    return MAPF_OK;
+}
+
+int mapf_multi_destroy(mapf_multi_t *m) {
+    if (!m) return MAPF_OK;
+    DeviceGuard guard(m->device);
+    (void)hipFree(m->table_dev);
+    delete m;
+    return MAPF_OK;
+}
+
+int mapf_multi_num_workgroups(const mapf_multi_t *m) { return m ? m->blocks : MAPF_ERR_INVALID_ARG; }
+
+int mapf_multi_step(mapf_multi_t *m, void *stream) {
+    if (!m) return MAPF_ERR_INVALID_ARG;
+    DeviceGuard guard(m->device);
+    hipLaunchKernelGGL(env_step_multi_kernel<true>, dim3(m->blocks), dim3(64), m->smem, static_cast<hipStream_t>(stream), m->table_dev);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+int mapf_multi_observe_masked(mapf_multi_t *m, void *stream) {
+    if (!m) return MAPF_ERR_INVALID_ARG;
+    DeviceGuard guard(m->device);
+    hipLaunchKernelGGL(env_step_multi_kernel<false>, dim3(m->blocks), dim3(64), m->smem, static_cast<hipStream_t>(stream), m->table_dev);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+int mapf_multi_reset(mapf_multi_t *m, float density, const uint64_t *tick_dev, void *stream) {
+    if (!m || density >= 1.0f || (reinterpret_cast<uintptr_t>(tick_dev) & 7)) return MAPF_ERR_INVALID_ARG;
+    DeviceGuard guard(m->device);
+    hipLaunchKernelGGL(reset_multi_kernel, dim3(m->envs), dim3(64), 0, static_cast<hipStream_t>(stream), m->table_dev, density,
+                       reinterpret_cast<const unsigned long long *>(tick_dev));
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
 int mapf_get_navi(mapf_env_t *h, uint8_t *navi_dev, void *stream) {
     if (!h || !navi_dev) return MAPF_ERR_INVALID_ARG;
     if (!h->navi_ready) return MAPF_ERR_NOT_READY;
@@ -1558,8 +1396,15 @@ int mapf_check_status(mapf_env_t *h, void *stream) {
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
     int32_t st = 0;
-    HIP_TRY(hipMemcpyAsync(&st, h->status, sizeof(st), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    // behind everything the stream holds, INCLUDING replayed graphs: on this runtime a pageable hipMemcpyAsync + hipStreamSynchronize did
+    // not wait for a preceding hipGraphLaunch on the stream (measured: stale reads right after graph replays), an event does
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e1 = hipEventRecord(ev, s);
+    if (e1 == hipSuccess) e1 = hipEventSynchronize(ev);
+    (void)hipEventDestroy(ev);
+    HIP_TRY(e1);
+    HIP_TRY(hipMemcpy(&st, h->status, sizeof(st), hipMemcpyDeviceToHost));
     if (st != 0) {
         HIP_TRY(hipMemsetAsync(h->status, 0, sizeof(int32_t), s));
         HIP_TRY(hipStreamSynchronize(s));

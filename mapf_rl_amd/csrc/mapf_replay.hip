@@ -485,13 +485,28 @@ int mapf_replay_destroy(mapf_replay_t *r) {
 int mapf_replay_row_dwords(const mapf_replay_t *r) { return r ? r->RD : MAPF_ERR_INVALID_ARG; }
 int mapf_replay_capacity(const mapf_replay_t *r) { return r ? r->capacity : MAPF_ERR_INVALID_ARG; }
 
+// the stream reads of the ring state are ordered behind (mapf_replay_size / _counter); a launch that is being CAPTURED into a graph
+// executes later, on whatever stream replays the graph: a capturing stream is not recorded
+static void note_stream(mapf_replay_t *r, hipStream_t s) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs == hipStreamCaptureStatusNone) r->last_stream = s;
+}
+
 // {ptr, size, counter, last flush count, sampled-while-empty flag}: a 40-byte read ordered behind the handle's most recent stream
 // (blocks the host)
 static int read_state(mapf_replay_t *r, int64_t st[5], void *stream) {
     DeviceGuard guard(r->device);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : r->last_stream;
-    HIP_TRY(hipMemcpyAsync(st, r->state, 40, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    // behind everything the stream holds, INCLUDING replayed graphs: on this runtime a pageable hipMemcpyAsync + hipStreamSynchronize did
+    // not wait for a preceding hipGraphLaunch on the stream (measured: the ring state of 18 replayed actor iterations read as empty),
+    // an event does
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e1 = hipEventRecord(ev, s);
+    if (e1 == hipSuccess) e1 = hipEventSynchronize(ev);
+    (void)hipEventDestroy(ev);
+    HIP_TRY(e1);
+    HIP_TRY(hipMemcpy(st, r->state, 40, hipMemcpyDeviceToHost));
     return MAPF_OK;
 }
 int mapf_replay_state(mapf_replay_t *r, int64_t out[4], void *stream) {
@@ -542,7 +557,7 @@ int mapf_replay_tree_update(mapf_replay_t *r, const int64_t *idx_dev, const doub
                             void *stream) {
     if (!r || !idx_dev || !pri_dev || n < 0) return MAPF_ERR_INVALID_ARG;
     DeviceGuard guard(r->device);
-    r->last_stream = static_cast<hipStream_t>(stream);
+    note_stream(r, static_cast<hipStream_t>(stream));
     return tree_update(r, idx_dev, pri_dev, n, alpha, nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -550,7 +565,7 @@ int mapf_replay_tree_sample(mapf_replay_t *r, const double *uniforms_dev, int n,
                             int64_t *old_ptr_dev, void *stream) {
     if (!r || !uniforms_dev || !idx_dev || !pri_dev || n < 1) return MAPF_ERR_INVALID_ARG;
     DeviceGuard guard(r->device);
-    r->last_stream = static_cast<hipStream_t>(stream);
+    note_stream(r, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(tree_sample_kernel, dim3((n + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), r->tree,
                        r->leaves, r->layers, uniforms_dev, n, unit_uniforms, idx_dev, pri_dev, r->state, old_ptr_dev);
     HIP_TRY(hipGetLastError());
@@ -560,7 +575,7 @@ int mapf_replay_tree_sample(mapf_replay_t *r, const double *uniforms_dev, int n,
 int mapf_replay_tree_read(mapf_replay_t *r, double *tree_dev, void *stream) {
     if (!r || !tree_dev) return MAPF_ERR_INVALID_ARG;
     DeviceGuard guard(r->device);
-    r->last_stream = static_cast<hipStream_t>(stream);
+    note_stream(r, static_cast<hipStream_t>(stream));
     HIP_TRY(hipMemcpyAsync(tree_dev, r->tree, (size_t)(2 * r->leaves - 1) * 8, hipMemcpyDeviceToDevice,
                            static_cast<hipStream_t>(stream)));
     return MAPF_OK;
@@ -591,7 +606,7 @@ static int flush(mapf_replay_t *r, FlushParams &p, hipStream_t s) {
     p.tree = r->tree;
     p.leaves = r->leaves;
     p.cap_log2 = r->cap_log2;
-    r->last_stream = s;
+    note_stream(r, s);
     hipLaunchKernelGGL(flush_scan_kernel, dim3(1), dim3(1024), 0, s, p);
     hipLaunchKernelGGL(flush_copy_kernel, dim3(p.E), dim3(256), 0, s, p);
     hipLaunchKernelGGL(flush_top_kernel, dim3(1), dim3(1024), 0, s, r->tree, r->cap_log2, r->state);
@@ -694,7 +709,7 @@ int mapf_replay_update_priorities(mapf_replay_t *r, const int64_t *idx_dev, cons
                                   void *stream) {
     if (!r || !idx_dev || !pri_dev || n < 0 || !old_ptr_dev) return MAPF_ERR_INVALID_ARG;
     DeviceGuard guard(r->device);
-    r->last_stream = static_cast<hipStream_t>(stream);
+    note_stream(r, static_cast<hipStream_t>(stream));
     return tree_update(r, idx_dev, pri_dev, n, kAlpha, old_ptr_dev, static_cast<hipStream_t>(stream));
 }
 

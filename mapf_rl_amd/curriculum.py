@@ -102,6 +102,8 @@ class CurriculumActors:
     refreshed every that many iterations; None = on `model` itself."""
 
     BATCHED = True
+    MERGED = True   # the levels' environment step / reset / re-observation as one launch each (environment.MultiEnvironment)
+    GRAPH = True    # ... and the whole iteration replayed from a captured HIP graph
 
     def __init__(self, model, buffer, envs_per_level=256, device=None, seed=0, max_steps=256, reward_fn=None, weights_period=None):
         self.source_model, self.buffer, self.weights_period = model, buffer, weights_period
@@ -117,7 +119,9 @@ class CurriculumActors:
         self.device = buffer.device if device is None else torch.device(device)
         self.actors = {}
         self.retired_env_steps = 0
-        self.obs_all = self.latents = None
+        self.obs_all = self.latents = self.multi = self._graph = self._cap_stream = None
+        self._warm = self.graph_replays = 0
+        self.tick = torch.zeros(1, dtype=torch.int64, device=self.device)  # iteration counter on the device (exploration / scenario streams)
         self.sync_levels()
 
     def _make(self, key):
@@ -147,23 +151,100 @@ class CurriculumActors:
 
     def _layout(self):
         """The levels' observation buffers back to back in ONE tensor (every environment handle then writes its observations
-        straight into its slice) + one latent cache over it."""
+        straight into its slice) + one latent cache over it; the recurrent states likewise in one tensor; and -- where the shapes
+        allow it -- the set that steps / resets / re-observes all levels by one launch each (environment.MultiEnvironment)."""
         from .fused import LatentCache
 
         acts = list(self.actors.values())
         total = sum(a.E * a.N for a in acts)
         self.obs_all = torch.empty((max(total, 1), 6, 9, 9), dtype=torch.uint8, device=self.device)
+        self.hidden_all = torch.zeros((max(total, 1), 256), dtype=torch.bfloat16, device=self.device)
+        self.hidden_new = torch.zeros_like(self.hidden_all)
         off = 0
         for a in acts:
             view = self.obs_all[off:off + a.E * a.N].view(a.E, a.N, 6, 9, 9)
             view.copy_(a.obs)              # (the current observation: the environments' state does not change here)
             a.env.obs = a.obs = view
+            h = self.hidden_all[off:off + a.E * a.N]
+            if a.hidden is not None:       # (None = episode start everywhere = the zero state, model.py:186-189)
+                h.copy_(a.hidden.reshape(a.E * a.N, 256))
+            a.hidden = h
             a.latents = None               # the shared cache below takes over
+            if a._act8 is None:
+                a.last_policy_actions = torch.empty((a.E, a.N), dtype=torch.int64, device=self.device)
+                a._act8 = torch.empty((a.E, a.N), dtype=torch.int8, device=self.device)
             off += a.E * a.N
         self.latents = LatentCache() if (VecActor.REUSE_LATENTS and self.device.type == "cuda") else None
+        self.multi = None
+        self._graph = None
+        self._warm = 0
+        if self.MERGED and self.BATCHED and self.device.type == "cuda" and acts and all(a.on_device_reset and not a.keep_flushed for a in acts):
+            from ._lib import ERR_UNSUPPORTED, MapfError
+            from .environment import MultiEnvironment
+
+            try:
+                # (the streams a level's own actor would use: scenario_seed + 1, + 2, ... per iteration; exploration: counter 0, 1, ...)
+                self.tick.zero_()
+                for a in acts:
+                    a._explore_base = a._explore_counter
+                self.multi = MultiEnvironment([a.env for a in acts], [a._act8 for a in acts], [a.bits for a in acts], [a.finished for a in acts],
+                                              reset_seeds=[a.scenario_seed + 1 for a in acts])
+            except MapfError as ex:
+                if ex.status != ERR_UNSUPPORTED:
+                    raise
+
+    # ---- one iteration of all levels with the environment launches merged (worker.py:376-414 for every level at once) ----
+    def _iteration(self):
+        from ._lib import check, lib
+        from .actor import _ptr, _stream
+
+        acts = list(self.actors.values())
+        inputs = [a.policy_inputs() for a in acts]
+        outs = self.model.step_levels([(a.E, a.N, a.pos, a.hidden, cm) for a, (cm, _) in zip(acts, inputs)], self.obs_all, self.latents,
+                                      hidden_out=self.hidden_new, packed_inplace=True)
+        st = _stream(self.device)
+        for a, (actions, q, hidden, _) in zip(acts, outs):
+            # worker.py:380-382: only agent 0 explores; the draw is a function of (seed, iteration counter on the device, environment)
+            check(lib.mapf_actor_explore_dev(a.E, a.N, _ptr(actions), _ptr(a.last_policy_actions), _ptr(a._act8), _ptr(a.eps), a.explore_seed,
+                                             a._explore_base, _ptr(self.tick), st), "mapf_actor_explore_dev")
+        self.multi.step()
+        for a, (cm, packed), (actions, q, hidden, _) in zip(acts, inputs, outs):
+            e = a.env
+            check(lib.mapf_actor_record(a.E, a.N, a.max_steps, a.RD, a.RDA, a.A, _ptr(q), _ptr(actions), _ptr(e.reward), _ptr(hidden), _ptr(packed),
+                                        _ptr(a.bits), _ptr(e.done), _ptr(a.t), _ptr(a.lb_q), _ptr(a.lb_act), _ptr(a.lb_rew), _ptr(a.lb_hid), _ptr(a.lb_comm),
+                                        _ptr(a.lb_obs), _ptr(a.finished), st), "mapf_actor_record")
+            if a.buffer is not None:
+                a.buffer.add_finished(a.N, a.finished, a.t, e.done, a.lb_obs, a.lb_comm, a.lb_act, a.lb_rew, a.lb_hid, a.lb_q)
+            check(lib.mapf_actor_log(a.E, _ptr(a.finished), _ptr(e.done), _ptr(a.stat_mask), _ptr(a.stat_log), a.STAT_LOG, _ptr(a.counters), st),
+                  "mapf_actor_log")
+        self.multi.reset(acts[0].density, self.tick)   # Actor.reset (worker.py:422-428) of every finished episode
+        self.multi.observe_masked()
+        for a, (actions, q, hidden, _) in zip(acts, outs):
+            check(lib.mapf_actor_rewind(a.E, a.N, a.max_steps, a.RD, a.RDA, _ptr(a.finished), _ptr(a.bits), _ptr(a.t), _ptr(a.lb_obs), _ptr(hidden), st),
+                  "mapf_actor_rewind")
+        self.hidden_all.copy_(self.hidden_new)
+        self.tick.add_(1)
+
+    def _capture(self):
+        """The launches of one iteration as a HIP graph (replayed until the level set changes).  No gc / cache flush around the
+        capture (torch.cuda.graph does both); this stream is idle when it starts."""
+        dev = self.device
+        cur = torch.cuda.current_stream(dev)
+        cur.synchronize()
+        if self._cap_stream is None:
+            self._cap_stream = torch.cuda.Stream(device=dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(self._cap_stream):
+            g.capture_begin()
+            try:
+                self._iteration()
+            finally:
+                g.capture_end()
+        return g
 
     def step(self):
         acts = list(self.actors.values())
+        pulled = False
         if self.weights_period is not None:  # worker.py:416-420
             if self._since_pull >= self.weights_period:
                 from .actor import _wait_for_default_stream
@@ -171,10 +252,28 @@ class CurriculumActors:
                 _wait_for_default_stream(self.device)
                 self.model.load_state_dict(self.source_model.state_dict())
                 self._since_pull = 0
+                pulled = True
             self._since_pull += 1
         if not self.BATCHED:
             for a in acts:
                 a.step()
+            return
+        if self.multi is not None:
+            # merged environment launches; and, once the allocator and the libraries have seen the iteration twice, its launches
+            # replayed from a graph.  After a weight pull one iteration is issued directly: it re-packs the weight images (in place)
+            # and re-encodes every observation (fused.LatentCache), which the captured sequence does not contain.
+            if self.GRAPH and not pulled and self._warm >= 2:
+                if self._graph is None:
+                    self._graph = self._capture()
+                self._graph.replay()
+                self.graph_replays += 1
+            else:
+                self._iteration()
+                self._warm += 1
+            for a in acts:  # (host mirrors of what moved on the device: a later re-layout continues the levels' own streams)
+                a.env_steps += a.E
+                a._explore_counter += 1
+                a.scenario_seed += 1
             return
         inputs = [a.policy_inputs() for a in acts]
         outs = self.model.step_levels([(a.E, a.N, a.pos, a.hidden, cm) for a, (cm, _) in zip(acts, inputs)], self.obs_all, self.latents)

@@ -207,6 +207,56 @@ class VecEnvironment:
         return out
 
 
+class MultiEnvironment:
+    """Several `VecEnvironment`s of DIFFERENT shapes stepped, reset and re-observed by one launch each (include/mapf_env.h:
+    mapf_multi_*).  The reference draws a (num_agents, map side) level per episode inside one actor (environment.py:148-151,
+    worker.py:422-428); here every active level of the curriculum is a handle, and this set is what steps them together.
+
+    envs: the handles (their persistent `obs` / `pos` / `reward_class` / `reward` / `done` buffers receive the outputs, as with
+    `VecEnvironment.step`); actions: per handle the int8 [E, N] buffer the step reads (persistent: its contents change, its address
+    does not); obs_bits: per handle an int32 [E, row dwords] buffer for the bit-packed observation (or None); masks: per handle the
+    uint8 [E] flags `reset()` and `observe_masked()` act on; reset_seeds: per handle the base of its scenario stream.  Raises MapfError(ERR_UNSUPPORTED) for shapes outside the merged
+    launch's limits (more than 25 agents, more than 16 handles)."""
+
+    def __init__(self, envs, actions, obs_bits, masks, reset_seeds=None):
+        n = len(envs)
+        assert n >= 1 and len(actions) == n and len(obs_bits) == n and len(masks) == n
+        self.envs, self.device = list(envs), envs[0].device
+        for e, a, b, m in zip(envs, actions, obs_bits, masks):
+            assert a.dtype == torch.int8 and a.is_contiguous() and a.shape == (e.num_envs, e.num_agents)
+            assert m.dtype == torch.uint8 and m.is_contiguous() and m.shape == (e.num_envs,)
+            assert b is None or (b.is_contiguous() and b.shape == (e.num_envs, e.obs_bits_row_dwords))
+        self._keep = (list(actions), list(obs_bits), list(masks), [e.obs for e in envs])
+        arr = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
+        self._h = ctypes.c_void_p()
+        check(lib.mapf_multi_create(n, (ctypes.c_void_p * n)(*[e._h.value for e in envs]), arr(actions), arr([e.obs for e in envs]), arr(obs_bits),
+                                    arr([e.pos for e in envs]), arr([e.reward_class for e in envs]), arr([e.reward for e in envs]),
+                                    arr([e.done for e in envs]), arr(masks),
+                                    None if reset_seeds is None else (ctypes.c_uint64 * n)(*[int(v) & 0xFFFFFFFFFFFFFFFF for v in reset_seeds]),
+                                    ctypes.byref(self._h)), "mapf_multi_create")
+        self.num_workgroups = lib.mapf_multi_num_workgroups(self._h)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value and lib is not None:
+            lib.mapf_multi_destroy(h)
+            self._h = ctypes.c_void_p()
+
+    def step(self):
+        """Environment.step of every handle on the actions in their buffers: one launch."""
+        check(lib.mapf_multi_step(self._h, _stream(self.device)), "mapf_multi_step")
+
+    def reset(self, density=-1.0, tick=None):
+        """On-device reset of the environments flagged in the handles' masks: one launch; handle i draws from the scenario stream
+        reset_seeds[i] + tick.  tick: optional int64 [1] device tensor, the caller's iteration counter (read on the device, so a
+        captured graph draws new scenarios at every replay)."""
+        check(lib.mapf_multi_reset(self._h, float(density), _ptr(tick), _stream(self.device)), "mapf_multi_reset")
+
+    def observe_masked(self):
+        """Re-observation of the flagged environments into the handles' buffers: one launch."""
+        check(lib.mapf_multi_observe_masked(self._h, _stream(self.device)), "mapf_multi_observe_masked")
+
+
 class Environment:
     """Source-compatible single environment (reference environment.py:74-467).
 

@@ -419,9 +419,10 @@ RECUR_WEIGHT_ELEMS = 548864
 RECUR_BIAS_ELEMS = 3456
 
 
-def recurrent_infer(gi, h0, comm, weights, bias, want_agent0=False):
+def recurrent_infer(gi, h0, comm, weights, bias, want_agent0=False, out=None):
     """gi bf16 [T, E, N, 768]; h0 bf16 [E, N, 256] or None; comm bool/u8 [T, E, N, N]
-    -> (hidden bf16 [E, N, 256], agent-0 states bf16 [T, E, 256] or None)."""
+    -> (hidden bf16 [E, N, 256], agent-0 states bf16 [T, E, 256] or None).  out: optional bf16 [E, N, 256] buffer for the hidden states
+    (not h0's: a workgroup writes its environment's rows while others may still be reading theirs -- fine -- but callers keep h0)."""
     T, E, N, _ = gi.shape
     assert gi.is_cuda and gi.dtype == torch.bfloat16 and gi.shape[3] == 768 and N <= RECUR_MAX_AGENTS
     assert tuple(comm.shape) == (T, E, N, N)
@@ -430,7 +431,11 @@ def recurrent_infer(gi, h0, comm, weights, bias, want_agent0=False):
     comm = comm.view(torch.uint8) if comm.dtype == torch.bool else comm.to(torch.uint8)
     if h0 is not None:
         h0 = h0.to(torch.bfloat16).reshape(E, N, 256).contiguous()
-    h_out = torch.empty((E, N, 256), dtype=torch.bfloat16, device=gi.device)
+    if out is not None:
+        assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.numel() == E * N * 256
+        h_out = out.view(E, N, 256)
+    else:
+        h_out = torch.empty((E, N, 256), dtype=torch.bfloat16, device=gi.device)
     a0 = torch.empty((T, E, 256), dtype=torch.bfloat16, device=gi.device) if want_agent0 else None
     check(lib.mapf_recurrent_infer(_ptr(gi), _ptr(h0), _ptr(comm), _ptr(weights), _ptr(bias), T, E, N, _ptr(h_out), _ptr(a0), None, 0,
                                    _stream(gi.device)), "mapf_recurrent_infer")

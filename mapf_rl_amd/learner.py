@@ -27,6 +27,7 @@ GAMMA = 0.99          # hard-coded in the reference (worker.py:306), config.gamm
 GRAD_CLIP = 40.0      # worker.py:319
 TARGET_SYNC = 2500    # config.target_network_update_freq (config.py:27)
 FORWARD_STEPS = 2     # config.forward_steps (config.py:65)
+SIDE_STREAM_PRIORITY = 1   # (HIP: a larger number is a LOWER priority; clamped to the device's range)
 
 
 def huber_loss(td_error, kappa=1.0):
@@ -134,7 +135,10 @@ class Learner:
         # running the update on a high-priority stream -- so that the target forward would only fill idle CUs -- gave 39.7: the chip
         # is saturated by the update's own kernels, the update is ~39.5 ms of work whichever way it is ordered.)
         self.prefetch = bool(prefetch) and buffer is not None and self.device.type == "cuda"
-        self._side = torch.cuda.Stream(device=self.device) if self.prefetch else None
+        # (lower priority than the stream the update itself runs on: the online chain -- encoder, recurrence, backward -- is the
+        # update's critical path; the target network's forward and the next batch's sample only have to be done before the head /
+        # the next update, and otherwise steal CUs from it: measured at 6 agents, tools/update_timeline.py)
+        self._side = torch.cuda.Stream(device=self.device, priority=SIDE_STREAM_PRIORITY) if self.prefetch else None
         self._pre = None
 
     def current_lr(self):

@@ -479,14 +479,17 @@ class Network(nn.Module):
         return q.argmax(-1), q, hidden, comm_mask
 
     @torch.no_grad()
-    def step_levels(self, levels, obs_all, cache=None):
+    def step_levels(self, levels, obs_all, cache=None, hidden_out=None, packed_inplace=False):
         """One actor step for SEVERAL groups of environments of different shapes at once -- the reference draws a (num_agents, map)
         level per episode inside one actor (environment.py:148-151, worker.py:422-428); here every active level is a group of E_l
         lock-step environments of N_l agents.  The encoder and the GRU input projection are per observation and do not care about
         the shape: ONE encoder launch and ONE GEMM over the concatenated observations; the recurrence (attention mixes the agents of
         one environment) runs per level; ONE Q head over the concatenated hidden states.
         levels: list of (E, N, pos [E, N, 2], hidden [E*N, 256] or None, comm bool [E, N, N]); obs_all uint8 [sum E_l N_l, 6, 9, 9],
-        the levels' observations back to back (every level's `obs` is a view of it).  Returns per level what step_batch returns."""
+        the levels' observations back to back (every level's `obs` is a view of it).  Returns per level what step_batch returns.
+        hidden_out: optional bf16 [sum E_l N_l, 256] buffer the levels' new hidden states are written into (the returned `hidden`s are
+        views of it, and the Q head reads it as one tensor); packed_inplace: re-pack changed weights into the buffers of the last pack
+        (callers that replay this launch sequence from a captured graph: the graph holds the buffers' addresses)."""
         dev = obs_all.device
         if not (self.FUSED_RECURRENCE and self.FUSED_INFERENCE and dev.type == "cuda" and all(lv[1] <= RECUR_MAX_AGENTS for lv in levels)):
             outs, off = [], 0
@@ -505,14 +508,15 @@ class Network(nn.Module):
                 latent = cache.encode(obs_all, self._packed, self.obs_encoder, self.weights_epoch)
             else:
                 latent = self.encode(obs_all)
-            w, b = self._packed_recur.get(self)
+            w, b = self._packed_recur.get(self, inplace=packed_inplace)
             gi_all = mm_rows(latent, self.recurrent.weight_ih.detach().to(torch.bfloat16))
             hs, off = [], 0
             for E, N, pos, hidden, comm in levels:
                 h0 = None if hidden is None else hidden.reshape(E, N, self.latent_dim)
-                hs.append(recurrent_infer(gi_all[off:off + E * N].view(1, E, N, 768), h0, comm.unsqueeze(0), w, b, False)[0].view(E * N, self.latent_dim))
+                out = None if hidden_out is None else hidden_out[off:off + E * N]
+                hs.append(recurrent_infer(gi_all[off:off + E * N].view(1, E, N, 768), h0, comm.unsqueeze(0), w, b, False, out=out)[0].view(E * N, self.latent_dim))
                 off += E * N
-            q_all = self.q_head(torch.cat(hs) if len(hs) > 1 else hs[0]).float()
+            q_all = self.q_head(hidden_out if hidden_out is not None else (torch.cat(hs) if len(hs) > 1 else hs[0])).float()
         act_all = q_all.argmax(-1)  # (one launch for all levels; the per-level results are views)
         outs, off = [], 0
         for (E, N, pos, hidden, comm), h in zip(levels, hs):

@@ -19,6 +19,7 @@ head, the loss, gradient accumulation, the clip, Adam, weight re-packing and the
 
 Parameters, gradients and Adam moments live in flat fp32 buffers (`FlatParams`): the module's parameters are views of them, so
 `state_dict()` / `load_state_dict()` / checkpoints are unaffected, and the data-parallel all-reduce is one collective over one buffer."""
+import contextlib
 import ctypes
 
 import numpy as np
@@ -245,6 +246,7 @@ class FusedUpdate:
         self._graphs = {}       # (stage, key) -> [graph, ctx, last use]
         self._pools = {}
         self._capturing = False
+        self._cap_stream = None
         self._tar_w_ih = None
         self._tick = 0
         self.graph_replays = self.graph_captures = 0
@@ -581,14 +583,24 @@ class FusedUpdate:
         hin0, _, hr, _, ctxs, info, _, _ = saves
         hrf = hr.view(2 * R, 256)
         rows_k = WGRAD_SPLIT if compact else 8192
-        _tall_tn_into(flat.mem(G, "recurrent.weight_hh"), d_gh1, hin0, rows_k)
-        _tall_tn_into(flat.span(G, "comm.self_attn.W_Q.weight", "comm.self_attn.W_V.weight"), d_qkv.view(2 * R, 384), hrf, rows_k)
-        _tall_tn_into(flat.mem(G, "comm.self_attn.W_O.weight"), d_info.view(2 * R, 64), ctxs.view(2 * R, 128), rows_k)
-        _tall_tn_into(flat.mem(G, "comm.update_cell.weight_ih"), d_gi2.view(2 * R, 768), info.view(2 * R, 64), rows_k)
-        _tall_tn_into(flat.mem(G, "comm.update_cell.weight_hh"), d_gh2.view(2 * R, 768), hrf, rows_k)
-        bias_names = ("recurrent.bias_ih", "recurrent.bias_hh", "comm.self_attn.W_Q.bias", "comm.self_attn.W_K.bias", "comm.self_attn.W_V.bias",
-                      "comm.update_cell.bias_ih", "comm.update_cell.bias_hh")
-        check(lib.mapf_recurrent_bias_grads(_ptr(bsum), B, _ptr_array([flat.mem(G, k) for k in bias_names]), st), "mapf_recurrent_bias_grads")
+        # the recurrence's weight / bias gradients (five tall GEMMs + their sums: ~0.3 ms of small launches at few agents) depend only
+        # on what the BPTT kernel wrote, the encoder's backward chain below only on d_gi1: inside a capture they become two branches
+        # of the graph (a second stream that forks here and joins before the optimizer step).  Everything the branch reads is held by
+        # `c` / `outs_b` until the join; what it allocates, it allocates on its own stream.
+        aux = self.lr._side if self._capturing else None
+        cur_s = torch.cuda.current_stream(dev)
+        if aux is not None:
+            aux.wait_stream(cur_s)
+        with (torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext()):
+            st_x = _stream(dev)
+            _tall_tn_into(flat.mem(G, "recurrent.weight_hh"), d_gh1, hin0, rows_k)
+            _tall_tn_into(flat.span(G, "comm.self_attn.W_Q.weight", "comm.self_attn.W_V.weight"), d_qkv.view(2 * R, 384), hrf, rows_k)
+            _tall_tn_into(flat.mem(G, "comm.self_attn.W_O.weight"), d_info.view(2 * R, 64), ctxs.view(2 * R, 128), rows_k)
+            _tall_tn_into(flat.mem(G, "comm.update_cell.weight_ih"), d_gi2.view(2 * R, 768), info.view(2 * R, 64), rows_k)
+            _tall_tn_into(flat.mem(G, "comm.update_cell.weight_hh"), d_gh2.view(2 * R, 768), hrf, rows_k)
+            bias_names = ("recurrent.bias_ih", "recurrent.bias_hh", "comm.self_attn.W_Q.bias", "comm.self_attn.W_K.bias", "comm.self_attn.W_V.bias",
+                          "comm.update_cell.bias_ih", "comm.update_cell.bias_hh")
+            check(lib.mapf_recurrent_bias_grads(_ptr(bsum), B, _ptr_array([flat.mem(G, k) for k in bias_names]), st_x), "mapf_recurrent_bias_grads")
         # ---- input projection ----
         if compact:
             d_gi_rows = d_gi1[:M]
@@ -606,6 +618,8 @@ class FusedUpdate:
         _tall_tn_into(flat.mem(G, "recurrent.weight_ih"), d_gi_rows, c.lat, rows=4096)
         # ---- encoder: backward-data chain in one kernel, then the weight-gradient kernels ----
         self._encoder_backward(po.obs_rows, Mu, c.acts, c.lat, c.bits, g_lat, c.wpt)
+        if aux is not None:
+            cur_s.wait_stream(aux)
         # ---- the only collective, clip, Adam ----
         lr.bucket.all_reduce_mean()
         if lr.grad_hook is not None:
@@ -681,6 +695,33 @@ class FusedUpdate:
         return dict(loss=c.loss[0], td=c.outs[2].view(B, 1), priorities=c.prio, grad_norm=grad_norm, q=c.outs[0].view(B, 1), q_next=c.outs[1].view(B, 1))
 
     # ------------------------------------------------------------------ graph mode
+    def _capture(self, pool, fn):
+        """Captures the launches of fn() into a new graph whose allocations come from the private pool `pool`.  (Not
+        `torch.cuda.graph(...)`: that context manager runs gc.collect() and empties the allocator's cache around every capture --
+        tens of milliseconds each, and new buckets keep appearing while the curriculum moves.)  The learner's two streams are idle
+        when the capture starts; other streams (the actors') may be busy."""
+        dev = self.dev
+        cur = torch.cuda.current_stream(dev)
+        cur.synchronize()
+        if self.lr._side is not None:
+            self.lr._side.synchronize()
+        if self._cap_stream is None:
+            self._cap_stream = torch.cuda.Stream(device=dev)
+        g = torch.cuda.CUDAGraph()
+        self._capturing = True
+        try:
+            with torch.cuda.stream(self._cap_stream):
+                g.capture_begin(pool=self._pools.get(pool))
+                try:
+                    out = fn()
+                finally:
+                    g.capture_end()
+        finally:
+            self._capturing = False
+        self._pools.setdefault(pool, g.pool())
+        self.graph_captures += 1
+        return g, out
+
     def _graph(self, stage, key, pool, fn):
         """The captured graph of `stage` for `key` (captured now if new).  Returns (graph, what fn returned at capture time)."""
         self._tick += 1
@@ -689,17 +730,9 @@ class FusedUpdate:
             same = [k for k in self._graphs if k[0] == stage]
             if len(same) >= self.GRAPH_CACHE:
                 del self._graphs[min(same, key=lambda k: self._graphs[k][2])]
-            g = torch.cuda.CUDAGraph()
-            self._capturing = True
-            try:
-                with torch.cuda.graph(g, pool=self._pools.get(pool)):
-                    out = fn()
-            finally:
-                self._capturing = False
-            self._pools.setdefault(pool, g.pool())
+            g, out = self._capture(pool, fn)
             ent = [g, out, self._tick]
             self._graphs[(stage, key)] = ent
-            self.graph_captures += 1
         ent[2] = self._tick
         return ent[0], ent[1]
 
@@ -799,16 +832,9 @@ class FusedUpdate:
         ent = c_o.backward.get(lr_value)  # (kept with the online graph whose saved tensors it reads: evicted together)
         if ent is None:
             saved_step, saved_epoch = flat.step_host, lr.model.weights_epoch
-            g_b = torch.cuda.CUDAGraph()
-            self._capturing = True
-            try:
-                with torch.cuda.graph(g_b, pool=self._pools.get("main")):
-                    norm = cap_backward()
-            finally:
-                self._capturing = False
+            g_b, norm = self._capture("main", cap_backward)
             flat.step_host, lr.model.weights_epoch = saved_step, saved_epoch  # (a capture runs adam_step's Python without executing it)
             ent = c_o.backward[lr_value] = (g_b, norm)
-            self.graph_captures += 1
         g_b, norm = ent
         g_b.replay()
         flat.step_host += 1

@@ -51,40 +51,49 @@ def test_level_promotion_and_mixed_levels():
     assert float(obs[:, :, 0].abs().sum()) > 0
 
 
-def test_level_batched_step_equals_serial_steps():
+@pytest.mark.parametrize("mode", ["batched", "merged", "graph"])
+def test_level_batched_step_equals_serial_steps(mode):
     """CurriculumActors.step with all active levels through ONE change detection / encoder launch / projection GEMM / Q head
     (Network.step_levels) against the levels stepped one after the other (BATCHED = False), from the same seeds: every recorded
     row -- observations, actions, rewards, comm rows, episode sizes, the replay's ring state and sum tree -- is identical; Q-values
-    and hidden states agree to bf16 rounding (the GEMM runs on another row count)."""
+    and hidden states agree to bf16 rounding (the GEMM runs on another row count).
+    mode "merged": also the levels' environment step / reset / re-observation as ONE launch each (mapf_multi_*, per-level scenario
+    and exploration streams kept: same episodes); mode "graph": and the whole iteration replayed from a captured HIP graph (the
+    iteration counter that moves those streams lives on the device)."""
     from mapf_rl_amd.curriculum import CurriculumActors
     from mapf_rl_amd.model import Network
     from mapf_rl_amd.replay import GlobalBuffer
 
-    levels = [(1, 10), (2, 10), (3, 15), (6, 20), (4, 25), (5, 10)]
+    levels = [(1, 10), (2, 10), (3, 15), (6, 20), (4, 25), (5, 10), (6, 35), (2, 40)]
     runs = {}
+    saved = (CurriculumActors.BATCHED, CurriculumActors.MERGED, CurriculumActors.GRAPH)
     try:
         for batched in (True, False):
-            CurriculumActors.BATCHED = batched
+            CurriculumActors.BATCHED, CurriculumActors.MERGED, CurriculumActors.GRAPH = batched, mode in ("merged", "graph"), mode == "graph"
             torch.manual_seed(0)
             net = Network().cuda().eval()
             buf = GlobalBuffer(1024, max_agents=6, init_set=(1, 10), max_map_length=40, pass_rate=0.9)
             buf.stat_dict = {k: [] for k in levels}
             cur = CurriculumActors(net, buf, envs_per_level=32, seed=3, max_steps=12)
             assert sorted(cur.actors) == sorted(levels)
+            assert (cur.multi is not None) == (batched and mode != "batched")
             for _ in range(30):
                 cur.step()
             torch.cuda.synchronize()
+            for a in cur.actors.values():
+                a.env.check_status()
             rec = {k: dict(obs=a.lb_obs.clone(), act=a.lb_act.clone(), rew=a.lb_rew.clone(), comm=a.lb_comm.clone(), t=a.t.clone(), q=a.lb_q.clone(),
-                           hid=a.lb_hid.clone(), pos=a.pos.clone(), eps=a.episodes) for k, a in cur.actors.items()}
-            runs[batched] = (rec, buf.state(), buf.priority_tree.tree().clone(), cur.latents)
+                           hid=a.lb_hid.clone(), pos=a.pos.clone(), eps=a.episodes, steps=a.env_steps) for k, a in cur.actors.items()}
+            runs[batched] = (rec, buf.state(), buf.priority_tree.tree().clone(), cur.latents, cur.graph_replays)
     finally:
-        CurriculumActors.BATCHED = True
-    (ra, sa, ta, lat), (rb, sb, tb, _) = runs[True], runs[False]
-    assert lat is not None and lat.calls == 30 and lat.full == 1  # one cache over all levels; re-encoded in full only at the start
-    assert sa == sb
+        CurriculumActors.BATCHED, CurriculumActors.MERGED, CurriculumActors.GRAPH = saved
+    (ra, sa, ta, lat, replays), (rb, sb, tb, _, _) = runs[True], runs[False]
+    assert lat is not None and lat.full == 1  # one cache over all levels; re-encoded in full only at the start
+    assert replays == (28 if mode == "graph" else 0) and lat.calls == (3 if mode == "graph" else 30)  # (2 direct iterations + the capture)
+    assert sa == sb and sa[2] > 0
     for k in levels:
         for f in ("obs", "act", "rew", "comm", "t", "pos"):
             assert torch.equal(ra[k][f], rb[k][f]), (k, f)
-        assert ra[k]["eps"] == rb[k]["eps"]
+        assert ra[k]["eps"] == rb[k]["eps"] and ra[k]["eps"] >= 32 and ra[k]["steps"] == rb[k]["steps"] == 30 * 32
         assert torch.allclose(ra[k]["q"], rb[k]["q"], rtol=2e-2, atol=2e-2) and torch.allclose(ra[k]["hid"].float(), rb[k]["hid"].float(), rtol=2e-2, atol=2e-2)
     assert torch.allclose(ta, tb, rtol=1e-2, atol=1e-6)  # priorities are |td| of those Q-values

@@ -382,3 +382,99 @@ def test_single_env_facade_matches_reference_api(M):
     assert o.shape == (5, 6, 9, 9) and p.shape == (5, 2)
     o, p = env2.reset(num_agents=3, map_length=10)
     assert o.shape == (3, 6, 9, 9) and env2.map_size == (10, 10)
+
+
+@pytest.mark.parametrize("E", [512, 40])
+def test_multi_handle_launch_equals_per_handle_launches(M, E):
+    """mapf_multi_* (include/mapf_env.h): the curriculum's levels -- handles of different (agents, map side) -- stepped, reset and
+    re-observed by ONE launch each.  Two identical sets of handles; one is driven through MultiEnvironment, the other handle by
+    handle through mapf_step / mapf_observe_masked: every output of every step is identical (byte observations, bit rows,
+    positions, reward classes, rewards, done), the trajectories equal the sequential oracle's, and after the merged reset the
+    flagged environments hold fresh valid scenarios (navi fields == oracle BFS of the read-back maps / goals) while the others are
+    untouched; the merged masked re-observation equals a full observe."""
+    from mapf_rl_amd.environment import MultiEnvironment
+
+    levels = [(1, 10), (2, 15), (3, 20), (4, 25), (5, 30), (6, 35), (6, 40), (12, 24), (16, 40), (7, 33)]
+    rng = np.random.RandomState(E)
+    sets = []
+    scen = [M.generate_scenarios(E, L, N, 0.2, seed=100 * N + L)[:3] for N, L in levels]
+    for k in range(2):
+        envs = []
+        for (N, L), (maps, agents, goals) in zip(levels, scen):
+            env = M.VecEnvironment(E, L, N)
+            env.load(maps, agents, goals)
+            envs.append(env)
+        sets.append(envs)
+    acts = [torch.zeros((E, N), dtype=torch.int8, device="cuda") for N, L in levels]
+    bits = [[torch.zeros((E, env.obs_bits_row_dwords), dtype=torch.int32, device="cuda") for env in envs] for envs in sets]
+    masks = [torch.zeros(E, dtype=torch.uint8, device="cuda") for _ in levels]
+    multi = MultiEnvironment(sets[0], acts, bits[0], masks)
+    assert multi.num_workgroups <= sum(E for _ in levels)
+    obs = []
+    for k in range(2):
+        for env, b in zip(sets[k], bits[k]):
+            o, _ = env.observe(obs_bits_out=b)
+            if k == 0:
+                obs.append(o)
+    T = 30
+    tapes = [np.zeros((T, E, N), np.int8) for N, L in levels]
+    for t in range(T):
+        for i, (N, L) in enumerate(levels):
+            tapes[i][t] = _heuristic_tape_step(_np(obs[i]), rng, (0.5, 0.9, 1.0)[t % 3])
+            acts[i].copy_(torch.from_numpy(tapes[i][t]))
+        multi.step()
+        for i, env in enumerate(sets[1]):
+            o, p, r, d, rc = env.step(acts[i], obs_bits_out=bits[1][i])
+            a = sets[0][i]
+            assert torch.equal(a.obs, o) and torch.equal(a.pos, p) and torch.equal(a.reward, r) and torch.equal(a.done, d), (t, levels[i])
+            assert torch.equal(a.reward_class, rc) and torch.equal(bits[0][i], bits[1][i]), (t, levels[i])
+    for i, ((N, L), (maps, agents, goals)) in enumerate(zip(levels, scen)):
+        sets[0][i].check_status()
+        nv = oracle.navi_batch(maps, goals)
+        ref = oracle.rollout(maps, agents, goals, nv, tapes[i], want_obs_last=True)
+        assert np.array_equal(_np(sets[0][i].agents_pos()), ref["final_agents"]) and np.array_equal(_np(sets[0][i].obs), ref["obs_last"]), levels[i]
+        assert np.array_equal(_np(sets[0][i].steps()), np.full(E, T, np.int32))
+    # merged reset of the flagged environments, then the merged masked re-observation
+    before = [(_np(env.maps()).copy(), _np(env.agents_pos()).copy(), _np(env.goals_pos()).copy()) for env in sets[0]]
+    for i, m in enumerate(masks):
+        flag = (rng.random_sample(E) < 0.3).astype(np.uint8)
+        flag[0], flag[E - 1] = 1, 0
+        m.copy_(torch.from_numpy(flag))
+    tick = torch.zeros(1, dtype=torch.int64, device="cuda")
+    multi.reset(0.2, tick)
+    multi.observe_masked()
+    for i, ((N, L), env) in enumerate(zip(levels, sets[0])):
+        env.check_status()
+        flag = _np(masks[i]).astype(bool)
+        maps, ag, go = _np(env.maps()), _np(env.agents_pos()), _np(env.goals_pos())
+        assert np.array_equal(maps[~flag], before[i][0][~flag]) and np.array_equal(ag[~flag], before[i][1][~flag]) and np.array_equal(go[~flag], before[i][2][~flag])
+        assert (np.abs(maps[flag].astype(int) - before[i][0][flag]).sum(axis=(1, 2)) > 0).mean() > 0.9   # fresh maps
+        steps = _np(env.steps())
+        assert (steps[flag] == 0).all() and (steps[~flag] == T).all()
+        ee = np.arange(E)[:, None]
+        assert maps[ee, ag[..., 0], ag[..., 1]].sum() == 0 and maps[ee, go[..., 0], go[..., 1]].sum() == 0
+        keys = np.sort(np.concatenate([ag[..., 0] * L + ag[..., 1], go[..., 0] * L + go[..., 1]], axis=1).astype(np.int64), axis=1)
+        assert np.all(keys[flag][:, 1:] != keys[flag][:, :-1])                 # 2 N distinct cells (environment.py:118-138)
+        assert np.array_equal(_np(env.navi_map()), oracle.navi_batch(maps, go))
+        full_obs, full_bits = torch.empty_like(env.obs), torch.empty_like(bits[0][i])
+        held = env.obs.clone()
+        _, full_pos = env.observe(obs_out=full_obs, obs_bits_out=full_bits)
+        assert torch.equal(held, full_obs) and torch.equal(bits[0][i], full_bits)
+    # two resets draw different scenarios (the set's iteration counter moves the stream)
+    m0 = _np(sets[0][0].maps()).copy()
+    tick += 1
+    multi.reset(0.2, tick)
+    multi.observe_masked()
+    f0 = _np(masks[0]).astype(bool)
+    assert (np.abs(_np(sets[0][0].maps())[f0].astype(int) - m0[f0]).sum(axis=(1, 2)) > 0).mean() > 0.9
+
+
+def test_multi_handle_set_rejects_wide_shapes(M):
+    from mapf_rl_amd import _lib
+    from mapf_rl_amd.environment import MultiEnvironment
+
+    env = M.VecEnvironment(8, 32, 40)
+    env.reset_envs(None, 0.2, seed=1)
+    with pytest.raises(_lib.MapfError) as ex:
+        MultiEnvironment([env], [torch.zeros((8, 40), dtype=torch.int8, device="cuda")], [None], [torch.zeros(8, dtype=torch.uint8, device="cuda")])
+    assert ex.value.status == _lib.ERR_UNSUPPORTED

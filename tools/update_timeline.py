@@ -9,9 +9,9 @@ import sys
 
 
 def short(n):
+    n = n.replace("void ", "").replace("(anonymous namespace)::", "").replace("at::native::", "")
     n = re.sub(r"\(.*", "", n)
     n = re.sub(r"<.*", "", n)
-    n = n.replace("void ", "").replace("(anonymous namespace)::", "").replace("at::native::", "")
     return n[-70:]
 
 
