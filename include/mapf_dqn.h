@@ -169,6 +169,18 @@ int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M
 int mapf_recurrent_infer(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev,
                          const uint16_t *weights_dev, const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev,
                          uint16_t *agent0_out_dev, const int32_t *row_index_dev, int64_t num_rows, void *stream);
+/*
+ * One step (T = 1) of E environments of DIFFERENT agent counts (each <= 16) in ONE launch -- the policy recurrence of all active
+ * curriculum levels of an actor iteration (the reference draws a (num_agents, map) level per episode, environment.py:148-151, and
+ * runs model.step per environment, worker.py:378).  The environments' agent rows lie back to back: gi bf16 [rows][768], h0 / h_out bf16
+ * [rows][256] (h0 may be NULL = zero state), comm_dev u8: environment e's [N_e][N_e] mask at byte offset envtab[e].z.
+ * envtab_dev int32 [E][4] (16-byte aligned): {N_e, first row of environment e, byte offset of its mask, n_e}.  n_e = 0 or N_e: one
+ * environment.  0 < n_e < N_e: entry e stands for N_e / n_e consecutive environments of n_e agents each (rows and masks back to back)
+ * stepped by ONE workgroup under the block-diagonal mask -- a step streams the 1.1 MB of weights once per workgroup, so few-agent
+ * environments are packed up to the 16 rows of an agent tile (same results up to the summation order of the softmax).
+ */
+int mapf_recurrent_infer_multi(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
+                               const float *bias_dev, int E, const int32_t *envtab_dev, uint16_t *h_out_dev, void *stream);
 
 /*
  * Training pair of mapf_recurrent_infer (csrc/mapf_recur.hip, csrc/mapf_recur_bwd.hip): the same forward, additionally
@@ -209,6 +221,11 @@ int mapf_recurrent_backward(const uint16_t *const *saved_dev, const uint8_t *com
  */
 int mapf_comm_mask(const int16_t *pos_dev, int E, int N, int obs_radius, int max_comm, uint8_t *mask_dev,
                    int32_t *packed_dev, int cw, void *stream);
+/* The same for E environments of different agent counts whose agents' positions lie back to back (pos_dev int16 [rows][2]):
+ * envtab_dev int32 [E][4] = {agents, first agent row, byte offset of the environment's [N][N] mask in mask_dev, unused}; packed rows go
+ * to packed_dev [rows][cw]. */
+int mapf_comm_mask_multi(const int16_t *pos_dev, int E, const int32_t *envtab_dev, int obs_radius, int max_comm, uint8_t *mask_dev,
+                         int32_t *packed_dev, int cw, void *stream);
 
 /*
  * Which (step, window, agent) entries of a training batch can influence `Network.bootstrap`'s output at all.  The reference

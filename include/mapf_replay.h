@@ -97,6 +97,13 @@ int mapf_replay_add_many(mapf_replay_t *r, int num_envs, int num_agents, int loc
                          const int64_t *sizes_dev, const uint8_t *done_dev, const uint32_t *obs_bits_dev,
                          const uint32_t *comm_bits_dev, const uint8_t *act_dev, const uint16_t *rew_dev,
                          const uint16_t *hid_dev, const float *q_dev, void *stream);
+/* The same for environments of DIFFERENT agent counts (several curriculum levels whose local buffers lie back to back, all at the
+ * replay's row width): num_agents_dev int32 [E] instead of one count.  Episodes are appended in environment order, as by per-level
+ * calls one after the other. */
+int mapf_replay_add_many_env(mapf_replay_t *r, int num_envs, const int32_t *num_agents_dev, int local_steps, const uint8_t *finished_dev,
+                             const int64_t *sizes_dev, const uint8_t *done_dev, const uint32_t *obs_bits_dev,
+                             const uint32_t *comm_bits_dev, const uint8_t *act_dev, const uint16_t *rew_dev, const uint16_t *hid_dev,
+                             const float *q_dev, void *stream);
 
 /*
  * Per-step bookkeeping of a vectorised actor (reference worker.py:376-414 for E lock-step environments; csrc/mapf_actor.hip).
@@ -137,6 +144,28 @@ int mapf_actor_explore(int num_envs, int num_agents, int64_t *actions_dev, int64
  * be replayed from a captured HIP graph while the caller advances the counter on the device. */
 int mapf_actor_explore_dev(int num_envs, int num_agents, int64_t *actions_dev, int64_t *policy_dev, int8_t *act8_dev,
                            const double *eps_dev, uint64_t seed, uint64_t counter, const uint64_t *tick_dev, void *stream);
+/*
+ * Several levels -- environments of different agent counts whose per-agent arrays (actions, q, reward, hidden, packed comm rows) and
+ * per-environment arrays (t, finished, done, eps, local buffers) lie back to back -- by ONE launch each.
+ * envtab_dev int32 [E][4] (16-byte aligned) per environment: {agents, first agent row, byte offset of its comm mask
+ * (mapf_comm_mask_multi / mapf_recurrent_infer_multi of mapf_dqn.h), dword offset of its bit-packed observation row in obs_bits_dev}.
+ *   mapf_actor_explore_multi: aux_dev int64 [E][3] = {exploration seed of the environment's level, base counter, index of the
+ *     environment within its level}: the draws are those of mapf_actor_explore_dev(seed, base, tick) for that level alone;
+ *   mapf_actor_record_multi / mapf_actor_rewind_multi: mapf_actor_record / mapf_actor_rewind with the per-environment table;
+ *   mapf_actor_log_multi: mapf_actor_log per level l over the environments [level_start[l], level_start[l + 1]) (host array of
+ *     num_levels + 1 entries, num_levels <= 16) into that level's log / counters (host arrays of device pointers).
+ */
+int mapf_actor_explore_multi(int num_envs, const int32_t *envtab_dev, const int64_t *aux_dev, int64_t *actions_dev, int64_t *policy_dev,
+                             int8_t *act8_dev, const double *eps_dev, const uint64_t *tick_dev, void *stream);
+int mapf_actor_record_multi(int num_envs, int local_steps, int row_dwords, int max_agents, const int32_t *envtab_dev, const float *q_dev,
+                            const int64_t *actions_dev, const float *reward_dev, const uint16_t *hidden_dev, const int32_t *comm_dev,
+                            const int32_t *obs_bits_dev, const uint8_t *done_dev, int64_t *t_dev, float *lb_q_dev, uint8_t *lb_act_dev,
+                            uint16_t *lb_rew_dev, uint16_t *lb_hid_dev, int32_t *lb_comm_dev, int32_t *lb_obs_dev, uint8_t *finished_dev,
+                            void *stream);
+int mapf_actor_rewind_multi(int num_envs, int local_steps, int row_dwords, const int32_t *envtab_dev, const uint8_t *finished_dev,
+                            const int32_t *obs_bits_dev, int64_t *t_dev, int32_t *lb_obs_dev, uint16_t *hidden_dev, void *stream);
+int mapf_actor_log_multi(int num_levels, const int32_t *level_start, uint8_t *const *log_dev, int64_t *const *counters_dev, int log_size,
+                         const uint8_t *finished_dev, const uint8_t *done_dev, const uint8_t *stat_mask_dev, void *stream);
 /*
  * Everything of one actor iteration behind the policy's forward (worker.py:380-428), as ONE call: mapf_actor_explore, mapf_step
  * (include/mapf_env.h), mapf_actor_record, mapf_replay_add_many (replay may be NULL), mapf_actor_log, mapf_reset_envs +

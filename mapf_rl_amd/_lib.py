@@ -60,6 +60,11 @@ SYMBOLS = [
     ("mapf_replay_tree_read", _i, [_vp, _vp, _vp]),
     ("mapf_replay_add", _i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_replay_add_many", _i, [_vp, _i, _i, _i] + [_vp] * 10),
+    ("mapf_replay_add_many_env", _i, [_vp, _i, _vp, _i] + [_vp] * 10),
+    ("mapf_actor_explore_multi", _i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("mapf_actor_record_multi", _i, [_i, _i, _i, _i] + [_vp] * 17),
+    ("mapf_actor_rewind_multi", _i, [_i, _i, _i] + [_vp] * 7),
+    ("mapf_actor_log_multi", _i, [_i, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _vp, _vp, _vp, _vp]),
     ("mapf_actor_record", _i, [_i] * 6 + [_vp] * 16),
     ("mapf_actor_rewind", _i, [_i] * 5 + [_vp] * 6),
     ("mapf_actor_explore", _i, [_i, _i, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, _vp]),
@@ -73,9 +78,11 @@ SYMBOLS = [
     ("mapf_bias_res_relu_fwd", _i, [_vp, _vp, _vp, ctypes.c_int64, _i, _vp]),
     ("mapf_bias_res_relu_bwd", _i, [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp]),
     ("mapf_recurrent_infer", _i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, ctypes.c_int64, _vp]),
+    ("mapf_recurrent_infer_multi", _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     ("mapf_recurrent_forward_save", _i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, ctypes.POINTER(_vp), _vp, ctypes.c_int64, _vp]),
     ("mapf_recurrent_backward", _i, [ctypes.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(_vp), _vp, ctypes.c_int64, _vp]),
     ("mapf_comm_mask", _i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    ("mapf_comm_mask_multi", _i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
     ("mapf_window_relevance", _i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     ("mapf_encoder_pack", _i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _vp, _vp, _vp]),
     ("mapf_encoder_forward", _i, [_vp, _i, ctypes.c_int64, _vp, _vp, _vp, _vp]),

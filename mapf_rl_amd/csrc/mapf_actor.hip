@@ -31,6 +31,8 @@ struct RecordParams {
     int32_t *lb_comm;         // [E][S+1][A][CW]
     int32_t *lb_obs;          // [E][S+1][RDA]
     uint8_t *finished;        // [E] out
+    const int4 *envtab;       // optional (several levels in one launch): per environment {agents, first agent row, -, dword offset of its bit row};
+                              // q / actions / reward / hidden / comm are then indexed by agent row, bits by the dword offset
 };
 
 __device__ __forceinline__ uint16_t f32_to_f16_bits(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
@@ -45,21 +47,28 @@ __global__ void __launch_bounds__(256) actor_record_kernel(RecordParams p) {
     __syncthreads();
     const long long t = s_t;
     const size_t tr = (size_t)e * p.S + t;
+    int N = p.N, RD = p.RD;
+    size_t row0 = (size_t)e * p.N, boff = (size_t)e * p.RD;
+    if (p.envtab) {
+        const int4 d = p.envtab[e];
+        N = d.x, row0 = (size_t)d.y, boff = (size_t)d.w;
+        RD = ((N * 486 + 31) / 32 + 3) & ~3;
+    }
     // worker.py:388 -> buffer.py:140-151 (agent 0's q / action / reward / hidden; the joint comm mask; the next observation)
-    p.lb_hid[tr * 256 + tid] = f32_to_f16_bits(bf16_to_f32(p.hidden[(size_t)e * p.N * 256 + tid]));
-    if (tid < 5) p.lb_q[tr * 5 + tid] = p.q[(size_t)e * p.N * 5 + tid];
+    p.lb_hid[tr * 256 + tid] = f32_to_f16_bits(bf16_to_f32(p.hidden[row0 * 256 + tid]));
+    if (tid < 5) p.lb_q[tr * 5 + tid] = p.q[row0 * 5 + tid];
     const bool dn = p.done[e] != 0;
     const bool fin = dn || (t + 1 >= p.S);  // worker.py:390
     if (tid == 0) {
-        p.lb_act[tr] = (uint8_t)p.actions[(size_t)e * p.N];
-        p.lb_rew[tr] = f32_to_f16_bits(p.reward[(size_t)e * p.N]);
+        p.lb_act[tr] = (uint8_t)p.actions[row0];
+        p.lb_rew[tr] = f32_to_f16_bits(p.reward[row0]);
         p.t[e] = t + 1;
         p.finished[e] = fin ? 1 : 0;
     }
     const int crow = p.A * p.CW;
     int32_t *c_now = p.lb_comm + ((size_t)e * (p.S + 1) + t) * crow, *c_last = c_now + crow;
-    const int32_t *cs = p.comm + (size_t)e * p.N * p.CW;
-    for (int i = tid; i < p.N * p.CW; i += 256) {
+    const int32_t *cs = p.comm + row0 * p.CW;
+    for (int i = tid; i < N * p.CW; i += 256) {
         const int32_t v = cs[i];
         c_now[i] = v;
         // the row behind a finished episode's last transition: zeros after `done` (buffer.py:124), the mask of the stale
@@ -67,8 +76,8 @@ __global__ void __launch_bounds__(256) actor_record_kernel(RecordParams p) {
         if (fin) c_last[i] = dn ? 0 : v;
     }
     int32_t *o = p.lb_obs + ((size_t)e * (p.S + 1) + t + 1) * p.RDA;
-    const int32_t *b = p.bits + (size_t)e * p.RD;
-    for (int i = tid; i < p.RD; i += 256) o[i] = b[i];
+    const int32_t *b = p.bits + boff;
+    for (int i = tid; i < RD; i += 256) o[i] = b[i];
 }
 
 struct RewindParams {
@@ -78,17 +87,25 @@ struct RewindParams {
     int64_t *t;               // [E]
     int32_t *lb_obs;          // [E][S+1][RDA]
     uint16_t *hidden;         // [E][N][256] bf16
+    const int4 *envtab;       // optional, as in RecordParams
 };
 
 __global__ void __launch_bounds__(256) actor_rewind_kernel(RewindParams p) {
     const int e = blockIdx.x, tid = threadIdx.x;
     if (p.finished[e] == 0) return;
+    int N = p.N, RD = p.RD;
+    size_t row0 = (size_t)e * p.N, boff = (size_t)e * p.RD;
+    if (p.envtab) {
+        const int4 d = p.envtab[e];
+        N = d.x, row0 = (size_t)d.y, boff = (size_t)d.w;
+        RD = ((N * 486 + 31) / 32 + 3) & ~3;
+    }
     if (tid == 0) p.t[e] = 0;
     int32_t *o = p.lb_obs + (size_t)e * (p.S + 1) * p.RDA;
-    const int32_t *b = p.bits + (size_t)e * p.RD;
-    for (int i = tid; i < p.RD; i += 256) o[i] = b[i];
-    uint4 *h = reinterpret_cast<uint4 *>(p.hidden + (size_t)e * p.N * 256);  // model.reset(): GRUCell(x, None) == zero state
-    for (int i = tid; i < p.N * 32; i += 256) h[i] = make_uint4(0, 0, 0, 0);
+    const int32_t *b = p.bits + boff;
+    for (int i = tid; i < RD; i += 256) o[i] = b[i];
+    uint4 *h = reinterpret_cast<uint4 *>(p.hidden + row0 * 256);  // model.reset(): GRUCell(x, None) == zero state
+    for (int i = tid; i < N * 32; i += 256) h[i] = make_uint4(0, 0, 0, 0);
 }
 
 // episode counter + outcomes of the statistics-bearing environments (actor id >= 10, worker.py:74) in environment order into a
@@ -236,9 +253,136 @@ __global__ void __launch_bounds__(256) actor_explore_kernel(long long total, int
     act8[idx] = (int8_t)a;
 }
 
+// the same log for several levels in one launch: block l owns the environments [start[l], start[l + 1]) and its own log / counters
+struct LogLevels {
+    int n;
+    int start[17];
+    uint8_t *log[16];
+    int64_t *counters[16];
+    int log_size;
+};
+__global__ void __launch_bounds__(1024) actor_log_multi_kernel(LogLevels lv, const uint8_t *finished, const uint8_t *done, const uint8_t *stat_mask) {
+    __shared__ int s_cnt[1024], s_fin[1024];
+    const int l = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    const int E0 = lv.start[l], E = lv.start[l + 1] - E0;
+    uint8_t *log = lv.log[l];
+    int64_t *counters = lv.counters[l];
+    finished += E0, done += E0, stat_mask += E0;
+    const int per = (E + nth - 1) / nth, e0 = tid * per, e1 = min(E, e0 + per);
+    int cnt = 0, fin = 0;
+    for (int e = e0; e < e1; ++e) {
+        fin += finished[e] != 0;
+        cnt += (finished[e] != 0 && stat_mask[e] != 0);
+    }
+    s_cnt[tid] = cnt;
+    s_fin[tid] = fin;
+    __syncthreads();
+    for (int d = 1; d < nth; d <<= 1) {
+        const int v = tid >= d ? s_cnt[tid - d] : 0, f = tid >= d ? s_fin[tid - d] : 0;
+        __syncthreads();
+        s_cnt[tid] += v;
+        s_fin[tid] += f;
+        __syncthreads();
+    }
+    const long long base = counters[1];
+    long long pos = base + s_cnt[tid] - cnt;
+    for (int e = e0; e < e1; ++e)
+        if (finished[e] != 0 && stat_mask[e] != 0) log[(pos++) % lv.log_size] = done[e] != 0;
+    __syncthreads();
+    if (tid == 0) {
+        counters[0] += s_fin[nth - 1];
+        counters[1] = base + s_cnt[nth - 1];
+    }
+}
+
+// exploration for environments of different agent counts: one thread per environment (agent 0 explores, worker.py:380-382; the other
+// agents' greedy actions are copied).  aux int64 [E][3] = {seed of the environment's level, base counter, index within the level}: the
+// draws of (seed, base + tick, index) are the ones actor_explore_kernel makes for that level alone.
+__global__ void __launch_bounds__(256) actor_explore_multi_kernel(int E, const int4 *__restrict__ envtab, const long long *__restrict__ aux,
+                                                                  int64_t *__restrict__ actions, int64_t *__restrict__ policy, int8_t *__restrict__ act8,
+                                                                  const double *__restrict__ eps, const unsigned long long *__restrict__ tick) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int4 d = envtab[e];
+    const long long row0 = d.y;
+    const uint64_t seed = (uint64_t)aux[3 * e], counter = (uint64_t)aux[3 * e + 1] + (tick ? (uint64_t)tick[0] : 0ull), el = (uint64_t)aux[3 * e + 2];
+    for (int a = 0; a < d.x; ++a) {
+        int64_t act = actions[row0 + a];
+        if (policy) policy[row0 + a] = act;
+        if (a == 0) {
+            const uint64_t r0 = splitmix64(seed ^ splitmix64(counter * 0xD6E8FEB86659FD93ull + el));
+            const double u = (double)(r0 >> 11) * (1.0 / 9007199254740992.0);  // [0, 1)
+            if (u < eps[e]) {
+                act = (int64_t)(splitmix64(r0) % 5ull);
+                actions[row0] = act;
+            }
+        }
+        act8[row0 + a] = (int8_t)act;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+// ---- several levels (environments of different agent counts, their agent rows back to back) in one launch each: the per-environment
+// table envtab int32 [E][4] = {agents, first agent row, byte offset of the comm mask (mapf_comm_mask_multi / mapf_recurrent_infer_multi),
+// dword offset of the bit-packed observation row}; see include/mapf_replay.h ----
+int mapf_actor_explore_multi(int num_envs, const int32_t *envtab_dev, const int64_t *aux_dev, int64_t *actions_dev, int64_t *policy_dev, int8_t *act8_dev,
+                             const double *eps_dev, const uint64_t *tick_dev, void *stream) {
+    if (num_envs < 1 || !envtab_dev || !aux_dev || !actions_dev || !act8_dev || !eps_dev || (reinterpret_cast<uintptr_t>(envtab_dev) & 15) ||
+        (reinterpret_cast<uintptr_t>(tick_dev) & 7))
+        return MAPF_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(actor_explore_multi_kernel, dim3((num_envs + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), num_envs,
+                       reinterpret_cast<const int4 *>(envtab_dev), reinterpret_cast<const long long *>(aux_dev), actions_dev, policy_dev, act8_dev, eps_dev,
+                       reinterpret_cast<const unsigned long long *>(tick_dev));
+    return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
+}
+
+int mapf_actor_record_multi(int num_envs, int local_steps, int row_dwords, int max_agents, const int32_t *envtab_dev, const float *q_dev,
+                            const int64_t *actions_dev, const float *reward_dev, const uint16_t *hidden_dev, const int32_t *comm_dev,
+                            const int32_t *obs_bits_dev, const uint8_t *done_dev, int64_t *t_dev, float *lb_q_dev, uint8_t *lb_act_dev, uint16_t *lb_rew_dev,
+                            uint16_t *lb_hid_dev, int32_t *lb_comm_dev, int32_t *lb_obs_dev, uint8_t *finished_dev, void *stream) {
+    if (num_envs < 1 || max_agents < 1 || local_steps < 1 || local_steps > MAPF_REPLAY_MAX_STEPS || row_dwords < 1 || !envtab_dev ||
+        (reinterpret_cast<uintptr_t>(envtab_dev) & 15))
+        return MAPF_ERR_INVALID_ARG;
+    if (!q_dev || !actions_dev || !reward_dev || !hidden_dev || !comm_dev || !obs_bits_dev || !done_dev || !t_dev || !lb_q_dev || !lb_act_dev ||
+        !lb_rew_dev || !lb_hid_dev || !lb_comm_dev || !lb_obs_dev || !finished_dev)
+        return MAPF_ERR_INVALID_ARG;
+    RecordParams p{num_envs, 0, local_steps, 0, row_dwords, max_agents, (max_agents + 31) / 32, q_dev, actions_dev, reward_dev,
+                   hidden_dev, comm_dev, obs_bits_dev, done_dev, t_dev, lb_q_dev, lb_act_dev, lb_rew_dev, lb_hid_dev, lb_comm_dev, lb_obs_dev,
+                   finished_dev, reinterpret_cast<const int4 *>(envtab_dev)};
+    hipLaunchKernelGGL(actor_record_kernel, dim3(num_envs), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
+}
+
+int mapf_actor_rewind_multi(int num_envs, int local_steps, int row_dwords, const int32_t *envtab_dev, const uint8_t *finished_dev,
+                            const int32_t *obs_bits_dev, int64_t *t_dev, int32_t *lb_obs_dev, uint16_t *hidden_dev, void *stream) {
+    if (num_envs < 1 || local_steps < 1 || row_dwords < 1 || !envtab_dev || !finished_dev || !obs_bits_dev || !t_dev || !lb_obs_dev || !hidden_dev ||
+        (reinterpret_cast<uintptr_t>(hidden_dev) & 15) || (reinterpret_cast<uintptr_t>(envtab_dev) & 15))
+        return MAPF_ERR_INVALID_ARG;
+    RewindParams p{num_envs, 0, local_steps, 0, row_dwords, finished_dev, obs_bits_dev, t_dev, lb_obs_dev, hidden_dev,
+                   reinterpret_cast<const int4 *>(envtab_dev)};
+    hipLaunchKernelGGL(actor_rewind_kernel, dim3(num_envs), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
+}
+
+int mapf_actor_log_multi(int num_levels, const int32_t *level_start, uint8_t *const *log_dev, int64_t *const *counters_dev, int log_size,
+                         const uint8_t *finished_dev, const uint8_t *done_dev, const uint8_t *stat_mask_dev, void *stream) {
+    if (num_levels < 1 || num_levels > 16 || !level_start || !log_dev || !counters_dev || log_size < 1 || !finished_dev || !done_dev || !stat_mask_dev)
+        return MAPF_ERR_INVALID_ARG;
+    LogLevels lv{};
+    lv.n = num_levels;
+    lv.log_size = log_size;
+    for (int l = 0; l <= num_levels; ++l) lv.start[l] = level_start[l];
+    for (int l = 0; l < num_levels; ++l) {
+        if (!log_dev[l] || !counters_dev[l] || lv.start[l + 1] <= lv.start[l]) return MAPF_ERR_INVALID_ARG;
+        lv.log[l] = log_dev[l];
+        lv.counters[l] = counters_dev[l];
+    }
+    hipLaunchKernelGGL(actor_log_multi_kernel, dim3(num_levels), dim3(1024), 0, static_cast<hipStream_t>(stream), lv, finished_dev, done_dev, stat_mask_dev);
+    return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
+}
 
 int mapf_actor_explore(int num_envs, int num_agents, int64_t *actions_dev, int64_t *policy_dev, int8_t *act8_dev, const double *eps_dev,
                        uint64_t seed, uint64_t counter, void *stream) {
@@ -272,7 +416,7 @@ int mapf_actor_record(int num_envs, int num_agents, int local_steps, int env_row
         return MAPF_ERR_INVALID_ARG;
     RecordParams p{num_envs, num_agents, local_steps, env_row_dwords, row_dwords, max_agents, (max_agents + 31) / 32, q_dev, actions_dev, reward_dev,
                    hidden_dev, comm_dev, obs_bits_dev, done_dev, t_dev, lb_q_dev, lb_act_dev, lb_rew_dev, lb_hid_dev, lb_comm_dev, lb_obs_dev,
-                   finished_dev};
+                   finished_dev, nullptr};
     hipLaunchKernelGGL(actor_record_kernel, dim3(num_envs), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
 }
@@ -282,7 +426,7 @@ int mapf_actor_rewind(int num_envs, int num_agents, int local_steps, int env_row
     if (num_envs < 1 || num_agents < 1 || local_steps < 1 || env_row_dwords < 1 || row_dwords < env_row_dwords || !finished_dev || !obs_bits_dev ||
         !t_dev || !lb_obs_dev || !hidden_dev || (reinterpret_cast<uintptr_t>(hidden_dev) & 15))
         return MAPF_ERR_INVALID_ARG;
-    RewindParams p{num_envs, num_agents, local_steps, env_row_dwords, row_dwords, finished_dev, obs_bits_dev, t_dev, lb_obs_dev, hidden_dev};
+    RewindParams p{num_envs, num_agents, local_steps, env_row_dwords, row_dwords, finished_dev, obs_bits_dev, t_dev, lb_obs_dev, hidden_dev, nullptr};
     hipLaunchKernelGGL(actor_rewind_kernel, dim3(num_envs), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
 }

@@ -89,10 +89,17 @@ __global__ void __launch_bounds__(256) bias_res_relu_bwd_kernel(const uint4 *g, 
 constexpr int COMM_MAX_K = 8;
 
 __global__ void __launch_bounds__(128) comm_mask_kernel(const short2 *__restrict__ pos, int N, int radius, int k,
-                                                        uint8_t *__restrict__ mask, int32_t *__restrict__ packed, int cw) {
+                                                        uint8_t *__restrict__ mask, int32_t *__restrict__ packed, int cw,
+                                                        const int4 *__restrict__ envtab) {
     __shared__ short2 s_pos[128];
     const int e = blockIdx.x, i = threadIdx.x;
-    if (i < N) s_pos[i] = pos[(long long)e * N + i];
+    long long row0 = (long long)e * N, moff = (long long)e * N * N;
+    if (envtab) {  // environments of different agent counts, their agents' rows back to back: {agents, first row, byte offset of the mask, -}
+        const int4 d = envtab[e];
+        N = d.x, row0 = d.y, moff = d.z;
+        k = k < N ? k : N;
+    }
+    if (i < N) s_pos[i] = pos[row0 + i];
     __syncthreads();
     if (i >= N) return;
     const int px = s_pos[i].x, py = s_pos[i].y;
@@ -115,8 +122,8 @@ __global__ void __launch_bounds__(128) comm_mask_kernel(const short2 *__restrict
 #pragma unroll
     for (int t = 0; t < COMM_MAX_K; ++t)
         if (t == k - 1) kth = best[t];
-    uint8_t *mrow = mask ? mask + ((long long)e * N + i) * N : nullptr;
-    int32_t *prow = packed ? packed + ((long long)e * N + i) * cw : nullptr;
+    uint8_t *mrow = mask ? mask + moff + (long long)i * N : nullptr;
+    int32_t *prow = packed ? packed + (row0 + i) * cw : nullptr;
     uint32_t word = 0;
     for (int j = 0; j < N; ++j) {
         const int dx = px - s_pos[j].x, dy = py - s_pos[j].y;
@@ -225,7 +232,19 @@ int mapf_comm_mask(const int16_t *pos_dev, int E, int N, int obs_radius, int max
     if (E == 0) return MAPF_OK;
     const int k = max_comm < N ? max_comm : N;
     hipLaunchKernelGGL(comm_mask_kernel, dim3(E), dim3(128), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const short2 *>(pos_dev), N, obs_radius, k, mask_dev, packed_dev, cw);
+                       reinterpret_cast<const short2 *>(pos_dev), N, obs_radius, k, mask_dev, packed_dev, cw, (const int4 *)nullptr);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+int mapf_comm_mask_multi(const int16_t *pos_dev, int E, const int32_t *envtab_dev, int obs_radius, int max_comm, uint8_t *mask_dev,
+                         int32_t *packed_dev, int cw, void *stream) {
+    if (E < 0 || obs_radius < 0 || max_comm < 1 || max_comm > COMM_MAX_K || !pos_dev || !envtab_dev || (!mask_dev && !packed_dev) || (packed_dev && cw < 1) ||
+        (reinterpret_cast<uintptr_t>(pos_dev) & 3) || (reinterpret_cast<uintptr_t>(envtab_dev) & 15))
+        return MAPF_ERR_INVALID_ARG;
+    if (E == 0) return MAPF_OK;
+    hipLaunchKernelGGL(comm_mask_kernel, dim3(E), dim3(128), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const short2 *>(pos_dev), 128,
+                       obs_radius, max_comm, mask_dev, packed_dev, cw, reinterpret_cast<const int4 *>(envtab_dev));
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }

@@ -204,12 +204,27 @@ __device__ __forceinline__ void gru_block(int cblk, const uint16_t *__restrict__
 template <bool SAVE>
 __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t *__restrict__ gi, const uint16_t *__restrict__ h0,
                                                                   const uint8_t *__restrict__ comm, const uint16_t *__restrict__ W,
-                                                                  const float *__restrict__ bias, int T, int E, int N,
+                                                                  const float *__restrict__ bias, int T, int E, int N_arg,
                                                                   uint16_t *__restrict__ h_out, uint16_t *__restrict__ agent0_out,
-                                                                  RecurSave sv, const int32_t *__restrict__ rowidx, long long nrows) {
+                                                                  RecurSave sv, const int32_t *__restrict__ rowidx, long long nrows,
+                                                                  const int4 *__restrict__ envtab) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lh = lane >> 4;
     const int e = blockIdx.x;
+    // envtab (mapf_recurrent_infer_multi: one step of environments of DIFFERENT agent counts -- the curriculum's levels -- in one
+    // launch): per environment {agents, first row of its agents in gi / h0 / h_out, byte offset of its mask in comm, -}
+    int n_env = N_arg, n_real = N_arg;
+    long long hrow0 = (long long)e * N_arg, coff = 0;
+    if (envtab != nullptr) {
+        const int4 d = envtab[e];
+        n_env = __builtin_amdgcn_readfirstlane(d.x);
+        hrow0 = __builtin_amdgcn_readfirstlane(d.y);
+        coff = __builtin_amdgcn_readfirstlane(d.z);
+        n_real = __builtin_amdgcn_readfirstlane(d.w);
+        if (n_real <= 0) n_real = n_env;
+    }
+    const int N = n_env;   // agent rows this workgroup steps
+    const int NR = n_real;  // ... of which every NR consecutive ones are one environment (their masks [NR][NR] back to back): see below
     const int rot = blockIdx.x;  // workgroups walk the weight tiles in rotated order: they run in step, and would otherwise all
                                  // request the same cache lines at the same moment
 
@@ -220,7 +235,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
         for (int i = tid; i < N * 32; i += NTHR) {  // 32 chunks of 16 B per agent
             const int a = i >> 5, ch = i & 31;
             *reinterpret_cast<uint4 *>(smem + OFF_H0 + a * H_ROW + ch * 16) =
-                *reinterpret_cast<const uint4 *>(h0 + ((long long)e * N + a) * D + ch * 8);
+                *reinterpret_cast<const uint4 *>(h0 + (hrow0 + a) * D + ch * 8);
         }
     __syncthreads();
 
@@ -242,17 +257,21 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
         }
     };
     for (int t = 0; t < T; ++t) {
-        const long long row0 = ((long long)t * E + e) * N;  // first dense row of this (step, environment)
+        const long long row0 = envtab ? hrow0 : ((long long)t * E + e) * N;  // first dense row of this (step, environment)
         // ---------------- this step's communication mask -> bit rows in LDS (the softmax loops must not touch global memory:
         // 120 dependent byte loads per row made the first version 10x slower than its MFMAs) ----------------
-        const uint8_t *comm_t = comm + ((long long)t * E + e) * N * N;
+        const uint8_t *comm_t = comm + (envtab ? coff : ((long long)t * E + e) * N * N);
         if (tid < NA * 2) mb[tid] = 0u;
         if (tid < NA) ridx[tid] = tid < N ? (rowidx ? rowidx[row0 + tid] : (int)(row0 + tid)) : -1;
         __syncthreads();
         if (SAVE) save_hidden(sv.hin0, Hc);
-        for (int idx = tid; idx < N * N; idx += NTHR)
+        // (mapf_recurrent_infer_multi packs several small environments of one level into one workgroup -- their agents' rows are
+        // consecutive everywhere, and the weights, which is what a step streams, are fetched once for all of them: row i = agent i % NR
+        // of environment i / NR reads that environment's mask row, its partners are the columns of that environment: a block-diagonal
+        // mask.  NR == N: one environment, the plain case.)
+        for (int idx = tid; idx < N * NR; idx += NTHR)
             if (comm_t[idx] != 0) {
-                const int i = idx / N, j = idx - i * N;
+                const int i = idx / NR, j = (i / NR) * NR + (idx - i * NR);
                 atomicOr(&mb[2 * i + (j >> 5)], 1u << (j & 31));
             }
         // ---------------- recurrent GRU cell: Hc -> Hn (the barrier behind it also publishes the mask bits) ----------------
@@ -424,7 +443,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
     }
     for (int i = tid; i < N * 32; i += NTHR) {
         const int a = i >> 5, ch = i & 31;
-        *reinterpret_cast<uint4 *>(h_out + ((long long)e * N + a) * D + ch * 8) = *reinterpret_cast<const uint4 *>(Hc + a * H_ROW + ch * 16);
+        *reinterpret_cast<uint4 *>(h_out + (hrow0 + a) * D + ch * 8) = *reinterpret_cast<const uint4 *>(Hc + a * H_ROW + ch * 16);
     }
 }
 
@@ -469,7 +488,7 @@ int RECUR_ENTRY(mapf_recurrent_infer)(const uint16_t *gi_dev, const uint16_t *h0
         return mapf_recur_wide_forward(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, nullptr,
                                        static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(recurrent_infer_kernel<false>, dim3(E), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
-                       weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, RecurSave{}, row_index_dev, (long long)num_rows);
+                       weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, RecurSave{}, row_index_dev, (long long)num_rows, (const int4 *)nullptr);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }
@@ -497,10 +516,28 @@ int RECUR_ENTRY(mapf_recurrent_forward_save)(const uint16_t *gi_dev, const uint1
         return mapf_recur_wide_forward(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, &sv,
                                        static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(recurrent_infer_kernel<true>, dim3(E), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
-                       weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, sv, row_index_dev, (long long)num_rows);
+                       weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, sv, row_index_dev, (long long)num_rows, (const int4 *)nullptr);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }
+
+#if MAPF_RECUR_NT == 1
+// One step of E environments of DIFFERENT agent counts (each <= 16) in one launch: the policy recurrence of all active curriculum
+// levels (reference worker.py:378 runs model.step per environment; the levels' (num_agents, map) differ, environment.py:148-151).
+extern "C" int mapf_recurrent_infer_multi(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
+                                          const float *bias_dev, int E, const int32_t *envtab_dev, uint16_t *h_out_dev, void *stream) {
+    if (E < 0 || !gi_dev || !comm_dev || !weights_dev || !bias_dev || !h_out_dev || !envtab_dev) return MAPF_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(gi_dev) & 7) || (reinterpret_cast<uintptr_t>(h0_dev) & 15) || (reinterpret_cast<uintptr_t>(weights_dev) & 15) ||
+        (reinterpret_cast<uintptr_t>(bias_dev) & 15) || (reinterpret_cast<uintptr_t>(h_out_dev) & 15) || (reinterpret_cast<uintptr_t>(envtab_dev) & 15))
+        return MAPF_ERR_INVALID_ARG;
+    if (E == 0) return MAPF_OK;
+    hipLaunchKernelGGL(recurrent_infer_kernel<false>, dim3(E), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
+                       weights_dev, bias_dev, 1, E, 1, h_out_dev, (uint16_t *)nullptr, RecurSave{}, (const int32_t *)nullptr, 0ll,
+                       reinterpret_cast<const int4 *>(envtab_dev));
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+#endif
 
 #if MAPF_RECUR_NT == 3
 }  // extern "C"

@@ -247,6 +247,7 @@ struct FlushParams {
     const uint16_t *hid;       // [E][S][256] f16
     const float *q;            // [E][S][5] or nullptr when td is given
     const double *td;          // [E][256] or nullptr
+    const int32_t *nag_env;    // [E] or nullptr: agents of environment e (several levels in one flush) instead of num_agents
     int32_t *slot_of;          // [E] scratch: ring slot or -1
     int64_t *state;
     uint32_t *dst_obs, *dst_comm;
@@ -287,7 +288,7 @@ __global__ void __launch_bounds__(1024) flush_scan_kernel(FlushParams p) {
                 dsize += size - p.dst_size[slot];      // worker.py:90-91
                 p.dst_size[slot] = size;
                 p.dst_done[slot] = p.done[e] != 0;
-                p.dst_nag[slot] = p.num_agents;
+                p.dst_nag[slot] = p.nag_env ? p.nag_env[e] : p.num_agents;
             }
             ++rank;
         }
@@ -655,6 +656,31 @@ int mapf_replay_add_many(mapf_replay_t *r, int num_envs, int num_agents, int loc
     p.E = num_envs;
     p.S = local_steps;
     p.num_agents = num_agents;
+    p.finished = finished_dev;
+    p.sizes = sizes_dev;
+    p.done = done_dev;
+    p.obs_bits = obs_bits_dev;
+    p.comm_bits = comm_bits_dev;
+    p.act = act_dev;
+    p.rew = rew_dev;
+    p.hid = hid_dev;
+    p.q = q_dev;
+    p.td = nullptr;
+    return flush(r, p, static_cast<hipStream_t>(stream));
+}
+
+int mapf_replay_add_many_env(mapf_replay_t *r, int num_envs, const int32_t *num_agents_dev, int local_steps, const uint8_t *finished_dev,
+                             const int64_t *sizes_dev, const uint8_t *done_dev, const uint32_t *obs_bits_dev, const uint32_t *comm_bits_dev,
+                             const uint8_t *act_dev, const uint16_t *rew_dev, const uint16_t *hid_dev, const float *q_dev, void *stream) {
+    if (!r || !num_agents_dev || !sizes_dev || !done_dev || !obs_bits_dev || !comm_bits_dev || !act_dev || !rew_dev || !hid_dev || !q_dev)
+        return MAPF_ERR_INVALID_ARG;
+    if (num_envs < 1 || local_steps < 1 || local_steps > kMaxSteps) return MAPF_ERR_INVALID_ARG;
+    DeviceGuard guard(r->device);
+    FlushParams p{};
+    p.E = num_envs;
+    p.S = local_steps;
+    p.num_agents = 0;
+    p.nag_env = num_agents_dev;
     p.finished = finished_dev;
     p.sizes = sizes_dev;
     p.done = done_dev;

@@ -104,6 +104,7 @@ class CurriculumActors:
     BATCHED = True
     MERGED = True   # the levels' environment step / reset / re-observation as one launch each (environment.MultiEnvironment)
     GRAPH = True    # ... and the whole iteration replayed from a captured HIP graph
+    PACK_RECURRENCE = True  # 16 // N environments of a level per workgroup of the policy recurrence (the weight stream is shared)
 
     def __init__(self, model, buffer, envs_per_level=256, device=None, seed=0, max_steps=256, reward_fn=None, weights_period=None):
         self.source_model, self.buffer, self.weights_period = model, buffer, weights_period
@@ -150,35 +151,76 @@ class CurriculumActors:
         return want
 
     def _layout(self):
-        """The levels' observation buffers back to back in ONE tensor (every environment handle then writes its observations
-        straight into its slice) + one latent cache over it; the recurrent states likewise in one tensor; and -- where the shapes
-        allow it -- the set that steps / resets / re-observes all levels by one launch each (environment.MultiEnvironment)."""
+        """Everything the levels' iteration reads or writes back to back in ONE tensor per kind -- observations, positions, recurrent
+        states, Q-values, actions, rewards, comm masks / packed rows, bit-packed observation rows, the per-environment episode
+        state and the local buffers (all at the replay's row width) -- with every level's actor / environment handle holding
+        views; one latent cache over the observations; a per-environment table {agents, first agent row, offset of the comm mask,
+        offset of the bit row}; and the set that steps / resets / re-observes all levels by one launch each
+        (environment.MultiEnvironment).  An iteration is then ~30 launches whatever the number of levels (`_iteration`)."""
         from .fused import LatentCache
 
         acts = list(self.actors.values())
-        total = sum(a.E * a.N for a in acts)
-        self.obs_all = torch.empty((max(total, 1), 6, 9, 9), dtype=torch.uint8, device=self.device)
-        self.hidden_all = torch.zeros((max(total, 1), 256), dtype=torch.bfloat16, device=self.device)
-        self.hidden_new = torch.zeros_like(self.hidden_all)
-        off = 0
-        for a in acts:
-            view = self.obs_all[off:off + a.E * a.N].view(a.E, a.N, 6, 9, 9)
-            view.copy_(a.obs)              # (the current observation: the environments' state does not change here)
-            a.env.obs = a.obs = view
-            h = self.hidden_all[off:off + a.E * a.N]
-            if a.hidden is not None:       # (None = episode start everywhere = the zero state, model.py:186-189)
-                h.copy_(a.hidden.reshape(a.E * a.N, 256))
-            a.hidden = h
-            a.latents = None               # the shared cache below takes over
-            if a._act8 is None:
-                a.last_policy_actions = torch.empty((a.E, a.N), dtype=torch.int64, device=self.device)
-                a._act8 = torch.empty((a.E, a.N), dtype=torch.int8, device=self.device)
-            off += a.E * a.N
-        self.latents = LatentCache() if (VecActor.REUSE_LATENTS and self.device.type == "cuda") else None
-        self.multi = None
+        d = self.device
+        rows, Et = sum(a.E * a.N for a in acts), sum(a.E for a in acts)
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=d)
+        self.obs_all = torch.empty((max(rows, 1), 6, 9, 9), dtype=torch.uint8, device=d)
+        self.hidden_all, self.hidden_new = z((max(rows, 1), 256), torch.bfloat16), z((max(rows, 1), 256), torch.bfloat16)
+        self.latents = LatentCache() if (VecActor.REUSE_LATENTS and d.type == "cuda") else None
+        self.multi = self.envtab = None
         self._graph = None
         self._warm = 0
-        if self.MERGED and self.BATCHED and self.device.type == "cuda" and acts and all(a.on_device_reset and not a.keep_flushed for a in acts):
+        if not acts:
+            return
+        a0 = acts[0]
+        S, A, CW, RDA = a0.max_steps, a0.A, a0.CW, a0.RDA
+        assert all((a.max_steps, a.A, a.CW, a.RDA) == (S, A, CW, RDA) for a in acts)
+        per_row = dict(pos=((2,), torch.int16), reward=((), torch.float32), reward_class=((), torch.int8), act8=((), torch.int8),
+                       policy=((), torch.int64), comm_packed=((CW,), torch.int32))
+        per_env = dict(done=((), torch.uint8), finished=((), torch.uint8), t=((), torch.int64), eps=((), torch.float64), stat_mask=((), torch.uint8),
+                       lb_obs=((S + 1, RDA), torch.int32), lb_comm=((S + 1, A, CW), torch.int32), lb_act=((S,), torch.uint8), lb_rew=((S,), torch.float16),
+                       lb_hid=((S, 256), torch.float16), lb_q=((S, 5), torch.float32))
+        self.cat = {k: z((rows,) + sh, dt) for k, (sh, dt) in per_row.items()}
+        self.cat.update({k: z((Et,) + sh, dt) for k, (sh, dt) in per_env.items()})
+        self.cat["q"], self.cat["act"] = z((rows, 5), torch.float32), z((rows,), torch.int64)
+        self.cat["bits"] = z((sum(a.E * a.RD for a in acts),), torch.int32)
+        self.cat["comm"] = z((sum(a.E * a.N * a.N for a in acts),), torch.uint8)
+        self.cat["nag"] = torch.cat([torch.full((a.E,), a.N, dtype=torch.int32) for a in acts]).to(d)
+        tab, aux, self._views = [], [], []
+        r0 = e0 = c0 = b0 = 0
+        for a in acts:
+            E, N = a.E, a.N
+            rs, es = slice(r0, r0 + E * N), slice(e0, e0 + E)
+
+            def home(obj, name, view):  # the tensor moves into its slice of the shared buffer
+                old = getattr(obj, name)
+                if old is not None:
+                    view.copy_(old.reshape(view.shape))
+                setattr(obj, name, view)
+
+            home(a.env, "obs", self.obs_all[rs].view(E, N, 6, 9, 9))
+            home(a.env, "pos", self.cat["pos"][rs].view(E, N, 2))
+            home(a.env, "reward", self.cat["reward"][rs].view(E, N))
+            home(a.env, "reward_class", self.cat["reward_class"][rs].view(E, N))
+            home(a.env, "done", self.cat["done"][es])
+            a.obs, a.pos = a.env.obs, a.env.pos
+            home(a, "hidden", self.hidden_all[rs])   # (None = episode start everywhere = the zero state, model.py:186-189)
+            home(a, "_act8", self.cat["act8"][rs].view(E, N))
+            home(a, "last_policy_actions", self.cat["policy"][rs].view(E, N))
+            home(a, "bits", self.cat["bits"][b0:b0 + E * a.RD].view(E, a.RD))
+            for k in ("finished", "t", "eps", "stat_mask", "lb_obs", "lb_comm", "lb_act", "lb_rew", "lb_hid", "lb_q"):
+                home(a, k, self.cat[k][es])
+            a.latents = None               # the shared cache takes over
+            a._state = None                # (the fused per-level tail's struct names the old buffers)
+            e = torch.arange(E, dtype=torch.int64)
+            tab.append(torch.stack([torch.full((E,), N, dtype=torch.int64), r0 + e * N, c0 + e * N * N, b0 + e * a.RD], dim=1))
+            aux.append(torch.stack([torch.full((E,), a.explore_seed - (1 << 64) if a.explore_seed >= (1 << 63) else a.explore_seed, dtype=torch.int64),
+                                    torch.full((E,), a._explore_counter, dtype=torch.int64), e], dim=1))
+            self._views.append((self.cat["comm"][c0:c0 + E * N * N], self.cat["comm_packed"][rs].view(E, N, CW), rs))
+            r0, e0, c0, b0 = r0 + E * N, e0 + E, c0 + E * N * N, b0 + E * a.RD
+        self.level_start = [0]
+        for a in acts:
+            self.level_start.append(self.level_start[-1] + a.E)
+        if self.MERGED and self.BATCHED and d.type == "cuda" and all(a.on_device_reset and not a.keep_flushed for a in acts):
             from ._lib import ERR_UNSUPPORTED, MapfError
             from .environment import MultiEnvironment
 
@@ -189,17 +231,68 @@ class CurriculumActors:
                     a._explore_base = a._explore_counter
                 self.multi = MultiEnvironment([a.env for a in acts], [a._act8 for a in acts], [a.bits for a in acts], [a.finished for a in acts],
                                               reset_seeds=[a.scenario_seed + 1 for a in acts])
+                if all(a.N <= 16 for a in acts):
+                    self.envtab = torch.cat(tab).to(torch.int32).contiguous().to(d)
+                    self.aux = torch.cat(aux).contiguous().to(d)
+                    # the recurrence's own table: 16 // N consecutive environments of a level per workgroup (one agent tile of rows;
+                    # a step streams the weights once per workgroup, include/mapf_dqn.h: mapf_recurrent_infer_multi)
+                    rt, r0, c0 = [], 0, 0
+                    for a in acts:
+                        k = max(1, 16 // a.N) if self.PACK_RECURRENCE else 1
+                        for e in range(0, a.E, k):
+                            m = min(k, a.E - e)
+                            rt.append((m * a.N, r0 + e * a.N, c0 + e * a.N * a.N, a.N))
+                        r0, c0 = r0 + a.E * a.N, c0 + a.E * a.N * a.N
+                    self.rtab = torch.tensor(rt, dtype=torch.int32).contiguous().to(d)
             except MapfError as ex:
                 if ex.status != ERR_UNSUPPORTED:
                     raise
 
-    # ---- one iteration of all levels with the environment launches merged (worker.py:376-414 for every level at once) ----
+    # ---- one iteration of all levels (worker.py:376-414 for every level at once) ----
     def _iteration(self):
+        if self.envtab is None:
+            return self._iteration_per_level()
+        import ctypes
+
         from ._lib import check, lib
         from .actor import _ptr, _stream
 
         acts = list(self.actors.values())
-        inputs = [a.policy_inputs() for a in acts]
+        c, a0, st = self.cat, acts[0], _stream(self.device)
+        Et, n = self.level_start[-1], len(acts)
+        # communication masks of all levels (reference model.py:195-208) + the replay's packed rows: one launch
+        check(lib.mapf_comm_mask_multi(_ptr(c["pos"]), Et, _ptr(self.envtab), 4, 3, _ptr(c["comm"]), _ptr(c["comm_packed"]), a0.CW, st), "mapf_comm_mask_multi")
+        # policy: change detection, encoder on the changed rows, projection GEMM, ONE recurrence launch, Q head, arg-max
+        self.model.step_levels([(a.E, a.N, a.pos, a.hidden, None) for a in acts], self.obs_all, self.latents, hidden_out=self.hidden_new,
+                               packed_inplace=True, merged=(self.rtab, c["comm"], self.hidden_all), q_out=c["q"], act_out=c["act"])
+        # worker.py:380-382: agent 0 of every environment explores (its level's own stream: seed, base counter + tick, index in the level)
+        check(lib.mapf_actor_explore_multi(Et, _ptr(self.envtab), _ptr(self.aux), _ptr(c["act"]), _ptr(c["policy"]), _ptr(c["act8"]), _ptr(c["eps"]),
+                                           _ptr(self.tick), st), "mapf_actor_explore_multi")
+        self.multi.step()
+        check(lib.mapf_actor_record_multi(Et, a0.max_steps, a0.RDA, a0.A, _ptr(self.envtab), _ptr(c["q"]), _ptr(c["act"]), _ptr(c["reward"]),
+                                          _ptr(self.hidden_new), _ptr(c["comm_packed"]), _ptr(c["bits"]), _ptr(c["done"]), _ptr(c["t"]), _ptr(c["lb_q"]),
+                                          _ptr(c["lb_act"]), _ptr(c["lb_rew"]), _ptr(c["lb_hid"]), _ptr(c["lb_comm"]), _ptr(c["lb_obs"]), _ptr(c["finished"]), st),
+              "mapf_actor_record_multi")
+        if self.buffer is not None:  # every finished episode of every level into the replay, in level / environment order
+            self.buffer.add_finished_env(c["nag"], c["finished"], c["t"], c["done"], c["lb_obs"], c["lb_comm"], c["lb_act"], c["lb_rew"], c["lb_hid"], c["lb_q"])
+        check(lib.mapf_actor_log_multi(n, (ctypes.c_int32 * (n + 1))(*self.level_start), (ctypes.c_void_p * n)(*[a.stat_log.data_ptr() for a in acts]),
+                                       (ctypes.c_void_p * n)(*[a.counters.data_ptr() for a in acts]), a0.STAT_LOG, _ptr(c["finished"]), _ptr(c["done"]),
+                                       _ptr(c["stat_mask"]), st), "mapf_actor_log_multi")
+        self.multi.reset(a0.density, self.tick)   # Actor.reset (worker.py:422-428) of every finished episode
+        self.multi.observe_masked()
+        check(lib.mapf_actor_rewind_multi(Et, a0.max_steps, a0.RDA, _ptr(self.envtab), _ptr(c["finished"]), _ptr(c["bits"]), _ptr(c["t"]), _ptr(c["lb_obs"]),
+                                          _ptr(self.hidden_new), st), "mapf_actor_rewind_multi")
+        self.hidden_all.copy_(self.hidden_new)
+        self.tick.add_(1)
+
+    def _iteration_per_level(self):
+        """Merged environment launches, everything else per level (a level of more than 16 agents is among them)."""
+        from ._lib import check, lib
+        from .actor import _ptr, _stream
+        from .fused import comm_mask
+
+        acts = list(self.actors.values())
+        inputs = [comm_mask(a.pos, packed_words=a.CW, out_mask=cm, out_packed=pk) for a, (cm, pk, _) in zip(acts, self._views)]
         outs = self.model.step_levels([(a.E, a.N, a.pos, a.hidden, cm) for a, (cm, _) in zip(acts, inputs)], self.obs_all, self.latents,
                                       hidden_out=self.hidden_new, packed_inplace=True)
         st = _stream(self.device)

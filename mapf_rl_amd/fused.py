@@ -284,14 +284,23 @@ def window_relevance(comm_mask_bt, steps):
     return rel
 
 
-def comm_mask(pos, obs_radius=4, max_comm=3, packed_words=0):
+def comm_mask(pos, obs_radius=4, max_comm=3, packed_words=0, out_mask=None, out_packed=None):
     """pos int16 [E, N, 2] on a HIP device -> (bool [E, N, N], int32 [E, N, packed_words] or None):
-    include/mapf_dqn.h mapf_comm_mask (reference model.py:195-208)."""
+    include/mapf_dqn.h mapf_comm_mask (reference model.py:195-208).  out_mask (bool / uint8, E*N*N elements) / out_packed (int32,
+    E*N*packed_words): write into the caller's buffers."""
     assert pos.is_cuda and pos.dtype == torch.int16 and pos.dim() == 3 and pos.shape[2] == 2
     pos = pos.contiguous()
     E, N, _ = pos.shape
-    mask = torch.empty((E, N, N), dtype=torch.bool, device=pos.device)
-    packed = torch.empty((E, N, packed_words), dtype=torch.int32, device=pos.device) if packed_words else None
+    if out_mask is not None:
+        assert out_mask.is_contiguous() and out_mask.numel() == E * N * N and out_mask.element_size() == 1
+        mask = out_mask.view(torch.bool).view(E, N, N)
+    else:
+        mask = torch.empty((E, N, N), dtype=torch.bool, device=pos.device)
+    if out_packed is not None:
+        assert packed_words and out_packed.is_contiguous() and out_packed.dtype == torch.int32 and out_packed.numel() == E * N * packed_words
+        packed = out_packed.view(E, N, packed_words)
+    else:
+        packed = torch.empty((E, N, packed_words), dtype=torch.int32, device=pos.device) if packed_words else None
     check(lib.mapf_comm_mask(_ptr(pos), E, N, obs_radius, max_comm, _ptr(mask), _ptr(packed), packed_words, _stream(pos.device)),
           "mapf_comm_mask")
     return mask, packed
@@ -440,6 +449,18 @@ def recurrent_infer(gi, h0, comm, weights, bias, want_agent0=False, out=None):
     check(lib.mapf_recurrent_infer(_ptr(gi), _ptr(h0), _ptr(comm), _ptr(weights), _ptr(bias), T, E, N, _ptr(h_out), _ptr(a0), None, 0,
                                    _stream(gi.device)), "mapf_recurrent_infer")
     return h_out, a0
+
+
+def recurrent_infer_multi(gi_all, h0_all, comm_all, weights, bias, envtab, out):
+    """One policy step of environments of different agent counts (<= 16 each) in one launch (include/mapf_dqn.h:
+    mapf_recurrent_infer_multi): gi_all bf16 [rows, 768], h0_all bf16 [rows, 256] or None, comm_all uint8 [bytes], envtab int32 [E, 4],
+    out bf16 [rows, 256] (not h0_all)."""
+    assert gi_all.dtype == torch.bfloat16 and gi_all.is_contiguous() and gi_all.shape[1] == 768 and out.dtype == torch.bfloat16 and out.is_contiguous()
+    assert envtab.dtype == torch.int32 and envtab.is_contiguous() and envtab.shape[1] == 4 and comm_all.dtype == torch.uint8
+    assert h0_all is None or (h0_all.dtype == torch.bfloat16 and h0_all.is_contiguous() and h0_all.data_ptr() != out.data_ptr())
+    check(lib.mapf_recurrent_infer_multi(_ptr(gi_all), _ptr(h0_all), _ptr(comm_all), _ptr(weights), _ptr(bias), envtab.shape[0], _ptr(envtab), _ptr(out),
+                                         _stream(gi_all.device)), "mapf_recurrent_infer_multi")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -479,7 +479,7 @@ class Network(nn.Module):
         return q.argmax(-1), q, hidden, comm_mask
 
     @torch.no_grad()
-    def step_levels(self, levels, obs_all, cache=None, hidden_out=None, packed_inplace=False):
+    def step_levels(self, levels, obs_all, cache=None, hidden_out=None, packed_inplace=False, merged=None, q_out=None, act_out=None):
         """One actor step for SEVERAL groups of environments of different shapes at once -- the reference draws a (num_agents, map)
         level per episode inside one actor (environment.py:148-151, worker.py:422-428); here every active level is a group of E_l
         lock-step environments of N_l agents.  The encoder and the GRU input projection are per observation and do not care about
@@ -489,7 +489,10 @@ class Network(nn.Module):
         the levels' observations back to back (every level's `obs` is a view of it).  Returns per level what step_batch returns.
         hidden_out: optional bf16 [sum E_l N_l, 256] buffer the levels' new hidden states are written into (the returned `hidden`s are
         views of it, and the Q head reads it as one tensor); packed_inplace: re-pack changed weights into the buffers of the last pack
-        (callers that replay this launch sequence from a captured graph: the graph holds the buffers' addresses)."""
+        (callers that replay this launch sequence from a captured graph: the graph holds the buffers' addresses); merged: optional
+        (envtab int32 [sum E_l, 4], comm_all uint8, hidden_all bf16 [rows, 256]) -- the levels' masks and incoming states in ONE buffer
+        each plus the per-environment table of fused.recurrent_infer_multi: the recurrence of all levels is then one launch (every
+        level <= 16 agents; needs hidden_out); q_out f32 [rows, 5] / act_out int64 [rows]: buffers for the Q-values and greedy actions."""
         dev = obs_all.device
         if not (self.FUSED_RECURRENCE and self.FUSED_INFERENCE and dev.type == "cuda" and all(lv[1] <= RECUR_MAX_AGENTS for lv in levels)):
             outs, off = [], 0
@@ -511,13 +514,23 @@ class Network(nn.Module):
             w, b = self._packed_recur.get(self, inplace=packed_inplace)
             gi_all = mm_rows(latent, self.recurrent.weight_ih.detach().to(torch.bfloat16))
             hs, off = [], 0
-            for E, N, pos, hidden, comm in levels:
-                h0 = None if hidden is None else hidden.reshape(E, N, self.latent_dim)
-                out = None if hidden_out is None else hidden_out[off:off + E * N]
-                hs.append(recurrent_infer(gi_all[off:off + E * N].view(1, E, N, 768), h0, comm.unsqueeze(0), w, b, False, out=out)[0].view(E * N, self.latent_dim))
-                off += E * N
-            q_all = self.q_head(hidden_out if hidden_out is not None else (torch.cat(hs) if len(hs) > 1 else hs[0])).float()
-        act_all = q_all.argmax(-1)  # (one launch for all levels; the per-level results are views)
+            if merged is not None:
+                from .fused import recurrent_infer_multi
+
+                envtab, comm_all, hidden_all = merged
+                recurrent_infer_multi(gi_all, hidden_all, comm_all, w, b, envtab, hidden_out)
+                for E, N, pos, hidden, comm in levels:
+                    hs.append(hidden_out[off:off + E * N])
+                    off += E * N
+            else:
+                for E, N, pos, hidden, comm in levels:
+                    h0 = None if hidden is None else hidden.reshape(E, N, self.latent_dim)
+                    out = None if hidden_out is None else hidden_out[off:off + E * N]
+                    hs.append(recurrent_infer(gi_all[off:off + E * N].view(1, E, N, 768), h0, comm.unsqueeze(0), w, b, False, out=out)[0].view(E * N, self.latent_dim))
+                    off += E * N
+            q_all = self.q_head(hidden_out if hidden_out is not None else (torch.cat(hs) if len(hs) > 1 else hs[0]))
+            q_all = q_all.float() if q_out is None else q_out.copy_(q_all)
+        act_all = q_all.argmax(-1) if act_out is None else torch.argmax(q_all, dim=-1, out=act_out)  # (one launch for all levels; the per-level results are views)
         outs, off = [], 0
         for (E, N, pos, hidden, comm), h in zip(levels, hs):
             outs.append((act_all[off:off + E * N].view(E, N), q_all[off:off + E * N].view(E, N, 5), h, comm))

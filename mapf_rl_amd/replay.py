@@ -169,6 +169,17 @@ class GlobalBuffer:
             check(lib.mapf_replay_add_many(self._h, E, int(num_agents), S, _ptr(fin), _ptr(sizes), _ptr(dn), _ptr(obs_bits), _ptr(comm_bits),
                                            _ptr(act), _ptr(rew), _ptr(hid), _ptr(q), _stream(self.device)), "mapf_replay_add_many")
 
+    def add_finished_env(self, num_agents_env, finished, sizes, done, obs_bits, comm_bits, act, rew, hid, q):
+        """`add_finished` for environments of different agent counts (several curriculum levels, their local buffers back to back):
+        num_agents_env int32 [E] (include/mapf_replay.h: mapf_replay_add_many_env)."""
+        E, S = act.shape
+        assert obs_bits.shape == (E, S + 1, self.row_dwords) and comm_bits.shape[:2] == (E, S + 1) and q.shape == (E, S, 5)
+        assert sizes.dtype == torch.int64 and hid.shape == (E, S, 256) and num_agents_env.dtype == torch.int32 and num_agents_env.shape == (E,)
+        assert finished.dtype == torch.uint8 and done.dtype == torch.uint8
+        with self.lock:
+            check(lib.mapf_replay_add_many_env(self._h, E, _ptr(num_agents_env), S, _ptr(finished), _ptr(sizes), _ptr(done), _ptr(obs_bits),
+                                               _ptr(comm_bits), _ptr(act), _ptr(rew), _ptr(hid), _ptr(q), _stream(self.device)), "mapf_replay_add_many_env")
+
     def add(self, buffer_list):
         """reference signature (worker.py:71): list of LocalBuffer.finish() tuples
         (actor_id, num_agents, map_len, obs, act, rew, hid, td_errors, done, size, comm_mask)."""

@@ -12,8 +12,10 @@ from mapf_rl_amd.replay import GlobalBuffer
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 levels = [(4, 15), (3, 20), (2, 25), (6, 15), (5, 20), (1, 30), (4, 25)]  # the level set of profiles/r02_train_curriculum_5min.log's last interval
-for batched, reuse, merged, graph in ((True, True, True, True), (True, True, True, False), (True, True, False, False), (True, False, False, False),
-                                      (False, False, False, False)):
+MODES = ((True, True, True, True), (True, True, True, False), (True, True, False, False), (True, False, False, False), (False, False, False, False))
+if os.environ.get("MODES") == "graph":  # (profiling runs: the graph-replayed iteration only, last in the trace)
+    MODES = MODES[:1]
+for batched, reuse, merged, graph in MODES:
     CurriculumActors.BATCHED, VecActor.REUSE_LATENTS, CurriculumActors.MERGED, CurriculumActors.GRAPH = batched, reuse, merged, graph
     torch.manual_seed(0)
     net = Network().cuda().eval()
