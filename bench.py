@@ -432,7 +432,7 @@ def main():
             def timed_actor(tape, iters):
                 """ms per actor iteration + share of agent rows the encoder saw (an unchanged observation keeps its latent)."""
                 enc = 0
-                for _ in range(24):  # untimed: let the population of moving / standing agents settle under this policy
+                for _ in range(60):  # untimed: let the population of moving / standing agents settle under this policy (steady state: >= 50)
                     actor.step(actions_override=heuristic_actions(actor.obs, gen).long() if tape else None)
                 torch.cuda.synchronize()
                 t_ = time.perf_counter()
@@ -486,9 +486,11 @@ def main():
             reach = float(relevance(probe[7][:, :-2], probe[5]).float().mean())
             reach_min = reach_max = reach
             distinct = 1.0
+            rows_enc = rows_enc_min = rows_enc_max = None
             if learner._fused is not None:
                 pl = learner._fused._finish_plan(learner._fused.plan(probe))
                 distinct = pl["online"].urows / max(1, pl["online"].rows)
+                rows_enc = rows_enc_min = rows_enc_max = int(pl["online"].urows)  # the online encoder's batch of this rank's probe window
             # interleaved: the loop train.py runs (one update per actor iteration; the actor iteration on its own stream beside the
             # update, the replay ordered by the learner's two events -- train.py --overlap-actors, its default)
             astream = torch.cuda.Stream(device=dev)
@@ -522,9 +524,12 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dt_upd, dt_act, dt_train, dt_upd_all, dt_act_tape, dt_act_all = [float(v) for v in tt.tolist()]
                 # the pruned update's encoder batch is data-dependent, hence per rank: make the spread visible
-                rmm = torch.tensor([reach, -reach], dtype=torch.float64, device=dev)
+                re = float(rows_enc or 0)
+                rmm = torch.tensor([reach, -reach, re, -re], dtype=torch.float64, device=dev)
                 dist.all_reduce(rmm, op=dist.ReduceOp.MAX)
                 reach_max, reach_min = float(rmm[0]), -float(rmm[1])
+                if rows_enc is not None:  # (the time a rank reaches the collective follows its encoder batch)
+                    rows_enc_max, rows_enc_min = int(rmm[2]), int(-rmm[3])
             # the dominant kernel of the actor loop: the fused inference encoder (MFMA-bound), timed alone on the
             # actor's batch with HIP events on the launch stream
             obs_flat = actor.obs.reshape(E * N, 6, 9, 9)
@@ -544,6 +549,7 @@ def main():
                 "learner_reachable_fraction": reach, "learner_reachable_fraction_min": reach_min,
                 "learner_reachable_fraction_max": reach_max,
                 "learner_distinct_fraction": distinct,
+                "learner_rows_encoded": rows_enc, "learner_rows_encoded_min": rows_enc_min, "learner_rows_encoded_max": rows_enc_max,
                 "learner_note": "only agent 0's Q-value is learned from (reference model.py:248): an update encodes the observations that can "
                                 "reach it through the communication masks (learner_reachable_fraction of the window; same Q-values, "
                                 "tests/test_relevance_gpu.py), and of those only the DISTINCT ones (learner_distinct_fraction: an agent that "

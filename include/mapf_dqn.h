@@ -267,7 +267,8 @@ int mapf_plan_rows(int T, int B, int N, int Nc, const int16_t *order_dev, const 
                    void *stream);
 /*
  * Repeated observations (exact reuse: the encoder is a deterministic per-observation function).  mapf_obs_dup: dup u8 [T][B][N] = the
- * entry (in the target window's closure) carries the same 486 values as the same agent one step earlier; ucnt_online / ucnt_target
+ * FIRST step of the window at which the same agent carried the same 486 values (<= t; t itself for a new observation and for entries
+ * outside the target window's closure; compared value by value, a hash only preselects); ucnt_online / ucnt_target
  * int32 [B] (zeroed by mapf_plan_mark when given there) += the DISTINCT observations of either closure per window.  With dup_dev,
  * mapf_plan_rows numbers the distinct observations like the rows (duplicates skipped): umap int32 [rows] = the distinct row an entry
  * uses, row_src / obs_rows then hold the num_rows = sum(ucnt) DISTINCT observations only; row_tbp int32 [rows] (optional) =

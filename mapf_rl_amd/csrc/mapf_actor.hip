@@ -148,6 +148,10 @@ __global__ void __launch_bounds__(1024) actor_log_kernel(int E, const uint8_t *f
 // pair -- 80 k atomics on one address per call when most agents move, ~0.8 ms), and the packed rows have a 488-byte stride
 // (MAPF_ENC_PACKED_OBS_STRIDE) so that they are written with dword stores whatever the slot's parity (first version: 486-byte stride,
 // 2-byte stores).
+__global__ void zero_words_kernel(uint32_t *p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+}
+
 constexpr int CH_PAIRS = 8;
 __global__ void __launch_bounds__(256) obs_changed_kernel(const uint32_t *__restrict__ obs, uint32_t *__restrict__ prev, long long rows,
                                                           int32_t *__restrict__ list, int32_t *__restrict__ count, uint32_t *__restrict__ packed) {
@@ -437,7 +441,9 @@ int mapf_obs_changed(const uint8_t *obs_dev, uint8_t *prev_dev, int64_t rows, in
         return MAPF_ERR_INVALID_ARG;
     if (rows == 0) return MAPF_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(count_dev, 0, 4, s) != hipSuccess) return MAPF_ERR_HIP;
+    // (a kernel, not hipMemsetAsync: this call is captured into the actors' HIP graph, and on this runtime a graph that holds a memset
+    // node faulted at a later replay once the learner's own launches had run in between -- tools/micro/graph_gemm_probe.py)
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<uint32_t *>(count_dev), 1);
     long long blocks = (((rows + 1) / 2 + CH_PAIRS - 1) / CH_PAIRS + 3) / 4;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(obs_changed_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(obs_dev),

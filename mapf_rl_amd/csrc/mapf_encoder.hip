@@ -215,10 +215,16 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
     unsigned char *const act = smem;
     const InT *const raw = reinterpret_cast<const InT *>(smem + ACT_BYTES);
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid_o = threadIdx.x;
+  for (long long wg = blockIdx.x;; wg += gridDim.x) {  // (one pass unless IDX)
+    // IDX: the thread index goes through an opaque move at the top of every walk step: everything per-lane below (tile addresses,
+    // masks, staging offsets) is otherwise loop-invariant, gets hoisted in front of the walk and spilled (80 bytes of scratch per
+    // lane until round 4)
+    int tid = tid_o;
+    if constexpr (IDX) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, w = tid >> 6;
     const int cb = w;
     const int lr = lane & 15, lh = lane >> 4;
-  for (long long wg = blockIdx.x;; wg += gridDim.x) {  // (one pass unless IDX)
     // IDX: an opaque zero (the row count is never negative) added to the weight / bias bases -- otherwise every layer's per-lane
     // weight address is loop-invariant, gets hoisted in front of the walk and spilled (44 registers in scratch)
     int z = 0;
@@ -475,6 +481,10 @@ __device__ __forceinline__ float grad_scale_from_max(uint32_t max_bits) {
     k = k < -24 ? -24 : (k > 60 ? 60 : k);
     return __uint_as_float((uint32_t)(k + 127) << 23);
 }
+__global__ void zero_scale_kernel(uint32_t *p) {
+    if (threadIdx.x < 2) p[threadIdx.x] = 0u;
+}
+
 __global__ void __launch_bounds__(256) grad_absmax_kernel(const uint4 *__restrict__ g, long long chunks, uint32_t *__restrict__ out) {
     uint32_t m = 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long long)gridDim.x * 256) {
@@ -848,7 +858,8 @@ int mapf_encoder_backward(const uint16_t *g_latent_dev, const uint16_t *latent_d
     hipStream_t st = static_cast<hipStream_t>(stream);
     // the loss scale: largest |g_latent| -> grad_scale_dev[0]; the chain below derives the power of two from it and leaves its
     // inverse in grad_scale_dev[1] for the weight-gradient kernels
-    HIP_TRY(hipMemsetAsync(grad_scale_dev, 0, 8, st));
+    // (a kernel, not hipMemsetAsync: this call is captured into the update's HIP graphs; see mapf_obs_changed in csrc/mapf_actor.hip)
+    hipLaunchKernelGGL(zero_scale_kernel, dim3(1), dim3(64), 0, st, grad_scale_dev);
     const long long chunks = M * 98;  // 784 bf16 = 98 x 16 bytes per observation
     hipLaunchKernelGGL(grad_absmax_kernel, dim3((unsigned)(chunks < 256 * 1024 ? (chunks + 255) / 256 : 1024)), dim3(256), 0, st,
                        reinterpret_cast<const uint4 *>(g_latent_dev), chunks, grad_scale_dev);

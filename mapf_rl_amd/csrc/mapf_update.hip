@@ -111,11 +111,12 @@ __global__ void __launch_bounds__(128) plan_mark_kernel(PlanMarkArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// obs_dup: an agent that stands still in an unchanged neighbourhood has the SAME observation at consecutive steps of a window, and
-// the encoder is a deterministic per-observation function: 34-37 % of the rows a batch would encode repeat the row of the same
-// agent one step earlier (tools/obs_reuse_probe.py).  One wavefront per (step >= 1, window, agent) entry that is needed (in the
-// target window's closure, a superset of the online window's): dup = the 486 values equal the previous step's; the distinct
-// observations of every window are counted for both closures.
+// obs_dup: an agent that stands still in an unchanged neighbourhood -- or comes back to a cell whose neighbourhood looks the same -- has
+// the SAME observation at several steps of a window, and the encoder is a deterministic per-observation function: 37 % of the rows a
+// batch would encode repeat an EARLIER row of the same agent in the same window (26 % the row one step earlier, which is all round 3
+// reused; tools/dup_probe.py).  One wavefront per (window, agent): a 64-bit hash of every needed step's 486 values (one read of the
+// row), then per step the first earlier step with the same hash, confirmed value by value (exact, not probabilistic):
+// first[t][b][j] = that step, or t itself.  The distinct observations of every window are counted for both closures.
 // ---------------------------------------------------------------------------------------------------------------------------
 struct ObsDupArgs {
     int T, To, B, N;  // target window steps, online window steps
@@ -123,32 +124,61 @@ struct ObsDupArgs {
     long long o_sB, o_sT;
     const int16_t *slot_o, *slot_t;  // [B][N]
     const int32_t *nact_o, *nact_t;  // [To][B], [T][B]
-    uint8_t *dup;                    // [T][B][N]
+    uint8_t *dup;                    // [T][B][N]: the first step of the window at which this agent saw the same observation (<= t)
     int32_t *ucnt_o, *ucnt_t;        // [B]
 };
 
+__device__ __forceinline__ unsigned long long mix64u(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
 __global__ void __launch_bounds__(256) obs_dup_kernel(ObsDupArgs p) {
-    const int lane = threadIdx.x & 63;
-    const long long total = (long long)p.T * p.B * p.N;
-    for (long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); w < total; w += (long long)gridDim.x * 4) {
-        const int j = (int)(w % p.N), b = (int)((w / p.N) % p.B), t = (int)(w / ((long long)p.N * p.B));
-        const int st = p.slot_t[(size_t)b * p.N + j];
-        const bool in_t = st >= 0 && st < p.nact_t[(size_t)t * p.B + b];
-        bool same = false;
-        if (in_t && t > 0) {  // (wave-uniform)
-            const uint32_t *cur = reinterpret_cast<const uint32_t *>(p.obs + (long long)b * p.o_sB + (long long)t * p.o_sT + (long long)j * 486);
-            const uint32_t *prv = reinterpret_cast<const uint32_t *>(p.obs + (long long)b * p.o_sB + (long long)(t - 1) * p.o_sT + (long long)j * 486);
-            bool diff = false;
-            for (int d = lane; d < 243; d += 64) diff |= cur[d] != prv[d];
-            same = __ballot(diff) == 0ull;
+    __shared__ unsigned long long s_hash[4][MAPF_PLAN_MAX_STEPS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long total = (long long)p.B * p.N;
+    for (long long w = (long long)blockIdx.x * 4 + wv; w < total; w += (long long)gridDim.x * 4) {
+        const int j = (int)(w % p.N), b = (int)(w / p.N);
+        const int st = p.slot_t[(size_t)b * p.N + j], so = p.slot_o[(size_t)b * p.N + j];
+        // the steps at which this agent is needed form a prefix 0 .. nt - 1 (the needed set only shrinks going forward)
+        int nt = 0, no = 0;
+        for (int t = 0; t < p.T; ++t) nt += (st >= 0 && st < p.nact_t[(size_t)t * p.B + b]) ? 1 : 0;
+        for (int t = 0; t < p.To; ++t) no += (so >= 0 && so < p.nact_o[(size_t)t * p.B + b]) ? 1 : 0;
+        const uint16_t *base = p.obs + (long long)b * p.o_sB + (long long)j * 486;
+        for (int t = 0; t < nt; ++t) {  // (wave-uniform trip count)
+            const uint32_t *row = reinterpret_cast<const uint32_t *>(base + (long long)t * p.o_sT);
+            unsigned long long h = 0;
+            for (int d = lane; d < 243; d += 64) h += mix64u(((unsigned long long)row[d] << 8) ^ (unsigned long long)d);
+#pragma unroll
+            for (int s2 = 32; s2 > 0; s2 >>= 1) h += __shfl_xor(h, s2, 64);
+            if (lane == 0) s_hash[wv][t] = h;
+        }
+        int distinct_t = 0, distinct_o = 0;
+        for (int t = 0; t < p.T; ++t) {
+            int first = t;
+            if (t < nt) {
+                const unsigned long long h = s_hash[wv][t];
+                for (int t0 = 0; t0 < t; ++t0) {
+                    if (s_hash[wv][t0] != h) continue;
+                    const uint32_t *cur = reinterpret_cast<const uint32_t *>(base + (long long)t * p.o_sT);
+                    const uint32_t *old = reinterpret_cast<const uint32_t *>(base + (long long)t0 * p.o_sT);
+                    bool diff = false;
+                    for (int d = lane; d < 243; d += 64) diff |= cur[d] != old[d];
+                    if (__ballot(diff) == 0ull) {
+                        first = t0;
+                        break;
+                    }
+                }
+                distinct_t += first == t;
+                distinct_o += (first == t && t < no);
+            }
+            if (lane == 0) p.dup[((size_t)t * p.B + b) * p.N + j] = (uint8_t)first;
         }
         if (lane == 0) {
-            p.dup[w] = (uint8_t)same;
-            if (in_t && !same) {
-                atomicAdd(&p.ucnt_t[b], 1);
-                const int so = p.slot_o[(size_t)b * p.N + j];
-                if (t < p.To && so >= 0 && so < p.nact_o[(size_t)t * p.B + b]) atomicAdd(&p.ucnt_o[b], 1);
-            }
+            if (distinct_t) atomicAdd(&p.ucnt_t[b], distinct_t);
+            if (distinct_o) atomicAdd(&p.ucnt_o[b], distinct_o);
         }
     }
 }
@@ -261,8 +291,9 @@ __global__ void __launch_bounds__(256) plan_rows_kernel(PlanRowsArgs p) {
             }
         return;
     }
-    // distinct observations: position i keeps the id of its current run; a new run starts where the observation changed
-    __shared__ int s_uid[128], s_flag[128];
+    // distinct observations: position i remembers the id its observation got at every step; an entry whose observation first appeared at
+    // an earlier step t0 (dup[t] = t0 < t) takes the id of (t0, i)
+    __shared__ int s_uid[128][MAPF_PLAN_MAX_STEPS + 1], s_flag[128];
     int upart = 0;
     for (int k = tid; k < b; k += 256) upart += p.ucnt[k];
     s_red[tid] = upart;
@@ -274,16 +305,22 @@ __global__ void __launch_bounds__(256) plan_rows_kernel(PlanRowsArgs p) {
     int next = s_red[0];  // first distinct row of this window (identical in every thread)
     for (int t = 0; t < T; ++t) {
         const int na = s_nact[t];
-        if (tid < 128) s_flag[tid] = (tid < na) && !(t > 0 && p.dup[((size_t)t * B + b) * N + s_ord[tid]] != 0);
+        int t0 = t;
+        if (tid < na) t0 = p.dup[((size_t)t * B + b) * N + s_ord[tid]];
+        if (tid < 128) s_flag[tid] = (tid < na) && t0 >= t;
         __syncthreads();
         if (tid < na) {
             if (s_flag[tid]) {
                 int before = 0;
                 for (int k = 0; k < tid; ++k) before += s_flag[k];
-                s_uid[tid] = next + before;
+                s_uid[tid][t] = next + before;
                 p.row_src[next + before] = (long long)b * p.o_sB + (long long)t * p.o_sT + (long long)s_ord[tid] * 486;
+            } else {
+                s_uid[tid][t] = s_uid[tid][t0];
             }
-            p.umap[offset + s_base[t] + tid] = s_uid[tid];
+            p.umap[offset + s_base[t] + tid] = s_uid[tid][t];
+            // (row_tbp was written above without the flag: an entry that reuses an earlier row is not the head of its id)
+            if (p.row_tbp && !s_flag[tid]) p.row_tbp[offset + s_base[t] + tid] |= 1 << 30;
         }
         int tot = 0;
         for (int k = 0; k < na; ++k) tot += s_flag[k];
@@ -293,8 +330,8 @@ __global__ void __launch_bounds__(256) plan_rows_kernel(PlanRowsArgs p) {
 }
 
 // d_u[u][:] = sum over the entries r with umap[r] == u of d_rows[r][:] (fp32 sum, one bf16 rounding): the gradient of a distinct
-// observation's row is the sum over the run of consecutive steps that share it.  One wavefront per row; the run's FIRST entry does
-// the sum, walking forward through gidx (the same position at later steps), the others return.
+// observation's row is the sum over the steps of the same (window, agent) that share it.  One wavefront per row; the id's FIRST entry
+// (row_tbp bit 30 clear) does the sum, walking forward through gidx (the same position at later steps), the others return.
 struct DedupSumArgs {
     int T, B, Nc, W8;  // W8: row width in 8-element (16-byte) chunks
     long long rows;
@@ -309,8 +346,8 @@ __global__ void __launch_bounds__(256) dedup_sum_kernel(DedupSumArgs p) {
     for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < p.rows; r += (long long)gridDim.x * 4) {
         const int tbp = p.row_tbp[r];
         if (tbp < 0) continue;  // (a padding entry of a bucket-sized launch: the caller filled row_tbp with -1 behind the real rows)
+        if (tbp & (1 << 30)) continue;  // an entry that reuses the row of an earlier step: the head of the id does the sum
         const int t = tbp >> 24, pos = (tbp >> 16) & 255, b = tbp & 0xFFFF, u = p.umap[r];
-        if (t > 0 && p.umap[p.gidx[((size_t)(t - 1) * p.B + b) * p.Nc + pos]] == u) continue;  // not the head of its run
         for (int c = lane; c < p.W8; c += 64) {
             float acc[8];
             {
@@ -322,9 +359,10 @@ __global__ void __launch_bounds__(256) dedup_sum_kernel(DedupSumArgs p) {
                     acc[2 * k + 1] = bf16_to_f32(w[k] >> 16);
                 }
             }
-            for (int t2 = t + 1; t2 < p.T; ++t2) {
+            for (int t2 = t + 1; t2 < p.T; ++t2) {  // every later step of the same position that carries the same id (in step order: fixed sum order)
                 const int r2 = p.gidx[((size_t)t2 * p.B + b) * p.Nc + pos];
-                if (r2 < 0 || p.umap[r2] != u) break;
+                if (r2 < 0) break;  // (the needed set only shrinks going forward)
+                if (p.umap[r2] != u) continue;
                 const uint4 v = p.d_rows[(long long)r2 * p.W8 + c];
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -431,13 +469,24 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(HeadArgs p) {
         dueling(d_o2, p.b_adv, p.b_st, q_o2);
         // worker.py:300-303: max_a Q_target; double-DQN: the ONLINE network picks (first maximum, as torch.argmax)
         int pick = 0;
+        float best = p.a0_on2 ? q_o2[0] : q_tg[0];
+#pragma unroll
         for (int k = 1; k < 5; ++k) {
-            const float cur = p.a0_on2 ? q_o2[k] : q_tg[k], best = p.a0_on2 ? q_o2[pick] : q_tg[pick];
-            if (cur > best) pick = k;
+            const float cur = p.a0_on2 ? q_o2[k] : q_tg[k];
+            if (cur > best) {
+                pick = k;
+                best = cur;
+            }
         }
-        const float qn = (1.f - p.done[b]) * q_tg[pick];
+        // (selects, not q[pick] / q[act]: a dynamically indexed local array lives in scratch memory)
+        float q_pick = q_tg[0];
+#pragma unroll
+        for (int k = 1; k < 5; ++k) q_pick = pick == k ? q_tg[k] : q_pick;
+        const float qn = (1.f - p.done[b]) * q_pick;
         const int act = (int)p.action[b];
-        const float qa = q_on[act];
+        float qa = q_on[0];
+#pragma unroll
+        for (int k = 1; k < 5; ++k) qa = act == k ? q_on[k] : qa;
         const float td = qa - (p.reward[b] + powf(p.gamma, p.steps[b]) * qn);  // worker.py:306
         const float a = fabsf(td), wgt = p.weights[b];
         const float hub = a < 1.f ? 0.5f * a * a : a - 0.5f;  // worker.py:341-344, kappa = 1
@@ -881,7 +930,7 @@ int mapf_obs_dup(int T, int To, int B, int N, const uint16_t *obs_bf16_dev, int6
     if (B == 0) return MAPF_OK;
     ObsDupArgs p{T, To, B, N, obs_bf16_dev, obs_stride_b, obs_stride_t, slot_online_dev, slot_target_dev, nact_online_dev, nact_target_dev, dup_dev,
                  ucnt_online_dev, ucnt_target_dev};
-    long long blocks = ((long long)T * B * N + 3) / 4;
+    long long blocks = ((long long)B * N + 3) / 4;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(obs_dup_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     HIP_TRY(hipGetLastError());

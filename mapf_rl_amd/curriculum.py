@@ -14,6 +14,8 @@ The reference's 16 actors each draw a random level per episode.  Here every acti
 into ONE device replay whose rows are laid out for `config.max_num_agetns` agents (smaller levels are a zero-padded
 prefix of the row, see actor.py).  `sync_levels()` follows the level table after every `stats()` call: levels that
 appeared get actors, levels that were promoted away are retired."""
+import os
+
 import torch
 
 from .actor import VecActor
@@ -102,8 +104,9 @@ class CurriculumActors:
     refreshed every that many iterations; None = on `model` itself."""
 
     BATCHED = True
-    MERGED = True   # the levels' environment step / reset / re-observation as one launch each (environment.MultiEnvironment)
-    GRAPH = True    # ... and the whole iteration replayed from a captured HIP graph
+    # (the environment variables: A/B and diagnostic runs of train.py)
+    MERGED = os.environ.get("MAPF_ACTOR_MERGED", "1") != "0"   # every per-level launch of an iteration merged over all levels (`_iteration`)
+    GRAPH = os.environ.get("MAPF_ACTOR_GRAPH", "1") != "0"     # ... and the whole iteration replayed from a captured HIP graph
     PACK_RECURRENCE = True  # 16 // N environments of a level per workgroup of the policy recurrence (the weight stream is shared)
 
     def __init__(self, model, buffer, envs_per_level=256, device=None, seed=0, max_steps=256, reward_fn=None, weights_period=None):
@@ -282,7 +285,7 @@ class CurriculumActors:
         self.multi.observe_masked()
         check(lib.mapf_actor_rewind_multi(Et, a0.max_steps, a0.RDA, _ptr(self.envtab), _ptr(c["finished"]), _ptr(c["bits"]), _ptr(c["t"]), _ptr(c["lb_obs"]),
                                           _ptr(self.hidden_new), st), "mapf_actor_rewind_multi")
-        self.hidden_all.copy_(self.hidden_new)
+        torch.mul(self.hidden_new, 1, out=self.hidden_all)   # (an element-wise kernel rather than a memcpy node of the captured graph)
         self.tick.add_(1)
 
     def _iteration_per_level(self):

@@ -68,24 +68,58 @@ class FlatGradBucket:
             yield self._view_like(self.flat[off:off + p.numel()], p)
             off += p.numel()
 
-    def all_reduce_mean(self, group=None):
+    # ---- the data-parallel exchange: ONE buffer, reduced in (up to) two pieces ----
+    # The encoder's gradients (the first `split` elements in both layouts: module order and update.PARAM_ORDER start with
+    # obs_encoder.*; 88 % of the bytes) are the LAST thing a backward pass produces; recurrence + head (12 %) are final before the
+    # encoder's backward chain starts.  `begin(lo, hi)` issues the asynchronous all-reduce of flat[lo:hi] (on the backend's own
+    # stream, behind what the current stream has queued), `finish()` waits for the pieces and divides by the world size -- the
+    # fused update calls begin(split, n) in front of the encoder backward (update.FusedUpdate._backward), the autograd path reduces
+    # the same two pieces back to back.  Nothing happens on one rank.
+    split = None       # element index where the encoder's gradients end (None: one piece)
+    pieces = 0         # collectives issued by the last exchange (tests)
+    _pending = ()
+
+    def _world(self, group=None):
         import torch.distributed as dist
 
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.div_(dist.get_world_size(group))
+        return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def begin(self, lo, hi, group=None):
+        import torch.distributed as dist
+
+        if self._world(group) > 1 and hi > lo:
+            self._pending = tuple(self._pending) + (dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True),)
+
+    def finish(self, group=None):
+        w = self._world(group)
+        self.pieces = len(self._pending)
+        for work in self._pending:
+            work.wait()
+        self._pending = ()
+        if w > 1:
+            self.flat.div_(w)
+
+    def all_reduce_mean(self, group=None):
+        n = self.flat.numel()
+        if self._world(group) > 1:
+            k = self.split if (self.split is not None and 0 < self.split < n) else n
+            if k < n:
+                self.begin(k, n, group)
+            self.begin(0, k, group)
+        self.finish(group)
 
 
 class _FlatView:
     """FlatGradBucket's interface over a gradient buffer that already is flat (update.FlatParams.grads)."""
 
-    def __init__(self, flat):
-        self.flat = flat
+    def __init__(self, flat, split=None):
+        self.flat, self.split = flat, split
 
     def zero(self):
         self.flat.zero_()
 
-    all_reduce_mean = FlatGradBucket.all_reduce_mean
+    pieces, _pending = 0, ()
+    _world, begin, finish, all_reduce_mean = FlatGradBucket._world, FlatGradBucket.begin, FlatGradBucket.finish, FlatGradBucket.all_reduce_mean
 
 
 class Learner:
@@ -109,12 +143,13 @@ class Learner:
 
             # parameters, gradients and Adam moments as flat buffers; clip + Adam (worker.py:260,319-322) are one kernel pair there
             self._fused = FusedUpdate(self)
-            self.bucket = _FlatView(self._fused.flat.grads)
+            self.bucket = _FlatView(self._fused.flat.grads, split=self._fused.flat.offsets["recurrent.weight_ih"])
             self.optimizer = self.scheduler = None
         else:
             self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr)                       # worker.py:260
             self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=list(milestones), gamma=0.5)  # :261
             self.bucket = FlatGradBucket(self.model.parameters())
+            self.bucket.split = sum(p.numel() for p in self.model.obs_encoder.parameters() if p.requires_grad)
         self.buffer, self.batch_size, self.save_path = buffer, batch_size, save_path
         # config.double_q (config.py:46) is dead in the reference (quirk Q6: worker.py:300-303 always takes max_a Q_target).
         # Opt-in here for BASELINE config 5 ("prioritized replay + double-DQN"): the ONLINE network picks the action, the
@@ -236,9 +271,21 @@ class Learner:
             return out
         if isinstance(plan, dict):
             plan = None
-        if self.optimizer is None:  # a batch outside the fused kernels' limits on a Learner that was built for them
-            self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.base_lr)
-            self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, milestones=list(self.milestones), gamma=0.5)
+        fallback = self._fused is not None  # a batch outside the fused kernels' limits on a Learner that was built for them
+        if fallback:
+            # ONE optimizer state whichever path takes a step: torch's Adam runs on the flat buffers' own moment tensors (views), at
+            # the step count and learning rate the fused path is at, and the count moves on afterwards
+            flat = self._fused.flat
+            flat.sync()
+            if self.optimizer is None:
+                self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.base_lr)
+                for name, p in zip(flat.names, flat._plist):
+                    self.optimizer.state[p] = dict(step=torch.tensor(float(flat.step)), exp_avg=flat._as_param(flat.exp_avg, name),
+                                                   exp_avg_sq=flat._as_param(flat.exp_avg_sq, name))
+            for p in flat._plist:
+                self.optimizer.state[p]["step"].fill_(float(flat.step))
+            for g in self.optimizer.param_groups:
+                g["lr"] = self.current_lr()
         q_next = None
         rows_o = None
         if own_batch and self.prefetch:
@@ -285,7 +332,12 @@ class Learner:
             self.grad_hook(self)
         grad_norm = nn.utils.clip_grad_norm_(self.model.parameters(), GRAD_CLIP)                 # worker.py:319
         self.optimizer.step()
-        self.scheduler.step()
+        if fallback:
+            self._fused.flat.step = self._fused.flat.step + 1
+            self._fused.flat.refresh_bf16()
+            self.model.weights_epoch += 1
+        else:
+            self.scheduler.step()
         self.counter += 1
         self._last = (loss.detach(), grad_norm.detach())
         if self.counter % TARGET_SYNC == 0:                                                      # worker.py:336-338

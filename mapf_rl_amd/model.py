@@ -35,6 +35,9 @@ RECUR_NARROW_AGENTS = 48  # the one-workgroup-per-environment kernels (csrc/mapf
 BPTT_MAX_AGENTS = 128
 
 
+Q_HEAD_ROW_CHUNK = 32768  # rows per Q-head GEMM on a HIP device (see Network.q_head)
+
+
 class ResBlock(nn.Module):
     """Two 3x3 pad-1 convolutions with an identity skip, no normalisation (reference model.py:7-42, type='cnn')."""
 
@@ -445,6 +448,10 @@ class Network(nn.Module):
         self._packed_recur.get(self)
 
     def q_head(self, hidden):
+        if hidden.is_cuda and hidden.dim() == 2 and hidden.shape[0] > Q_HEAD_ROW_CHUNK:
+            # tall GEMMs (beyond ~10^5 rows: 4096 x 40 actor rows) make hipBLASLt pick stream-K kernels, whose workgroups spin on peers
+            # that may not be resident next to another stream's work (fused.mm_rows; the actors run beside the update): row chunks
+            return torch.cat([self.q_head(h) for h in hidden.split(Q_HEAD_ROW_CHUNK)])
         adv = self.adv(hidden)
         return self.state(hidden) + adv - adv.mean(-1, keepdim=True)  # model.py:218,262
 

@@ -21,6 +21,7 @@ Parameters, gradients and Adam moments live in flat fp32 buffers (`FlatParams`):
 `state_dict()` / `load_state_dict()` / checkpoints are unaffected, and the data-parallel all-reduce is one collective over one buffer."""
 import contextlib
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -225,7 +226,7 @@ class FusedUpdate:
     # consumer of a tensor a later capture placed there.  Hence three pools: "main" (pack, online, backward: the saved tensors of an
     # online graph live until its backward graph has run, and only `head` runs in between), "head", and "side" (target, prefetch:
     # nothing of theirs outlives its graph; their results land in buffers allocated outside any capture).
-    GRAPH = True
+    GRAPH = os.environ.get("MAPF_UPDATE_GRAPH", "1") != "0"   # (the variable: A/B runs of train.py)
     GRAPH_MAX_AGENTS = 16       # replay rows wider than this are GPU-bound (no gain) and would need many more buckets
     GRAPH_ROW_STEP = 2048       # bucket of the entry count (== WGRAD_SPLIT: the weight-gradient GEMMs' K is padded to it anyway)
     GRAPH_UROW_STEP = 1024      # bucket of the distinct-observation count (the encoder kernels' batch)
@@ -391,11 +392,19 @@ class FusedUpdate:
         p.umap = rows_buffer((), max(p.rows, 1), (), torch.int32, dev) if p.dup is not None else None
         p.row_tbp = rows_buffer((), max(p.rows, 1), (), torch.int32, dev) if p.dup is not None else None
         if padded:
-            row_src.zero_()
+            # (fill kernels, not zero_() / torch.zeros: those are hipMemsetAsync calls, i.e. memset NODES of the captured graph -- and on
+            # this runtime a graph holding a (small) memset node faulted at a later replay once other memsets had been issued in
+            # between; see mapf_obs_changed in csrc/mapf_actor.hip.  Nothing that is captured calls hipMemsetAsync.)
+            row_src.fill_(0)
             if p.umap is not None:
-                p.umap.zero_()
+                p.umap.fill_(0)
                 p.row_tbp.fill_(-1)
         cm, obs, hid = v["comm"], v["obs"], v["hidden"]
+        if os.environ.get("MAPF_DEBUG_PLAN"):
+            torch.cuda.synchronize()
+            print("plan_rows: T %d B %d N %d Nc %d rows %d urows %d padded %s | cnt sum %d nag max %d ucnt sum %d nact max %d | order range %d..%d | obs %s %s | hid %s | cm %s %s dup %s" % (
+                T, B, N, Nc, p.rows, p.urows, padded, int(p.cnt.sum()), int(p.nag.max()), int(p.ucnt.sum()), int(p.nact.max()), int(p.order.min()), int(p.order.max()),
+                tuple(obs.shape), obs.stride(), tuple(hid.shape), tuple(cm.shape), cm.stride(), None if p.dup is None else (tuple(p.dup.shape), int(p.dup.max()))), flush=True)
         check(lib.mapf_plan_rows(T, B, N, Nc, _ptr(p.order), _ptr(p.nact), _ptr(p.cnt), _ptr(p.nag), _ptr(cm), cm.stride(0), cm.stride(1),
                                  _ptr(hid), int(hid.dtype == torch.bfloat16), _ptr(obs), obs.stride(0), obs.stride(1), _ptr(p.gidx),
                                  _ptr(p.comm_c), _ptr(p.h0_c), p.urows, _ptr(row_src), _ptr(p.obs_rows), _ptr(p.dup), _ptr(p.ucnt), _ptr(p.umap),
@@ -512,7 +521,7 @@ class FusedUpdate:
         if c.padded:
             # one allocation for everything the tall GEMMs read, one memset: [saves 0, 2, 4, 5 | outputs of the backward 0..5]
             widths = [256, 2 * 256, 2 * 128, 2 * 64, 768, 768, 2 * 768, 2 * 768, 2 * 64, 2 * 384]
-            zero = torch.zeros(R * sum(widths), dtype=bf, device=dev)
+            zero = torch.empty(R * sum(widths), dtype=bf, device=dev).fill_(0)  # (a fill kernel, not a memset node: see _plan_rows)
             parts, off = [], 0
             for w in widths:
                 parts.append(zero[off:off + R * w])
@@ -536,7 +545,7 @@ class FusedUpdate:
         """Dueling heads, TD error, priorities, loss and their gradients; then the priority write-back."""
         lr, dev, flat = self.lr, self.dev, self.flat
         tar, G, B = lr.tar_model, flat.grads, v["B"]
-        flat.grads.zero_()
+        flat.grads.fill_(0)  # (a fill kernel, not a memset node: see _plan_rows)
         c.outs = self._out(c, "outs", (3, B), torch.float32)  # q, q_next, td
         c.prio = self._out(c, "prio", (B,), torch.float64)
         c.loss = self._out(c, "loss", (1,), torch.float32)
@@ -610,18 +619,28 @@ class FusedUpdate:
         if po.umap is not None:  # gradient of a shared row = the sum over the entries that use it
             d_gi_u = rows_buffer((), Mu, (768,), bf, dev)
             if c.padded:
-                d_gi_u.zero_()  # (distinct rows behind the real ones have no entry: their gradient must read zero)
+                d_gi_u.fill_(0)  # (distinct rows behind the real ones have no entry: their gradient must read zero)
             check(lib.mapf_dedup_sum(To, B, Nc, M, 1536, _ptr(po.gidx), _ptr(po.umap), _ptr(po.row_tbp), _ptr(d_gi_rows), _ptr(d_gi_u), st),
                   "mapf_dedup_sum")
             d_gi_rows = d_gi_u
         g_lat = mm_rows(d_gi_rows, c.w_ih, transpose_w=False)
         _tall_tn_into(flat.mem(G, "recurrent.weight_ih"), d_gi_rows, c.lat, rows=4096)
+        # the recurrence's and the head's gradients are final: their piece of the exchange (12 % of the bytes) travels while the
+        # encoder's backward chain runs (several ranks only; learner.FlatGradBucket.begin)
+        n_all, split = flat.grads.numel(), lr.bucket.split
+        two_pieces = split is not None and 0 < split < n_all and lr.grad_hook is None and aux is None
+        if two_pieces:
+            lr.bucket.begin(split, n_all)
         # ---- encoder: backward-data chain in one kernel, then the weight-gradient kernels ----
         self._encoder_backward(po.obs_rows, Mu, c.acts, c.lat, c.bits, g_lat, c.wpt)
         if aux is not None:
             cur_s.wait_stream(aux)
-        # ---- the only collective, clip, Adam ----
-        lr.bucket.all_reduce_mean()
+        # ---- the exchange (its second piece: the encoder's gradients), clip, Adam ----
+        if two_pieces:
+            lr.bucket.begin(0, split)
+            lr.bucket.finish()
+        else:
+            lr.bucket.all_reduce_mean()
         if lr.grad_hook is not None:
             lr.grad_hook(lr)
         return flat.adam_step(lr_value)
@@ -861,7 +880,7 @@ class FusedUpdate:
                  "obs_encoder.4.block1", "obs_encoder.4.block2", "obs_encoder.5"]
         # bias gradients: the kernel's per-workgroup partials, summed in two stages (see fused._EncoderTrain.backward)
         pad = (-nblk) % 256
-        gp = gb_part if pad == 0 else torch.cat([gb_part, gb_part.new_zeros((7, pad, 128))], dim=1)
+        gp = gb_part if pad == 0 else torch.cat([gb_part, gb_part.new_empty((7, pad, 128)).fill_(0)], dim=1)
         torch.sum(gp.view(7, -1, 256, 128).sum(dim=2), dim=1, out=flat.span(G, names[0] + ".bias", names[6] + ".bias").view(7, 128))
         torch.sum(gb7_part, dim=0, out=flat.mem(G, names[7] + ".bias"))
         ws = torch.empty((ENC_WGRAD_PARTS, 128, 3, 3, 128), dtype=torch.float32, device=dev)

@@ -97,3 +97,44 @@ def test_level_batched_step_equals_serial_steps(mode):
         assert ra[k]["eps"] == rb[k]["eps"] and ra[k]["eps"] >= 32 and ra[k]["steps"] == rb[k]["steps"] == 30 * 32
         assert torch.allclose(ra[k]["q"], rb[k]["q"], rtol=2e-2, atol=2e-2) and torch.allclose(ra[k]["hid"].float(), rb[k]["hid"].float(), rtol=2e-2, atol=2e-2)
     assert torch.allclose(ta, tb, rtol=1e-2, atol=1e-6)  # priorities are |td| of those Q-values
+
+
+@pytest.mark.parametrize("update_graph", [False, True])
+def test_graph_replayed_actor_iterations_interleaved_with_learner_updates(update_graph):
+    """train.py's loop in small: the curriculum actors' iteration replayed from its HIP graph, learner updates in between (issued
+    directly, or replayed from the update's own graphs).  Regression for a runtime limit found in round 4: a captured graph that
+    holds a small hipMemsetAsync NODE (mapf_obs_changed zeroed its 4-byte row counter that way) faulted at a later replay once the
+    learner's launches -- which issue hipMemsetAsync themselves -- had run in between (tools/micro/graph_gemm_probe.py).  Nothing
+    that can be captured calls hipMemsetAsync any more (tiny kernels / fill kernels instead)."""
+    import config
+    from mapf_rl_amd.curriculum import CurriculumActors
+    from mapf_rl_amd.learner import Learner
+    from mapf_rl_amd.replay import GlobalBuffer
+    from mapf_rl_amd.update import FusedUpdate
+
+    saved, FusedUpdate.GRAPH = FusedUpdate.GRAPH, update_graph
+    try:
+        torch.manual_seed(0)
+        levels = [(1, 10), (3, 15), (6, 20)]
+        buf = GlobalBuffer(2048, max_agents=6, init_set=(1, 10), max_map_length=40, pass_rate=0.9)
+        buf.stat_dict = {k: [] for k in levels}
+        lr = Learner(buf, device="cuda", batch_size=64)
+        cur = CurriculumActors(lr.model, buf, envs_per_level=128, seed=0, max_steps=24, reward_fn=config.reward_fn, weights_period=40)
+        for _ in range(60):
+            cur.step()
+        assert cur.graph_replays >= 55 and len(buf) >= 64 * 18
+        for rnd in range(30):
+            for _ in range(2):
+                out = lr.update()
+            for _ in range(5):
+                cur.step()
+        torch.cuda.synchronize()
+        for a in cur.actors.values():
+            a.env.check_status()
+        assert bool(torch.isfinite(out["loss"])) and lr.counter == 60
+        assert lr._fused.graph_replays == (60 if update_graph else 0)
+        tree = buf.priority_tree.tree()
+        leaves = tree[-buf.priority_tree.capacity:]
+        assert abs(float(tree[0]) - float(leaves.sum())) < 1e-6 * float(tree[0])
+    finally:
+        FusedUpdate.GRAPH = saved

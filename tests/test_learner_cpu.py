@@ -93,6 +93,7 @@ def _rank_main(rank, world, port, root, ret):
     lr.update(part)
     out = {k: v.detach().clone() for k, v in lr.model.state_dict().items() if k in ("adv.bias", "state.weight", "recurrent.bias_hh")}
     out["flat"] = lr.bucket.flat.clone()
+    out["pieces"] = lr.bucket.pieces   # the exchange went out as recurrence + head first, encoder second (learner.FlatGradBucket)
     ret[rank] = out
     dist.destroy_process_group()
 
@@ -111,6 +112,7 @@ def test_two_rank_gloo_equals_single_rank():
     mp.spawn(_rank_main, args=(2, port, root, ret), nprocs=2, join=True)
     f0, f1 = ret[0]["flat"], ret[1]["flat"]
     assert torch.equal(f0, f1)  # identical averaged gradients on both ranks
+    assert ret[0]["pieces"] == ret[1]["pieces"] == 2 and lr.bucket.pieces == 0   # two collectives per exchange; none on one rank
     # clip_grad_norm_ scales in place only above 40; the norm here is ~0.6, so the buckets hold raw averaged grads
     assert torch.allclose(f0, single, rtol=1e-4, atol=1e-6), (f0 - single).abs().max()
     for k in ("adv.bias", "state.weight", "recurrent.bias_hh"):

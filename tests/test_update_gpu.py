@@ -429,9 +429,10 @@ def test_recurrence_kernels_compact_rows_equal_dense_rows(B, T, N, p):
 
 @pytest.mark.parametrize("B,T,N,p", [(24, 18, 40, 0.05), (4, 18, 128, 0.02), (7, 5, 3, 0.5)])
 def test_repeated_observations_are_found_numbered_and_summed(B, T, N, p):
-    """mapf_obs_dup / mapf_plan_rows(dup) / mapf_dedup_sum: an entry that carries the same 486 values as the same agent one step earlier
-    shares its row of distinct observations -- obs_rows[umap[r]] is entry r's observation for EVERY entry --, the distinct rows are
-    counted per window for both closures, and the gradient of a shared row is the sum over its entries."""
+    """mapf_obs_dup / mapf_plan_rows(dup) / mapf_dedup_sum: an entry that carries the same 486 values as the same agent at ANY earlier
+    step of the window (consecutive or not: an agent that comes back to a cell whose neighbourhood looks the same) shares that step's
+    row of distinct observations -- obs_rows[umap[r]] is entry r's observation for EVERY entry --, the distinct rows are counted per
+    window for both closures, and the gradient of a shared row is the sum over its entries."""
     from mapf_rl_amd._lib import check, lib
 
     comm, steps, g = _random_windows(B, T, N, p, 21 + N, True)
@@ -453,20 +454,27 @@ def test_repeated_observations_are_found_numbered_and_summed(B, T, N, p):
         plans.append((Tk, slot, order, nact, cnt, nag, rel))
     obs = torch.rand((T, B, N, 486), device="cuda", generator=g).to(torch.bfloat16)
     rep = torch.rand((T, B, N), device="cuda", generator=g) < 0.5
-    for t in range(1, T):  # runs of identical observations of the same agent
-        obs[t] = torch.where(rep[t].unsqueeze(-1), obs[t - 1], obs[t])
+    back = torch.randint(1, 6, (T, B, N), device="cuda", generator=g)
+    for t in range(1, T):  # the observation of the same agent 1..5 steps earlier again (runs, and repeats with other observations in between)
+        src = torch.clamp(t - back[t], min=0)
+        old = torch.gather(obs[:t].permute(1, 2, 0, 3), 2, src.view(B, N, 1, 1).expand(B, N, 1, 486)).squeeze(2)
+        obs[t] = torch.where(rep[t].unsqueeze(-1), old, obs[t])
     obs = obs.transpose(0, 1)  # [B, T, N, 486] view of time-major memory
     dup = torch.empty((T, B, N), dtype=torch.uint8, device="cuda")
     check(lib.mapf_obs_dup(T, To, B, N, _p(obs), obs.stride(0), obs.stride(1), _p(plans[0][1]), _p(plans[1][1]), _p(plans[0][3]), _p(plans[1][3]), _p(dup),
                            _p(ucnt[0]), _p(ucnt[1]), None), "mapf_obs_dup")
     torch.cuda.synchronize()
-    same = torch.zeros((T, B, N), dtype=torch.bool, device="cuda")
-    same[1:] = (obs.transpose(0, 1)[1:] == obs.transpose(0, 1)[:-1]).all(dim=-1)
+    ot = obs.transpose(0, 1)                                          # [T, B, N, 486]
+    eq = (ot.unsqueeze(1) == ot.unsqueeze(0)).all(dim=-1)             # eq[t, t0]: same observation at steps t and t0
+    tri = torch.tril(torch.ones((T, T), dtype=torch.bool, device="cuda"))
+    first = (eq & tri.view(T, T, 1, 1)).float().argmax(dim=1)          # the first step t0 <= t with the same values
     rel_t = plans[1][6].bool()
-    assert torch.equal(dup.bool() & rel_t, same & rel_t) and not (dup.bool() & ~rel_t).any()
+    ar = torch.arange(T, device="cuda").view(T, 1, 1)
+    assert torch.equal(dup.long()[rel_t], first[rel_t]) and torch.equal(dup.long()[~rel_t], ar.expand(T, B, N)[~rel_t])
+    assert int(((first < ar - 1) & rel_t).sum()) > 0                  # (non-consecutive repeats are present)
     for k in range(2):
         Tk, rel = plans[k][0], plans[k][6].bool()
-        assert torch.equal(ucnt[k].long(), (rel & ~same[:Tk]).sum(dim=(0, 2)))
+        assert torch.equal(ucnt[k].long(), (rel & (first[:Tk] == ar[:Tk])).sum(dim=(0, 2)))
     hidden = torch.zeros((B * N, 256), dtype=torch.float16, device="cuda")
     for k in range(2):
         Tk, slot, order, nact, cnt, nag, rel = plans[k]

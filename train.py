@@ -115,8 +115,15 @@ def main(argv=None):
                               max_map_length=config.max_map_lenght, pass_rate=config.pass_rate)
     learner = Learner(buffer, device=dev, batch_size=a.batch_size, save_path=config.save_path, double_q=a.double_q)
     if world > 1:  # identical initial weights on every rank
-        for p in learner.model.parameters():
-            dist.broadcast(p.data, src=0)
+        if learner._fused is not None:
+            # the parameters are views of ONE flat buffer: one collective; then the bf16 copy the kernels read follows explicitly (a write
+            # through .data does not move the version counters FlatParams.sync() watches)
+            dist.broadcast(learner._fused.flat.params, src=0)
+            learner._fused.flat.refresh_bf16()
+            learner.model.weights_epoch += 1
+        else:
+            for p in learner.model.parameters():
+                dist.broadcast(p.data, src=0)
         learner.sync_target()
     # the actors act on a snapshot of the learner's weights, pulled every config.actor_update_steps iterations (worker.py:416-420)
     if fixed:
