@@ -226,6 +226,13 @@ int mapf_comm_mask(const int16_t *pos_dev, int E, int N, int obs_radius, int max
  * to packed_dev [rows][cw]. */
 int mapf_comm_mask_multi(const int16_t *pos_dev, int E, const int32_t *envtab_dev, int obs_radius, int max_comm, uint8_t *mask_dev,
                          int32_t *packed_dev, int cw, void *stream);
+/*
+ * Dueling Q head of the policy's forward + arg-max (reference model.py:216-220: adv = adv(h), state = state(h),
+ * q = state + adv - adv.mean(-1); actions = argmax(q)): hidden bf16 [rows][256], the head's fp32 parameters (adv.weight [5][256],
+ * adv.bias [5], state.weight [1][256], state.bias [1]) -> q f32 [rows][5], action int64 [rows] (optional; first maximum).
+ */
+int mapf_q_head(const uint16_t *hidden_dev, int64_t rows, const float *adv_weight_dev, const float *adv_bias_dev,
+                const float *state_weight_dev, const float *state_bias_dev, float *q_dev, int64_t *action_dev, void *stream);
 
 /*
  * Which (step, window, agent) entries of a training batch can influence `Network.bootstrap`'s output at all.  The reference

@@ -140,6 +140,59 @@ __global__ void __launch_bounds__(128) comm_mask_kernel(const short2 *__restrict
         for (int w = (N + 31) / 32; w < cw; ++w) prow[w] = 0;
 }
 
+// ---- dueling Q head of the policy's forward (reference model.py:218: q = V + A - mean(A)) + its arg-max: one wavefront per agent row.
+// hidden bf16 [rows][256]; adv.weight f32 [5][256], adv.bias [5], state.weight [256], state.bias [1]; fp32 accumulation.  As PyTorch
+// operations under autocast this was a dozen launches of a few microseconds each (two linears, mean, add / sub, casts, arg-max) -- a
+// sixth of an actor iteration at curriculum shapes. ----
+__global__ void __launch_bounds__(256) q_head_kernel(const uint16_t *__restrict__ hidden, long long rows, const float *__restrict__ w_adv,
+                                                     const float *__restrict__ b_adv, const float *__restrict__ w_st, const float *__restrict__ b_st,
+                                                     float *__restrict__ q, long long *__restrict__ act) {
+    const int lane = threadIdx.x & 63;
+    const long long stride = (long long)gridDim.x * 4;
+    float wa[5][4], ws[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) wa[k][j] = w_adv[k * 256 + 4 * lane + j];
+        ws[j] = w_st[4 * lane + j];
+    }
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += stride) {
+        const uint2 hv = *reinterpret_cast<const uint2 *>(hidden + r * 256 + 4 * lane);  // this lane's 4 channels
+        const float h[4] = {__uint_as_float(hv.x << 16), __uint_as_float(hv.x & 0xFFFF0000u), __uint_as_float(hv.y << 16), __uint_as_float(hv.y & 0xFFFF0000u)};
+        float d[6];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) d[k] = h[0] * wa[k][0] + h[1] * wa[k][1] + h[2] * wa[k][2] + h[3] * wa[k][3];
+        d[5] = h[0] * ws[0] + h[1] * ws[1] + h[2] * ws[2] + h[3] * ws[3];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int s2 = 32; s2 > 0; s2 >>= 1) d[k] += __shfl_xor(d[k], s2, 64);
+        if (lane == 0) {
+            float a[5], mean = 0.f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                a[k] = d[k] + b_adv[k];
+                mean += a[k];
+            }
+            mean *= 0.2f;
+            const float v = d[5] + b_st[0];
+            int best = 0;
+            float qb = v + a[0] - mean;
+            q[r * 5] = qb;
+#pragma unroll
+            for (int k = 1; k < 5; ++k) {
+                const float qk = v + a[k] - mean;
+                q[r * 5 + k] = qk;
+                if (qk > qb) {  // first maximum, as torch.argmax
+                    qb = qk;
+                    best = k;
+                }
+            }
+            if (act) act[r] = best;
+        }
+    }
+}
+
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \
         hipError_t _e = (expr);                                                            \
@@ -245,6 +298,20 @@ int mapf_comm_mask_multi(const int16_t *pos_dev, int E, const int32_t *envtab_de
     if (E == 0) return MAPF_OK;
     hipLaunchKernelGGL(comm_mask_kernel, dim3(E), dim3(128), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const short2 *>(pos_dev), 128,
                        obs_radius, max_comm, mask_dev, packed_dev, cw, reinterpret_cast<const int4 *>(envtab_dev));
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+int mapf_q_head(const uint16_t *hidden_dev, int64_t rows, const float *adv_weight_dev, const float *adv_bias_dev, const float *state_weight_dev,
+                const float *state_bias_dev, float *q_dev, int64_t *action_dev, void *stream) {
+    if (rows < 0 || !hidden_dev || !adv_weight_dev || !adv_bias_dev || !state_weight_dev || !state_bias_dev || !q_dev ||
+        (reinterpret_cast<uintptr_t>(hidden_dev) & 7) || (reinterpret_cast<uintptr_t>(action_dev) & 7))
+        return MAPF_ERR_INVALID_ARG;
+    if (rows == 0) return MAPF_OK;
+    long long blocks = (rows + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(q_head_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), hidden_dev, (long long)rows, adv_weight_dev,
+                       adv_bias_dev, state_weight_dev, state_bias_dev, q_dev, reinterpret_cast<long long *>(action_dev));
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }

@@ -451,6 +451,20 @@ def recurrent_infer(gi, h0, comm, weights, bias, want_agent0=False, out=None):
     return h_out, a0
 
 
+def q_head_infer(hidden, adv, state, q_out=None, act_out=None):
+    """Dueling head + arg-max of the policy's forward in one launch (include/mapf_dqn.h: mapf_q_head): hidden bf16 [rows, 256],
+    adv / state the network's nn.Linear modules (fp32 parameters) -> (q f32 [rows, 5], actions int64 [rows])."""
+    rows = hidden.shape[0]
+    assert hidden.is_cuda and hidden.dtype == torch.bfloat16 and hidden.is_contiguous() and hidden.shape[1] == 256
+    ps = (adv.weight, adv.bias, state.weight, state.bias)
+    assert all(p.dtype == torch.float32 and p.is_contiguous() for p in ps)
+    q = torch.empty((rows, 5), dtype=torch.float32, device=hidden.device) if q_out is None else q_out
+    act = torch.empty(rows, dtype=torch.int64, device=hidden.device) if act_out is None else act_out
+    assert q.dtype == torch.float32 and q.is_contiguous() and q.numel() == rows * 5 and act.dtype == torch.int64 and act.is_contiguous()
+    check(lib.mapf_q_head(_ptr(hidden), rows, _ptr(ps[0]), _ptr(ps[1]), _ptr(ps[2]), _ptr(ps[3]), _ptr(q), _ptr(act), _stream(hidden.device)), "mapf_q_head")
+    return q, act
+
+
 def recurrent_infer_multi(gi_all, h0_all, comm_all, weights, bias, envtab, out):
     """One policy step of environments of different agent counts (<= 16 each) in one launch (include/mapf_dqn.h:
     mapf_recurrent_infer_multi): gi_all bf16 [rows, 768], h0_all bf16 [rows, 256] or None, comm_all uint8 [bytes], envtab int32 [E, 4],

@@ -455,6 +455,18 @@ class Network(nn.Module):
         adv = self.adv(hidden)
         return self.state(hidden) + adv - adv.mean(-1, keepdim=True)  # model.py:218,262
 
+    def _policy_head(self, hidden, q_out=None, act_out=None):
+        """(Q-values f32 [rows, 5], greedy actions int64 [rows]) of hidden [rows, 256] (model.py:216-220): one kernel on a HIP device
+        (fp32 accumulation over the bf16 states and the fp32 head parameters), the module path otherwise."""
+        if self.FUSED_INFERENCE and hidden.is_cuda and hidden.dtype == torch.bfloat16 and hidden.is_contiguous() and self.adv.weight.dtype == torch.float32:
+            from .fused import q_head_infer
+
+            return q_head_infer(hidden, self.adv, self.state, q_out, act_out)
+        q = self.q_head(hidden).float()
+        if q_out is not None:
+            q = q_out.copy_(q)
+        return q, (q.argmax(-1) if act_out is None else torch.argmax(q, dim=-1, out=act_out))
+
     # ------------------------------------------------------------------ actor side
     @torch.no_grad()
     def step_batch(self, obs, pos, hidden: Optional[torch.Tensor], comm_mask: Optional[torch.Tensor] = None, cache=None):
@@ -482,8 +494,8 @@ class Network(nn.Module):
             else:
                 hidden = self.recurrent(latent) if hidden is None else self.recurrent(latent, hidden.to(latent.dtype))
                 hidden = self.comm(hidden.view(E, N, self.latent_dim), comm_mask).reshape(E * N, self.latent_dim)
-            q = self.q_head(hidden).float().view(E, N, 5)
-        return q.argmax(-1), q, hidden, comm_mask
+            q, act = self._policy_head(hidden)
+        return act.view(E, N), q.view(E, N, 5), hidden, comm_mask
 
     @torch.no_grad()
     def step_levels(self, levels, obs_all, cache=None, hidden_out=None, packed_inplace=False, merged=None, q_out=None, act_out=None):
@@ -535,9 +547,8 @@ class Network(nn.Module):
                     out = None if hidden_out is None else hidden_out[off:off + E * N]
                     hs.append(recurrent_infer(gi_all[off:off + E * N].view(1, E, N, 768), h0, comm.unsqueeze(0), w, b, False, out=out)[0].view(E * N, self.latent_dim))
                     off += E * N
-            q_all = self.q_head(hidden_out if hidden_out is not None else (torch.cat(hs) if len(hs) > 1 else hs[0]))
-            q_all = q_all.float() if q_out is None else q_out.copy_(q_all)
-        act_all = q_all.argmax(-1) if act_out is None else torch.argmax(q_all, dim=-1, out=act_out)  # (one launch for all levels; the per-level results are views)
+            h_all = hidden_out if hidden_out is not None else (torch.cat(hs) if len(hs) > 1 else hs[0])
+            q_all, act_all = self._policy_head(h_all, q_out, act_out)  # (one launch for all levels; the per-level results are views)
         outs, off = [], 0
         for (E, N, pos, hidden, comm), h in zip(levels, hs):
             outs.append((act_all[off:off + E * N].view(E, N), q_all[off:off + E * N].view(E, N, 5), h, comm))

@@ -199,3 +199,27 @@ def test_bptt_kernels_match_pytorch_recurrence(B, T, N):
     for k in res[True][1]:
         a, b = res[True][1][k], res[False][1][k]
         assert float((a - b).norm()) <= 8e-2 * float(b.norm()) + 1e-4 * scale, (k, float((a - b).norm()), float(b.norm()))
+
+
+def test_policy_head_kernel_equals_the_module_statement():
+    """mapf_q_head (dueling head + arg-max of the policy's forward, one launch) against model.py:216-220 in fp32 on the same bf16
+    states: Q-values to 1e-5, the greedy action equal wherever the top-2 gap exceeds that."""
+    from mapf_rl_amd.fused import q_head_infer
+    from mapf_rl_amd.model import Network
+
+    torch.manual_seed(5)
+    net = Network().cuda().eval()
+    for rows in (1, 7, 4096, 50001):
+        h = (torch.randn((rows, 256), device="cuda") * 0.7).to(torch.bfloat16)
+        q, act = q_head_infer(h, net.adv, net.state)
+        with torch.no_grad():
+            adv = torch.nn.functional.linear(h.float(), net.adv.weight, net.adv.bias)
+            want = torch.nn.functional.linear(h.float(), net.state.weight, net.state.bias) + adv - adv.mean(-1, keepdim=True)
+        assert q.shape == (rows, 5) and act.shape == (rows,) and act.dtype == torch.int64
+        assert torch.allclose(q, want, rtol=1e-5, atol=1e-5), float((q - want).abs().max())
+        top2 = want.topk(2, dim=-1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+        assert torch.equal(act[clear], want.argmax(-1)[clear]) and torch.equal(act, q.argmax(-1))
+    q_out, a_out = torch.empty((7, 5), device="cuda"), torch.empty(7, dtype=torch.int64, device="cuda")
+    q2, a2 = q_head_infer(h[:7].contiguous(), net.adv, net.state, q_out, a_out)
+    assert q2.data_ptr() == q_out.data_ptr() and a2.data_ptr() == a_out.data_ptr()

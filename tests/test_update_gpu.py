@@ -499,7 +499,7 @@ def test_repeated_observations_are_found_numbered_and_summed(B, T, N, p):
         first = np.sort(np.unique(um, return_index=True)[1])
         assert np.array_equal(um[first], np.arange(urows))
         for r in range(0, rows, max(1, rows // 400)):
-            t, i, b = tb[r] >> 24, (tb[r] >> 16) & 255, tb[r] & 0xFFFF
+            t, i, b = (tb[r] >> 24) & 31, (tb[r] >> 16) & 255, tb[r] & 0xFFFF   # (bit 30: the entry reuses an earlier step's row)
             assert G[t, b, i] == r and np.array_equal(ou[um[r]], ob[b, t, O[b, i]])
         # gradient of a shared row
         d_rows = (torch.randn((rows, 768), device="cuda", generator=g) * 0.3).to(torch.bfloat16)
