@@ -386,6 +386,9 @@ def main():
             result["roofline"]["traffic"] = tj.get("env_step_kernel_bytes_per_launch")
             # NOT measured in this run: PMC counters need rocprofv3 around the process (separate --pmc passes)
             result["roofline"]["traffic_source"] = "profiles/traffic.json (%s)" % tj.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes")
+            # the same counters at the two larger launches (same kernel, same passes): per-launch HBM bytes beside frac_out_of_cache / frac_hbm_proper
+            result["roofline"]["traffic_out_of_cache"] = tj.get("e16384_bytes_per_launch")
+            result["roofline"]["traffic_hbm_proper"] = tj.get("e32768_bytes_per_launch")
         except Exception:
             pass
 

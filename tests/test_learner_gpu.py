@@ -206,6 +206,59 @@ def test_actors_on_their_own_stream_leave_the_replay_consistent():
     assert all(bool(torch.isfinite(p).all()) for p in lr.model.parameters())
 
 
+def test_overlapped_actors_equal_the_serial_order():
+    """The same loop twice from the same seeds -- actors on their own stream beside the update (ordered only by the two events), and
+    everything on one stream, strictly alternating: with the actors acting on a weight snapshot that is never refreshed inside the run
+    (weights_period beyond its length) nothing they do depends on WHEN the update runs, so the episodes, the replay (ring state, every
+    sum-tree node), the sampled batches and the parameters after 40 updates must be the SAME BITS.  A missing or misplaced
+    dependency between the actors' episode flush and the learner's priority write-back / prioritized sample would show here."""
+    import mapf_rl_amd as M
+    from mapf_rl_amd.actor import VecActor
+    from mapf_rl_amd.learner import Learner
+    from mapf_rl_amd.model import Network
+    from mapf_rl_amd.replay import GlobalBuffer
+
+    def run(overlap):
+        torch.manual_seed(0)
+        torch.cuda.manual_seed(0)
+        dev = torch.device("cuda")
+        E, N, L = 96, 3, 12
+        buf = GlobalBuffer(256, max_agents=N, device=dev, init_set=(N, L), fixed_level=True)
+        lr = Learner(buf, device=dev, batch_size=32, model=Network())
+        env = M.VecEnvironment(E, L, N, device=dev)
+        maps, agents, goals, _ = M.generate_scenarios(E, L, N, 0.2, seed=2)
+        env.load(maps, agents, goals)
+        actor = VecActor(env, lr.model, buf, seed=1, density=0.2, max_steps=12, weights_period=10 ** 9)
+        astream = torch.cuda.Stream(device=dev) if overlap else None
+        for _ in range(30):
+            actor.step()
+        torch.cuda.synchronize()
+        tds = []
+        for it in range(40):
+            if overlap:
+                if lr.replay_released is not None:
+                    astream.wait_event(lr.replay_released)
+                with torch.cuda.stream(astream):
+                    actor.step()
+                    ev = torch.cuda.Event()
+                    ev.record(astream)
+                lr.replay_gate = ev
+            else:
+                actor.step()
+            tds.append(lr.update()["td"].clone())
+        torch.cuda.synchronize()
+        return (torch.stack(tds), [p.detach().clone() for p in lr.model.parameters()], buf.priority_tree.tree().clone(), buf.state(), actor.episodes,
+                actor.lb_obs.clone(), actor.t.clone())
+
+    a, b = run(True), run(False)
+    assert a[3] == b[3] and a[4] == b[4] and a[4] > 0
+    assert torch.equal(a[5], b[5]) and torch.equal(a[6], b[6])
+    assert torch.equal(a[2], b[2])
+    assert torch.equal(a[0], b[0])
+    for x, y in zip(a[1], b[1]):
+        assert torch.equal(x, y)
+
+
 def _filled_replay(A=6, episodes=24, seed=1):
     from mapf_rl_amd.replay import GlobalBuffer
 

@@ -1,6 +1,6 @@
 # round 4: the whole GPU suite (timed), the full bench line, the merged-launch sweep
 cd $GRAFT_REPO_ROOT
-/usr/bin/time -v timeout -k 10 1000 python -m pytest tests -q -m gpu -x > gpurun_out/r04_m_gputests.log 2> gpurun_out/r04_m_gputests.time; rc=$?; echo gputests=$rc; tail -4 gpurun_out/r04_m_gputests.log; grep "Elapsed" gpurun_out/r04_m_gputests.time
+t0=$(date +%s); timeout -k 10 1000 python -m pytest tests -q -m gpu -x > gpurun_out/r04_m_gputests.log 2>&1; rc=$?; echo gputests=$rc seconds=$(( $(date +%s) - t0 )); tail -4 gpurun_out/r04_m_gputests.log
 if [ $rc -ne 0 ] || grep -q "Memory access fault" gpurun_out/r04_m_gputests.log; then exit 1; fi
 timeout -k 10 500 python bench.py > gpurun_out/r04_m_bench.json 2> gpurun_out/r04_m_bench.err; echo bench=$?
 python -c "

@@ -39,36 +39,27 @@ def main():
                 obs, *_ = env.step(tape[t])
             tapes.append(tape)
         multi = MultiEnvironment(envs, acts, bits, masks)
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         res = {}
         for mode in ("merged", "per level"):
             ts = []
             for rnd in range(3):
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(T)]
                 torch.cuda.synchronize()
-                s.record()
                 for t in range(T):
+                    for a, tape in zip(acts, tapes):
+                        a.copy_(tape[t])       # (the actions land in the buffers the set reads; outside the timed bracket)
+                    evs[t][0].record()         # HIP events around the step launch(es) of this iteration only
                     if mode == "merged":
-                        for a, tape in zip(acts, tapes):
-                            a.copy_(tape[t])       # (7 small copies per step in both modes: the actions land in the buffers the set reads)
                         multi.step()
                     else:
-                        for env, a, tape, b in zip(envs, acts, tapes, bits):
-                            a.copy_(tape[t])
+                        for env, a, b in zip(envs, acts, bits):
                             env.step(a, obs_bits_out=b)
-                e.record()
+                    evs[t][1].record()
                 torch.cuda.synchronize()
-                ts.append(s.elapsed_time(e) * 1e3 / T)
+                ts.append(sum(x.elapsed_time(y) for x, y in evs) * 1e3 / T)
             res[mode] = sorted(ts)[1]
-        # the copies alone
-        s.record()
-        for t in range(T):
-            for a, tape in zip(acts, tapes):
-                a.copy_(tape[t])
-        e.record()
-        torch.cuda.synchronize()
-        cp = s.elapsed_time(e) * 1e3 / T
+        m, p = res["merged"], res["per level"]
         alg = sum(L * L + 821 * N + 1 for N, L in LEVELS) * E
-        m, p = res["merged"] - cp, res["per level"] - cp
         print("| %d | %d | %.1f | %.1f | %.1f | %.2f | %.3f | %.3f |" % (E, len(LEVELS), m, p, alg / 1e6, alg / m / 1e6, alg / m / 8e6, alg / p / 8e6), flush=True)
         for env in envs:
             env.check_status()
