@@ -1282,6 +1282,13 @@ int mapf_multi_create(int n, mapf_env_t *const *envs, const int8_t *const *actio
         const size_t sm = step_smem_bytes(h, G, plane);
         if (sm > smem) smem = sm;
     }
+    // non-temporal observation stores when ONE launch of the set writes more observation bytes than the Infinity Cache holds on to
+    // (the single-handle rule, step_nt_store, on the set's total)
+    size_t obs_bytes = 0;
+    for (int i = 0; i < n; ++i)
+        if (tab.seg[i].obs) obs_bytes += (size_t)m->env[i]->E * m->env[i]->N * 486;
+    const bool nt = m->env[0]->tune_nt >= 0 ? m->env[0]->tune_nt != 0 : obs_bytes >= ((size_t)176 << 20);
+    for (int i = 0; i < n; ++i) tab.seg[i].nt_store = (nt && tab.seg[i].obs) ? 1 : 0;
     m->blocks = blocks;
     m->envs = total_envs;
     m->smem = smem;
