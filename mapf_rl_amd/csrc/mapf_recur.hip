@@ -40,6 +40,39 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 #define MAPF_RECUR_NT 3  // csrc/mapf_recur.hip itself, 1 (up to 16) in csrc/mapf_recur_nt1.hip, which includes this file
 #endif
 constexpr int NT = MAPF_RECUR_NT;
+#ifdef MAPF_RECUR_TRACE  // diagnostic builds only (tools/micro/recur_trace.py): cycle stamps of wave 0 of workgroup MAPF_RECUR_TRACE_WG
+#ifndef MAPF_RECUR_TRACE_WG
+#define MAPF_RECUR_TRACE_WG 0
+#endif
+__device__ unsigned long long g_trace[128];
+__device__ int g_trace_n;
+// stamps go to LDS (s_memtime and ds_write wait on lgkmcnt only): a stamp that touched global memory would wait for every weight load
+// in flight (vmcnt retires in order) and so serialise exactly what is being measured
+__shared__ unsigned long long trace_lds[128];
+__shared__ int trace_lds_n;
+#define TRACE_POINT(id)                                                                                                 \
+    do {                                                                                                                \
+        if (threadIdx.x == 0 && blockIdx.x == MAPF_RECUR_TRACE_WG) {                                                    \
+            const int k_ = trace_lds_n;                                                                                 \
+            if (k_ < 126) {                                                                                             \
+                trace_lds[k_] = ((unsigned long long)(id) << 56) | (__builtin_readcyclecounter() & 0xFFFFFFFFFFFFFFull); \
+                trace_lds_n = k_ + 1;                                                                                   \
+            }                                                                                                           \
+        }                                                                                                               \
+    } while (0)
+#define TRACE_BEGIN() do { if (threadIdx.x == 0) trace_lds_n = 0; } while (0)
+#define TRACE_END()                                                                  \
+    do {                                                                             \
+        if (threadIdx.x == 0 && blockIdx.x == MAPF_RECUR_TRACE_WG) {                 \
+            for (int k_ = 0; k_ < trace_lds_n; ++k_) g_trace[k_] = trace_lds[k_];    \
+            g_trace_n = trace_lds_n;                                                 \
+        }                                                                            \
+    } while (0)
+#else
+#define TRACE_POINT(id) do { } while (0)
+#define TRACE_BEGIN() do { } while (0)
+#define TRACE_END() do { } while (0)
+#endif
 constexpr int NA = 16 * NT;
 constexpr int D = 256;           // hidden size (config.latent_dim)
 constexpr int HD = 64;           // attention head dim (comm output_dim)
@@ -58,15 +91,20 @@ constexpr int OFF_H0 = 0, OFF_H1 = OFF_H0 + H_BYTES;
 constexpr int OFF_QK = OFF_H1 + H_BYTES;
 constexpr int OFF_VT = OFF_QK + NA * QK_ROW;
 constexpr int OFF_P = OFF_VT + 128 * VT_ROW;
-constexpr int OFF_CTX = OFF_P + 2 * NA * P_ROW;
+// ctx and info live in q|k's bytes: q|k is dead once the scores are out (two barriers before ctx is written), and the next q|k is
+// written only behind the update cell that reads info; every phase writes all NA rows of the columns the next one reads
+constexpr int OFF_CTX = OFF_QK;
 constexpr int OFF_INFO = OFF_CTX + NA * CTX_ROW;
-constexpr int OFF_S = OFF_INFO + NA * INFO_ROW;
+static_assert(OFF_INFO + NA * INFO_ROW <= OFF_VT, "ctx | info must fit in q | k");
+constexpr int OFF_S = OFF_P + 2 * NA * P_ROW;
 constexpr int OFF_UPD = OFF_S + 2 * NA * S_ROW * 4;
 constexpr int OFF_MB = OFF_UPD + 64 * 4;     // comm mask of the step as bits: 2 words per agent row
 constexpr int OFF_RIDX = OFF_MB + NA * 2 * 4;  // global row of every agent at this step (-1: none), see recurrent_infer_kernel
-constexpr int LDS_BYTES = OFF_RIDX + NA * 4;
+constexpr int OFF_BSUM = OFF_RIDX + NA * 4;   // gate biases of both cells as the accumulators want them: [cell][r: b_ir + b_hr | z: b_iz + b_hz | b_in | b_hn][256] f32
+constexpr int LDS_BYTES = OFF_BSUM + 2 * 4 * 256 * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-static_assert(OFF_S % 16 == 0 && OFF_UPD % 16 == 0, "");
+static_assert(NTHR == 512, "gru_pair: a wave owns exactly two of the 16 channel blocks");
+static_assert(OFF_S % 16 == 0 && OFF_UPD % 16 == 0 && OFF_BSUM % 16 == 0, "");
 
 // weight buffer (bf16 elements) and bias buffer (f32 elements), see mapf_dqn.h
 constexpr int W_HH = 0, W_QKV = W_HH + 768 * 256, W_O = W_QKV + 384 * 256, U_IH = W_O + 64 * 128, U_HH = U_IH + 768 * 64;
@@ -80,8 +118,10 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
 }
 __device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 2.f / (1.f + __expf(-2.f * x)) - 1.f; }
+// v_rcp_f32 (1 ulp) instead of an IEEE division (ten instructions): the cells' pointwise math is VALU time of the same order as their
+// MFMA time (tools/micro/recur_trace.py), and every result is rounded to bf16 next
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return __builtin_fmaf(2.f, __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)), -1.f); }
 
 // value of another lane of the same DPP quad (0x4E: lanes 2,3,0,1; 0xB1: lanes 1,0,3,2) -- VALU only, no LDS-pipe shuffle
 template <int CTRL>
@@ -89,7 +129,8 @@ __device__ __forceinline__ float quad_perm(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
 
-// acc[n] += (tile `t` of 16 rows of W) * X^T for the NT agent tiles; W packed [tile][k-step][lane][8] (see gemm3x16),
+// acc[n] += (tile `t` of 16 rows of W) * X^T for the NT agent tiles; W packed [tile][k-step][lane][8] in MFMA A-fragment order (one wave load = one
+// contiguous 1 KiB = 8 full cache lines; row-major weights cost 16 half lines per load and ran the L2 -> CU path at a quarter of its rate),
 // X an LDS image with `xrow` bytes per agent row.  All KS A fragments are loaded before the first MFMA.
 template <int KS>
 __device__ __forceinline__ void gemm16(f32x4 (&acc)[NT], const uint16_t *__restrict__ W, int t, const unsigned char *X, int xrow, int lane) {
@@ -107,25 +148,38 @@ __device__ __forceinline__ void gemm16(f32x4 (&acc)[NT], const uint16_t *__restr
         }
 }
 
-// Three output tiles at once (tiles t0, t1, t2 of 16 rows of W), sharing every B fragment.  W is packed in MFMA
-// A-fragment order, [tile][k-step][lane][8]: one wave load = one contiguous 1 KiB = 8 full cache lines (row-major
-// weights cost 16 half lines per load and ran the L2 -> CU path at a quarter of its rate).
+// ---- the weight stream ----
+// A wave's weight fragments for one phase (three output tiles x 8 k-steps = 24 KiB) live in one register array, `wf`, for the whole
+// kernel.  Whoever consumes a k-step of it requests the same k-step of the NEXT job of this wave into the registers just freed
+// (stream_mfma<.., true>), across the phase barriers: second channel block of a cell, the q|k|v tiles behind a cell, the update
+// cell's tiles behind q|k|v (they arrive during the attention phases), the next step's first block behind the last update cell.
+// The L2 -> CU stream, which a step is bound by together with its barriers, then runs under the pointwise math and the attention
+// phases instead of starting at the top of every phase (tools/micro/recur_trace.py: 2.7-8 k cycles of exposed load time per phase
+// before, of ~100 k per step at 40 agents).
+struct Frag3 {  // the fragments of three 16-row tiles of a packed matrix, already at this lane: k-step kk of tile g is p[g][kk * 64]
+    const bf16x8 *p[3];
+};
+__device__ __forceinline__ Frag3 frag3(const uint16_t *__restrict__ W, int t0, int t1, int t2, int KS, int lane) {
+    const bf16x8 *b = reinterpret_cast<const bf16x8 *>(W) + lane;
+    return Frag3{{b + (long long)t0 * KS * 64, b + (long long)t1 * KS * 64, b + (long long)t2 * KS * 64}};
+}
+__device__ __forceinline__ Frag3 gate_frags(const uint16_t *__restrict__ W, int cblk, int KS, int lane) {  // gate tiles r, z, n of a channel block
+    return frag3(W, cblk, 16 + cblk, 32 + cblk, KS, lane);
+}
+
 template <int KS>
-__device__ __forceinline__ void gemm3x16(f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], f32x4 (&acc2)[NT], const uint16_t *__restrict__ W, int t0,
-                                         int t1, int t2, const unsigned char *X, int xrow, int lane) {
-    const int lr = lane & 15, lh = lane >> 4;
-    const bf16x8 *w0 = reinterpret_cast<const bf16x8 *>(W) + (long long)t0 * KS * 64 + lane;
-    const bf16x8 *w1 = reinterpret_cast<const bf16x8 *>(W) + (long long)t1 * KS * 64 + lane;
-    const bf16x8 *w2 = reinterpret_cast<const bf16x8 *>(W) + (long long)t2 * KS * 64 + lane;
-    // ALL A fragments of the call are requested before the first MFMA (up to 96 VGPRs; one wave per SIMD, 512 available)
-    bf16x8 a[KS][3];
+__device__ __forceinline__ void load_frags(bf16x8 (&a)[KS][3], const Frag3 &f) {
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-        a[kk][0] = w0[kk * 64];
-        a[kk][1] = w1[kk * 64];
-        a[kk][2] = w2[kk * 64];
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) a[kk][g] = f.p[g][kk * 64];
+}
+
+// acc_g[n] += a[kk][g] x X for all k-steps; with RELOAD every k-step's fragments are replaced by `next`'s once used
+template <int KS, bool RELOAD>
+__device__ __forceinline__ void stream_mfma(f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], f32x4 (&acc2)[NT], bf16x8 (&a)[KS][3], const unsigned char *X,
+                                            int xrow, int lane, const Frag3 &next) {
+    const int lr = lane & 15, lh = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
 #pragma unroll
@@ -135,45 +189,68 @@ __device__ __forceinline__ void gemm3x16(f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], f
             acc1[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][1], b, acc1[n], 0, 0, 0);
             acc2[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][2], b, acc2[n], 0, 0, 0);
         }
+        if (RELOAD) {  // pinned behind this k-step's MFMAs: left to itself the scheduler hoists every reload to the top (into NEW registers: 430 spills)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) a[kk][g] = next.p[g][kk * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
-// One GRU cell for the 16-channel block `cblk`, all agents: gates from registers, pointwise math, new state to Hout.
+// ---- GRU cell of a 16-channel block, all agents: gates accumulated in registers, pointwise math, new state to Hout ----
 //   r = s(gi_r + b_ir + W_hr h + b_hr), z likewise, n = tanh(gi_n + b_in + r (W_hn h + b_hn)), h' = (1-z) n + z h
 // gi_* comes either from global memory (GI_GLOBAL: precomputed input projection, bf16 [row][768]) or from a GEMM of
-// W_i (ldwi = KI*32 columns) with the LDS image Xi.  `upd` (LDS int per agent, or nullptr): keep h where it is 0.
-// `ridx` (LDS int per agent): the agent's row in gi_glob / gsave at this step, -1 = none (no input projection, nothing saved).
-template <bool GI_GLOBAL, int KI>
-__device__ __forceinline__ void gru_block(int cblk, const uint16_t *__restrict__ gi_glob, const uint16_t *__restrict__ Wi,
-                                          const unsigned char *Xi, int xirow, const uint16_t *__restrict__ Wh, const float *__restrict__ bi,
-                                          const float *__restrict__ bh, const unsigned char *Hin, unsigned char *Hout, const int *upd,
-                                          const int *ridx, int lr, int lh, uint16_t *__restrict__ gsave = nullptr) {
-    f32x4 ar[NT], az[NT], ani[NT], anh[NT];
+// W_i (KI*32 columns) with the LDS image Xi.  `upd` (LDS int per agent, or nullptr): keep h where it is 0.
+// `ridx` (LDS int per agent): the agent's row in gsave at this step, -1 = none (nothing saved).
+// A wave owns TWO channel blocks per cell (16 blocks, 8 waves): gru_pair.
+
+// what a block's gate accumulators start from besides the biases (LDS, OFF_BSUM): with GI_GLOBAL, the precomputed input projection
+struct GruInit {
+    uint2 gr[NT], gz[NT], gn[NT];
+    int row[NT];
+};
+
+// row[n]: the row of agent 16 n + lr in gi_glob, -1 = none
+__device__ __forceinline__ void gru_fetch_gi(GruInit &s, int cblk, const uint16_t *__restrict__ gi_glob, const int (&row)[NT], int lh) {
     const int c0 = 16 * cblk + 4 * lh;  // this lane's 4 channels
-    const float4 bir = *reinterpret_cast<const float4 *>(bi + c0), biz = *reinterpret_cast<const float4 *>(bi + 256 + c0),
-                 bin = *reinterpret_cast<const float4 *>(bi + 512 + c0);
-    const float4 bhr = *reinterpret_cast<const float4 *>(bh + c0), bhz = *reinterpret_cast<const float4 *>(bh + 256 + c0),
-                 bhn = *reinterpret_cast<const float4 *>(bh + 512 + c0);
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        ar[n] = f32x4{bir.x + bhr.x, bir.y + bhr.y, bir.z + bhr.z, bir.w + bhr.w};
-        az[n] = f32x4{biz.x + bhz.x, biz.y + bhz.y, biz.z + bhz.z, biz.w + bhz.w};
-        ani[n] = f32x4{bin.x, bin.y, bin.z, bin.w};
-        anh[n] = f32x4{bhn.x, bhn.y, bhn.z, bhn.w};
-        if (GI_GLOBAL) {
-            const int row = ridx[16 * n + lr];
-            if (row >= 0) {
-                const uint16_t *g = gi_glob + (long long)row * 768 + c0;
-                const uint2 gr = *reinterpret_cast<const uint2 *>(g), gz = *reinterpret_cast<const uint2 *>(g + 256),
-                            gn = *reinterpret_cast<const uint2 *>(g + 512);
-                ar[n] += f32x4{bf16_lo(gr.x), bf16_hi(gr.x), bf16_lo(gr.y), bf16_hi(gr.y)};
-                az[n] += f32x4{bf16_lo(gz.x), bf16_hi(gz.x), bf16_lo(gz.y), bf16_hi(gz.y)};
-                ani[n] += f32x4{bf16_lo(gn.x), bf16_hi(gn.x), bf16_lo(gn.y), bf16_hi(gn.y)};
-            }
+        s.row[n] = row[n];
+        s.gr[n] = s.gz[n] = s.gn[n] = make_uint2(0u, 0u);
+        if (row[n] >= 0) {
+            const uint16_t *g = gi_glob + (long long)row[n] * 768 + c0;
+            s.gr[n] = *reinterpret_cast<const uint2 *>(g);
+            s.gz[n] = *reinterpret_cast<const uint2 *>(g + 256);
+            s.gn[n] = *reinterpret_cast<const uint2 *>(g + 512);
         }
     }
-    if (!GI_GLOBAL) gemm3x16<KI>(ar, az, ani, Wi, cblk, 16 + cblk, 32 + cblk, Xi, xirow, 16 * lh + lr);
-    gemm3x16<8>(ar, az, anh, Wh, cblk, 16 + cblk, 32 + cblk, Hin, H_ROW, 16 * lh + lr);
+}
+
+// bsum: the cell's [4][256] f32 block of OFF_BSUM
+template <bool GI_GLOBAL>
+__device__ __forceinline__ void gru_start(const GruInit &s, const float *bsum, int c0, f32x4 (&ar)[NT], f32x4 (&az)[NT], f32x4 (&ani)[NT],
+                                          f32x4 (&anh)[NT]) {
+    const f32x4 br = *reinterpret_cast<const f32x4 *>(bsum + c0), bz = *reinterpret_cast<const f32x4 *>(bsum + 256 + c0),
+                bni = *reinterpret_cast<const f32x4 *>(bsum + 512 + c0), bnh = *reinterpret_cast<const f32x4 *>(bsum + 768 + c0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        ar[n] = br;
+        az[n] = bz;
+        ani[n] = bni;
+        anh[n] = bnh;
+        if (GI_GLOBAL && s.row[n] >= 0) {
+            ar[n] += f32x4{bf16_lo(s.gr[n].x), bf16_hi(s.gr[n].x), bf16_lo(s.gr[n].y), bf16_hi(s.gr[n].y)};
+            az[n] += f32x4{bf16_lo(s.gz[n].x), bf16_hi(s.gz[n].x), bf16_lo(s.gz[n].y), bf16_hi(s.gz[n].y)};
+            ani[n] += f32x4{bf16_lo(s.gn[n].x), bf16_hi(s.gn[n].x), bf16_lo(s.gn[n].y), bf16_hi(s.gn[n].y)};
+        }
+    }
+}
+
+__device__ __forceinline__ void gru_finish(int cblk, const f32x4 (&ar)[NT], const f32x4 (&az)[NT], const f32x4 (&ani)[NT], const f32x4 (&anh)[NT],
+                                           const unsigned char *Hin, unsigned char *Hout, const int *upd, const int *ridx, int lr, int lh,
+                                           uint16_t *__restrict__ gsave) {
+    const int c0 = 16 * cblk + 4 * lh;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int agent = 16 * n + lr;
@@ -184,7 +261,7 @@ __device__ __forceinline__ void gru_block(int cblk, const uint16_t *__restrict__
         for (int r = 0; r < 4; ++r) {
             const float rg = sigmoidf_(ar[n][r]), zg = sigmoidf_(az[n][r]);
             const float ng = tanhf_(ani[n][r] + rg * anh[n][r]);
-            o[r] = (1.f - zg) * ng + zg * h[r];
+            o[r] = __builtin_fmaf(1.f - zg, ng, zg * h[r]);  // (spelled out: which product the compiler fuses must not depend on the code around it)
             rg4[r] = rg;
             zg4[r] = zg;
             ng4[r] = ng;
@@ -201,6 +278,42 @@ __device__ __forceinline__ void gru_block(int cblk, const uint16_t *__restrict__
     }
 }
 
+// The cell for the wave's two channel blocks cA, cB.  On entry wf holds W_h's gate tiles of cA (and wi W_i's, KI k-steps, when the
+// input projection is computed here); on exit wf holds `next` (wi is spent).  sA / sB: the blocks' input projection rows (GI_GLOBAL).
+template <bool GI_GLOBAL, int KI>
+__device__ __forceinline__ void gru_pair(int cA, int cB, const GruInit &sA, const GruInit &sB, bf16x8 (&wf)[8][3], bf16x8 (&wi)[KI][3],
+                                         const uint16_t *__restrict__ Wi, const unsigned char *Xi, int xirow, const uint16_t *__restrict__ Wh,
+                                         const float *bsum, const unsigned char *Hin, unsigned char *Hout, const int *upd, const int *ridx, int lr,
+                                         int lh, uint16_t *__restrict__ gsave, const Frag3 &next) {
+    const int lane = 16 * lh + lr;
+    f32x4 ar[NT], az[NT], ani[NT], anh[NT];
+    TRACE_POINT(20);
+    gru_start<GI_GLOBAL>(sA, bsum, 16 * cA + 4 * lh, ar, az, ani, anh);
+    if (!GI_GLOBAL) stream_mfma<KI, true>(ar, az, ani, wi, Xi, xirow, lane, gate_frags(Wi, cB, KI, lane));
+    stream_mfma<8, true>(ar, az, anh, wf, Hin, H_ROW, lane, gate_frags(Wh, cB, 8, lane));
+    TRACE_POINT(21);
+    gru_finish(cA, ar, az, ani, anh, Hin, Hout, upd, ridx, lr, lh, gsave);
+    __builtin_amdgcn_sched_barrier(0);
+    TRACE_POINT(22);
+    gru_start<GI_GLOBAL>(sB, bsum, 16 * cB + 4 * lh, ar, az, ani, anh);
+    if (!GI_GLOBAL) stream_mfma<KI, false>(ar, az, ani, wi, Xi, xirow, lane, next);
+    stream_mfma<8, true>(ar, az, anh, wf, Hin, H_ROW, lane, next);
+    TRACE_POINT(23);
+    gru_finish(cB, ar, az, ani, anh, Hin, Hout, upd, ridx, lr, lh, gsave);
+    __builtin_amdgcn_sched_barrier(0);
+    TRACE_POINT(24);
+}
+
+// Barrier between two phases of a step.  The weight loads are loads from read-only, non-aliased memory: the instruction scheduler moves
+// them up across s_barrier (and then spills what it fetched early) unless the barrier is also a scheduling boundary.
+__device__ __forceinline__ void phase_sync(int id = 0) {
+    __builtin_amdgcn_sched_barrier(0);
+    TRACE_POINT(id);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    TRACE_POINT(id + 100);
+}
+
 template <bool SAVE>
 __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t *__restrict__ gi, const uint16_t *__restrict__ h0,
                                                                   const uint8_t *__restrict__ comm, const uint16_t *__restrict__ W,
@@ -209,7 +322,8 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                                                                   RecurSave sv, const int32_t *__restrict__ rowidx, long long nrows,
                                                                   const int4 *__restrict__ envtab) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lh = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lh = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction; said so, its tiles' addresses stay in scalar registers
     const int e = blockIdx.x;
     // envtab (mapf_recurrent_infer_multi: one step of environments of DIFFERENT agent counts -- the curriculum's levels -- in one
     // launch): per environment {agents, first row of its agents in gi / h0 / h_out, byte offset of its mask in comm, -}
@@ -228,9 +342,26 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
     const int rot = blockIdx.x;  // workgroups walk the weight tiles in rotated order: they run in step, and would otherwise all
                                  // request the same cache lines at the same moment
 
+    TRACE_BEGIN();
+    TRACE_POINT(30);
+    // the weight stream (see stream_mfma): this wave's channel blocks / q|k|v tiles are the same in every phase of every step
+    const int cA = (w + rot) & 15, cB = (w + 8 + rot) & 15, wq = (w + rot) & 7;
+    bf16x8 wf[8][3], wi[2][3];
+    load_frags<8>(wf, gate_frags(W + W_HH, cA, 8, lane));  // first job: the recurrent cell's block cA; under way during the prologue
+
     // hidden state of this environment (rows >= N stay zero: they are computed like real agents and never stored)
     for (int i = tid; i < LDS_BYTES / 16; i += NTHR) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
+    float *bsum = reinterpret_cast<float *>(smem + OFF_BSUM);
+    for (int i = tid; i < 2 * 256; i += NTHR) {  // same sums, same order as the accumulators used to start from
+        const int cell = i >> 8, c = i & 255;
+        const float *bi = bias + (cell ? UB_IH : B_IH), *bh = bias + (cell ? UB_HH : B_HH);
+        float *d = bsum + cell * 1024 + c;
+        d[0] = bi[c] + bh[c];
+        d[256] = bi[256 + c] + bh[256 + c];
+        d[512] = bi[512 + c];
+        d[768] = bh[512 + c];
+    }
     if (h0 != nullptr)
         for (int i = tid; i < N * 32; i += NTHR) {  // 32 chunks of 16 B per agent
             const int a = i >> 5, ch = i & 31;
@@ -239,6 +370,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
         }
     __syncthreads();
 
+    TRACE_POINT(31);
     unsigned char *Hc = smem + OFF_H0, *Hn = smem + OFF_H1;
     int *upd = reinterpret_cast<int *>(smem + OFF_UPD);
     float *S = reinterpret_cast<float *>(smem + OFF_S);
@@ -256,29 +388,61 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
             if (row >= 0) *reinterpret_cast<uint4 *>(dst + (long long)row * D + ch * 8) = *reinterpret_cast<const uint4 *>(H + a * H_ROW + ch * 16);
         }
     };
+    const uint16_t *const W_arg = W;
+    const float *const bias_arg = bias;
     for (int t = 0; t < T; ++t) {
+        // The weight and bias addresses of a wave are the same at every step; opaque copies of the base pointers keep the compiler from
+        // hoisting those loads out of the step loop (it did, once the cells' channel blocks became loop-invariant: 430 spilled registers).
+        int opaque0 = 0;  // (an opaque OFFSET: through the asm the pointers themselves would lose their address space -> flat loads)
+        asm volatile("" : "+s"(opaque0));
+        const uint16_t *__restrict__ W = W_arg + opaque0;
+        const float *__restrict__ bias = bias_arg + opaque0;
         const long long row0 = envtab ? hrow0 : ((long long)t * E + e) * N;  // first dense row of this (step, environment)
         // ---------------- this step's communication mask -> bit rows in LDS (the softmax loops must not touch global memory:
         // 120 dependent byte loads per row made the first version 10x slower than its MFMAs) ----------------
         const uint8_t *comm_t = comm + (envtab ? coff : ((long long)t * E + e) * N * N);
+        // the mask bytes first (vmcnt retires in order: requested behind the input projection they would wait for it), ...
+        constexpr int CI = (NA * NA + NTHR - 1) / NTHR;
+        uint8_t cbyte[CI];
+#pragma unroll
+        for (int q = 0; q < CI; ++q) {
+            const int idx = tid + q * NTHR;
+            cbyte[q] = idx < N * NR ? comm_t[idx] : (uint8_t)0;
+        }
+        // ... then the recurrent cell's input projection rows of this lane's agents, for both channel blocks: requested before anything
+        // else of the step (they come from HBM -- 60 KB per 40-agent environment, by all workgroups at about the same time)
+        GruInit sA, sB;
+        {
+            int grow[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int a = 16 * n + lr;
+                grow[n] = a < N ? (rowidx ? rowidx[row0 + a] : (int)(row0 + a)) : -1;
+            }
+            if (!(MAPF_RECUR_ABLATE & 1)) {
+                gru_fetch_gi(sA, cA, gi, grow, lh);
+                gru_fetch_gi(sB, cB, gi, grow, lh);
+            }
+        }
         if (tid < NA * 2) mb[tid] = 0u;
         if (tid < NA) ridx[tid] = tid < N ? (rowidx ? rowidx[row0 + tid] : (int)(row0 + tid)) : -1;
-        __syncthreads();
+        phase_sync(1);
         if (SAVE) save_hidden(sv.hin0, Hc);
         // (mapf_recurrent_infer_multi packs several small environments of one level into one workgroup -- their agents' rows are
         // consecutive everywhere, and the weights, which is what a step streams, are fetched once for all of them: row i = agent i % NR
         // of environment i / NR reads that environment's mask row, its partners are the columns of that environment: a block-diagonal
         // mask.  NR == N: one environment, the plain case.)
-        for (int idx = tid; idx < N * NR; idx += NTHR)
-            if (comm_t[idx] != 0) {
-                const int i = idx / NR, j = (i / NR) * NR + (idx - i * NR);
+#pragma unroll
+        for (int q = 0; q < CI; ++q)
+            if (cbyte[q] != 0) {
+                const int idx = tid + q * NTHR, i = idx / NR, j = (i / NR) * NR + (idx - i * NR);
                 atomicOr(&mb[2 * i + (j >> 5)], 1u << (j & 31));
             }
         // ---------------- recurrent GRU cell: Hc -> Hn (the barrier behind it also publishes the mask bits) ----------------
-        for (int c = w; c < 16 && !(MAPF_RECUR_ABLATE & 1); c += NTHR / 64)
-            gru_block<true, 1>((c + rot) & 15, gi, nullptr, nullptr, 0, W + W_HH, bias + B_IH, bias + B_HH, Hc, Hn, nullptr, ridx, lr, lh,
-                               SAVE ? sv.g1 : nullptr);
-        __syncthreads();
+        if (!(MAPF_RECUR_ABLATE & 1))
+            gru_pair<true, 2>(cA, cB, sA, sB, wf, wi, nullptr, nullptr, 0, W + W_HH, bsum, Hc, Hn, nullptr, ridx, lr, lh, SAVE ? sv.g1 : nullptr,
+                              frag3(W + W_QKV, wq, wq + 8, wq + 16, 8, lane));
+        phase_sync(2);
         {
             unsigned char *tmp = Hc;
             Hc = Hn;
@@ -286,10 +450,12 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
         }
         // ---------------- two communication rounds (shared weights): Hc -> Hn -> swap ----------------
         for (int round = 0; round < 2; ++round) {
+            asm volatile("" : "+s"(opaque0));  // (both rounds read the same weights: without this the second round's loads are "the first round's
+            W = W_arg + opaque0;               //  values", kept in registers across the whole round)
+            bias = bias_arg + opaque0;
             if (SAVE) save_hidden(sv.hr + (long long)round * RTOT * D, Hc);
             // q | k | v = W_qkv h + b: 24 output tiles of 16
-            for (int wq0 = w; wq0 < 8 && !(MAPF_RECUR_ABLATE & 2); wq0 += NTHR / 64) {
-                const int wq = (wq0 + rot) & 7;
+            if (!(MAPF_RECUR_ABLATE & 2)) {  // (one job per wave)
                 f32x4 acc[3][NT];  // tiles wq (q), wq + 8 (k), wq + 16 (v)
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
@@ -297,7 +463,9 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
 #pragma unroll
                     for (int n = 0; n < NT; ++n) acc[g][n] = f32x4{b4.x, b4.y, b4.z, b4.w};
                 }
-                gemm3x16<8>(acc[0], acc[1], acc[2], W + W_QKV, wq, wq + 8, wq + 16, Hc, H_ROW, lane);
+                stream_mfma<8, true>(acc[0], acc[1], acc[2], wf, Hc, H_ROW, lane, gate_frags(W + U_HH, cA, 8, lane));  // next: the update cell
+                load_frags<2>(wi, gate_frags(W + U_IH, cA, 2, lane));
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const int agent = 16 * n + lr, c0 = 16 * wq + 4 * lh;
@@ -321,7 +489,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                     }
                 }
             }
-            __syncthreads();
+            phase_sync(3);
             // scores S[head][i][j] = q_i . k_j / 8: 2 heads x 3 x 3 tiles, K = 64
             for (int job = w; job < 2 * NT * NT && !(MAPF_RECUR_ABLATE & 4); job += NTHR / 64) {
                 const int hd = job / (NT * NT), ti = (job / NT) % NT, tj = job % NT;
@@ -335,7 +503,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
 #pragma unroll
                 for (int r = 0; r < 4; ++r) S[(hd * NA + 16 * ti + 4 * lh + r) * S_ROW + 16 * tj + lr] = acc[r] * scale;
             }
-            __syncthreads();
+            phase_sync(4);
             // masked softmax per (head, agent i) row -> P bf16 (zero for j >= N and for rows i >= N); update flags.
             // Four lanes (one DPP quad) per row, 12 columns each: row maximum and sum through quad permutations
             // (one thread per row left 416 of the 512 threads idle behind a 48-element serial chain)
@@ -382,7 +550,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                     upd[i] = 0;
                 }
             }
-            __syncthreads();
+            phase_sync(5);
             if (SAVE) {  // P rows (2 heads x 48 agents x 64 slots = 128 B each) -> global
                 uint16_t *pd = sv.P + (((long long)round * T + t) * E + e) * (2 * NA * 64);
                 for (int i = tid; i < 2 * NA * 8; i += NTHR) {
@@ -413,7 +581,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                         *reinterpret_cast<uint2 *>(sv.ctx + ((long long)round * RTOT + ridx[16 * n + lr]) * 128 + hd * HD + 16 * td + 4 * lh) = v;
                 }
             }
-            __syncthreads();
+            phase_sync(6);
             // info = W_O ctx (no bias): 4 output tiles, K = 128
             for (int ot = w; ot < 4 && !(MAPF_RECUR_ABLATE & 8); ot += NTHR / 64) {
                 f32x4 acc[NT];
@@ -428,12 +596,13 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                         *reinterpret_cast<uint2 *>(sv.info + ((long long)round * RTOT + ridx[16 * n + lr]) * 64 + 16 * ot + 4 * lh) = v;
                 }
             }
-            __syncthreads();
+            phase_sync(7);
             // update cell: Hc -> Hn where the agent has a partner
-            for (int c = w; c < 16 && !(MAPF_RECUR_ABLATE & 16); c += NTHR / 64)
-                gru_block<false, 2>((c + rot) & 15, nullptr, W + U_IH, smem + OFF_INFO, INFO_ROW, W + U_HH, bias + UB_IH, bias + UB_HH, Hc, Hn, upd, ridx, lr, lh,
-                                    SAVE ? sv.g2 + (long long)round * RTOT * 1024 : nullptr);
-            __syncthreads();
+            if (!(MAPF_RECUR_ABLATE & 16))  // behind it: the second round's q|k|v, or the next step's recurrent cell (a wasted fetch at the last step)
+                gru_pair<false, 2>(cA, cB, sA, sB, wf, wi, W + U_IH, smem + OFF_INFO, INFO_ROW, W + U_HH, bsum + 1024, Hc, Hn, upd, ridx, lr, lh,
+                                   SAVE ? sv.g2 + (long long)round * RTOT * 1024 : nullptr,
+                                   round == 0 ? frag3(W + W_QKV, wq, wq + 8, wq + 16, 8, lane) : gate_frags(W + W_HH, cA, 8, lane));
+            phase_sync(8);
             unsigned char *tmp = Hc;
             Hc = Hn;
             Hn = tmp;
@@ -445,6 +614,8 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
         const int a = i >> 5, ch = i & 31;
         *reinterpret_cast<uint4 *>(h_out + (hrow0 + a) * D + ch * 8) = *reinterpret_cast<const uint4 *>(Hc + a * H_ROW + ch * 16);
     }
+    TRACE_POINT(32);
+    TRACE_END();
 }
 
 #define HIP_TRY(expr)                                                                        \
@@ -541,4 +712,18 @@ extern "C" int mapf_recurrent_infer_multi(const uint16_t *gi_dev, const uint16_t
 
 #if MAPF_RECUR_NT == 3
 }  // extern "C"
+#endif
+#ifdef MAPF_RECUR_TRACE
+#define RECUR_TRACE_NAME2(a, b) a##b
+#define RECUR_TRACE_NAME(a, b) RECUR_TRACE_NAME2(a, b)
+extern "C" int RECUR_TRACE_NAME(mapf_recur_trace_read_nt, MAPF_RECUR_NT)(unsigned long long *out, int reset) {
+    int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_trace_n), sizeof(int)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
+    if (reset) {
+        const int zero = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_n), &zero, sizeof(int)) != hipSuccess) return -1;
+    }
+    return n;
+}
 #endif

@@ -19,13 +19,15 @@ def so(mode):
 def build():
     for m in MODES:
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-                               "-DMAPF_RECUR_ABLATE=%d" % m, os.path.join(ROOT, "mapf_rl_amd", "csrc", "mapf_recur.hip"), "-o", so(m)])
+                               "-I" + os.path.join(ROOT, "mapf_rl_amd", "csrc"), "-mllvm", "-pragma-unroll-threshold=262144",
+                               "-DMAPF_RECUR_ABLATE=%d" % m] + [os.path.join(ROOT, "mapf_rl_amd", "csrc", f) for f in
+                               ("mapf_recur.hip", "mapf_recur_nt1.hip", "mapf_recur_nt2.hip", "mapf_recur_wide.hip")] + ["-o", so(m)])
 
 
 def run():
     import torch
 
-    T, E, N = 1, 4096, 40
+    T, E, N = 1, 4096, int(os.environ.get("ABLATE_AGENTS", "40"))
     gi = (torch.randn((T, E, N, 768), device="cuda") * 0.5).to(torch.bfloat16)
     h0 = (torch.randn((E, N, 256), device="cuda") * 0.3).to(torch.bfloat16)
     comm = (torch.rand((T, E, N, N), device="cuda") < 0.1).to(torch.uint8)
@@ -34,9 +36,9 @@ def run():
     out = torch.empty((E, N, 256), dtype=torch.bfloat16, device="cuda")
     for m in MODES:
         fn = ctypes.CDLL(so(m)).mapf_recurrent_infer
-        fn.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3
+        fn.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p]
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        args = (gi.data_ptr(), h0.data_ptr(), comm.data_ptr(), w.data_ptr(), b.data_ptr(), T, E, N, out.data_ptr(), None, st)
+        args = (gi.data_ptr(), h0.data_ptr(), comm.data_ptr(), w.data_ptr(), b.data_ptr(), T, E, N, out.data_ptr(), None, None, 0, st)
         for _ in range(2):
             fn(*args)
         torch.cuda.synchronize()
