@@ -37,7 +37,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-#ifndef MAPF_ENC_ABLATE  // diagnostic builds only (tools/micro/enc_ablate.py): 1 = no saved-activation copies, 2 = no ReLU sign words
+#ifndef MAPF_ENC_ABLATE  // diagnostic builds only (tools/micro/enc_ablate.py): 1 = no saved-activation copies, 2 = no ReLU sign words, 4 = 16 consecutive LDS rows per position tile
 #define MAPF_ENC_ABLATE 0
 #endif
 constexpr int G = MAPF_ENC_OBS_PER_BLOCK;  // observations per workgroup
@@ -270,6 +270,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
         const bool v = p < 49 * nobs;
         const int o = p / 49, q = p - 49 * o, y = q / 7, x = q - 7 * y;
         addr[n] = (v ? (64 * o + 8 * y + x) * ROWB : 0) + lh * 16;
+        if (MAPF_ENC_ABLATE & 4) addr[n] = (n * 16 + lr) * ROWB + lh * 16;  // diagnostic: 16 CONSECUTIVE rows per tile (wrong results, conflict-free reads)
         vmask |= (v ? 1u : 0u) << n;
     }
     __syncthreads();

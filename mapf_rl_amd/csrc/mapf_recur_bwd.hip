@@ -45,6 +45,37 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #define MAPF_RECUR_NT 3
 #endif
 constexpr int NT = MAPF_RECUR_NT, NA = 16 * NT, D = 256, HD = 64, NTHR = 512;
+#ifdef MAPF_RECUR_TRACE  // diagnostic builds only (tools/micro/recur_bwd_trace.py): cycle stamps of wave 0 of one workgroup, as in csrc/mapf_recur.hip
+#ifndef MAPF_RECUR_TRACE_WG
+#define MAPF_RECUR_TRACE_WG 0
+#endif
+__device__ unsigned long long g_btrace[128];
+__device__ int g_btrace_n;
+__shared__ unsigned long long btrace_lds[128];
+__shared__ int btrace_lds_n;
+#define TRACE_POINT(id)                                                                                                  \
+    do {                                                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.x == MAPF_RECUR_TRACE_WG) {                                                     \
+            const int k_ = btrace_lds_n;                                                                                 \
+            if (k_ < 126) {                                                                                              \
+                btrace_lds[k_] = ((unsigned long long)(id) << 56) | (__builtin_readcyclecounter() & 0xFFFFFFFFFFFFFFull); \
+                btrace_lds_n = k_ + 1;                                                                                   \
+            }                                                                                                            \
+        }                                                                                                                \
+    } while (0)
+#define TRACE_BEGIN() do { if (threadIdx.x == 0) btrace_lds_n = 0; } while (0)
+#define TRACE_END()                                                                    \
+    do {                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x == MAPF_RECUR_TRACE_WG) {                   \
+            for (int k_ = 0; k_ < btrace_lds_n; ++k_) g_btrace[k_] = btrace_lds[k_];   \
+            g_btrace_n = btrace_lds_n;                                                 \
+        }                                                                              \
+    } while (0)
+#else
+#define TRACE_POINT(id) do { } while (0)
+#define TRACE_BEGIN() do { } while (0)
+#define TRACE_END() do { } while (0)
+#endif
 constexpr int H_ROW = D * 2 + 32;     // 544
 constexpr int INFO_ROW = 64 * 2 + 32;  // 160
 constexpr int CTX_ROW = 128 * 2 + 32;  // 288
@@ -322,6 +353,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
     for (int i = tid; i < LDS_BYTES / 16; i += NTHR) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
 
+    TRACE_BEGIN();
     for (int t = T - 1; t >= 0; --t) {
         const long long row0 = ((long long)t * E + e) * N;
         // ---- external gradient of agent 0's state after step t; partner counts of this step's mask ----
@@ -339,22 +371,30 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
             const int a = tid - 128;
             ridx[a] = a < N ? (A.rowidx ? A.rowidx[row0 + a] : (int)(row0 + a)) : -1;
         }
+        TRACE_POINT(1);
         __syncthreads();
+        TRACE_POINT(101);
         {
             const uint8_t *cm = A.comm + ((long long)t * E + e) * N * N;
             for (int idx = tid; idx < N * N; idx += NTHR)
                 if (cm[idx] != 0) atomicAdd(&upd[idx / N], 1);
         }
+        TRACE_POINT(2);
         __syncthreads();
+        TRACE_POINT(102);
         if (tid < 64) upd[tid] = upd[tid] > 1 ? 1 : 0;  // model.py:103
+        TRACE_POINT(3);
         __syncthreads();
+        TRACE_POINT(103);
 
         for (int q = 1; q >= 0; --q) {
             const long long rq = (long long)q * RTOT;  // first row of round q's tensors
             uint16_t *dgi2 = A.d_gi2 + rq * 768, *dgh2 = A.d_gh2 + rq * 768;
             // (1) update-cell backward
             if (!(MAPF_RBWD_ABLATE & 1)) gru_bwd_elementwise(DH, smem + OFF_G, A.g2 + rq * 1024, A.hr + rq * D, upd, dgi2, dgh2, ridx, tid);
+            TRACE_POINT(4);
             __syncthreads();
+            TRACE_POINT(104);
             // (2) DH += U_hh^T d_gh (2 output tiles per wave); d_info = U_ih^T d_gi (waves 0-3, one tile each)
             if (!(MAPF_RBWD_ABLATE & 1)) bias_colsum(smem + OFF_G, reinterpret_cast<float *>(smem + OFF_BSUM), tid);
             if (!(MAPF_RBWD_ABLATE & 2)) {
@@ -380,7 +420,9 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
                     }
                 }
             }
+            TRACE_POINT(5);
             __syncthreads();
+            TRACE_POINT(105);
             // (3) d_ctx = W_O^T d_info: 8 output tiles, K = 64
             if (!(MAPF_RBWD_ABLATE & 4)) {
                 f32x4 acc[NT];
@@ -393,7 +435,9 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
                     *reinterpret_cast<uint2 *>(smem + OFF_DCTX + (16 * n + lr) * CTX_ROW + (16 * w + 4 * lh) * 2) = pack4(o);
                 }
             }
+            TRACE_POINT(6);
             __syncthreads();
+            TRACE_POINT(106);
             // (4) attention backward, one head at a time
             for (int hd = 0; hd < 2 && !(MAPF_RBWD_ABLATE & 4); ++hd) {
                 // images: q, k, v rows [agent][64] of this head (zero rows for agents >= N); P rows [agent i][64 slots j] (zero rows
@@ -415,7 +459,9 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
                     *reinterpret_cast<uint4 *>(dst + OFF_VI) = vv;
                     *reinterpret_cast<uint4 *>(dst + OFF_PI) = vp;
                 }
+                TRACE_POINT(7);
                 __syncthreads();
+                TRACE_POINT(107);
                 // dP[i][j] = sum_d d_ctx[i][d] v[j][d]
                 for (int job = w; job < NT * NT; job += NTHR / 64) {
                     const int ti = job / NT, tj = job % NT;
@@ -427,7 +473,9 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) SF[(16 * ti + 4 * lh + r) * SF_ROW + 16 * tj + lr] = acc[r];
                 }
+                TRACE_POINT(8);
                 __syncthreads();
+                TRACE_POINT(108);
                 // softmax backward per row i, 4 lanes x 12 columns each: dS = P (dP - sum_j dP P) / 8; slots 48..63 and rows 48..63 of
                 // the dS image are zero (K padding)
                 if (tid < 4 * NA) {
@@ -470,7 +518,9 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
                     const int k = tid - 4 * NA;
                     *reinterpret_cast<uint4 *>(smem + OFF_DSI + (NA + (k >> 3)) * IMG_ROW + (k & 7) * 16) = make_uint4(0, 0, 0, 0);
                 }
+                TRACE_POINT(9);
                 __syncthreads();
+                TRACE_POINT(109);
                 // dv, dq, dk: 3 products x 4 d-tiles x 3 agent tiles, each K = 64 (image rows / slots 48..63 are zero)
                 for (int job = w; job < 3 * 4 * NT; job += NTHR / 64) {
                     const int prod = job / (4 * NT), td = (job / NT) % 4, ta = job % NT;
@@ -494,7 +544,9 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
                     const float o[4] = {acc[0], acc[1], acc[2], acc[3]};
                     *reinterpret_cast<uint2 *>(smem + OFF_DQKV + (16 * ta + lr) * QKV_ROW + colbase * 2) = pack4(o);
                 }
+                TRACE_POINT(10);
                 __syncthreads();
+                TRACE_POINT(110);
             }
             // (5) d_qkv rows -> global; DH += W_qkv^T d_qkv (2 output tiles per wave, K = 384)
             if (tid < 384) {  // column sums of d_qkv (rows >= N are zero)
@@ -515,11 +567,15 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
                 add_to_dh(DH, acc0, w, lr, lh);
                 add_to_dh(DH, acc1, w + 8, lr, lh);
             }
+            TRACE_POINT(11);
             __syncthreads();
+            TRACE_POINT(111);
         }
         // ---- recurrent cell backward: d_gi1 is the gradient w.r.t. the GRU input projection ----
         if (!(MAPF_RBWD_ABLATE & 16)) gru_bwd_elementwise(DH, smem + OFF_G, A.g1, A.hin0, nullptr, A.d_gi1, A.d_gh1, ridx, tid);
+        TRACE_POINT(12);
         __syncthreads();
+        TRACE_POINT(112);
         if (!(MAPF_RBWD_ABLATE & 16)) {
             bias_colsum(smem + OFF_G, reinterpret_cast<float *>(smem + OFF_BSUM) + 1024, tid);
             f32x4 acc0[NT], acc1[NT];
@@ -533,9 +589,12 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
             add_to_dh(DH, acc0, w, lr, lh);
             add_to_dh(DH, acc1, w + 8, lr, lh);
         }
+        TRACE_POINT(13);
         __syncthreads();
+        TRACE_POINT(113);
     }
     for (int i = tid; i < NBSUM; i += NTHR) A.bsum[(long long)e * NBSUM + i] = reinterpret_cast<const float *>(smem + OFF_BSUM)[i];
+    TRACE_END();
 }
 
 #define HIP_TRY(expr)                                                                            \
@@ -615,4 +674,18 @@ int RECUR_ENTRY(mapf_recurrent_backward)(const uint16_t *const *saved_dev, const
 
 #if MAPF_RECUR_NT == 3
 }  // extern "C"
+#endif
+#ifdef MAPF_RECUR_TRACE
+#define RBWD_TRACE_NAME2(a, b) a##b
+#define RBWD_TRACE_NAME(a, b) RBWD_TRACE_NAME2(a, b)
+extern "C" int RBWD_TRACE_NAME(mapf_recur_btrace_read_nt, MAPF_RECUR_NT)(unsigned long long *out, int reset) {
+    int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_btrace_n), sizeof(int)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_btrace), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
+    if (reset) {
+        const int zero = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_btrace_n), &zero, sizeof(int)) != hipSuccess) return -1;
+    }
+    return n;
+}
 #endif

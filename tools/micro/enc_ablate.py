@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-MODES = [0, 1, 2, 3]
+MODES = [0, 1, 2, 3, 4]
 
 
 def so(mode):

@@ -77,6 +77,27 @@ def run():
             torch.cuda.synchronize()
             outs[name] = (out, a0)
             print("T=%2d E=%4d N=%2d %-5s rc=%d %.3f ms per launch" % (T, E, N, name, rc, e0.elapsed_time(e1) / 5), flush=True)
+        if T > 1:  # the training forward (saves what the backward needs)
+            R = T * E * N
+            sizes = [R * 256, R * 1024, 2 * R * 256, 2 * R * 384, 2 * R * 128, 2 * R * 64, 2 * R * 1024, 2 * T * E * 2 * 48 * 64]
+            for name in ("base", "cand"):
+                fs = ctypes.CDLL(so(name)).mapf_recurrent_forward_save
+                fs.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_void_p]
+                bufs = [torch.zeros(n, dtype=torch.bfloat16, device="cuda") for n in sizes]
+                ptrs = (ctypes.c_void_p * 8)(*[b_.data_ptr() for b_ in bufs])
+                out = torch.zeros((E, N, 256), dtype=torch.bfloat16, device="cuda")
+                a0 = torch.zeros((T, E, 256), dtype=torch.bfloat16, device="cuda")
+                args = (gi.data_ptr(), h0.data_ptr(), comm.data_ptr(), w.data_ptr(), b.data_ptr(), T, E, N, out.data_ptr(), a0.data_ptr(), ptrs, None, 0, st)
+                for _ in range(2):
+                    rc = fs(*args)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    fs(*args)
+                e1.record()
+                torch.cuda.synchronize()
+                print("T=%2d E=%4d N=%2d %-5s rc=%d %.3f ms per forward_save launch" % (T, E, N, name, rc, e0.elapsed_time(e1) / 5), flush=True)
         d = (outs["base"][0].float() - outs["cand"][0].float()).abs()
         print("   max |diff| %.4g, differing elements %.4g, nan base/cand %d/%d" % (d.max().item(), (d > 0).float().mean().item(), outs["base"][0].isnan().sum().item(), outs["cand"][0].isnan().sum().item()))
         print("   hidden bit-identical=%s  agent-0 trace bit-identical=%s" % (torch.equal(outs["base"][0], outs["cand"][0]), torch.equal(outs["base"][1], outs["cand"][1])), flush=True)
