@@ -349,6 +349,34 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
     bf16x8 wf[8][3], wi[2][3];
     load_frags<8>(wf, gate_frags(W + W_HH, cA, 8, lane));  // first job: the recurrent cell's block cA; under way during the prologue
 
+    // What a step reads from global memory besides the weights: its mask bytes and the recurrent cell's input projection rows of this
+    // lane's agents, for both channel blocks (from HBM -- 60 KB per 40-agent environment, by all workgroups at about the same time: a
+    // one-step launch waited 18 k cycles for them behind its prologue).  Requested before anything else of the step; step 0's before
+    // the prologue.  The mask bytes first: vmcnt retires in order, requested behind the input projection they would wait for it.
+    constexpr int CI = (NA * NA + NTHR - 1) / NTHR;
+    uint8_t cbyte[CI];
+    GruInit sA, sB;
+    auto fetch_inputs = [&](int t) {
+        const long long row0 = envtab ? hrow0 : ((long long)t * E + e) * N;
+        const uint8_t *comm_t = comm + (envtab ? coff : ((long long)t * E + e) * N * N);
+#pragma unroll
+        for (int q = 0; q < CI; ++q) {
+            const int idx = tid + q * NTHR;
+            cbyte[q] = idx < N * NR ? comm_t[idx] : (uint8_t)0;
+        }
+        int grow[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int a = 16 * n + lr;
+            grow[n] = a < N ? (rowidx ? rowidx[row0 + a] : (int)(row0 + a)) : -1;
+        }
+        if (!(MAPF_RECUR_ABLATE & 1)) {
+            gru_fetch_gi(sA, cA, gi, grow, lh);
+            gru_fetch_gi(sB, cB, gi, grow, lh);
+        }
+    };
+    fetch_inputs(0);
+
     // hidden state of this environment (rows >= N stay zero: they are computed like real agents and never stored)
     for (int i = tid; i < LDS_BYTES / 16; i += NTHR) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -390,7 +418,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
     };
     const uint16_t *const W_arg = W;
     const float *const bias_arg = bias;
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0;;) {  // (T >= 1)
         // The weight and bias addresses of a wave are the same at every step; opaque copies of the base pointers keep the compiler from
         // hoisting those loads out of the step loop (it did, once the cells' channel blocks became loop-invariant: 430 spilled registers).
         int opaque0 = 0;  // (an opaque OFFSET: through the asm the pointers themselves would lose their address space -> flat loads)
@@ -400,30 +428,6 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
         const long long row0 = envtab ? hrow0 : ((long long)t * E + e) * N;  // first dense row of this (step, environment)
         // ---------------- this step's communication mask -> bit rows in LDS (the softmax loops must not touch global memory:
         // 120 dependent byte loads per row made the first version 10x slower than its MFMAs) ----------------
-        const uint8_t *comm_t = comm + (envtab ? coff : ((long long)t * E + e) * N * N);
-        // the mask bytes first (vmcnt retires in order: requested behind the input projection they would wait for it), ...
-        constexpr int CI = (NA * NA + NTHR - 1) / NTHR;
-        uint8_t cbyte[CI];
-#pragma unroll
-        for (int q = 0; q < CI; ++q) {
-            const int idx = tid + q * NTHR;
-            cbyte[q] = idx < N * NR ? comm_t[idx] : (uint8_t)0;
-        }
-        // ... then the recurrent cell's input projection rows of this lane's agents, for both channel blocks: requested before anything
-        // else of the step (they come from HBM -- 60 KB per 40-agent environment, by all workgroups at about the same time)
-        GruInit sA, sB;
-        {
-            int grow[NT];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int a = 16 * n + lr;
-                grow[n] = a < N ? (rowidx ? rowidx[row0 + a] : (int)(row0 + a)) : -1;
-            }
-            if (!(MAPF_RECUR_ABLATE & 1)) {
-                gru_fetch_gi(sA, cA, gi, grow, lh);
-                gru_fetch_gi(sB, cB, gi, grow, lh);
-            }
-        }
         if (tid < NA * 2) mb[tid] = 0u;
         if (tid < NA) ridx[tid] = tid < N ? (rowidx ? rowidx[row0 + tid] : (int)(row0 + tid)) : -1;
         phase_sync(1);
@@ -609,6 +613,8 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
         }
         if (agent0_out != nullptr && tid < 32)  // agent 0's state after this step (model.py:248)
             *reinterpret_cast<uint4 *>(agent0_out + ((long long)t * E + e) * D + tid * 8) = *reinterpret_cast<const uint4 *>(Hc + tid * 16);
+        if (++t >= T) break;
+        fetch_inputs(t);  // the next step's (step 0's were requested in front of the prologue)
     }
     for (int i = tid; i < N * 32; i += NTHR) {
         const int a = i >> 5, ch = i & 31;
