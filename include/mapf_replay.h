@@ -152,6 +152,9 @@ int mapf_actor_explore_dev(int num_envs, int num_agents, int64_t *actions_dev, i
  *   mapf_actor_explore_multi: aux_dev int64 [E][3] = {exploration seed of the environment's level, base counter, index of the
  *     environment within its level}: the draws are those of mapf_actor_explore_dev(seed, base, tick) for that level alone;
  *   mapf_actor_record_multi / mapf_actor_rewind_multi: mapf_actor_record / mapf_actor_rewind with the per-environment table;
+ *     rewind_multi optionally (hidden_out_dev != NULL, a different buffer) writes EVERY environment's hidden rows to hidden_out_dev --
+ *     hidden_dev's for the running episodes, zeros for the finished ones -- i.e. the policy's next input, and (tick_dev != NULL)
+ *     increments the iteration counter: the two element-wise launches that otherwise end a graph-replayed iteration;
  *   mapf_actor_log_multi: mapf_actor_log per level l over the environments [level_start[l], level_start[l + 1]) (host array of
  *     num_levels + 1 entries, num_levels <= 16) into that level's log / counters (host arrays of device pointers).
  */
@@ -163,7 +166,8 @@ int mapf_actor_record_multi(int num_envs, int local_steps, int row_dwords, int m
                             uint16_t *lb_rew_dev, uint16_t *lb_hid_dev, int32_t *lb_comm_dev, int32_t *lb_obs_dev, uint8_t *finished_dev,
                             void *stream);
 int mapf_actor_rewind_multi(int num_envs, int local_steps, int row_dwords, const int32_t *envtab_dev, const uint8_t *finished_dev,
-                            const int32_t *obs_bits_dev, int64_t *t_dev, int32_t *lb_obs_dev, uint16_t *hidden_dev, void *stream);
+                            const int32_t *obs_bits_dev, int64_t *t_dev, int32_t *lb_obs_dev, uint16_t *hidden_dev, uint16_t *hidden_out_dev,
+                            uint64_t *tick_dev, void *stream);
 int mapf_actor_log_multi(int num_levels, const int32_t *level_start, uint8_t *const *log_dev, int64_t *const *counters_dev, int log_size,
                          const uint8_t *finished_dev, const uint8_t *done_dev, const uint8_t *stat_mask_dev, void *stream);
 /*

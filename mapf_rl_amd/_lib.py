@@ -63,7 +63,7 @@ SYMBOLS = [
     ("mapf_replay_add_many_env", _i, [_vp, _i, _vp, _i] + [_vp] * 10),
     ("mapf_actor_explore_multi", _i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_actor_record_multi", _i, [_i, _i, _i, _i] + [_vp] * 17),
-    ("mapf_actor_rewind_multi", _i, [_i, _i, _i] + [_vp] * 7),
+    ("mapf_actor_rewind_multi", _i, [_i, _i, _i] + [_vp] * 9),
     ("mapf_actor_log_multi", _i, [_i, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _vp, _vp, _vp, _vp]),
     ("mapf_actor_record", _i, [_i] * 6 + [_vp] * 16),
     ("mapf_actor_rewind", _i, [_i] * 5 + [_vp] * 6),

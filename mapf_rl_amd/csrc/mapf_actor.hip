@@ -88,11 +88,14 @@ struct RewindParams {
     int32_t *lb_obs;          // [E][S+1][RDA]
     uint16_t *hidden;         // [E][N][256] bf16
     const int4 *envtab;       // optional, as in RecordParams
+    uint16_t *hidden_out;     // optional: every environment's rows of `hidden` go there (zeros for the finished ones) instead of zeroing in place
+    unsigned long long *tick; // optional: incremented by one (the iteration counter a replayed graph reads, mapf_actor_explore_multi)
 };
 
 __global__ void __launch_bounds__(256) actor_rewind_kernel(RewindParams p) {
     const int e = blockIdx.x, tid = threadIdx.x;
-    if (p.finished[e] == 0) return;
+    if (p.tick != nullptr && e == 0 && tid == 0) *p.tick += 1ull;
+    if (p.finished[e] == 0 && p.hidden_out == nullptr) return;
     int N = p.N, RD = p.RD;
     size_t row0 = (size_t)e * p.N, boff = (size_t)e * p.RD;
     if (p.envtab) {
@@ -100,11 +103,17 @@ __global__ void __launch_bounds__(256) actor_rewind_kernel(RewindParams p) {
         N = d.x, row0 = (size_t)d.y, boff = (size_t)d.w;
         RD = ((N * 486 + 31) / 32 + 3) & ~3;
     }
+    if (p.finished[e] == 0) {  // a running episode: its new hidden states become the next iteration's input
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.hidden + row0 * 256);
+        uint4 *dst = reinterpret_cast<uint4 *>(p.hidden_out + row0 * 256);
+        for (int i = tid; i < N * 32; i += 256) dst[i] = src[i];
+        return;
+    }
     if (tid == 0) p.t[e] = 0;
     int32_t *o = p.lb_obs + (size_t)e * (p.S + 1) * p.RDA;
     const int32_t *b = p.bits + boff;
     for (int i = tid; i < RD; i += 256) o[i] = b[i];
-    uint4 *h = reinterpret_cast<uint4 *>(p.hidden + row0 * 256);  // model.reset(): GRUCell(x, None) == zero state
+    uint4 *h = reinterpret_cast<uint4 *>((p.hidden_out ? p.hidden_out : p.hidden) + row0 * 256);  // model.reset(): GRUCell(x, None) == zero state
     for (int i = tid; i < N * 32; i += 256) h[i] = make_uint4(0, 0, 0, 0);
 }
 
@@ -361,12 +370,14 @@ int mapf_actor_record_multi(int num_envs, int local_steps, int row_dwords, int m
 }
 
 int mapf_actor_rewind_multi(int num_envs, int local_steps, int row_dwords, const int32_t *envtab_dev, const uint8_t *finished_dev,
-                            const int32_t *obs_bits_dev, int64_t *t_dev, int32_t *lb_obs_dev, uint16_t *hidden_dev, void *stream) {
+                            const int32_t *obs_bits_dev, int64_t *t_dev, int32_t *lb_obs_dev, uint16_t *hidden_dev, uint16_t *hidden_out_dev,
+                            uint64_t *tick_dev, void *stream) {
     if (num_envs < 1 || local_steps < 1 || row_dwords < 1 || !envtab_dev || !finished_dev || !obs_bits_dev || !t_dev || !lb_obs_dev || !hidden_dev ||
-        (reinterpret_cast<uintptr_t>(hidden_dev) & 15) || (reinterpret_cast<uintptr_t>(envtab_dev) & 15))
+        (reinterpret_cast<uintptr_t>(hidden_dev) & 15) || (reinterpret_cast<uintptr_t>(envtab_dev) & 15) ||
+        (reinterpret_cast<uintptr_t>(hidden_out_dev) & 15) || (reinterpret_cast<uintptr_t>(tick_dev) & 7) || hidden_out_dev == hidden_dev)
         return MAPF_ERR_INVALID_ARG;
     RewindParams p{num_envs, 0, local_steps, 0, row_dwords, finished_dev, obs_bits_dev, t_dev, lb_obs_dev, hidden_dev,
-                   reinterpret_cast<const int4 *>(envtab_dev)};
+                   reinterpret_cast<const int4 *>(envtab_dev), hidden_out_dev, reinterpret_cast<unsigned long long *>(tick_dev)};
     hipLaunchKernelGGL(actor_rewind_kernel, dim3(num_envs), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
 }

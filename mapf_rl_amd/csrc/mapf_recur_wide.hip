@@ -77,8 +77,9 @@ __device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
 __device__ __forceinline__ uint2 pack4(const f32x4 v) { return make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])); }
 __device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 2.f / (1.f + __expf(-2.f * x)) - 1.f; }
+// (as in csrc/mapf_recur.hip: v_rcp_f32 instead of an IEEE division -- the cells' pointwise math is VALU time of the order of their MFMA time)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return __builtin_fmaf(2.f, __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)), -1.f); }
 // two accumulator tiles (4 consecutive k each) -> one B / A fragment of 8 bf16
 __device__ __forceinline__ bf16x8 frag_from_acc(const f32x4 lo, const f32x4 hi) {
     union {
@@ -179,7 +180,7 @@ __device__ __forceinline__ void gru_job(uint2 (&outv)[NTH], int cblk, int tile0,
         for (int r = 0; r < 4; ++r) {
             const float rg = sigmoidf_(ar[n][r]), zg = sigmoidf_(az[n][r]);
             const float ng = tanhf_(ani[n][r] + rg * anh[n][r]);
-            o[r] = (1.f - zg) * ng + zg * h[r];
+            o[r] = __builtin_fmaf(1.f - zg, ng, zg * h[r]);
             rg4[r] = rg;
             zg4[r] = zg;
             ng4[r] = ng;

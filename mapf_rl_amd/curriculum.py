@@ -284,9 +284,8 @@ class CurriculumActors:
         self.multi.reset(a0.density, self.tick)   # Actor.reset (worker.py:422-428) of every finished episode
         self.multi.observe_masked()
         check(lib.mapf_actor_rewind_multi(Et, a0.max_steps, a0.RDA, _ptr(self.envtab), _ptr(c["finished"]), _ptr(c["bits"]), _ptr(c["t"]), _ptr(c["lb_obs"]),
-                                          _ptr(self.hidden_new), st), "mapf_actor_rewind_multi")
-        torch.mul(self.hidden_new, 1, out=self.hidden_all)   # (an element-wise kernel rather than a memcpy node of the captured graph)
-        self.tick.add_(1)
+                                          _ptr(self.hidden_new), _ptr(self.hidden_all), _ptr(self.tick), st), "mapf_actor_rewind_multi")
+        # (the same launch hands the new hidden states on as the next iteration's input and counts the iteration)
 
     def _iteration_per_level(self):
         """Merged environment launches, everything else per level (a level of more than 16 agents is among them)."""
@@ -330,7 +329,8 @@ class CurriculumActors:
         if self._cap_stream is None:
             self._cap_stream = torch.cuda.Stream(device=dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(self._cap_stream):
+        from .fused import no_gc_during_capture
+        with no_gc_during_capture(), torch.cuda.stream(self._cap_stream):
             g.capture_begin()
             try:
                 self._iteration()

@@ -13,9 +13,27 @@ mapf_wgrad0.hip, mapf_recur.hip, mapf_recur_bwd.hip, mapf_recur_wide.hip, mapf_r
   * `bias_res_relu` / `_BiasResReLU`              fused bias + residual + ReLU epilogue of the layer-by-layer path (kept for
                                                   fp32 / FUSED_TRAINING = False runs and as the comparison path of the tests).
 Nothing here falls back to a CPU implementation: without the HIP library the import of `._lib` fails."""
+import contextlib
 import ctypes
 
 import torch
+
+
+@contextlib.contextmanager
+def no_gc_during_capture():
+    """Keeps Python's cyclic garbage collector from running while a stream is being captured.  A collection that happens to fall into
+    a capture can destroy objects that own HIP resources (graphs, events, streams of earlier learners / actors): their destructors call
+    the runtime, which a capture in global error mode turns into an exception inside a destructor -> abort (seen once in the full test
+    suite, in the backward stage's capture).  Reference counting still frees what the capture itself drops."""
+    import gc
+
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 from ._lib import check, lib
 
@@ -422,6 +440,19 @@ class PackedRecurrence:
             check(lib.mapf_recurrent_pack(ptrs, _ptr(self.weights), _ptr(self.bias), None, _stream(dev)), "mapf_recurrent_pack")
             self.key = key
         return self.weights, self.bias
+
+    def input_weight(self, net, inplace=False):
+        """bf16 copy of Network.recurrent.weight_ih (the input projection is a library GEMM in front of the kernel); converted when the
+        parameter changed, not once per step (it was a 2.4 MB element-wise launch in every actor iteration).  inplace: as in get()."""
+        p = net.recurrent.weight_ih
+        key = (getattr(net, "weights_epoch", 0), p.data_ptr(), p._version)
+        if key != getattr(self, "key_ih", None):
+            if inplace and getattr(self, "w_ih", None) is not None and self.w_ih.device == p.device:
+                self.w_ih.copy_(p.detach())
+            else:
+                self.w_ih = p.detach().to(torch.bfloat16)
+            self.key_ih = key
+        return self.w_ih
 
 
 RECUR_WEIGHT_ELEMS = 548864

@@ -531,7 +531,7 @@ class Network(nn.Module):
             else:
                 latent = self.encode(obs_all)
             w, b = self._packed_recur.get(self, inplace=packed_inplace)
-            gi_all = mm_rows(latent, self.recurrent.weight_ih.detach().to(torch.bfloat16))
+            gi_all = mm_rows(latent, self._packed_recur.input_weight(self, inplace=packed_inplace))
             hs, off = [], 0
             if merged is not None:
                 from .fused import recurrent_infer_multi
@@ -632,7 +632,7 @@ class Network(nn.Module):
             self._packed_recur = PackedRecurrence()
         w, b = self._packed_recur.get(self)
         T, E, N, _ = latent_t.shape
-        w_ih = self.recurrent.weight_ih.detach().to(torch.bfloat16)
+        w_ih = self._packed_recur.input_weight(self)
         from .fused import mm_rows  # (row-chunked: see there why one big GEMM call is avoided)
 
         if isinstance(latent_t, _SparseRows):  # the input projection of the reachable rows only (its bias is added in the kernel)

@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from ._lib import check, lib
-from .fused import (ENC_OBS_PER_BLOCK, ENC_WGRAD0_PARTS, ENC_WGRAD_PARTS, RECUR_NARROW_AGENTS, RECUR_WEIGHT_ELEMS, PackedEncoder,
+from .fused import (no_gc_during_capture, ENC_OBS_PER_BLOCK, ENC_WGRAD0_PARTS, ENC_WGRAD_PARTS, RECUR_NARROW_AGENTS, RECUR_WEIGHT_ELEMS, PackedEncoder,
                     PackedRecurrence, mm_rows, pack_encoder_backward, recurrence_params, rows_buffer, ENC_ELEMENT)
 
 GAMMA = 0.99
@@ -729,7 +729,7 @@ class FusedUpdate:
         g = torch.cuda.CUDAGraph()
         self._capturing = True
         try:
-            with torch.cuda.stream(self._cap_stream):
+            with no_gc_during_capture(), torch.cuda.stream(self._cap_stream):
                 g.capture_begin(pool=self._pools.get(pool))
                 try:
                     out = fn()
