@@ -27,7 +27,7 @@ GAMMA = 0.99          # hard-coded in the reference (worker.py:306), config.gamm
 GRAD_CLIP = 40.0      # worker.py:319
 TARGET_SYNC = 2500    # config.target_network_update_freq (config.py:27)
 FORWARD_STEPS = 2     # config.forward_steps (config.py:65)
-SIDE_STREAM_PRIORITY = 1   # (HIP: a larger number is a LOWER priority; clamped to the device's range)
+SIDE_STREAM_PRIORITY = int(os.environ.get("MAPF_SIDE_PRIORITY", "1"))   # (HIP: a larger number is a LOWER priority; clamped to the device's range)
 
 
 def huber_loss(td_error, kappa=1.0):

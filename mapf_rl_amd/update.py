@@ -596,7 +596,13 @@ class FusedUpdate:
         # on what the BPTT kernel wrote, the encoder's backward chain below only on d_gi1: inside a capture they become two branches
         # of the graph (a second stream that forks here and joins before the optimizer step).  Everything the branch reads is held by
         # `c` / `outs_b` until the join; what it allocates, it allocates on its own stream.
-        aux = self.lr._side if self._capturing else None
+        # Eagerly too on a single rank (config 2: nine ~50 us launches that would otherwise sit between the BPTT kernel and the encoder's
+        # backward); with several ranks the eager path keeps one stream, because there the recurrence's piece of the gradient exchange
+        # starts before the encoder's backward and needs these gradients in stream order.
+        import torch.distributed as dist
+
+        one_rank = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        aux = self.lr._side if (self._capturing or (one_rank and self.lr.grad_hook is None)) else None
         cur_s = torch.cuda.current_stream(dev)
         if aux is not None:
             aux.wait_stream(cur_s)
