@@ -32,7 +32,11 @@ from .fused import (no_gc_during_capture, ENC_OBS_PER_BLOCK, ENC_WGRAD0_PARTS, E
 
 GAMMA = 0.99
 GRAD_CLIP = 40.0
-SIDE_STREAM_MAX_ROWS = 262144
+# The target network's forward runs on the second stream beside the online forward only while neither fills the chip: measured (round 4,
+# tools/update_timeline.py) at config 2 -- ~10-18 k rows per network -- the two encoders just share the MFMA time (2.17 ms together, 1.1
+# each alone), and the two 192-workgroup recurrence kernels (one workgroup per CU each) make the head wait for the second of them:
+# 7.0 ms serial against 7.3 side by side; at 6 agents (~6 k rows) side by side wins (3.08 against 3.16 ms).
+SIDE_STREAM_MAX_ROWS = int(os.environ.get("MAPF_SIDE_MAX_ROWS", "8192"))
 WGRAD_SPLIT = 2048  # rows per batch of the recurrence's split-K weight-gradient GEMMs (compact rows are padded to a multiple)
 FORWARD_STEPS = 2
 BETAS, EPS = (0.9, 0.999), 1e-8  # torch.optim.Adam defaults (worker.py:260)
@@ -667,8 +671,7 @@ class FusedUpdate:
         # ---- weight images of the online network, on THIS stream before the side stream may read them (double-DQN) ----
         self._pack_online(c)
         # ---- target network (and double-DQN's online arg-max) on the second stream ----
-        # (beyond ~260 k rows -- every observation of 128-agent windows -- either network's kernels fill the chip for tens of
-        # milliseconds: a second stream buys nothing there and doubles the transient allocations)
+        # (only while the batches are small: see SIDE_STREAM_MAX_ROWS)
         side = lr._side if max(po.rows, pt.rows) <= SIDE_STREAM_MAX_ROWS else None
         if side is not None:
             side.wait_stream(cur)
