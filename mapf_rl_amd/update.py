@@ -633,8 +633,13 @@ class FusedUpdate:
             check(lib.mapf_dedup_sum(To, B, Nc, M, 1536, _ptr(po.gidx), _ptr(po.umap), _ptr(po.row_tbp), _ptr(d_gi_rows), _ptr(d_gi_u), st),
                   "mapf_dedup_sum")
             d_gi_rows = d_gi_u
+        if aux is not None:  # (the input projection's weight gradient joins the side branch: only the encoder's chain needs g_lat)
+            aux.wait_stream(cur_s)
+            with torch.cuda.stream(aux):
+                _tall_tn_into(flat.mem(G, "recurrent.weight_ih"), d_gi_rows, c.lat, rows=4096)
         g_lat = mm_rows(d_gi_rows, c.w_ih, transpose_w=False)
-        _tall_tn_into(flat.mem(G, "recurrent.weight_ih"), d_gi_rows, c.lat, rows=4096)
+        if aux is None:
+            _tall_tn_into(flat.mem(G, "recurrent.weight_ih"), d_gi_rows, c.lat, rows=4096)
         # the recurrence's and the head's gradients are final: their piece of the exchange (12 % of the bytes) travels while the
         # encoder's backward chain runs (several ranks only; learner.FlatGradBucket.begin)
         n_all, split = flat.grads.numel(), lr.bucket.split
