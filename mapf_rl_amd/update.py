@@ -404,11 +404,6 @@ class FusedUpdate:
                 p.umap.fill_(0)
                 p.row_tbp.fill_(-1)
         cm, obs, hid = v["comm"], v["obs"], v["hidden"]
-        if os.environ.get("MAPF_DEBUG_PLAN"):
-            torch.cuda.synchronize()
-            print("plan_rows: T %d B %d N %d Nc %d rows %d urows %d padded %s | cnt sum %d nag max %d ucnt sum %d nact max %d | order range %d..%d | obs %s %s | hid %s | cm %s %s dup %s" % (
-                T, B, N, Nc, p.rows, p.urows, padded, int(p.cnt.sum()), int(p.nag.max()), int(p.ucnt.sum()), int(p.nact.max()), int(p.order.min()), int(p.order.max()),
-                tuple(obs.shape), obs.stride(), tuple(hid.shape), tuple(cm.shape), cm.stride(), None if p.dup is None else (tuple(p.dup.shape), int(p.dup.max()))), flush=True)
         check(lib.mapf_plan_rows(T, B, N, Nc, _ptr(p.order), _ptr(p.nact), _ptr(p.cnt), _ptr(p.nag), _ptr(cm), cm.stride(0), cm.stride(1),
                                  _ptr(hid), int(hid.dtype == torch.bfloat16), _ptr(obs), obs.stride(0), obs.stride(1), _ptr(p.gidx),
                                  _ptr(p.comm_c), _ptr(p.h0_c), p.urows, _ptr(row_src), _ptr(p.obs_rows), _ptr(p.dup), _ptr(p.ucnt), _ptr(p.umap),
