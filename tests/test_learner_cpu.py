@@ -152,3 +152,27 @@ def test_row_buckets_bound_the_slack():
         assert b >= max(n, 1) and b >= prev and (n < 16 or b <= n * 1.125 + 1), (n, b)
         prev = b if n < 600 else 0
     assert len({row_bucket(n) for n in range(32768, 65536)}) <= 16
+
+
+def test_captures_run_with_the_cyclic_collector_off():
+    """fused.no_gc_during_capture (around every stream capture: a collection inside a capture can destroy an older graph / event
+    and abort the process): off inside, the previous state back afterwards -- also when the body raises, and when it was off before."""
+    import gc
+
+    from mapf_rl_amd.fused import no_gc_during_capture
+
+    assert gc.isenabled()
+    with no_gc_during_capture():
+        assert not gc.isenabled()
+    assert gc.isenabled()
+    with pytest.raises(RuntimeError):
+        with no_gc_during_capture():
+            raise RuntimeError("x")
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with no_gc_during_capture():
+            assert not gc.isenabled()
+        assert not gc.isenabled()
+    finally:
+        gc.enable()

@@ -223,3 +223,25 @@ def test_policy_head_kernel_equals_the_module_statement():
     q_out, a_out = torch.empty((7, 5), device="cuda"), torch.empty(7, dtype=torch.int64, device="cuda")
     q2, a2 = q_head_infer(h[:7].contiguous(), net.adv, net.state, q_out, a_out)
     assert q2.data_ptr() == q_out.data_ptr() and a2.data_ptr() == a_out.data_ptr()
+
+
+def test_cached_input_projection_weight_follows_the_parameter():
+    """PackedRecurrence.input_weight: the bf16 copy of recurrent.weight_ih is converted once per parameter version, not per step; a
+    changed parameter is picked up, in place (same address: a captured graph holds it) when asked to."""
+    from mapf_rl_amd.fused import PackedRecurrence
+    from mapf_rl_amd.model import Network
+
+    torch.manual_seed(11)
+    net = Network().cuda().eval()
+    pk = PackedRecurrence()
+    w0 = pk.input_weight(net)
+    assert w0.dtype == torch.bfloat16 and torch.equal(w0, net.recurrent.weight_ih.detach().to(torch.bfloat16))
+    assert pk.input_weight(net) is w0  # nothing changed: no conversion
+    with torch.no_grad():
+        net.recurrent.weight_ih.mul_(0.5)
+    w1 = pk.input_weight(net, inplace=True)
+    assert w1.data_ptr() == w0.data_ptr() and torch.equal(w1, net.recurrent.weight_ih.detach().to(torch.bfloat16))
+    with torch.no_grad():
+        net.recurrent.weight_ih.add_(1.0)
+    w2 = pk.input_weight(net)  # not in place: a fresh buffer (a launch in flight may still read the old one)
+    assert w2.data_ptr() != w1.data_ptr() and torch.equal(w2, net.recurrent.weight_ih.detach().to(torch.bfloat16))
