@@ -37,7 +37,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-#ifndef MAPF_ENC_ABLATE  // diagnostic builds only (tools/micro/enc_ablate.py): 1 = no saved-activation copies, 2 = no ReLU sign words, 4 = 16 consecutive LDS rows per position tile
+#ifndef MAPF_ENC_ABLATE  // diagnostic builds only (tools/micro/enc_ablate.py): 1 = no saved-activation copies, 2 = no ReLU sign words, 4 = 16 consecutive LDS rows per position tile, 8 = conv0 without its input gather (zeros), 64 = conv0 gathering one tile's window for all tiles, 16 = no LDS zero fill, 32 = no 1x1 head
 #define MAPF_ENC_ABLATE 0
 #endif
 constexpr int G = MAPF_ENC_OBS_PER_BLOCK;  // observations per workgroup
@@ -236,7 +236,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
     const int nobs = left < G ? (int)left : G;  // >= 1 by the grid size
 
     // ---- zero the activation image (its border rows must be zero; they are never written afterwards) ----
-    for (int i = tid; i < ACT_BYTES / 16; i += NTHREADS) reinterpret_cast<uint4 *>(act)[i] = make_uint4(0, 0, 0, 0);
+    if (!(MAPF_ENC_ABLATE & 16))
+        for (int i = tid; i < ACT_BYTES / 16; i += NTHREADS) reinterpret_cast<uint4 *>(act)[i] = make_uint4(0, 0, 0, 0);
     // ---- stage the raw observations of this block (contiguous in global memory); missing ones read as zero ----
     // (IDX: packed rows of RAW_STRIDE = 488 bytes, dword-aligned each; otherwise 486 * sizeof(InT) back to back)
     constexpr int RAW_STRIDE = IDX ? MAPF_ENC_PACKED_OBS_STRIDE : OBS_ELEMS;  // elements (IDX is u8 only)
@@ -303,13 +304,14 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
                 const int p = n * 16 + lr;
                 const bool v = (vmask >> n) & 1u;
                 const int o = p / 49, q = p - 49 * o, y = q / 7, x = q - 7 * y;
-                const int rb = v ? o * RAW_STRIDE + y * 9 + x : 0;
+                int rb = v ? o * RAW_STRIDE + y * 9 + x : 0;
+                if (MAPF_ENC_ABLATE & 64) rb = lr;  // diagnostic: every tile gathers tile 0's window (the compiler keeps one gather per k-step)
                 union {
                     el8 v8;
                     uint16_t u[8];
                 } b;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) b.u[j] = koff[j] >= 0 ? raw_to_el(raw[rb + koff[j]]) : (uint16_t)0;
+                for (int j = 0; j < 8; ++j) b.u[j] = (koff[j] >= 0 && !(MAPF_ENC_ABLATE & 8)) ? raw_to_el(raw[rb + koff[j]]) : (uint16_t)0;
                 acc[0][n] = el_mfma(a0, b.v8, acc[0][n]);
                 acc[1][n] = el_mfma(a1, b.v8, acc[1][n]);
             }
@@ -388,7 +390,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
 #pragma unroll
         for (int s = 0; s < 4; ++s) a7[s] = wv[s * 64];
         const float4 b4 = *reinterpret_cast<const float4 *>(bl + 4 * lh);
-        for (int n = w; n < NT; n += NTHREADS / 64) {
+        for (int n = w; n < NT && !(MAPF_ENC_ABLATE & 32); n += NTHREADS / 64) {
             const int p = n * 16 + lr;
             const bool v = p < 49 * nobs;
             const int o = p / 49, q = p - 49 * o, y = q / 7, x = q - 7 * y;

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""What does saving cost the training forward?  Builds csrc/mapf_encoder.hip with -DMAPF_ENC_ABLATE (1 = no saved-activation
+"""What does saving cost the training forward?  (Also: 4 = conflict-free LDS rows, 8 = conv0 on zeros -- NOT a measure of its input
+gather: all-zero activations let the chip clock higher, the whole kernel runs 23 % faster --, 64 = one gather per k-step: the gather is 2 %.)
+  Builds csrc/mapf_encoder.hip with -DMAPF_ENC_ABLATE (1 = no saved-activation
 copies, 2 = no ReLU sign words; outputs are incomplete, only the time matters) and times mapf_encoder_forward_save next to
 mapf_encoder_forward at the learner's shape.  `build` runs where hipcc is, `run` on the GPU."""
 import ctypes
@@ -9,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-MODES = [0, 1, 2, 3, 4]
+MODES = [0, 1, 2, 3, 4, 8, 64]
 
 
 def so(mode):
