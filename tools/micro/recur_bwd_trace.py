@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "mapf_rl_amd", "csrc")
-SO = os.path.join(HERE, "recur_bwd_trace.so")
+SO = os.path.join(HERE, os.environ.get("BT_SO", "recur_bwd_trace.so"))
 PHASES = ["", "external gradient, partner counts", "mask counts", "update flags", "(1) update-cell elementwise", "(2) U_hh^T, U_ih^T GEMMs", "(3) W_O^T",
           "(4) head 0: images", "head 0: dP", "head 0: softmax backward", "head 0: dv dq dk", "(5) W_qkv^T", "recurrent cell elementwise", "W_hh^T GEMM"]
 
