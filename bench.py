@@ -37,6 +37,10 @@ import subprocess
 import sys
 import time
 
+# the host driver of this pool supports dmabuf IPC only: RCCL (and CUDA-tensor sharing across processes) fails with
+# hipIpcGetMemHandle: invalid argument without it; set before anything initialises the GPU (also when a launcher started this rank)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -29,8 +29,10 @@ import os
 import random
 import time
 
-import numpy as np
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool: RCCL needs it (see bench.py)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 import config
 
