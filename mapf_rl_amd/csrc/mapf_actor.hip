@@ -164,15 +164,19 @@ __global__ void zero_words_kernel(uint32_t *p, int n) {
 constexpr int CH_PAIRS = 8;
 __global__ void __launch_bounds__(256) obs_changed_kernel(const uint32_t *__restrict__ obs, uint32_t *__restrict__ prev, long long rows,
                                                           int32_t *__restrict__ list, int32_t *__restrict__ count, uint32_t *__restrict__ packed) {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long pairs = (rows + 1) >> 1;
     const long long chunks = (pairs + CH_PAIRS - 1) / CH_PAIRS;
-    for (long long c = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); c < chunks; c += (long long)gridDim.x * 4) {
+    // The list slots of a WORKGROUP's four chunks come from one atomic (round 4; one per chunk was 10 k returning atomics on one address
+    // per call at 163,840 rows when most agents move -- most of the kernel's time): the loop is uniform over the workgroup.
+    __shared__ int s_cnt[4], s_base;
+    for (long long cb = (long long)blockIdx.x * 4; cb < chunks; cb += (long long)gridDim.x * 4) {
+        const long long c = cb + w;
         uint32_t cm = 0;  // bit 2 i: first row of pair i changed, bit 2 i + 1: its second row
 #pragma unroll
         for (int i = 0; i < CH_PAIRS; ++i) {
             const long long q = c * CH_PAIRS + i;
-            if (q >= pairs) break;  // (wave-uniform)
+            if (c >= chunks || q >= pairs) break;  // (wave-uniform)
             const bool two = 2 * q + 1 < rows;
             const int nd = two ? 243 : 122;  // a last single row: 121.5 dwords (its buffer ends on a 2-byte boundary: handled below)
             const uint32_t *cur = obs + q * 243;
@@ -209,10 +213,17 @@ __global__ void __launch_bounds__(256) obs_changed_kernel(const uint32_t *__rest
                 }
             }
         }
+        if (lane == 0) s_cnt[w] = __popc(cm);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            s_base = total ? atomicAdd(count, total) : 0;
+        }
+        __syncthreads();
+        int base = s_base;
+        for (int k = 0; k < w; ++k) base += s_cnt[k];
+        __syncthreads();  // (s_cnt / s_base are rewritten by the next pass)
         if (cm == 0u) continue;
-        int base = 0;
-        if (lane == 0) base = atomicAdd(count, __popc(cm));
-        base = __shfl(base, 0, 64);
         // list entries: lane r (< 16) owns row r of the chunk
         if (lane < 2 * CH_PAIRS && ((cm >> lane) & 1u)) list[base + __popc(cm & ((1u << lane) - 1u))] = (int32_t)(2 * c * CH_PAIRS + lane);
         if (packed) {  // the changed rows, in list order, 122 dwords each (the last 2 bytes are padding): what mapf_encoder_forward_rows reads

@@ -501,7 +501,14 @@ __global__ void __launch_bounds__(256) grad_absmax_kernel(const uint4 *__restric
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    // one atomic per WORKGROUP: one per wave of a 1024-block grid was 4096 atomics on one address, ~40 of this kernel's 48 us
+    __shared__ uint32_t s_m[4];
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
+        if (m) atomicMax(out, m);
+    }
 }
 __device__ __forceinline__ float clamp_el(float v) { return __builtin_amdgcn_fmed3f(v, -EL_MAX, EL_MAX); }
 
@@ -864,7 +871,7 @@ int mapf_encoder_backward(const uint16_t *g_latent_dev, const uint16_t *latent_d
     // (a kernel, not hipMemsetAsync: this call is captured into the update's HIP graphs; see mapf_obs_changed in csrc/mapf_actor.hip)
     hipLaunchKernelGGL(zero_scale_kernel, dim3(1), dim3(64), 0, st, grad_scale_dev);
     const long long chunks = M * 98;  // 784 bf16 = 98 x 16 bytes per observation
-    hipLaunchKernelGGL(grad_absmax_kernel, dim3((unsigned)(chunks < 256 * 1024 ? (chunks + 255) / 256 : 1024)), dim3(256), 0, st,
+    hipLaunchKernelGGL(grad_absmax_kernel, dim3((unsigned)(chunks < 256 * 512 ? (chunks + 255) / 256 : 512)), dim3(256), 0, st,
                        reinterpret_cast<const uint4 *>(g_latent_dev), chunks, grad_scale_dev);
     hipLaunchKernelGGL(encoder_bwd_kernel<true>, dim3((unsigned)blocks), dim3(NTHREADS), 0, st, g_latent_dev,
                        (long long)M, relu_bits_dev, packed_bwd_dev, gz_dev, gbias_partial_dev, latent_dev, gz7_dev, gb7_partial_dev, grad_scale_dev);
