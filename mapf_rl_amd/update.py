@@ -642,7 +642,7 @@ class FusedUpdate:
         if two_pieces:
             lr.bucket.begin(split, n_all)
         # ---- encoder: backward-data chain in one kernel, then the weight-gradient kernels ----
-        self._encoder_backward(po.obs_rows, Mu, c.acts, c.lat, c.bits, g_lat, c.wpt)
+        self._encoder_backward(po.obs_rows, Mu, c.acts, c.lat, c.bits, g_lat, c.wpt, aux)
         if aux is not None:
             cur_s.wait_stream(aux)
         # ---- the exchange (its second piece: the encoder's gradients), clip, Adam ----
@@ -872,7 +872,9 @@ class FusedUpdate:
         outs, prio, loss = c_h.outs.clone(), c_h.prio.clone(), c_h.loss.clone()
         return dict(loss=loss[0], td=outs[2].view(B, 1), priorities=prio, grad_norm=norm.clone(), q=outs[0].view(B, 1), q_next=outs[1].view(B, 1))
 
-    def _encoder_backward(self, obs_rows, M, acts, lat, bits, g_lat, wpt):
+    def _encoder_backward(self, obs_rows, M, acts, lat, bits, g_lat, wpt, aux=None):
+        """aux: a second stream for what only needs the backward-data kernel's outputs besides the six 3x3 weight-gradient launches
+        (bias sums, conv0's and the 1x1 head's weight gradients: ~0.15 ms of small launches at few agents); the caller joins it."""
         dev, flat = self.dev, self.flat
         G, st, bf = flat.grads, _stream(dev), torch.bfloat16
         nblk = -(-M // ENC_OBS_PER_BLOCK)
@@ -887,22 +889,26 @@ class FusedUpdate:
                                         _ptr(scale), st), "mapf_encoder_backward")
         names = ["obs_encoder.0", "obs_encoder.2.block1", "obs_encoder.2.block2", "obs_encoder.3.block1", "obs_encoder.3.block2",
                  "obs_encoder.4.block1", "obs_encoder.4.block2", "obs_encoder.5"]
-        # bias gradients: the kernel's per-workgroup partials, summed in two stages (see fused._EncoderTrain.backward)
-        pad = (-nblk) % 256
-        gp = gb_part if pad == 0 else torch.cat([gb_part, gb_part.new_empty((7, pad, 128)).fill_(0)], dim=1)
-        torch.sum(gp.view(7, -1, 256, 128).sum(dim=2), dim=1, out=flat.span(G, names[0] + ".bias", names[6] + ".bias").view(7, 128))
-        torch.sum(gb7_part, dim=0, out=flat.mem(G, names[7] + ".bias"))
+        if aux is not None:
+            aux.wait_stream(torch.cuda.current_stream(dev))
+        with (torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext()):
+            st_x = _stream(dev)
+            # bias gradients: the kernel's per-workgroup partials, summed in two stages (see fused._EncoderTrain.backward)
+            pad = (-nblk) % 256
+            gp = gb_part if pad == 0 else torch.cat([gb_part, gb_part.new_empty((7, pad, 128)).fill_(0)], dim=1)
+            torch.sum(gp.view(7, -1, 256, 128).sum(dim=2), dim=1, out=flat.span(G, names[0] + ".bias", names[6] + ".bias").view(7, 128))
+            torch.sum(gb7_part, dim=0, out=flat.mem(G, names[7] + ".bias"))
+            ws0 = torch.empty((ENC_WGRAD0_PARTS, 128, 64), dtype=torch.float32, device=dev)
+            check(lib.mapf_encoder_wgrad0(_ptr(gz[0]), _ptr(obs_rows), 1, M, _ptr(scale), _ptr(ws0), st_x), "mapf_encoder_wgrad0")
+            # conv0: columns j = ci*9 + ky*3 + kx -> the weight's memory [co][ky][kx][ci]
+            flat.mem(G, names[0] + ".weight").copy_(ws0.sum(dim=0)[:, :54].view(128, 6, 3, 3).permute(0, 2, 3, 1))
+            g7 = flat.mem(G, names[7] + ".weight").view(16, 128)
+            _tall_tn_into(g7, gz7, acts[6].reshape(M * 49, 128))
+            g7.mul_(scale.view(torch.float32)[1])
         ws = torch.empty((ENC_WGRAD_PARTS, 128, 3, 3, 128), dtype=torch.float32, device=dev)
         for k in range(1, 7):
             check(lib.mapf_encoder_wgrad(_ptr(gz[k]), _ptr(acts[k - 1]), M, _ptr(scale), _ptr(ws), st), "mapf_encoder_wgrad")
             torch.sum(ws, dim=0, out=flat.mem(G, names[k] + ".weight"))  # [co][ky][kx][ci] == the weight's channels_last memory
-        ws0 = torch.empty((ENC_WGRAD0_PARTS, 128, 64), dtype=torch.float32, device=dev)
-        check(lib.mapf_encoder_wgrad0(_ptr(gz[0]), _ptr(obs_rows), 1, M, _ptr(scale), _ptr(ws0), st), "mapf_encoder_wgrad0")
-        # conv0: columns j = ci*9 + ky*3 + kx -> the weight's memory [co][ky][kx][ci]
-        flat.mem(G, names[0] + ".weight").copy_(ws0.sum(dim=0)[:, :54].view(128, 6, 3, 3).permute(0, 2, 3, 1))
-        g7 = flat.mem(G, names[7] + ".weight").view(16, 128)
-        _tall_tn_into(g7, gz7, acts[6].reshape(M * 49, 128))
-        g7.mul_(scale.view(torch.float32)[1])
 
 
 def _tall_tn_into(out, a, b, rows=8192):
