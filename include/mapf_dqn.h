@@ -213,6 +213,20 @@ int mapf_recurrent_backward(const uint16_t *const *saved_dev, const uint8_t *com
                             const int32_t *row_index_dev, int64_t num_rows, void *stream);
 
 /*
+ * Input projection of the recurrent cell for the ACTOR's step (reference model.py:191: the W_ih x half of `self.recurrent(latent, hidden)`;
+ * mapf_recurrent_infer adds the bias): gi[row] = W_ih latent[row] for the rows of a LIST with a device-side count -- the rows whose
+ * observation changed since the previous step (include/mapf_replay.h: mapf_obs_changed): an agent that keeps its latent keeps its gi
+ * row -- or, row_list_dev == row_count_dev == NULL, for all num_rows rows.  csrc/mapf_inproj.hip.
+ *   mapf_input_proj_pack: W_ih f32 [768][784] -> packed_dev bf16 [MAPF_INPROJ_PACKED_ELEMS] (MFMA fragment order, K padded to 800);
+ *   mapf_input_proj_rows: latent_dev bf16 [num_rows][784], gi_dev bf16 [num_rows][768] (rows not listed are left as they are);
+ *     with a list, min(*row_count_dev, num_rows) entries of row_list_dev are read.
+ */
+#define MAPF_INPROJ_PACKED_ELEMS 614400
+int mapf_input_proj_pack(const float *w_ih_dev, uint16_t *packed_dev, void *stream);
+int mapf_input_proj_rows(const uint16_t *latent_dev, int64_t num_rows, const int32_t *row_list_dev, const int32_t *row_count_dev,
+                         const uint16_t *packed_dev, uint16_t *gi_dev, void *stream);
+
+/*
  * Communication mask of `Network.step` (reference model.py:195-208): mask[e][i][j] = j lies inside i's FOV square
  * (|drow| <= r and |dcol| <= r) AND j is among i's `max_comm` nearest agents by Euclidean distance, i itself
  * included; distance ties go to the LOWEST agent index (the reference's CPU topk leaves ties unspecified).

@@ -83,6 +83,8 @@ SYMBOLS = [
     ("mapf_recurrent_backward", _i, [ctypes.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(_vp), _vp, ctypes.c_int64, _vp]),
     ("mapf_comm_mask", _i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     ("mapf_q_head", _i, [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("mapf_input_proj_pack", _i, [_vp, _vp, _vp]),
+    ("mapf_input_proj_rows", _i, [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_comm_mask_multi", _i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
     ("mapf_window_relevance", _i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     ("mapf_encoder_pack", _i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _vp, _vp, _vp]),

@@ -19,6 +19,22 @@ import ctypes
 import torch
 
 
+def warm_up_gemm_library(stream):
+    """One tiny library GEMM of each kind the captured sequences contain, on `stream`, BEFORE its first capture: hipBLASLt creates its
+    handle / workspace at the first call and refuses to do that while the stream is capturing ('operation not permitted when stream is
+    capturing').  Until round 4 the actors' own projection GEMM had always run first; it is a hand-written kernel now."""
+    with torch.cuda.stream(stream):
+        dev = stream.device
+        a = torch.zeros((64, 64), dtype=torch.bfloat16, device=dev)
+        torch.mm(a, a)
+        torch.mm(a, a, out_dtype=torch.float32)
+        torch.bmm(a.view(1, 64, 64), a.view(1, 64, 64), out_dtype=torch.float32)
+        h = a.to(torch.float16)
+        torch.mm(h, h, out_dtype=torch.float32)
+        torch.mm(a.float(), a.float())
+    stream.synchronize()
+
+
 @contextlib.contextmanager
 def no_gc_during_capture():
     """Keeps Python's cyclic garbage collector from running while a stream is being captured.  A collection that happens to fall into
@@ -256,15 +272,17 @@ class LatentCache:
 
     def __init__(self):
         self.key = None
-        self.lat = self.prev = self.packed = self.list = self.count = None
+        self.lat = self.prev = self.packed = self.list = self.count = self.gi = None
         self.calls = self.full = 0
 
-    def encode(self, obs, packed: "PackedEncoder", obs_encoder, epoch=0):
-        """obs uint8 [R, 6, 9, 9] (contiguous; the SAME buffer at every call) -> latent bf16 [R, 784] (owned by the cache)."""
+    def encode(self, obs, packed: "PackedEncoder", obs_encoder, epoch=0, proj=None):
+        """obs uint8 [R, 6, 9, 9] (contiguous; the SAME buffer at every call) -> latent bf16 [R, 784] (owned by the cache).
+        proj = (packed W_ih, its key) (PackedRecurrence.input_weight_packed): the cache also keeps the recurrent cell's input projection
+        of every row, self.gi bf16 [R, 768], recomputed for the same rows as the latent (an unchanged latent has an unchanged projection)."""
         assert obs.dtype == torch.uint8 and obs.is_contiguous() and tuple(obs.shape[1:]) == (6, 9, 9)
         R, dev = obs.shape[0], obs.device
         wp, bp = packed.get(obs_encoder, epoch)
-        key = (packed.key, obs.data_ptr(), R)
+        key = (packed.key, obs.data_ptr(), R, None if proj is None else proj[1])
         st = _stream(dev)
         self.calls += 1
         if key != self.key:
@@ -277,12 +295,18 @@ class LatentCache:
             check(lib.mapf_encoder_forward(_ptr(obs), _ENC_OBS_U8, R, _ptr(wp), _ptr(bp), _ptr(self.lat), st), "mapf_encoder_forward")
             self.prev.copy_(obs)
             self.count.fill_(R)
+            if proj is not None:
+                if self.gi is None or self.gi.shape[0] != R or self.gi.device != dev:
+                    self.gi = torch.empty((R, 768), dtype=torch.bfloat16, device=dev)
+                input_proj_rows(self.lat, proj[0], self.gi)
             self.key = key
             self.full += 1
         else:
             check(lib.mapf_obs_changed(_ptr(obs), _ptr(self.prev), R, _ptr(self.list), _ptr(self.count), _ptr(self.packed), st), "mapf_obs_changed")
             check(lib.mapf_encoder_forward_rows(_ptr(self.packed), R, _ptr(self.list), _ptr(self.count), _ptr(wp), _ptr(bp), _ptr(self.lat), st),
                   "mapf_encoder_forward_rows")
+            if proj is not None:
+                input_proj_rows(self.lat, proj[0], self.gi, self.list, self.count)
         return self.lat
 
     def last_encoded(self):
@@ -441,6 +465,20 @@ class PackedRecurrence:
             self.key = key
         return self.weights, self.bias
 
+    def input_weight_packed(self, net, inplace=False):
+        """(recurrent.weight_ih as bf16 MFMA fragments for input_proj_rows, the key of this pack): mapf_input_proj_pack, repacked when the
+        parameter changed; inplace: as in get()."""
+        p = net.recurrent.weight_ih
+        key = (getattr(net, "weights_epoch", 0), p.data_ptr(), p._version)
+        if key != getattr(self, "key_ihp", None):
+            if not (inplace and getattr(self, "w_ihp", None) is not None and self.w_ihp.device == p.device):
+                self.w_ihp = torch.empty(INPROJ_PACKED_ELEMS, dtype=torch.bfloat16, device=p.device)
+            src = p.detach()
+            src = src if (src.dtype == torch.float32 and src.is_contiguous()) else src.float().contiguous()
+            check(lib.mapf_input_proj_pack(_ptr(src), _ptr(self.w_ihp), _stream(p.device)), "mapf_input_proj_pack")
+            self.key_ihp = key
+        return self.w_ihp, self.key_ihp
+
     def input_weight(self, net, inplace=False):
         """bf16 copy of Network.recurrent.weight_ih (the input projection is a library GEMM in front of the kernel); converted when the
         parameter changed, not once per step (it was a 2.4 MB element-wise launch in every actor iteration).  inplace: as in get()."""
@@ -456,6 +494,24 @@ class PackedRecurrence:
 
 
 RECUR_WEIGHT_ELEMS = 548864
+INPROJ_PACKED_ELEMS = 614400
+
+
+def input_proj_rows(latent, packed_w, out=None, row_list=None, row_count=None):
+    """gi bf16 [R, 768] = W_ih latent (no bias) through mapf_input_proj_rows (csrc/mapf_inproj.hip): for all R rows, or -- row_list int32
+    [>= count], row_count int32 [1] on the device -- only for the listed ones, the other rows of `out` staying as they are."""
+    R = latent.shape[0]
+    assert latent.is_cuda and latent.dtype == torch.bfloat16 and latent.is_contiguous() and latent.shape[1] == 784
+    assert packed_w.dtype == torch.bfloat16 and packed_w.numel() == INPROJ_PACKED_ELEMS
+    if out is None:
+        assert row_list is None, "a row list updates an existing gi buffer"
+        out = torch.empty((R, 768), dtype=torch.bfloat16, device=latent.device)
+    assert out.dtype == torch.bfloat16 and out.is_contiguous() and tuple(out.shape) == (R, 768)
+    check(lib.mapf_input_proj_rows(_ptr(latent), R, _ptr(row_list), _ptr(row_count), _ptr(packed_w), _ptr(out), _stream(latent.device)),
+          "mapf_input_proj_rows")
+    return out
+
+
 RECUR_BIAS_ELEMS = 3456
 
 

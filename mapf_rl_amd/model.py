@@ -482,14 +482,18 @@ class Network(nn.Module):
 
                 if self._packed is None:
                     self._packed = PackedEncoder()
-                latent = cache.encode(obs.view(E * N, *OBS_SHAPE), self._packed, self.obs_encoder, self.weights_epoch)
+                fused_rec = self.FUSED_RECURRENCE and N <= RECUR_MAX_AGENTS
+                latent = cache.encode(obs.view(E * N, *OBS_SHAPE), self._packed, self.obs_encoder, self.weights_epoch,
+                                      proj=self._input_proj_weight() if fused_rec else None)
+                gi_cached = cache.gi if fused_rec else None
             else:
                 latent = self.encode(obs.reshape(E * N, *OBS_SHAPE))
+                gi_cached = None
             if comm_mask is None:
                 comm_mask = comm_mask_from_pos(pos)
             if self.FUSED_RECURRENCE and latent.is_cuda and latent.dtype == torch.bfloat16 and N <= RECUR_MAX_AGENTS:
                 # GRU cell + both communication rounds in one kernel, one workgroup per environment (csrc/mapf_recur.hip)
-                hidden = self._recur_kernel(latent.view(1, E, N, ENC_FEATURES), hidden, comm_mask.unsqueeze(0), False)[0]
+                hidden = self._recur_kernel(latent.view(1, E, N, ENC_FEATURES), hidden, comm_mask.unsqueeze(0), False, gi=gi_cached)[0]
                 hidden = hidden.view(E * N, self.latent_dim)
             else:
                 hidden = self.recurrent(latent) if hidden is None else self.recurrent(latent, hidden.to(latent.dtype))
@@ -519,19 +523,21 @@ class Network(nn.Module):
                 outs.append(self.step_batch(obs_all[off:off + E * N].view(E, N, *OBS_SHAPE), pos, hidden, comm))
                 off += E * N
             return outs
-        from .fused import PackedEncoder, PackedRecurrence, mm_rows, recurrent_infer
+        from .fused import PackedEncoder, PackedRecurrence, input_proj_rows, recurrent_infer
 
         with self._autocast(dev):
             if self._packed is None:
                 self._packed = PackedEncoder()
             if self._packed_recur is None:
                 self._packed_recur = PackedRecurrence()
+            proj = self._packed_recur.input_weight_packed(self, inplace=packed_inplace)
             if cache is not None and obs_all.dtype == torch.uint8 and obs_all.is_contiguous():
-                latent = cache.encode(obs_all, self._packed, self.obs_encoder, self.weights_epoch)
+                latent = cache.encode(obs_all, self._packed, self.obs_encoder, self.weights_epoch, proj=proj)
+                gi_all = cache.gi  # (kept beside the latents: recomputed for the rows whose observation changed)
             else:
                 latent = self.encode(obs_all)
+                gi_all = input_proj_rows(latent.contiguous(), proj[0])
             w, b = self._packed_recur.get(self, inplace=packed_inplace)
-            gi_all = mm_rows(latent, self._packed_recur.input_weight(self, inplace=packed_inplace))
             hs, off = [], 0
             if merged is not None:
                 from .fused import recurrent_infer_multi
@@ -623,21 +629,36 @@ class Network(nn.Module):
             q = self.q_head(sel)
         return q.float()
 
-    def _recur_kernel(self, latent_t, hidden, comm_t, want_agent0):
+    def _input_proj_weight(self, inplace=False):
+        from .fused import PackedRecurrence
+
+        if self._packed_recur is None:
+            self._packed_recur = PackedRecurrence()
+        return self._packed_recur.input_weight_packed(self, inplace=inplace)
+
+    def _recur_kernel(self, latent_t, hidden, comm_t, want_agent0, gi=None):
         """latent_t bf16 [T, E, N, 784] (time-major); hidden [E*N, 256] or None; comm_t bool [T, E, N, N]
-        -> (hidden bf16 [E, N, 256], agent-0 states [T, E, 256] or None) through mapf_recurrent_infer."""
-        from .fused import PackedRecurrence, recurrent_infer
+        -> (hidden bf16 [E, N, 256], agent-0 states [T, E, 256] or None) through mapf_recurrent_infer.
+        gi: the input projection of every row if the caller has it (fused.LatentCache keeps it beside the latents)."""
+        from .fused import PackedRecurrence, input_proj_rows, recurrent_infer
 
         if self._packed_recur is None:
             self._packed_recur = PackedRecurrence()
         w, b = self._packed_recur.get(self)
         T, E, N, _ = latent_t.shape
-        w_ih = self._packed_recur.input_weight(self)
         from .fused import mm_rows  # (row-chunked: see there why one big GEMM call is avoided)
 
-        if isinstance(latent_t, _SparseRows):  # the input projection of the reachable rows only (its bias is added in the kernel)
+        if gi is not None:
+            gi = gi.view(T, E, N, 768)
+        elif isinstance(latent_t, _SparseRows):  # the input projection of the reachable rows only (its bias is added in the kernel)
+            w_ih = self._packed_recur.input_weight(self)
             gi = latent_t.project(lambda x: mm_rows(x, w_ih), 768)
+        elif T == 1 and latent_t.is_contiguous():
+            # the actor's step: the kernel the latent cache uses for the rows that changed (csrc/mapf_inproj.hip), here on every row --
+            # the cached and the plain path stay bit-identical
+            gi = input_proj_rows(latent_t.view(E * N, ENC_FEATURES), self._input_proj_weight()[0]).view(T, E, N, 768)
         else:
+            w_ih = self._packed_recur.input_weight(self)
             gi = mm_rows(latent_t.reshape(T * E * N, ENC_FEATURES), w_ih).view(T, E, N, 768)
         h0 = None if hidden is None else hidden.reshape(E, N, self.latent_dim)
         return recurrent_infer(gi, h0, comm_t, w, b, want_agent0)

@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from ._lib import check, lib
-from .fused import (no_gc_during_capture, ENC_OBS_PER_BLOCK, ENC_WGRAD0_PARTS, ENC_WGRAD_PARTS, RECUR_NARROW_AGENTS, RECUR_WEIGHT_ELEMS, PackedEncoder,
+from .fused import (no_gc_during_capture, warm_up_gemm_library, ENC_OBS_PER_BLOCK, ENC_WGRAD0_PARTS, ENC_WGRAD_PARTS, RECUR_NARROW_AGENTS, RECUR_WEIGHT_ELEMS, PackedEncoder,
                     PackedRecurrence, mm_rows, pack_encoder_backward, recurrence_params, rows_buffer, ENC_ELEMENT)
 
 GAMMA = 0.99
@@ -735,6 +735,9 @@ class FusedUpdate:
             self.lr._side.synchronize()
         if self._cap_stream is None:
             self._cap_stream = torch.cuda.Stream(device=dev)
+            warm_up_gemm_library(self._cap_stream)
+            if self.lr._side is not None:
+                warm_up_gemm_library(self.lr._side)  # (the capture forks onto it)
         g = torch.cuda.CUDAGraph()
         self._capturing = True
         try:

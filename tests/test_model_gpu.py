@@ -245,3 +245,34 @@ def test_cached_input_projection_weight_follows_the_parameter():
         net.recurrent.weight_ih.add_(1.0)
     w2 = pk.input_weight(net)  # not in place: a fresh buffer (a launch in flight may still read the old one)
     assert w2.data_ptr() != w1.data_ptr() and torch.equal(w2, net.recurrent.weight_ih.detach().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("R", [1, 63, 64, 65, 1000, 40000])
+def test_input_projection_kernel_for_all_rows_and_for_a_row_list(R):
+    """mapf_input_proj_rows (csrc/mapf_inproj.hip; reference model.py:191, the W_ih x half of the GRUCell): every row against the fp32
+    product of the same bf16 operands (one bf16 rounding of the result: 2^-8 relative); with a row list + device-side count only the
+    listed rows are written, with the same bits as the all-rows launch; a count of zero writes nothing."""
+    from mapf_rl_amd._lib import check, lib
+    from mapf_rl_amd.fused import INPROJ_PACKED_ELEMS, _ptr, input_proj_rows
+
+    torch.manual_seed(R)
+    w = torch.randn(768, 784, device="cuda") * 0.05
+    wp = torch.empty(INPROJ_PACKED_ELEMS, dtype=torch.bfloat16, device="cuda")
+    check(lib.mapf_input_proj_pack(_ptr(w), _ptr(wp), None), "mapf_input_proj_pack")
+    x = (torch.randn(R, 784, device="cuda") * 0.5).to(torch.bfloat16)
+    want = x.float() @ w.to(torch.bfloat16).float().t()
+    got = input_proj_rows(x, wp)
+    assert got.shape == (R, 768) and got.dtype == torch.bfloat16
+    assert torch.all((got.float() - want).abs() <= 2.0 ** -8 * want.abs() + 1e-6), float((got.float() - want).abs().max())
+    n = max(1, R // 3)
+    rows = torch.randperm(R, device="cuda")[:n].to(torch.int32).contiguous()
+    cnt = torch.tensor([n], dtype=torch.int32, device="cuda")
+    out = torch.full((R, 768), 7.0, dtype=torch.bfloat16, device="cuda")
+    lst = torch.cat([rows, torch.full((5,), R - 1, dtype=torch.int32, device="cuda")])  # (entries behind the count are not read)
+    input_proj_rows(x, wp, out, lst, cnt)
+    sel = torch.zeros(R, dtype=torch.bool, device="cuda")
+    sel[rows.long()] = True
+    assert torch.equal(out[sel], got[sel]) and bool((out[~sel] == 7.0).all())
+    out.fill_(7.0)
+    input_proj_rows(x, wp, out, lst, torch.zeros(1, dtype=torch.int32, device="cuda"))
+    assert bool((out == 7.0).all())
