@@ -140,34 +140,56 @@ __global__ void __launch_bounds__(128) comm_mask_kernel(const short2 *__restrict
         for (int w = (N + 31) / 32; w < cw; ++w) prow[w] = 0;
 }
 
-// ---- dueling Q head of the policy's forward (reference model.py:218: q = V + A - mean(A)) + its arg-max: one wavefront per agent row.
+// ---- dueling Q head of the policy's forward (reference model.py:218: q = V + A - mean(A)) + its arg-max: sixteen lanes per agent row.
 // hidden bf16 [rows][256]; adv.weight f32 [5][256], adv.bias [5], state.weight [256], state.bias [1]; fp32 accumulation.  As PyTorch
 // operations under autocast this was a dozen launches of a few microseconds each (two linears, mean, add / sub, casts, arg-max) -- a
 // sixth of an actor iteration at curriculum shapes. ----
+// Sixteen lanes (one DPP row) per agent row, 16 channels each: the six dot products are reduced with DPP row rotations / quad
+// permutations (VALU only).  (The first version spent a whole wavefront per row and reduced with 36 __shfl_xor = LDS-pipe
+// instructions per row: 63 us for the 163,840 rows of config 2, whose 84 MB take 17 us to read.)
+template <int CTRL>
+__device__ __forceinline__ float qh_dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float qh_row_sum16(float v) {
+    v = qh_dpp_add<0x128>(v);  // row_ror:8
+    v = qh_dpp_add<0x124>(v);  // row_ror:4
+    v = qh_dpp_add<0x4E>(v);   // quad_perm:[2,3,0,1]
+    return qh_dpp_add<0xB1>(v);  // quad_perm:[1,0,3,2]
+}
 __global__ void __launch_bounds__(256) q_head_kernel(const uint16_t *__restrict__ hidden, long long rows, const float *__restrict__ w_adv,
                                                      const float *__restrict__ b_adv, const float *__restrict__ w_st, const float *__restrict__ b_st,
                                                      float *__restrict__ q, long long *__restrict__ act) {
-    const int lane = threadIdx.x & 63;
-    const long long stride = (long long)gridDim.x * 4;
-    float wa[5][4], ws[4];
+    const int q16 = threadIdx.x & 15;  // this lane's 16 channels: 16 q16 .. 16 q16 + 15
+    const long long stride = (long long)gridDim.x * 16;
+    float wa[5][16], ws[16];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 16; ++j) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) wa[k][j] = w_adv[k * 256 + 4 * lane + j];
-        ws[j] = w_st[4 * lane + j];
+        for (int k = 0; k < 5; ++k) wa[k][j] = w_adv[k * 256 + 16 * q16 + j];
+        ws[j] = w_st[16 * q16 + j];
     }
-    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += stride) {
-        const uint2 hv = *reinterpret_cast<const uint2 *>(hidden + r * 256 + 4 * lane);  // this lane's 4 channels
-        const float h[4] = {__uint_as_float(hv.x << 16), __uint_as_float(hv.x & 0xFFFF0000u), __uint_as_float(hv.y << 16), __uint_as_float(hv.y & 0xFFFF0000u)};
-        float d[6];
+    for (long long r0 = (long long)blockIdx.x * 16; r0 < rows; r0 += stride) {
+        const long long r = r0 + (threadIdx.x >> 4);
+        const bool live = r < rows;  // (the row's 16 lanes agree; the DPP reductions below run for every lane)
+        uint4 hv[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        if (live) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(hidden + r * 256 + 16 * q16);
+            hv[0] = src[0];
+            hv[1] = src[1];
+        }
+        const uint32_t hw[8] = {hv[0].x, hv[0].y, hv[0].z, hv[0].w, hv[1].x, hv[1].y, hv[1].z, hv[1].w};
+        float d[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 5; ++k) d[k] = h[0] * wa[k][0] + h[1] * wa[k][1] + h[2] * wa[k][2] + h[3] * wa[k][3];
-        d[5] = h[0] * ws[0] + h[1] * ws[1] + h[2] * ws[2] + h[3] * ws[3];
+        for (int j = 0; j < 16; ++j) {
+            const float h = (j & 1) ? __uint_as_float(hw[j >> 1] & 0xFFFF0000u) : __uint_as_float(hw[j >> 1] << 16);
 #pragma unroll
-        for (int k = 0; k < 6; ++k)
+            for (int k = 0; k < 5; ++k) d[k] += h * wa[k][j];
+            d[5] += h * ws[j];
+        }
 #pragma unroll
-            for (int s2 = 32; s2 > 0; s2 >>= 1) d[k] += __shfl_xor(d[k], s2, 64);
-        if (lane == 0) {
+        for (int k = 0; k < 6; ++k) d[k] = qh_row_sum16(d[k]);
+        if (live && q16 == 0) {
             float a[5], mean = 0.f;
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
@@ -305,10 +327,10 @@ int mapf_comm_mask_multi(const int16_t *pos_dev, int E, const int32_t *envtab_de
 int mapf_q_head(const uint16_t *hidden_dev, int64_t rows, const float *adv_weight_dev, const float *adv_bias_dev, const float *state_weight_dev,
                 const float *state_bias_dev, float *q_dev, int64_t *action_dev, void *stream) {
     if (rows < 0 || !hidden_dev || !adv_weight_dev || !adv_bias_dev || !state_weight_dev || !state_bias_dev || !q_dev ||
-        (reinterpret_cast<uintptr_t>(hidden_dev) & 7) || (reinterpret_cast<uintptr_t>(action_dev) & 7))
+        (reinterpret_cast<uintptr_t>(hidden_dev) & 15) || (reinterpret_cast<uintptr_t>(action_dev) & 7))
         return MAPF_ERR_INVALID_ARG;
     if (rows == 0) return MAPF_OK;
-    long long blocks = (rows + 3) / 4;
+    long long blocks = (rows + 15) / 16;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(q_head_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), hidden_dev, (long long)rows, adv_weight_dev,
                        adv_bias_dev, state_weight_dev, state_bias_dev, q_dev, reinterpret_cast<long long *>(action_dev));
