@@ -694,20 +694,24 @@ class FusedUpdate:
                     continue
                 t.record_stream(side)
         self._head(c, v, To, Tt, batch)
-        if lr.replay_gate is not None:  # (actors on their own stream: their last episode flush precedes this update's replay operations)
-            cur.wait_event(lr.replay_gate)
-        self._write_priorities(c, batch)
         pre_ready = None
-        if lr.prefetch and own_batch:
-            # the next batch is sampled and planned NOW (its priorities are in), on the second stream: ~0.5 ms of small kernels that
-            # fit beside the backward-through-time kernel (192 workgroups on 256 CUs) instead of in front of it
-            if lr._side is not None:
-                lr._side.wait_stream(cur)
-                with torch.cuda.stream(lr._side):
-                    lr._launch_prefetch()
-                    pre_ready = torch.cuda.Event()
-                    pre_ready.record(lr._side)
-            else:
+        if lr.prefetch and own_batch and lr._side is not None:
+            # the priority write-back (a 40 us sum-tree walk) and, with its priorities in, the next batch's sample and plan go to the second
+            # stream: ~0.5 ms of small kernels that fit beside the backward-through-time kernel (192 workgroups on 256 CUs) instead of
+            # in front of it
+            lr._side.wait_stream(cur)
+            with torch.cuda.stream(lr._side):
+                if lr.replay_gate is not None:  # (actors on their own stream: their last episode flush precedes this update's replay operations)
+                    lr._side.wait_event(lr.replay_gate)
+                self._write_priorities(c, batch)
+                lr._launch_prefetch()
+                pre_ready = torch.cuda.Event()
+                pre_ready.record(lr._side)
+        else:
+            if lr.replay_gate is not None:
+                cur.wait_event(lr.replay_gate)
+            self._write_priorities(c, batch)
+            if lr.prefetch and own_batch:
                 lr._launch_prefetch()
         # this update's replay operations (priority write-back, next sample) are enqueued: whoever else writes the replay waits for this
         lr.replay_released = pre_ready
