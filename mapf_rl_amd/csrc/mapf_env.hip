@@ -238,7 +238,7 @@ __device__ __forceinline__ W shfl_down_w(W v, int width) {
 template <typename W>
 __global__ void __launch_bounds__(256) navi_bfs_kernel(int E, int L, int N, const W *map_rows,
                                                       const int16_t *goals, NaviRec<W> *navi, int32_t *status,
-                                                      const int32_t *env_ids) {
+                                                      const int32_t *env_ids, const uint8_t *env_mask = nullptr) {
     constexpr int LPF = sizeof(W) == 4 ? 32 : 64;  // lanes per field
     constexpr int FPW = 64 / LPF;                  // fields per wavefront
     const int lane = threadIdx.x & 63;
@@ -249,12 +249,14 @@ __global__ void __launch_bounds__(256) navi_bfs_kernel(int E, int L, int N, cons
     int e = valid ? (int)(slot / N) : 0;
     if (env_ids) e = env_ids[e];                      // partial rebuild: E listed environments
     const long long field = (long long)e * N + (valid ? slot % N : 0);
-    const bool in_map = valid && row < L;
+    // partial rebuild by flags (mapf_reset_envs: the environments whose scenario was just re-drawn): the other fields' lanes idle along
+    const bool in_map = valid && row < L && (env_mask == nullptr || env_mask[e] != 0);
+    if (env_mask != nullptr && __ballot(in_map) == 0ull) return;
     const W lmask = (L == (int)(8 * sizeof(W))) ? ~(W)0 : (((W)1 << L) - 1);
     W freec = 0;
     if (in_map) freec = ~map_rows[(size_t)e * L + row] & lmask;
     int gx = -1, gy = 0;
-    if (valid) {
+    if (valid && (env_mask == nullptr || env_mask[e] != 0)) {
         gx = goals[field * 2];
         gy = goals[field * 2 + 1];
         if (gx < 0 || gx >= L || gy < 0 || gy >= L) {
@@ -354,12 +356,19 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
-template <typename W>
+// NAVI: the BFS from every goal also leaves the goal's navigation field (one wavefront does placement AND all N fields: 0.25-0.5 ms per
+// call at 40 agents, on the actor's critical path whenever an episode ended).  !NAVI (mapf_reset_envs, round 4): placement only --
+// the partition of a drawn goal cell is looked up among the partitions already seen on this map (the first few draws find the large
+// ones; a BFS only for a cell of a new partition), and the N fields are built afterwards by navi_bfs_kernel on the flagged
+// environments, one wavefront per field, in parallel.  Same draws, same scenario, same fields either way.
+constexpr int RESET_CACHED_PARTS = 16;
+template <typename W, bool NAVI>
 __device__ __forceinline__ void reset_body(const int e, int E, int L, int N, const uint8_t *mask, float density, uint64_t seed,
                                            W *map_rows, int16_t *agents, int16_t *goals, NaviRec<W> *navi,
                                            int32_t *steps, int32_t *epochs, int32_t *status) {
     const int lane = threadIdx.x;
     if (e >= E || (mask && !mask[e])) return;
+    __shared__ W s_part[NAVI ? 1 : RESET_CACHED_PARTS][64];  // !NAVI: row masks of the partitions seen on the current map
     const int row = lane;
     const bool in_map = row < L;
     const W lmask = (L == (int)(8 * sizeof(W))) ? ~(W)0 : (((W)1 << L) - 1);
@@ -382,6 +391,7 @@ __device__ __forceinline__ void reset_body(const int e, int E, int L, int N, con
         const W freec = in_map ? (~obst & lmask) : (W)0;
         W avail = freec, elig = freec;
         ok = true;
+        int nparts = 0;  // (wave-uniform) partitions cached in s_part for this map
         uint64_t draw = akey ^ 0x64726177ull;
         for (int i = 0; i < N && ok; ++i) {
             int gx = 0, gy = 0, cnt = 0;
@@ -394,6 +404,18 @@ __device__ __forceinline__ void reset_body(const int e, int E, int L, int N, con
                 }
                 draw = mix64(draw);
                 select_bit<W>(elig, (int)(draw % (uint64_t)total), lane, gx, gy);
+                if (!NAVI) {
+                    int hit = -1;
+                    for (int k = 0; k < nparts && hit < 0; ++k)
+                        if ((s_part[k][gx] >> gy) & (W)1) hit = k;  // (one address for the whole wave)
+                    if (hit >= 0) {
+                        vis = s_part[hit][row];
+                        cnt = wave_sum<W>(popc_w<W>(vis & avail));
+                        if (cnt >= 2) break;
+                        elig &= ~vis;
+                        continue;
+                    }
+                }
                 vis = (row == gx) ? ((W)1 << gy) : (W)0;
                 W fr = vis;
                 up = down = left = right = 0;
@@ -411,6 +433,11 @@ __device__ __forceinline__ void reset_body(const int e, int E, int L, int N, con
                     vis |= nw;
                     fr = nw;
                     if (__ballot(nw != 0) == 0ull) break;
+                }
+                if (!NAVI && nparts < RESET_CACHED_PARTS) {
+                    s_part[nparts][row] = vis;
+                    ++nparts;
+                    __builtin_amdgcn_wave_barrier();
                 }
                 cnt = wave_sum<W>(popc_w<W>(vis & avail));
                 if (cnt >= 2) break;
@@ -434,7 +461,7 @@ __device__ __forceinline__ void reset_body(const int e, int E, int L, int N, con
                 agents[o * 2] = (int16_t)sx;
                 agents[o * 2 + 1] = (int16_t)sy;
             }
-            if (in_map) {
+            if (NAVI && in_map) {
                 NaviRec<W> rec;
                 rec.w[0] = up;
                 rec.w[1] = down;
@@ -455,7 +482,7 @@ template <typename W>
 __global__ void __launch_bounds__(64) reset_kernel(int E, int L, int N, const uint8_t *mask, float density, uint64_t seed,
                                                    W *map_rows, int16_t *agents, int16_t *goals, NaviRec<W> *navi,
                                                    int32_t *steps, int32_t *epochs, int32_t *status) {
-    reset_body<W>((int)blockIdx.x, E, L, N, mask, density, seed, map_rows, agents, goals, navi, steps, epochs, status);
+    reset_body<W, false>((int)blockIdx.x, E, L, N, mask, density, seed, map_rows, agents, goals, navi, steps, epochs, status);
 }
 
 // mapf_reset_envs(mask) of every handle of a set in one launch: workgroup -> (segment, environment); the scenario stream of an
@@ -468,11 +495,11 @@ __global__ void __launch_bounds__(64) reset_multi_kernel(const MultiTable *tab, 
     const StepParams &p = tab->seg[seg];
     const uint64_t sd = (uint64_t)tab->reset_seed[seg] + (tick ? (uint64_t)tick[0] : 0ull);
     if (p.L > 32)
-        reset_body<uint64_t>(e, p.E, p.L, p.N, p.mask, density, sd, const_cast<uint64_t *>(static_cast<const uint64_t *>(p.map_rows)), p.agents,
+        reset_body<uint64_t, true>(e, p.E, p.L, p.N, p.mask, density, sd, const_cast<uint64_t *>(static_cast<const uint64_t *>(p.map_rows)), p.agents,
                              const_cast<int16_t *>(p.goals), const_cast<NaviRec<uint64_t> *>(static_cast<const NaviRec<uint64_t> *>(p.navi)), p.steps,
                              tab->epochs[seg], p.status);
     else
-        reset_body<uint32_t>(e, p.E, p.L, p.N, p.mask, density, sd, const_cast<uint32_t *>(static_cast<const uint32_t *>(p.map_rows)), p.agents,
+        reset_body<uint32_t, true>(e, p.E, p.L, p.N, p.mask, density, sd, const_cast<uint32_t *>(static_cast<const uint32_t *>(p.map_rows)), p.agents,
                              const_cast<int16_t *>(p.goals), const_cast<NaviRec<uint32_t> *>(static_cast<const NaviRec<uint32_t> *>(p.navi)), p.steps,
                              tab->epochs[seg], p.status);
 }
@@ -1097,6 +1124,17 @@ int mapf_reset_envs(mapf_env_t *h, const uint8_t *mask_dev, float density, uint6
         hipLaunchKernelGGL(reset_kernel<uint32_t>, dim3(h->E), dim3(64), 0, s, h->E, h->L, h->N, mask_dev, density, seed,
                            static_cast<uint32_t *>(h->map_rows), h->agents, h->goals, static_cast<NaviRec<uint32_t> *>(h->navi),
                            h->steps, h->epochs, h->status);
+    HIP_TRY(hipGetLastError());
+    // the navigation fields of the re-drawn environments: one wavefront per field (two per wavefront on <= 32 x 32 maps)
+    const long long fields = (long long)h->E * h->N;
+    if (h->wide)
+        hipLaunchKernelGGL(navi_bfs_kernel<uint64_t>, dim3(blocks_for(fields * 64, 256)), dim3(256), 0, s, h->E, h->L, h->N,
+                           static_cast<const uint64_t *>(h->map_rows), h->goals, static_cast<NaviRec<uint64_t> *>(h->navi), h->status,
+                           (const int32_t *)nullptr, mask_dev);
+    else
+        hipLaunchKernelGGL(navi_bfs_kernel<uint32_t>, dim3(blocks_for(((fields + 1) / 2) * 64, 256)), dim3(256), 0, s, h->E, h->L, h->N,
+                           static_cast<const uint32_t *>(h->map_rows), h->goals, static_cast<NaviRec<uint32_t> *>(h->navi), h->status,
+                           (const int32_t *)nullptr, mask_dev);
     HIP_TRY(hipGetLastError());
     if (!mask_dev) h->loaded = h->navi_ready = true;  // every environment now holds a complete scenario
     return MAPF_OK;
