@@ -478,3 +478,42 @@ def test_multi_handle_set_rejects_wide_shapes(M):
     with pytest.raises(_lib.MapfError) as ex:
         MultiEnvironment([env], [torch.zeros((8, 40), dtype=torch.int8, device="cuda")], [None], [torch.zeros(8, dtype=torch.uint8, device="cuda")])
     assert ex.value.status == _lib.ERR_UNSUPPORTED
+
+
+def test_two_kernel_reset_draws_the_merged_resets_scenarios(M):
+    """mapf_reset_envs builds a scenario in two launches (placement with the map's partitions looked up, then the N navigation fields
+    in parallel); the merged launch of a handle set keeps the one-wavefront version that floods from every drawn goal.  Same
+    scenario stream, same flags -> the same maps, starts, goals, fields and step counters, bit for bit (also for the environments a
+    mask leaves alone), on several shapes up to the merged launch's limit."""
+    from mapf_rl_amd.environment import MultiEnvironment
+
+    E = 48
+    levels = [(1, 10), (6, 20), (12, 24), (16, 40), (7, 33), (6, 40)]
+    seeds = [1000 + 17 * i for i in range(len(levels))]
+    rng = np.random.RandomState(5)
+    sets = []
+    for k in range(2):
+        envs = []
+        for N, L in levels:
+            env = M.VecEnvironment(E, L, N)
+            env.load(*M.generate_scenarios(E, L, N, 0.2, seed=100 * N + L)[:3])
+            envs.append(env)
+        sets.append(envs)
+    acts = [torch.zeros((E, N), dtype=torch.int8, device="cuda") for N, L in levels]
+    masks = [torch.zeros(E, dtype=torch.uint8, device="cuda") for _ in levels]
+    multi = MultiEnvironment(sets[0], acts, [None] * len(levels), masks, reset_seeds=seeds)
+    tick = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for rnd, density in enumerate((0.2, -1.0, 0.3)):
+        for m in masks:
+            flag = (rng.random_sample(E) < (1.0 if rnd == 0 else 0.4)).astype(np.uint8)
+            m.copy_(torch.from_numpy(flag))
+        tick.fill_(3 + rnd)
+        multi.reset(density, tick)
+        for i, env in enumerate(sets[1]):
+            env.reset_envs(masks[i], density, seed=seeds[i] + 3 + rnd)
+        for i, (a, b) in enumerate(zip(sets[0], sets[1])):
+            a.check_status()
+            b.check_status()
+            assert np.array_equal(_np(a.maps()), _np(b.maps())), (rnd, levels[i])
+            assert np.array_equal(_np(a.agents_pos()), _np(b.agents_pos())) and np.array_equal(_np(a.goals_pos()), _np(b.goals_pos())), (rnd, levels[i])
+            assert np.array_equal(_np(a.navi_map()), _np(b.navi_map())) and np.array_equal(_np(a.steps()), _np(b.steps())), (rnd, levels[i])
