@@ -340,6 +340,18 @@ class CurriculumActors:
                 g.capture_end()
         return g
 
+    _graph_wkey = None
+
+    def _weights_key(self):
+        """Identity of the weights the acting network holds now: its epoch (bumped by the fused optimizer step) and every
+        parameter's (address, version) -- what the packed-weight caches of fused.py key on."""
+        m = self.model
+        if self._wparams is None or self._wparams[0] is not m:
+            self._wparams = (m, list(m.parameters()))
+        return (getattr(m, "weights_epoch", 0),) + tuple((p.data_ptr(), p._version) for p in self._wparams[1])
+
+    _wparams = None
+
     def step(self):
         acts = list(self.actors.values())
         pulled = False
@@ -360,7 +372,11 @@ class CurriculumActors:
             # merged environment launches; and, once the allocator and the libraries have seen the iteration twice, its launches
             # replayed from a graph.  After a weight pull one iteration is issued directly: it re-packs the weight images (in place)
             # and re-encodes every observation (fused.LatentCache), which the captured sequence does not contain.
-            if self.GRAPH and not pulled and self._warm >= 2:
+            # The same after ANY other change of the acting network's weights (weights_period None: the actors act on the learner's
+            # module itself, which its optimizer step rewrites): the captured launches read the packed images and cached latents of
+            # the last directly issued iteration, so a replay would mix them with the live head parameters.
+            wkey = self._weights_key()
+            if self.GRAPH and not pulled and self._warm >= 2 and wkey == self._graph_wkey:
                 if self._graph is None:
                     self._graph = self._capture()
                 self._graph.replay()
@@ -368,6 +384,7 @@ class CurriculumActors:
             else:
                 self._iteration()
                 self._warm += 1
+                self._graph_wkey = wkey
             for a in acts:  # (host mirrors of what moved on the device: a later re-layout continues the levels' own streams)
                 a.env_steps += a.E
                 a._explore_counter += 1

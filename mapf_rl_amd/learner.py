@@ -27,7 +27,18 @@ GAMMA = 0.99          # hard-coded in the reference (worker.py:306), config.gamm
 GRAD_CLIP = 40.0      # worker.py:319
 TARGET_SYNC = 2500    # config.target_network_update_freq (config.py:27)
 FORWARD_STEPS = 2     # config.forward_steps (config.py:65)
-SIDE_STREAM_PRIORITY = int(os.environ.get("MAPF_SIDE_PRIORITY", "1"))   # (HIP: a larger number is a LOWER priority; clamped to the device's range)
+# tests / tools: treat an initialised ONE-rank process group as several ranks, i.e. run the multi-rank code path -- the collective
+# calls (RCCL on the one GPU of a test box), the stream orders around them, the graph stages split around the exchange
+FORCE_EXCHANGE = os.environ.get("MAPF_FORCE_EXCHANGE", "0") == "1"
+
+
+def exchanging(group=None):
+    """True when an update has to all-reduce its gradients: a process group with more than one rank (or FORCE_EXCHANGE)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or FORCE_EXCHANGE
 
 
 def huber_loss(td_error, kappa=1.0):
@@ -87,7 +98,7 @@ class FlatGradBucket:
     def begin(self, lo, hi, group=None):
         import torch.distributed as dist
 
-        if self._world(group) > 1 and hi > lo:
+        if exchanging(group) and hi > lo:
             self._pending = tuple(self._pending) + (dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True),)
 
     def finish(self, group=None):
@@ -101,7 +112,7 @@ class FlatGradBucket:
 
     def all_reduce_mean(self, group=None):
         n = self.flat.numel()
-        if self._world(group) > 1:
+        if exchanging(group):
             k = self.split if (self.split is not None and 0 < self.split < n) else n
             if k < n:
                 self.begin(k, n, group)
@@ -170,10 +181,9 @@ class Learner:
         # running the update on a high-priority stream -- so that the target forward would only fill idle CUs -- gave 39.7: the chip
         # is saturated by the update's own kernels, the update is ~39.5 ms of work whichever way it is ordered.)
         self.prefetch = bool(prefetch) and buffer is not None and self.device.type == "cuda"
-        # (lower priority than the stream the update itself runs on: the online chain -- encoder, recurrence, backward -- is the
-        # update's critical path; the target network's forward and the next batch's sample only have to be done before the head /
-        # the next update, and otherwise steal CUs from it: measured at 6 agents, tools/update_timeline.py)
-        self._side = torch.cuda.Stream(device=self.device, priority=SIDE_STREAM_PRIORITY) if self.prefetch else None
+        # (a plain second stream.  PyTorch maps `priority` to a stream pool by clamp(-priority, 0, max-1): a positive value does NOT make a
+        # lower-priority HIP stream, so rounds 3-4's `priority=1` was the default pool all along and the knob is gone.)
+        self._side = torch.cuda.Stream(device=self.device) if self.prefetch else None
         self._pre = None
 
     def current_lr(self):

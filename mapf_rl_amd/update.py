@@ -276,13 +276,11 @@ class FusedUpdate:
 
     # ------------------------------------------------------------------ graph mode: static buffers
     def graph_mode(self):
-        """Graph replay applies to the batches the learner samples itself from a device replay of narrow rows, single rank."""
+        """Graph replay applies to the batches the learner samples itself from a device replay of narrow rows.  With several ranks too
+        (round 5): the backward graph then ends where the gradients are final, the exchange and the optimizer step follow it as
+        ordinary stream work (_run_graphed)."""
         lr = self.lr
-        if not (self.GRAPH and lr.buffer is not None and lr.prefetch and lr.buffer.max_agents <= self.GRAPH_MAX_AGENTS and lr.grad_hook is None):
-            return False
-        import torch.distributed as dist
-
-        return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        return bool(self.GRAPH and lr.buffer is not None and lr.prefetch and lr.buffer.max_agents <= self.GRAPH_MAX_AGENTS and lr.grad_hook is None)
 
     def batch_slot(self):
         """The static buffers every prioritized sample of this learner is written into (graph mode), or None."""
@@ -595,14 +593,18 @@ class FusedUpdate:
         # on what the BPTT kernel wrote, the encoder's backward chain below only on d_gi1: inside a capture they become two branches
         # of the graph (a second stream that forks here and joins before the optimizer step).  Everything the branch reads is held by
         # `c` / `outs_b` until the join; what it allocates, it allocates on its own stream.
-        # Eagerly too on a single rank (config 2: nine ~50 us launches that would otherwise sit between the BPTT kernel and the encoder's
-        # backward); with several ranks the eager path keeps one stream, because there the recurrence's piece of the gradient exchange
-        # starts before the encoder's backward and needs these gradients in stream order.
-        import torch.distributed as dist
+        # Eagerly too (config 2: nine ~50 us launches that would otherwise sit between the BPTT kernel and the encoder's backward).
+        # Several ranks: the recurrence's and the head's piece of the gradient exchange is issued FROM the branch, behind the last
+        # gradient it contains (the collective is ordered behind the stream it is issued on), so it travels while the encoder's
+        # backward chain runs on the main stream.  (Rounds 3-4 kept one stream with several ranks and lost the overlap.)
+        from .learner import exchanging
 
-        one_rank = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-        aux = self.lr._side if (self._capturing or (one_rank and self.lr.grad_hook is None)) else None
+        ex = exchanging()
+        aux = self.lr._side if (self._capturing or self.lr.grad_hook is None) else None
         cur_s = torch.cuda.current_stream(dev)
+        n_all, split = flat.grads.numel(), lr.bucket.split
+        # (inside a capture no collective is issued: the captured stage ends where the gradients are final, see _run_graphed)
+        two_pieces = ex and not self._capturing and aux is not None and split is not None and 0 < split < n_all
         if aux is not None:
             aux.wait_stream(cur_s)
         with (torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext()):
@@ -632,19 +634,18 @@ class FusedUpdate:
             aux.wait_stream(cur_s)
             with torch.cuda.stream(aux):
                 _tall_tn_into(flat.mem(G, "recurrent.weight_ih"), d_gi_rows, c.lat, rows=4096)
+                # the recurrence's and the head's gradients are final on this branch: their piece of the exchange (12 % of the bytes)
+                if two_pieces:
+                    lr.bucket.begin(split, n_all)
         g_lat = mm_rows(d_gi_rows, c.w_ih, transpose_w=False)
         if aux is None:
             _tall_tn_into(flat.mem(G, "recurrent.weight_ih"), d_gi_rows, c.lat, rows=4096)
-        # the recurrence's and the head's gradients are final: their piece of the exchange (12 % of the bytes) travels while the
-        # encoder's backward chain runs (several ranks only; learner.FlatGradBucket.begin)
-        n_all, split = flat.grads.numel(), lr.bucket.split
-        two_pieces = split is not None and 0 < split < n_all and lr.grad_hook is None and aux is None
-        if two_pieces:
-            lr.bucket.begin(split, n_all)
         # ---- encoder: backward-data chain in one kernel, then the weight-gradient kernels ----
         self._encoder_backward(po.obs_rows, Mu, c.acts, c.lat, c.bits, g_lat, c.wpt, aux)
         if aux is not None:
             cur_s.wait_stream(aux)
+        if ex and self._capturing:
+            return None  # several ranks, captured: the exchange and the optimizer step follow the graph (_run_graphed)
         # ---- the exchange (its second piece: the encoder's gradients), clip, Adam ----
         if two_pieces:
             lr.bucket.begin(0, split)
@@ -872,12 +873,21 @@ class FusedUpdate:
             ent = c_o.backward[lr_value] = (g_b, norm)
         g_b, norm = ent
         g_b.replay()
-        flat.step_host += 1
-        lr.model.weights_epoch += 1
+        if norm is None:
+            # several ranks: the captured stage ended where this rank's gradients are final -- the one collective of an update and
+            # the optimizer step (two launches, device-side step count) are ordinary stream work behind it.  RCCL's collective is
+            # stream-ordered (no host wait); the second piece is not overlapped here as in the eager path: at the shapes that replay
+            # graphs an update is launch-latency-bound and the 8.2 MB exchange a fraction of it.
+            lr.bucket.all_reduce_mean()
+            norm = flat.adam_step(lr_value)
+        else:
+            flat.step_host += 1
+            lr.model.weights_epoch += 1
+            norm = norm.clone()
         cur.wait_event(pre_ready)
         self.graph_replays += 1
         outs, prio, loss = c_h.outs.clone(), c_h.prio.clone(), c_h.loss.clone()
-        return dict(loss=loss[0], td=outs[2].view(B, 1), priorities=prio, grad_norm=norm.clone(), q=outs[0].view(B, 1), q_next=outs[1].view(B, 1))
+        return dict(loss=loss[0], td=outs[2].view(B, 1), priorities=prio, grad_norm=norm, q=outs[0].view(B, 1), q_next=outs[1].view(B, 1))
 
     def _encoder_backward(self, obs_rows, M, acts, lat, bits, g_lat, wpt, aux=None):
         """aux: a second stream for what only needs the backward-data kernel's outputs besides the six 3x3 weight-gradient launches

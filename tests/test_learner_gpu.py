@@ -1,5 +1,7 @@
 """GPU (bf16 autocast): Learner.update against the reference golden (fp32): td error / loss within the bf16
 tolerance, and the end-to-end device path replay.sample_batch -> update -> update_priorities."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -336,3 +338,58 @@ def test_graph_replayed_update_follows_the_eager_update(double_q):
 
 def buf_leaves(tree):
     return (tree.numel() + 1) // 2
+
+
+def _run_ranks(world, backend, n_updates, timeout=900):
+    """Starts tests/dist_graph_worker.py as `world` ranks (all on GPU 0) and returns their JSON lines."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, PYTHONPATH=root, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "dist_graph_worker.py"), backend, str(n_updates)], env=env, cwd=root,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    assert [p.returncode for p in procs] == [0] * world, [o[1][-2500:] for o in outs]
+    return [json.loads([l for l in o[0].splitlines() if l.startswith("{")][-1]) for o in outs]
+
+
+def _check_rank_report(r, n):
+    assert r["graph_mode_on"] and r["replays_eager"] == 0 and r["replays_graph"] == n and r["steps"] == [n, n] and r["finite"]
+    # the exchange ran in BOTH launch sequences: two pieces and one wait per update
+    assert r["exchange_calls"] == {"begin": 4 * n, "finish": 2 * n}, r["exchange_calls"]
+    assert r["grad_err"] <= 2e-2, r                       # every parameter tensor's (exchanged, clipped) gradient: graph vs eager
+    assert r["td_err"] <= 2e-2 and r["q_err"] <= 2e-2, r
+    assert abs(r["loss"][0] - r["loss"][1]) <= 2e-2 * max(1.0, abs(r["loss"][0]))
+    assert abs(r["grad_norm"][0] - r["grad_norm"][1]) <= 3e-2 * r["grad_norm"][0]
+    assert r["param_diff_over_travel"] <= 0.1, r
+    assert r["same_params_on_all_ranks"], r
+
+
+def test_graph_replayed_update_with_the_exchange_inside_two_ranks():
+    """Round-4 review: graph replay was switched off on more than one rank.  Two ranks (gloo, sharing GPU 0, each with its own
+    episodes) run the eager launch sequence and the graph-replayed one with the gradient all-reduce inside: the graph path is on,
+    the exchange is issued, both ranks end with bit-identical parameters, and replay follows eager within the tolerances of the
+    single-rank test above."""
+    n = 6
+    for r in _run_ranks(2, "gloo", n):
+        assert r["world"] == 2 and r["backend"] == "gloo"
+        _check_rank_report(r, n)
+
+
+def test_update_exchange_over_rccl_on_one_rank():
+    """The collective calls themselves over RCCL (backend nccl): a ONE-rank group driven through the multi-rank code path
+    (learner.FORCE_EXCHANGE) -- communicator creation, the two asynchronous all-reduce pieces issued from the side branch, the
+    stream-ordered wait, graph stages with the exchange between them -- on the one GPU a test box has."""
+    n = 6
+    (r,) = _run_ranks(1, "nccl", n)
+    assert r["world"] == 1 and r["backend"] == "nccl"
+    _check_rank_report(r, n)

@@ -16,8 +16,10 @@ deviation, for throughput runs): outcomes are still printed per level, but no le
 Several ranks.  Every `learner.update()` contains the gradient all-reduce, so all ranks must run the same number of
 updates: whether training has started (every rank's replay holds `--learning-starts` transitions), whether it is
 time to print statistics / advance the curriculum (rank 0's clock), and whether to stop (`--minutes` on any rank,
-or the curriculum's stop criterion on the POOLED level statistics) are decided once per iteration from one small
-all-reduced flag vector, identically on every rank.
+or the curriculum's stop criterion on the POOLED level statistics) are decided every `--decide-every` iterations from
+one small flag vector reduced asynchronously over a host-side (gloo) group one period earlier, identically on every
+rank; no iteration waits for another rank outside the gradient exchange (reference worker.py:282-340: one learner
+loop, no per-step barrier).
 
 Printed statistics keep the reference's wording (worker.py:206-210,348-350): buffer update speed (= env steps/s
 summed over this rank's environments), buffer size, per-level success, number of updates, update speed, loss.
@@ -70,6 +72,8 @@ def main(argv=None):
                     "update (their episode flush ordered between two updates' replay operations by events); 0: one stream, strictly "
                     "alternating; -1 (default): 1 up to 48 agents per environment (curriculum, 5 minutes: 59 k -> 72.5 k updates; fixed 32x32 / "
                     "40-agent level: 63.6 -> 69.7 updates/s), 0 beyond (40x40 / 64 agents: 106.7 -> 61.3 updates/s, 64x64 / 128 agents: no change)")
+    ap.add_argument("--decide-every", type=int, default=16, help="several ranks: actor iterations between two decision points (start of training, "
+                    "statistics, stop); the flags are reduced asynchronously on host tensors and read one period later")
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args(argv)
     fixed = a.agents is not None or a.map is not None
@@ -92,7 +96,6 @@ def main(argv=None):
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(a.dist_backend)
-    flag_dev = dev if (dist is None or a.dist_backend == "nccl") else torch.device("cpu")
 
     import mapf_rl_amd as M
     from mapf_rl_amd.actor import VecActor
@@ -156,36 +159,50 @@ def main(argv=None):
             done_ev.record(astream)
         learner.replay_gate = done_ev
 
+    # ---- decisions every rank must take identically (see module docstring) ----
+    # Round 4 all-reduced three flags on the device and read them back EVERY iteration: a host-blocking collective per 0.3 ms actor
+    # iteration.  Now the flags travel on a control-plane group of HOST tensors (gloo, whatever carries the gradients), once every
+    # `--decide-every` iterations and asynchronously: the reduction issued at one decision point is read at the NEXT one, when it has
+    # long completed, so the loop never waits for another rank outside the gradient exchange itself.  Every rank acts on the same
+    # reduced flags at the same iteration number, hence identically (start of training, statistics, stop); the price is a lag of
+    # one decision period.  The only blocking control-plane collective left is the pooled level statistics, once per interval.
+    ctrl, K = None, 1
+    if dist is not None:
+        ctrl = dist.new_group(backend="gloo") if a.dist_backend == "nccl" else dist.group.WORLD
+        K = max(1, a.decide_every)
+    cpu = torch.device("cpu")
+    pending = None
     t_start = t_last = time.time()
     debt = 0.0
     started = False
     stop = False
+    it = 0
     while learner.counter < a.max_updates and not stop:
         actor_step()
-        now = time.time()
-        # ---- decisions every rank must take identically (see module docstring): one MAX all-reduce of 3 flags ----
-        if astream is not None and not started:
-            astream.synchronize()  # (nothing orders the actors' flush before the read below until updates run)
-        not_ready = 0 if started else int(len(buffer) < a.learning_starts)  # (reads the device-side ring state)
-        time_up = int(a.minutes > 0 and (now - t_start) > a.minutes * 60)
-        stats_now = int(rank == 0 and now - t_last >= a.interval)
-        if dist is not None:
-            flags = torch.tensor([not_ready, time_up, stats_now], dtype=torch.int32, device=flag_dev)
-            dist.all_reduce(flags, op=dist.ReduceOp.MAX)
-            not_ready, time_up, stats_now = flags.tolist()
-        if not started and not not_ready:
-            started = True
-            if rank == 0:
-                print("start training")
-        if started:
-            debt += a.updates_per_iter
-            while debt >= 1.0 and learner.counter < a.max_updates:
-                learner.update()
-                debt -= 1.0
+        it += 1
+        stats_now = 0
+        if it % K == 0:
+            if dist is None:
+                now = time.time()
+                if astream is not None and not started:
+                    astream.synchronize()  # (nothing orders the actors' flush before the read below until updates run)
+                not_ready = 0 if started else int(len(buffer) < a.learning_starts)  # (reads the device-side ring state)
+                time_up = int(a.minutes > 0 and (now - t_start) > a.minutes * 60)
+                stats_now = int(now - t_last >= a.interval)
+            else:
+                not_ready, time_up, stats_now = int(not started), 0, 0
+                if pending is not None:
+                    pending[0].wait()
+                    not_ready, time_up, stats_now = pending[1].tolist()
+            if not started and not not_ready:
+                started = True
+                if rank == 0:
+                    print("start training")
         if stats_now:
+            now = time.time()
             if astream is not None:
                 astream.synchronize()  # (the statistics below read what the actors wrote)
-            pooled = buffer.pooled_counts(flag_dev) if dist is not None else None
+            pooled = buffer.pooled_counts(cpu, ctrl) if dist is not None else None
             with contextlib.nullcontext() if rank == 0 else contextlib.redirect_stdout(io.StringIO()):
                 # per-rank buffers keep their own counters; only rank 0 prints (its own speed, the pooled level statistics)
                 learner.stats(now - t_last)
@@ -197,10 +214,27 @@ def main(argv=None):
             if astream is not None:
                 astream.wait_stream(torch.cuda.current_stream(dev))  # (new levels were set up on this stream)
             t_last = now
-        stop = stop or bool(time_up)
+        if it % K == 0:
+            stop = stop or bool(time_up)
+            if dist is not None and not stop:
+                # this rank's flags as they are NOW (behind whatever the decisions above did), reduced by the next decision point
+                now = time.time()
+                if astream is not None and not started:
+                    astream.synchronize()
+                mine = torch.tensor([0 if started else int(len(buffer) < a.learning_starts),
+                                     int(a.minutes > 0 and (now - t_start) > a.minutes * 60),
+                                     int(rank == 0 and now - t_last >= a.interval)], dtype=torch.int32)
+                pending = (dist.all_reduce(mine, op=dist.ReduceOp.MAX, group=ctrl, async_op=True), mine)
+        if started:
+            debt += a.updates_per_iter
+            while debt >= 1.0 and learner.counter < a.max_updates:
+                learner.update()
+                debt -= 1.0
     if rank == 0:
         learner.save()
     if dist is not None:
+        if pending is not None:
+            pending[0].wait()  # (issued by every rank at the same decision point)
         dist.barrier()
         dist.destroy_process_group()
 
