@@ -95,17 +95,43 @@ class FlatGradBucket:
 
         return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
+    def _host_staged(self, group=None):
+        """True when the group's backend has no device collectives (gloo: the CPU-side tests and the one-GPU rehearsal of the
+        multi-rank path) and the buffer lives on a HIP device.  PyTorch's own gloo path for device tensors allocates a fresh pinned
+        buffer per call; with two streams busy those allocations (hipHostMalloc beside running kernels) stalled an update for
+        0.1-1 s at random (profiles/r05_two_rank_probe.md), so the staging is done here, through ONE persistent pinned buffer."""
+        import torch.distributed as dist
+
+        return self.flat.is_cuda and dist.get_backend(group) == "gloo"
+
     def begin(self, lo, hi, group=None):
         import torch.distributed as dist
 
-        if exchanging(group) and hi > lo:
-            self._pending = tuple(self._pending) + (dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True),)
+        if not (exchanging(group) and hi > lo):
+            return
+        if self._host_staged(group):
+            if getattr(self, "_stage", None) is None or self._stage.numel() != self.flat.numel():
+                self._stage = torch.empty(self.flat.numel(), dtype=self.flat.dtype, pin_memory=True)
+            self._stage[lo:hi].copy_(self.flat[lo:hi], non_blocking=True)  # behind the gradients, on the stream this is issued on
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.flat.device))
+            self._pending = tuple(self._pending) + ((lo, hi, ev),)
+            return
+        self._pending = tuple(self._pending) + (dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True),)
 
     def finish(self, group=None):
+        import torch.distributed as dist
+
         w = self._world(group)
         self.pieces = len(self._pending)
         for work in self._pending:
-            work.wait()
+            if isinstance(work, tuple):  # host-staged piece: wait for its copy, reduce on the host, hand it back on this stream
+                lo, hi, ev = work
+                ev.synchronize()
+                dist.all_reduce(self._stage[lo:hi], op=dist.ReduceOp.SUM, group=group)
+                self.flat[lo:hi].copy_(self._stage[lo:hi], non_blocking=True)
+            else:
+                work.wait()
         self._pending = ()
         if w > 1:
             self.flat.div_(w)
@@ -130,7 +156,8 @@ class _FlatView:
         self.flat.zero_()
 
     pieces, _pending = 0, ()
-    _world, begin, finish, all_reduce_mean = FlatGradBucket._world, FlatGradBucket.begin, FlatGradBucket.finish, FlatGradBucket.all_reduce_mean
+    _world, begin, finish, all_reduce_mean, _host_staged = (FlatGradBucket._world, FlatGradBucket.begin, FlatGradBucket.finish, FlatGradBucket.all_reduce_mean,
+                                                             FlatGradBucket._host_staged)
 
 
 class Learner:
