@@ -83,28 +83,23 @@ constexpr int H_ROW = D * 2 + 32;          // 544
 constexpr int H_BYTES = NA * H_ROW;        // one hidden buffer
 constexpr int QK_ROW = 256 * 2 + 32;       // q (2 heads x 64) | k (2 heads x 64)
 constexpr int VT_ROW = 64 * 2 + 32;        // v transposed: row = (head, d), 64 agent slots
-constexpr int P_ROW = 64 * 2 + 32;         // softmax weights bf16: row = (head, agent i), 64 agent slots j
 constexpr int CTX_ROW = 128 * 2 + 32;
 constexpr int INFO_ROW = 64 * 2 + 32;
-constexpr int S_ROW = NA + 4;              // scores fp32: row = (head, agent i), 16-byte aligned rows (float4 reads)
 constexpr int OFF_H0 = 0, OFF_H1 = OFF_H0 + H_BYTES;
 constexpr int OFF_QK = OFF_H1 + H_BYTES;
 constexpr int OFF_VT = OFF_QK + NA * QK_ROW;
-constexpr int OFF_P = OFF_VT + 128 * VT_ROW;
-// ctx and info live in q|k's bytes: q|k is dead once the scores are out (two barriers before ctx is written), and the next q|k is
-// written only behind the update cell that reads info; every phase writes all NA rows of the columns the next one reads
-constexpr int OFF_CTX = OFF_QK;
+// (round 5: the attention of a (head, agent tile) runs in one wave's registers -- no score / softmax images; ctx is written while
+// other waves still read q | k, so it has its own bytes)
+constexpr int OFF_CTX = OFF_VT + 128 * VT_ROW;
 constexpr int OFF_INFO = OFF_CTX + NA * CTX_ROW;
-static_assert(OFF_INFO + NA * INFO_ROW <= OFF_VT, "ctx | info must fit in q | k");
-constexpr int OFF_S = OFF_P + 2 * NA * P_ROW;
-constexpr int OFF_UPD = OFF_S + 2 * NA * S_ROW * 4;
+constexpr int OFF_UPD = OFF_INFO + NA * INFO_ROW;
 constexpr int OFF_MB = OFF_UPD + 64 * 4;     // comm mask of the step as bits: 2 words per agent row
 constexpr int OFF_RIDX = OFF_MB + NA * 2 * 4;  // global row of every agent at this step (-1: none), see recurrent_infer_kernel
 constexpr int OFF_BSUM = OFF_RIDX + NA * 4;   // gate biases of both cells as the accumulators want them: [cell][r: b_ir + b_hr | z: b_iz + b_hz | b_in | b_hn][256] f32
 constexpr int LDS_BYTES = OFF_BSUM + 2 * 4 * 256 * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(NTHR == 512, "gru_pair: a wave owns exactly two of the 16 channel blocks");
-static_assert(OFF_S % 16 == 0 && OFF_UPD % 16 == 0 && OFF_BSUM % 16 == 0, "");
+static_assert(OFF_CTX % 16 == 0 && OFF_INFO % 16 == 0 && OFF_UPD % 16 == 0 && OFF_BSUM % 16 == 0 && LDS_BYTES % 16 == 0, "");
 
 // weight buffer (bf16 elements) and bias buffer (f32 elements), see mapf_dqn.h
 constexpr int W_HH = 0, W_QKV = W_HH + 768 * 256, W_O = W_QKV + 384 * 256, U_IH = W_O + 64 * 128, U_HH = U_IH + 768 * 64;
@@ -342,6 +337,9 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
     const int rot = blockIdx.x;  // workgroups walk the weight tiles in rotated order: they run in step, and would otherwise all
                                  // request the same cache lines at the same moment
 
+#ifdef MAPF_RECUR_PRIO  // experiment: the two waves of a SIMD (w, w + 4) at different issue priorities, so that one's MFMA chain runs under the other's pointwise math
+    if (MAPF_RECUR_PRIO == 1 ? w < 4 : w >= 4) __builtin_amdgcn_s_setprio(2);
+#endif
     TRACE_BEGIN();
     TRACE_POINT(30);
     // the weight stream (see stream_mfma): this wave's channel blocks / q|k|v tiles are the same in every phase of every step
@@ -401,7 +399,6 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
     TRACE_POINT(31);
     unsigned char *Hc = smem + OFF_H0, *Hn = smem + OFF_H1;
     int *upd = reinterpret_cast<int *>(smem + OFF_UPD);
-    float *S = reinterpret_cast<float *>(smem + OFF_S);
     uint32_t *mb = reinterpret_cast<uint32_t *>(smem + OFF_MB);
     int *ridx = reinterpret_cast<int *>(smem + OFF_RIDX);
     const float scale = 0.125f;  // 1 / sqrt(64)
@@ -494,95 +491,83 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                 }
             }
             phase_sync(3);
-            // scores S[head][i][j] = q_i . k_j / 8: 2 heads x 3 x 3 tiles, K = 64
-            for (int job = w; job < 2 * NT * NT && !(MAPF_RECUR_ABLATE & 4); job += NTHR / 64) {
-                const int hd = job / (NT * NT), ti = (job / NT) % NT, tj = job % NT;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // Attention of one (head, agent tile) per wave, entirely in registers.  S^T = k q^T: an accumulator lane then holds, for ITS
+            // agent i = 16 ti + lr, the scores of the partners j = 16 tj + 4 lh + r -- which is, tile pair by tile pair, the B operand
+            // (32 k-slots x 16 agents) of ctx^T = v^T P^T once the k-slots are numbered  slot 8 lh + u  <->  j = 16 (2 kk + (u >> 2)) +
+            // 4 lh + (u & 3); v^T's A operand reads its columns in the same numbering (two 8-byte reads).  Rounds 1-4 went through a
+            // score image and a softmax image in LDS with a barrier behind each: 4.1 k of a step's ~30 k cycles per round at 40 agents.
+            for (int job = w; job < 2 * NT && !(MAPF_RECUR_ABLATE & 4); job += NTHR / 64) {
+                const int hd = job / NT, ti = job - NT * hd, i = 16 * ti + lr;
+                f32x4 sc[NT];
+                {
+                    bf16x8 qf[2];
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(smem + OFF_QK + (16 * ti + lr) * QK_ROW + (hd * HD + 32 * kk + 8 * lh) * 2);
-                    const bf16x8 b = *reinterpret_cast<const bf16x8 *>(smem + OFF_QK + (16 * tj + lr) * QK_ROW + (128 + hd * HD + 32 * kk + 8 * lh) * 2);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
-                }
+                    for (int kk = 0; kk < 2; ++kk) qf[kk] = *reinterpret_cast<const bf16x8 *>(smem + OFF_QK + i * QK_ROW + (hd * HD + 32 * kk + 8 * lh) * 2);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) S[(hd * NA + 16 * ti + 4 * lh + r) * S_ROW + 16 * tj + lr] = acc[r] * scale;
-            }
-            phase_sync(4);
-            // masked softmax per (head, agent i) row -> P bf16 (zero for j >= N and for rows i >= N); update flags.
-            // Four lanes (one DPP quad) per row, 12 columns each: row maximum and sum through quad permutations
-            // (one thread per row left 416 of the 512 threads idle behind a 48-element serial chain)
-            if (tid < 8 * NA && !(MAPF_RECUR_ABLATE & 4)) {
-                const int rowid = tid >> 2, part = tid & 3, hd = rowid / NA, i = rowid - NA * hd;
-                if (i < N) {
-                    const uint64_t bits = (uint64_t)mb[2 * i] | ((uint64_t)mb[2 * i + 1] << 32);  // bits >= N are 0
-                    const uint32_t mybits = (uint32_t)(bits >> (12 * part)) & 0xFFFu;
-                    const float4 *srow = reinterpret_cast<const float4 *>(S + (hd * NA + i) * S_ROW + 12 * part);
-                    float v[12];
+                    for (int tj = 0; tj < NT; ++tj) {
+                        sc[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const float4 x = srow[q];
-                        v[4 * q] = x.x;
-                        v[4 * q + 1] = x.y;
-                        v[4 * q + 2] = x.z;
-                        v[4 * q + 3] = x.w;
-                    }
-                    float mx = -3.0e38f;
-#pragma unroll
-                    for (int j = 0; j < 12; ++j) {
-                        // model.py:77 masked_fill(-1e9), columns >= N likewise (weight 0 below); as a bit select, not a
-                        // predicate: compile-time lane masks would live in scalar registers and spill
-                        const uint32_t m = 0u - ((mybits >> j) & 1u);
-                        v[j] = __uint_as_float((__float_as_uint(v[j]) & m) | (__float_as_uint(-1e9f) & ~m));
-                        mx = fmaxf(mx, v[j]);
-                    }
-                    mx = fmaxf(mx, quad_perm<0x4E>(mx));
-                    mx = fmaxf(mx, quad_perm<0xB1>(mx));
-                    float sum = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 12; ++j) {
-                        v[j] = __expf(v[j] - mx);  // masked and padded columns: exp(-1e9 - mx) == 0 (a row always holds its own agent)
-                        sum += v[j];
-                    }
-                    sum += quad_perm<0x4E>(sum);
-                    sum += quad_perm<0xB1>(sum);
-                    const float inv = 1.f / sum;
-                    uint32_t *p32 = reinterpret_cast<uint32_t *>(smem + OFF_P + (hd * NA + i) * P_ROW + 24 * part);
-#pragma unroll
-                    for (int j = 0; j < 12; j += 2) p32[j / 2] = pack2_bf16(v[j] * inv, v[j + 1] * inv);
-                    if (hd == 0 && part == 0) upd[i] = __popcll(bits) > 1 ? 1 : 0;  // model.py:103
-                } else if (hd == 0 && part == 0) {
-                    upd[i] = 0;
-                }
-            }
-            phase_sync(5);
-            if (SAVE) {  // P rows (2 heads x 48 agents x 64 slots = 128 B each) -> global
-                uint16_t *pd = sv.P + (((long long)round * T + t) * E + e) * (2 * NA * 64);
-                for (int i = tid; i < 2 * NA * 8; i += NTHR) {
-                    const int rowp = i >> 3, ch = i & 7;
-                    *reinterpret_cast<uint4 *>(pd + rowp * 64 + ch * 8) = *reinterpret_cast<const uint4 *>(smem + OFF_P + rowp * P_ROW + ch * 16);
-                }
-            }
-            // ctx^T[d][i] = sum_j vT[d][j] P[i][j]: 2 heads x 4 d-tiles, K = 64 agent slots -> CTX[agent][head*64 + d]
-            for (int job = w; job < 8 && !(MAPF_RECUR_ABLATE & 4); job += NTHR / 64) {
-                const int hd = job >> 2, td = job & 3;
-                f32x4 acc[NT];
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(smem + OFF_VT + (hd * HD + 16 * td + lr) * VT_ROW + (32 * kk + 8 * lh) * 2);
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        const bf16x8 b = *reinterpret_cast<const bf16x8 *>(smem + OFF_P + (hd * NA + 16 * n + lr) * P_ROW + (32 * kk + 8 * lh) * 2);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[n], 0, 0, 0);
+                        for (int kk = 0; kk < 2; ++kk) {
+                            const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(smem + OFF_QK + (16 * tj + lr) * QK_ROW + (128 + hd * HD + 32 * kk + 8 * lh) * 2);
+                            sc[tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], sc[tj], 0, 0, 0);
+                        }
                     }
                 }
+                // masked softmax over the row (model.py:75-78): columns without a mask bit (incl. j >= N) read -1e9; rows i >= N come out 0
+                const uint64_t bits = i < N ? ((uint64_t)mb[2 * i] | ((uint64_t)mb[2 * i + 1] << 32)) : 0ull;  // bits >= N are 0
+                float mx = -3.0e38f;
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const uint2 v = make_uint2(pack2_bf16(acc[n][0], acc[n][1]), pack2_bf16(acc[n][2], acc[n][3]));
-                    *reinterpret_cast<uint2 *>(smem + OFF_CTX + (16 * n + lr) * CTX_ROW + (hd * HD + 16 * td + 4 * lh) * 2) = v;
-                    if (SAVE && ridx[16 * n + lr] >= 0)
-                        *reinterpret_cast<uint2 *>(sv.ctx + ((long long)round * RTOT + ridx[16 * n + lr]) * 128 + hd * HD + 16 * td + 4 * lh) = v;
+                for (int tj = 0; tj < NT; ++tj) {
+                    const uint32_t nib = (uint32_t)(bits >> (16 * tj + 4 * lh));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // as a bit select, not a predicate: compile-time lane masks would live in scalar registers and spill
+                        const uint32_t m = 0u - ((nib >> r) & 1u);
+                        sc[tj][r] = __uint_as_float((__float_as_uint(sc[tj][r] * scale) & m) | (__float_as_uint(-1e9f) & ~m));
+                        mx = fmaxf(mx, sc[tj][r]);
+                    }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float sum = 0.f;
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sc[tj][r] = __expf(sc[tj][r] - mx);  // masked and padded columns: exp(-1e9 - mx) == 0 (a row always holds its own agent)
+                        sum += sc[tj][r];
+                    }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float inv = i < N ? 1.f / sum : 0.f;
+                uint2 pw[4];
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj)
+                    pw[tj] = tj < NT ? make_uint2(pack2_bf16(sc[tj < NT ? tj : 0][0] * inv, sc[tj < NT ? tj : 0][1] * inv),
+                                                  pack2_bf16(sc[tj < NT ? tj : 0][2] * inv, sc[tj < NT ? tj : 0][3] * inv))
+                                     : make_uint2(0u, 0u);
+                if (hd == 0 && lh == 0) upd[i] = (i < N && __popcll(bits) > 1) ? 1 : 0;  // model.py:103
+                if (SAVE) {  // P rows (2 heads x NA agents x 64 slots = 128 B each; slots >= NA zero) -> global
+                    uint16_t *pd = sv.P + ((((long long)round * T + t) * E + e) * 2 + hd) * (NA * 64) + i * 64 + 4 * lh;
+#pragma unroll
+                    for (int tj = 0; tj < 4; ++tj) *reinterpret_cast<uint2 *>(pd + 16 * tj) = pw[tj];
+                }
+                // ctx^T[d][i] = sum_j vT[d][j] P[i][j]: 4 d-tiles of this head -> CTX[agent][head*64 + d]
+#pragma unroll
+                for (int td = 0; td < 4; ++td) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const unsigned char *vr = smem + OFF_VT + (hd * HD + 16 * td + lr) * VT_ROW + 8 * lh;
+#pragma unroll
+                    for (int kk = 0; kk < (NT + 1) / 2; ++kk) {
+                        const uint2 alo = *reinterpret_cast<const uint2 *>(vr + 64 * kk), ahi = *reinterpret_cast<const uint2 *>(vr + 64 * kk + 32);
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, make_uint4(alo.x, alo.y, ahi.x, ahi.y));
+                        const bf16x8 b = __builtin_bit_cast(bf16x8, make_uint4(pw[2 * kk].x, pw[2 * kk].y, pw[2 * kk + 1].x, pw[2 * kk + 1].y));
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+                    }
+                    const uint2 v = make_uint2(pack2_bf16(acc[0], acc[1]), pack2_bf16(acc[2], acc[3]));
+                    *reinterpret_cast<uint2 *>(smem + OFF_CTX + i * CTX_ROW + (hd * HD + 16 * td + 4 * lh) * 2) = v;
+                    if (SAVE && ridx[i] >= 0)
+                        *reinterpret_cast<uint2 *>(sv.ctx + ((long long)round * RTOT + ridx[i]) * 128 + hd * HD + 16 * td + 4 * lh) = v;
                 }
             }
             phase_sync(6);

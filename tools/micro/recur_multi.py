@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Several builds of the narrow recurrence kernels side by side (round 5): `base` = csrc/mapf_recur*.hip at a git revision
+(`RECUR_BASE_REV`, default HEAD), every other variant = the working tree compiled with extra flags.
+
+    python tools/micro/recur_multi.py build prio=-DMAPF_RECUR_PRIO=1 "both=-DMAPF_RECUR_PRIO=1 -DMAPF_RECUR_X=2"     (where hipcc is)
+    python tools/micro/recur_multi.py run [shapes]                                                                    (on the GPU)
+
+Times mapf_recurrent_infer (and forward_save for T > 1) at the actor's and the learner's shapes and compares every variant's outputs
+with base's."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "mapf_rl_amd", "csrc")
+LIST = os.path.join(HERE, "recur_multi.json")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-mllvm", "-pragma-unroll-threshold=262144", "-shared", "-fPIC", "-ffp-contract=off",
+         "-I" + os.path.join(ROOT, "include")]
+FILES = ("mapf_recur.hip", "mapf_recur_nt1.hip", "mapf_recur_nt2.hip")
+
+
+def so(name):
+    return os.path.join(HERE, "recur_multi_%s.so" % name)
+
+
+def hipcc(srcdir, out, extra):
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + extra + ["-I" + srcdir, "-I" + CSRC] + [os.path.join(srcdir, f) for f in FILES] +
+                          [os.path.join(CSRC, "mapf_recur_wide.hip"), "-o", out])
+
+
+def build(specs):
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+
+    rev = os.environ.get("RECUR_BASE_REV", "HEAD")
+    tmp = tempfile.mkdtemp(prefix="recur_multi_")
+    for f in FILES + ("mapf_recur_internal.h",):
+        with open(os.path.join(tmp, f), "wb") as fh:
+            fh.write(subprocess.check_output(["git", "-C", ROOT, "show", rev + ":mapf_rl_amd/csrc/" + f]))
+    jobs = [(tmp, so("base"), [])]
+    names = ["base"]
+    for s in specs:
+        name, _, fl = s.partition("=")
+        jobs.append((CSRC, so(name), fl.split()))
+        names.append(name)
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        list(pool.map(lambda j: hipcc(*j), jobs))
+    shutil.rmtree(tmp)
+    json.dump(names, open(LIST, "w"))
+
+
+def run(shapes):
+    import torch
+
+    names = json.load(open(LIST))
+    libs = {n: ctypes.CDLL(so(n)) for n in names}
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    w = (torch.randn(548864, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(3456, device="cuda", generator=g) * 0.1
+
+    def timed(fn, args, reps=8):
+        for _ in range(3):
+            rc = fn(*args)
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn(*args)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / reps)
+        return rc, best
+
+    print("%-22s" % "shape" + "".join("%12s" % n for n in names))
+    for T, E, N in shapes:
+        gi = (torch.randn((T, E, N, 768), device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+        h0 = (torch.randn((E, N, 256), device="cuda", generator=g) * 0.3).to(torch.bfloat16)
+        comm = (torch.rand((T, E, N, N), device="cuda", generator=g) < 0.1).to(torch.uint8)
+        comm |= torch.eye(N, device="cuda", dtype=torch.uint8)
+        outs, row, row_s, saved = {}, [], [], {}
+        for n in names:
+            fn = libs[n].mapf_recurrent_infer
+            fn.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p]
+            out = torch.zeros((E, N, 256), dtype=torch.bfloat16, device="cuda")
+            a0 = torch.zeros((T, E, 256), dtype=torch.bfloat16, device="cuda")
+            rc, ms = timed(fn, (gi.data_ptr(), h0.data_ptr(), comm.data_ptr(), w.data_ptr(), b.data_ptr(), T, E, N, out.data_ptr(), a0.data_ptr(), None, 0, st))
+            assert rc == 0, (n, rc)
+            outs[n] = (out, a0)
+            row.append(ms)
+            if T > 1:
+                R = T * E * N
+                sizes = [R * 256, R * 1024, 2 * R * 256, 2 * R * 384, 2 * R * 128, 2 * R * 64, 2 * R * 1024, 2 * T * E * 2 * 48 * 64]
+                fs = libs[n].mapf_recurrent_forward_save
+                fs.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_void_p]
+                bufs = [torch.zeros(k, dtype=torch.bfloat16, device="cuda") for k in sizes]
+                ptrs = (ctypes.c_void_p * 8)(*[x.data_ptr() for x in bufs])
+                out2 = torch.zeros((E, N, 256), dtype=torch.bfloat16, device="cuda")
+                a02 = torch.zeros((T, E, 256), dtype=torch.bfloat16, device="cuda")
+                rc, ms = timed(fs, (gi.data_ptr(), h0.data_ptr(), comm.data_ptr(), w.data_ptr(), b.data_ptr(), T, E, N, out2.data_ptr(), a02.data_ptr(), ptrs, None, 0, st), 4)
+                assert rc == 0, (n, rc)
+                row_s.append(ms)
+                saved[n] = [x.float().abs().sum().item() for x in bufs] + [(out2.float() - out.float()).abs().max().item()]
+        tag = "T=%d E=%d N=%d" % (T, E, N)
+        print("%-22s" % tag + "".join("%9.3f ms" % v for v in row), flush=True)
+        if row_s:
+            print("%-22s" % "  forward_save" + "".join("%9.3f ms" % v for v in row_s), flush=True)
+        for n in names[1:]:
+            d = (outs["base"][0].float() - outs[n][0].float()).abs()
+            d0 = (outs["base"][1].float() - outs[n][1].float()).abs()
+            msg = "   %-10s max |dh| %.4g (differing %.3g), max |d agent0| %.4g, nan %d" % (n, d.max().item(), (d > 0).float().mean().item(), d0.max().item(),
+                                                                                     outs[n][0].isnan().sum().item())
+            if saved:
+                rel = max(abs(x - y) / (abs(y) + 1e-9) for x, y in zip(saved[n][:8], saved["base"][:8]))
+                msg += ", saved-tensor |sum| rel diff %.3g, save-vs-infer %.3g" % (rel, saved[n][8])
+            print(msg, flush=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1:2] == ["build"]:
+        build(sys.argv[2:])
+    else:
+        sh = [(1, 4096, 40), (18, 192, 40), (18, 192, 6), (1, 4096, 6), (1, 1400, 16), (3, 33, 17), (18, 192, 24)]
+        if len(sys.argv) > 2:
+            sh = [tuple(int(v) for v in s.split("x")) for s in sys.argv[2:]]
+        run(sh)

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "mapf_rl_amd", "csrc")
 SO = os.path.join(HERE, "recur_trace.so")
-NAMES = {30: "kernel entry", 31: "prologue: LDS zero fill, biases, h0 | barrier", 32: "h_out stored (issued)", 1: "gi requests, mask+ridx | barrier", 2: "GRU cell | barrier", 3: "QKV | barrier", 4: "scores | barrier", 5: "softmax | barrier", 6: "ctx | barrier",
+NAMES = {30: "kernel entry", 31: "prologue: LDS zero fill, biases, h0 | barrier", 32: "h_out stored (issued)", 1: "gi requests, mask+ridx | barrier", 2: "GRU cell | barrier", 3: "QKV | barrier", 6: "attention (scores, softmax, ctx in registers) | barrier",
          7: "W_O | barrier", 8: "update cell | barrier", 20: "cell: entered", 21: "cell: block A MFMAs + reloads issued", 22: "cell: block A pointwise",
          23: "cell: block B MFMAs", 24: "cell: block B pointwise"}
 
