@@ -21,6 +21,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "mapf_dqn.h"
 #include "mapf_env.h"
@@ -319,11 +320,14 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lh = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction; said so, its tiles' addresses stay in scalar registers
-    const int e = blockIdx.x;
+    // Persistent over environments (round 5): workgroup b steps environments b, b + gridDim.x, ...: the LDS fill, the bias sums and the
+    // first weight fragments are paid once per workgroup instead of once per environment, and a CU never waits for a new workgroup to
+    // be placed.  (envtab launches keep one environment per workgroup: their agent counts differ.)
+    int e = blockIdx.x;
     // envtab (mapf_recurrent_infer_multi: one step of environments of DIFFERENT agent counts -- the curriculum's levels -- in one
     // launch): per environment {agents, first row of its agents in gi / h0 / h_out, byte offset of its mask in comm, -}
     int n_env = N_arg, n_real = N_arg;
-    long long hrow0 = (long long)e * N_arg, coff = 0;
+    long long hrow0 = (long long)blockIdx.x * N_arg, coff = 0;
     if (envtab != nullptr) {
         const int4 d = envtab[e];
         n_env = __builtin_amdgcn_readfirstlane(d.x);
@@ -354,9 +358,9 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
     constexpr int CI = (NA * NA + NTHR - 1) / NTHR;
     uint8_t cbyte[CI];
     GruInit sA, sB;
-    auto fetch_inputs = [&](int t) {
-        const long long row0 = envtab ? hrow0 : ((long long)t * E + e) * N;
-        const uint8_t *comm_t = comm + (envtab ? coff : ((long long)t * E + e) * N * N);
+    auto fetch_inputs = [&](int ee, int t) {
+        const long long row0 = envtab ? hrow0 : ((long long)t * E + ee) * N;
+        const uint8_t *comm_t = comm + (envtab ? coff : ((long long)t * E + ee) * N * N);
 #pragma unroll
         for (int q = 0; q < CI; ++q) {
             const int idx = tid + q * NTHR;
@@ -373,7 +377,32 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
             gru_fetch_gi(sB, cB, gi, grow, lh);
         }
     };
-    fetch_inputs(0);
+    fetch_inputs(e, 0);
+    // initial hidden rows of an environment: 32 chunks of 16 B per agent, HP per thread, through registers into the LDS image
+    constexpr int HP = (NA * 32 + NTHR - 1) / NTHR;
+    uint4 hpre[HP];
+    auto fetch_h0 = [&](long long first_row) {
+#pragma unroll
+        for (int q = 0; q < HP; ++q) {
+            const int i = tid + q * NTHR, a = i >> 5, ch = i & 31;
+            hpre[q] = make_uint4(0, 0, 0, 0);
+            if (h0 != nullptr && a < N) hpre[q] = *reinterpret_cast<const uint4 *>(h0 + (first_row + a) * D + ch * 8);
+        }
+    };
+    auto store_h0 = [&](unsigned char *H) {  // rows >= N keep what they hold (zeros, or the padding rows' own bounded trajectory)
+#pragma unroll
+        for (int q = 0; q < HP; ++q) {
+            const int i = tid + q * NTHR, a = i >> 5, ch = i & 31;
+            if (a < N) *reinterpret_cast<uint4 *>(H + a * H_ROW + ch * 16) = hpre[q];
+        }
+    };
+    fetch_h0(hrow0);
+    // (Tried and dropped, round 5: pulling the NEXT environment's input lines into L2 ahead of time -- one dword per 128-byte line,
+    // either by every wave in front of the last update cell, or by waves 6-7, idle in the attention phase.  The first made the cell's
+    // own weight reloads wait for HBM (vmcnt retires in order): 0.62 -> 0.68 ms per 4096 x 40 step; the second cost 200 more spilled
+    // registers in a kernel that sits at its 256-register ceiling: 0.93 ms.  Holding the rows themselves in registers across the cell:
+    // 300 spills.  What is kept: the persistent loop, and the initial hidden rows through registers in front of the LDS fill --
+    // 0.61 -> 0.55 ms.  profiles/r05_recurrence_ab_persistent.txt)
 
     // hidden state of this environment (rows >= N stay zero: they are computed like real agents and never stored)
     for (int i = tid; i < LDS_BYTES / 16; i += NTHR) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
@@ -388,12 +417,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
         d[512] = bi[512 + c];
         d[768] = bh[512 + c];
     }
-    if (h0 != nullptr)
-        for (int i = tid; i < N * 32; i += NTHR) {  // 32 chunks of 16 B per agent
-            const int a = i >> 5, ch = i & 31;
-            *reinterpret_cast<uint4 *>(smem + OFF_H0 + a * H_ROW + ch * 16) =
-                *reinterpret_cast<const uint4 *>(h0 + (hrow0 + a) * D + ch * 8);
-        }
+    store_h0(smem + OFF_H0);
     __syncthreads();
 
     TRACE_POINT(31);
@@ -415,6 +439,8 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
     };
     const uint16_t *const W_arg = W;
     const float *const bias_arg = bias;
+    const int G = gridDim.x;
+    for (;;) {  // environments of this workgroup
     for (int t = 0;;) {  // (T >= 1)
         // The weight and bias addresses of a wave are the same at every step; opaque copies of the base pointers keep the compiler from
         // hoisting those loads out of the step loop (it did, once the cells' channel blocks became loop-invariant: 430 spilled registers).
@@ -587,7 +613,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
             }
             phase_sync(7);
             // update cell: Hc -> Hn where the agent has a partner
-            if (!(MAPF_RECUR_ABLATE & 16))  // behind it: the second round's q|k|v, or the next step's recurrent cell (a wasted fetch at the last step)
+            if (!(MAPF_RECUR_ABLATE & 16))  // behind it: the second round's q|k|v, or the next step's recurrent cell (a wasted fetch at the last step of the last environment)
                 gru_pair<false, 2>(cA, cB, sA, sB, wf, wi, W + U_IH, smem + OFF_INFO, INFO_ROW, W + U_HH, bsum + 1024, Hc, Hn, upd, ridx, lr, lh,
                                    SAVE ? sv.g2 + (long long)round * RTOT * 1024 : nullptr,
                                    round == 0 ? frag3(W + W_QKV, wq, wq + 8, wq + 16, 8, lane) : gate_frags(W + W_HH, cA, 8, lane));
@@ -599,14 +625,35 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
         if (agent0_out != nullptr && tid < 32)  // agent 0's state after this step (model.py:248)
             *reinterpret_cast<uint4 *>(agent0_out + ((long long)t * E + e) * D + tid * 8) = *reinterpret_cast<const uint4 *>(Hc + tid * 16);
         if (++t >= T) break;
-        fetch_inputs(t);  // the next step's (step 0's were requested in front of the prologue)
+        fetch_inputs(e, t);  // the next step's (step 0's were requested in front of the prologue)
     }
     for (int i = tid; i < N * 32; i += NTHR) {
         const int a = i >> 5, ch = i & 31;
         *reinterpret_cast<uint4 *>(h_out + (hrow0 + a) * D + ch * 8) = *reinterpret_cast<const uint4 *>(Hc + a * H_ROW + ch * 16);
     }
+    if (envtab != nullptr || e + G >= E) break;
+    e += G;
+    hrow0 = (long long)e * N_arg;
+    fetch_inputs(e, 0);
+    fetch_h0(hrow0);
+    __syncthreads();  // every row of the finished environment is on its way out before the next one's rows replace it
+    store_h0(Hc);     // (the first barrier of the step publishes them)
+    }
     TRACE_POINT(32);
     TRACE_END();
+}
+
+// One workgroup per CU (its LDS image and 8 waves of 256 registers fill one), each walking its share of the environments.
+// MAPF_RECUR_PERSIST=0 (A/B runs): one workgroup per environment, as in rounds 1-4.
+inline int persistent_grid(int E) {
+    static const int cus = [] {
+        const char *v = std::getenv("MAPF_RECUR_PERSIST");
+        if (v != nullptr && v[0] == '0') return 0;
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return n;
+    }();
+    return (cus > 0 && E > cus) ? cus : E;
 }
 
 #define HIP_TRY(expr)                                                                        \
@@ -649,7 +696,7 @@ int RECUR_ENTRY(mapf_recurrent_infer)(const uint16_t *gi_dev, const uint16_t *h0
     if (N > NA)  // 49..128 agents: csrc/mapf_recur_wide.hip
         return mapf_recur_wide_forward(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, nullptr,
                                        static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(recurrent_infer_kernel<false>, dim3(E), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
+    hipLaunchKernelGGL(recurrent_infer_kernel<false>, dim3(persistent_grid(E)), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
                        weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, RecurSave{}, row_index_dev, (long long)num_rows, (const int4 *)nullptr);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
@@ -677,7 +724,7 @@ int RECUR_ENTRY(mapf_recurrent_forward_save)(const uint16_t *gi_dev, const uint1
     if (N > NA)
         return mapf_recur_wide_forward(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, &sv,
                                        static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(recurrent_infer_kernel<true>, dim3(E), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
+    hipLaunchKernelGGL(recurrent_infer_kernel<true>, dim3(persistent_grid(E)), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
                        weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, sv, row_index_dev, (long long)num_rows, (const int4 *)nullptr);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
