@@ -825,108 +825,9 @@ StepParams make_params(mapf_env *h) {
 
 inline unsigned blocks_for(long long n, int threads) { return (unsigned)((n + threads - 1) / threads); }
 
-// ---- host RNG for the scenario generator (splitmix64 -> xoshiro256**) ----
-struct Rng {
-    uint64_t s[4];
-    static uint64_t splitmix(uint64_t &x) {
-        uint64_t z = (x += 0x9E3779B97F4A7C15ull);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        return z ^ (z >> 31);
-    }
-    explicit Rng(uint64_t seed) {
-        for (auto &v : s) v = splitmix(seed);
-    }
-    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
-    uint64_t next() {
-        uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
-        s[2] ^= s[0];
-        s[3] ^= s[1];
-        s[1] ^= s[2];
-        s[0] ^= s[3];
-        s[2] ^= t;
-        s[3] = rotl(s[3], 45);
-        return r;
-    }
-    double uniform() { return (next() >> 11) * (1.0 / 9007199254740992.0); }
-    uint32_t below(uint32_t n) {  // unbiased
-        uint64_t m = (uint64_t)(uint32_t)next() * n;
-        uint32_t l = (uint32_t)m;
-        if (l < n) {
-            uint32_t t = (0u - n) % n;
-            while (l < t) {
-                m = (uint64_t)(uint32_t)next() * n;
-                l = (uint32_t)m;
-            }
-        }
-        return (uint32_t)(m >> 32);
-    }
-};
-
-// one scenario by the reference's rule (environment.py:100-138); false = cells ran out (:120)
-bool generate_one(int L, int N, double density, Rng &rng, int8_t *map, int16_t *agents, int16_t *goals) {
-    for (int c = 0; c < L * L; ++c) map[c] = rng.uniform() < density ? 1 : 0;
-    // connected components of free cells (map_partition, :21-70)
-    std::vector<int> label(L * L, -1);
-    std::vector<std::vector<int>> parts;
-    std::vector<int> queue;
-    for (int c0 = 0; c0 < L * L; ++c0) {
-        if (map[c0] != 0 || label[c0] >= 0) continue;
-        int id = (int)parts.size();
-        parts.emplace_back();
-        queue.clear();
-        queue.push_back(c0);
-        label[c0] = id;
-        for (size_t h = 0; h < queue.size(); ++h) {
-            int c = queue[h], x = c / L, y = c % L;
-            parts[id].push_back(c);
-            const int nb[4][2] = {{x - 1, y}, {x + 1, y}, {x, y - 1}, {x, y + 1}};
-            for (auto &n : nb) {
-                if (n[0] < 0 || n[0] >= L || n[1] < 0 || n[1] >= L) continue;
-                int d = n[0] * L + n[1];
-                if (map[d] == 0 && label[d] < 0) {
-                    label[d] = id;
-                    queue.push_back(d);
-                }
-            }
-        }
-    }
-    auto prune = [&parts]() {
-        size_t k = 0;
-        for (size_t i = 0; i < parts.size(); ++i)
-            if (parts[i].size() >= 2) {
-                if (k != i) parts[k] = std::move(parts[i]);
-                ++k;
-            }
-        parts.resize(k);
-    };
-    prune();  // :105
-    if (parts.empty()) return false;
-    for (int i = 0; i < N; ++i) {
-        size_t pos_num = 0;
-        for (auto &p : parts) pos_num += p.size();
-        if (pos_num == 0) return false;  // reference: random.randint(0, -1) raises ValueError (:120)
-        uint32_t idx = rng.below((uint32_t)pos_num);
-        size_t pi = 0;
-        while (idx >= parts[pi].size()) {
-            idx -= (uint32_t)parts[pi].size();
-            ++pi;
-        }
-        auto &part = parts[pi];
-        uint32_t k = rng.below((uint32_t)part.size());
-        int c = part[k];
-        part.erase(part.begin() + k);
-        agents[2 * i] = (int16_t)(c / L);
-        agents[2 * i + 1] = (int16_t)(c % L);
-        k = rng.below((uint32_t)part.size());
-        c = part[k];
-        part.erase(part.begin() + k);
-        goals[2 * i] = (int16_t)(c / L);
-        goals[2 * i + 1] = (int16_t)(c % L);
-        prune();  // :137
-    }
-    return true;
-}
+// ---- host scenario generator (Rng, generate_one, generate_scenarios): host-only C++ kept in its own file so that the CPU
+// sanitizer target (tests/test_sanitize_cpu.py) compiles exactly these lines with g++ -fsanitize=address,undefined ----
+#include "mapf_generate_host.inc"
 
 }  // namespace
 
@@ -1474,30 +1375,7 @@ int mapf_obs_radius(const mapf_env_t *h) { return h ? h->R : MAPF_ERR_INVALID_AR
 
 int mapf_generate(int num_envs, int map_len, int num_agents, float density, uint64_t seed, int8_t *maps,
                   int16_t *agents, int16_t *goals, int32_t *redraws) {
-    if (num_envs < 1 || map_len < 2 || num_agents < 1 || !maps || !agents || !goals) return MAPF_ERR_INVALID_ARG;
-    if (density >= 1.0f) return MAPF_ERR_INVALID_ARG;
-    const int L = map_len, N = num_agents;
-    int total_redraws = 0;
-    for (int e = 0; e < num_envs; ++e) {
-        bool ok = false;
-        for (int attempt = 0; attempt < 1000 && !ok; ++attempt) {
-            Rng rng(seed * 0x9E3779B97F4A7C15ull + (uint64_t)e * 1000003ull + (uint64_t)attempt * 0xD1B54A32D192ED03ull);
-            double rho = density;
-            if (density < 0) {  // np.random.triangular(0, 0.33, 0.5), environment.py:100
-                const double a = 0.0, c = 0.33, b = 0.5;
-                double u = rng.uniform();
-                rho = (u < (c - a) / (b - a)) ? a + std::sqrt(u * (b - a) * (c - a)) : b - std::sqrt((1 - u) * (b - a) * (b - c));
-            }
-            ok = generate_one(L, N, rho, rng, maps + (size_t)e * L * L, agents + (size_t)e * N * 2, goals + (size_t)e * N * 2);
-            if (!ok) ++total_redraws;
-        }
-        if (!ok) {
-            if (redraws) *redraws = total_redraws;
-            return MAPF_ERR_NO_SPACE;
-        }
-    }
-    if (redraws) *redraws = total_redraws;
-    return MAPF_OK;
+    return generate_scenarios(num_envs, map_len, num_agents, density, seed, maps, agents, goals, redraws);
 }
 
 }  // extern "C"
