@@ -110,6 +110,12 @@ SYMBOLS = [
     ("mapf_adam_step_dev", _i, [ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _f, _vp]),
     ("mapf_to_bf16", _i, [_vp, _vp, ctypes.c_int64, _vp]),
     ("mapf_zero_rows", _i, [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, ctypes.c_int64, ctypes.c_int64, _vp]),
+    ("mapf_tall_tn_plan", _i, [ctypes.c_int64, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_int64)]),
+    ("mapf_tall_tn", _i, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int64, _i, _i, _i, _vp, _vp, _i, _vp, ctypes.c_int64, _vp, _i, _vp]),
+    ("mapf_sum_parts", _i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, ctypes.c_int64, _vp, _vp]),
+    ("mapf_encoder_small_grads", _i, [_vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, _vp, _i, _vp, _vp]),
+    ("mapf_latent_grad_pack", _i, [_vp, _vp, _vp]),
+    ("mapf_latent_grad_rows", _i, [_vp, ctypes.c_int64, _vp, _vp, _vp]),
     # include/mapf_search.h
     ("mapf_find_path", _i, [_i, _i, _vp, _vp, _vp, ctypes.c_double, _i, _vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     ("mapf_distance_field", _i, [_i, _vp, _i, _i, _vp]),

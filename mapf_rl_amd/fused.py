@@ -122,6 +122,64 @@ def mm_rows(x, w, transpose_w=True):
     return out
 
 
+# ---- this library's own dense products / reductions for the learner (csrc/mapf_gemm.hip) ----
+_TALL_WS = {}  # (device index, stream) -> (workspace f32, counters i32): launches on one stream are serial, streams must not share
+
+
+def _tall_ws(dev):
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _TALL_WS.get(key)
+    if ws is None:
+        # per output slab at most 2 MiB of partial slabs + one (mapf_tall_tn_plan); the widest output here, 768 x 784, has 42 slabs: 128 MiB
+        ws = _TALL_WS[key] = (torch.empty(32 << 20, dtype=torch.float32, device=dev), torch.zeros(256, dtype=torch.int32, device=dev))
+    return ws
+
+
+def prepare_tall_ws(dev, streams):
+    """Allocates the workspaces of `streams` now -- outside any capture: a workspace first touched while a stream is capturing would come
+    from the capture's private pool, and its zeroed counters would be a memset node (see update.FusedUpdate._plan_rows)."""
+    for s in streams:
+        if s is not None:
+            with torch.cuda.stream(s):
+                _tall_ws(dev)
+
+
+def tall_tn_into(out, a, b, scale=None, accumulate=False):
+    """out[m, n] (f32, contiguous) = [out +] scale * a^T b for 16-bit a [K, m], b [K, n] (rows may be strided views) with K in the
+    10^4 .. 10^6 range: mapf_tall_tn -- split over K, fp32 partial slabs summed in partition order by the last workgroup of a slab.
+    scale: the int32 [2] tensor of mapf_encoder_backward (bits of 1 / loss scale at [1]) or None."""
+    K, m = a.shape
+    n = b.shape[1]
+    assert b.shape[0] == K and out.shape == (m, n) and out.is_contiguous() and out.dtype == torch.float32 and a.dtype == b.dtype
+    assert a.stride(1) == 1 and b.stride(1) == 1
+    ws, cnt = _tall_ws(a.device)
+    check(lib.mapf_tall_tn(_ptr(a), a.stride(0) if K > 1 else m, _ptr(b), b.stride(0) if K > 1 else n, K, m, n, int(a.dtype == torch.float16), _ptr(out),
+                           _ptr(scale), int(accumulate), _ptr(ws), ws.numel(), _ptr(cnt), cnt.numel(), _stream(a.device)), "mapf_tall_tn")
+    return out
+
+
+def sum_parts_into(outs, parts, scale=None):
+    """outs[g] (f32, n elements each) = scale * parts[g].sum(0) for up to 8 (parts [P, ...], out) pairs in one launch."""
+    P = parts[0].shape[0]
+    n = outs[0].numel()
+    assert all(p.shape[0] == P and p.numel() == P * n and p.is_contiguous() and o.numel() == n and o.is_contiguous() for p, o in zip(parts, outs))
+    check(lib.mapf_sum_parts((ctypes.c_void_p * len(parts))(*[p.data_ptr() for p in parts]), (ctypes.c_void_p * len(outs))(*[o.data_ptr() for o in outs]),
+                             len(parts), P, n, _ptr(scale), _stream(outs[0].device)), "mapf_sum_parts")
+
+
+LATGRAD_PACKED_ELEMS = 602112
+
+
+def latent_grad_rows(d_gi, packed_wt, out=None):
+    """g_lat [rows, 784] bf16 = d_gi [rows, 768] @ W_ih (mapf_latent_grad_rows; packed_wt from mapf_latent_grad_pack)."""
+    rows = d_gi.shape[0]
+    assert d_gi.dtype == torch.bfloat16 and d_gi.is_contiguous() and d_gi.shape[1] == 768
+    if out is None:
+        out = rows_buffer((), rows, (784,), torch.bfloat16, d_gi.device)
+    check(lib.mapf_latent_grad_rows(_ptr(d_gi), rows, _ptr(packed_wt), _ptr(out), _stream(d_gi.device)), "mapf_latent_grad_rows")
+    return out
+
+
 class _BiasResReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, bias, res):

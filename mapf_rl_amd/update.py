@@ -28,7 +28,8 @@ import torch
 
 from ._lib import check, lib
 from .fused import (no_gc_during_capture, warm_up_gemm_library, ENC_OBS_PER_BLOCK, ENC_WGRAD0_PARTS, ENC_WGRAD_PARTS, RECUR_NARROW_AGENTS, RECUR_WEIGHT_ELEMS, PackedEncoder,
-                    PackedRecurrence, mm_rows, pack_encoder_backward, recurrence_params, rows_buffer, ENC_ELEMENT)
+                    PackedRecurrence, pack_encoder_backward, recurrence_params, rows_buffer, ENC_ELEMENT, INPROJ_PACKED_ELEMS, LATGRAD_PACKED_ELEMS,
+                    input_proj_rows, latent_grad_rows, sum_parts_into, tall_tn_into)
 
 GAMMA = 0.99
 GRAD_CLIP = 40.0
@@ -253,6 +254,9 @@ class FusedUpdate:
         self._capturing = False
         self._cap_stream = None
         self._tar_w_ih = None
+        # (allocated here, outside any capture: the pack launches of a captured stage write them in place)
+        self._on_w_ihp = torch.empty(INPROJ_PACKED_ELEMS, dtype=torch.bfloat16, device=self.dev)
+        self._on_w_iht = torch.empty(LATGRAD_PACKED_ELEMS, dtype=torch.bfloat16, device=self.dev)
         self._tick = 0
         self.graph_replays = self.graph_captures = 0
 
@@ -415,16 +419,19 @@ class FusedUpdate:
         return pl
 
     # ------------------------------------------------------------------ pieces
-    def _w_ih(self, net, own):
-        """bf16 [768, 784] input-projection weight: a view of the flat bf16 copy for the online network, a cast for the target (kept in
-        ONE buffer, refreshed in place when the target's weights changed: captured graphs hold its address)."""
+    def _w_ihp(self, net, own):
+        """recurrent.weight_ih as the bf16 fragment image of mapf_input_proj_rows (csrc/mapf_inproj.hip).  Online network: packed by
+        _pack_online with every update (its weights just changed); target network: kept in ONE buffer, re-packed in place when the
+        target's weights changed (captured graphs hold its address)."""
         if own:
-            return self.flat.mem(self.flat.bf16, "recurrent.weight_ih")
+            return self._on_w_ihp
         w = net.recurrent.weight_ih
         key = (id(net), net.weights_epoch, w.data_ptr(), w._version)
         if self._tar_w_ih is None or self._tar_w_ih[0] != key:
-            buf = self._tar_w_ih[1] if self._tar_w_ih is not None else torch.empty(tuple(w.shape), dtype=torch.bfloat16, device=w.device)
-            buf.copy_(w.detach())
+            buf = self._tar_w_ih[1] if self._tar_w_ih is not None else torch.empty(INPROJ_PACKED_ELEMS, dtype=torch.bfloat16, device=w.device)
+            src = w.detach()
+            src = src if (src.dtype == torch.float32 and src.is_contiguous()) else src.float().contiguous()
+            check(lib.mapf_input_proj_pack(_ptr(src), _ptr(buf), _stream(w.device)), "mapf_input_proj_pack")
             self._tar_w_ih = (key, buf)
         return self._tar_w_ih[1]
 
@@ -436,7 +443,7 @@ class FusedUpdate:
         wp, bp, w, b = images
         lat = rows_buffer((), p.urows, (784,), torch.bfloat16, dev)
         check(lib.mapf_encoder_forward(_ptr(p.obs_rows), 1, p.urows, _ptr(wp), _ptr(bp), _ptr(lat), st), "mapf_encoder_forward")
-        gi = self._expand(mm_rows(lat, self._w_ih(net, own)), p)  # [rows, 768]
+        gi = self._expand(input_proj_rows(lat, self._w_ihp(net, own), out=rows_buffer((), p.urows, (768,), torch.bfloat16, dev)), p)  # [rows, 768]
         compact = Nc <= RECUR_NARROW_AGENTS  # the <= 48-agent kernels read / write the rows that exist (gidx); the wide ones are dense
         if not compact:
             gi_rows, gi = gi, torch.empty((T, B, Nc, 768), dtype=torch.bfloat16, device=dev)
@@ -488,6 +495,10 @@ class FusedUpdate:
         c.wt = torch.empty(RECUR_WEIGHT_ELEMS, dtype=torch.bfloat16, device=dev)  # the backward kernel's transposed image
         check(lib.mapf_recurrent_pack(_ptr_array([p.detach() for p in recurrence_params(model)]), None, None, _ptr(c.wt), _stream(dev)), "mapf_recurrent_pack")
         c.wpt = pack_encoder_backward(model.obs_encoder)
+        # the input projection's weight as fragments of W_ih (forward) and of W_ih^T (gradient w.r.t. the latents), from the flat fp32 copy
+        w_ih32 = self.flat.mem(self.flat.params, "recurrent.weight_ih")
+        check(lib.mapf_input_proj_pack(_ptr(w_ih32), _ptr(self._on_w_ihp), _stream(dev)), "mapf_input_proj_pack")
+        check(lib.mapf_latent_grad_pack(_ptr(w_ih32), _ptr(self._on_w_iht), _stream(dev)), "mapf_latent_grad_pack")
 
     def _online_forward(self, c, po):
         """Online network forward on the online window, saving what the backward needs -> c.a0 and the saved tensors.
@@ -502,8 +513,7 @@ class FusedUpdate:
         c.bits = rows_buffer((7,), Mu, (49, 4), torch.int32, dev)
         check(lib.mapf_encoder_forward_save(_ptr(po.obs_rows), 1, Mu, _ptr(c.wp), _ptr(c.bp), _ptr(c.lat), _ptr(c.acts), _ptr(c.bits), st),
               "mapf_encoder_forward_save")
-        c.w_ih = self._w_ih(self.lr.model, True)
-        gi_rows = self._expand(mm_rows(c.lat, c.w_ih), po)
+        gi_rows = self._expand(input_proj_rows(c.lat, self._on_w_ihp, out=rows_buffer((), Mu, (768,), bf, dev)), po)
         c.compact = compact = Nc <= RECUR_NARROW_AGENTS
         # rows of the recurrence's saved tensors / gradient outputs: the M rows that exist (compact: the <= 48-agent kernels address
         # them through gidx) or all To x B x Nc (step, window, position) entries (the wide kernels)
@@ -637,7 +647,7 @@ class FusedUpdate:
                 # the recurrence's and the head's gradients are final on this branch: their piece of the exchange (12 % of the bytes)
                 if two_pieces:
                     lr.bucket.begin(split, n_all)
-        g_lat = mm_rows(d_gi_rows, c.w_ih, transpose_w=False)
+        g_lat = latent_grad_rows(d_gi_rows, self._on_w_iht)
         if aux is None:
             _tall_tn_into(flat.mem(G, "recurrent.weight_ih"), d_gi_rows, c.lat, rows=4096)
         # ---- encoder: backward-data chain in one kernel, then the weight-gradient kernels ----
@@ -743,6 +753,9 @@ class FusedUpdate:
             warm_up_gemm_library(self._cap_stream)
             if self.lr._side is not None:
                 warm_up_gemm_library(self.lr._side)  # (the capture forks onto it)
+        from .fused import prepare_tall_ws
+
+        prepare_tall_ws(dev, (self._cap_stream, self.lr._side))
         g = torch.cuda.CUDAGraph()
         self._capturing = True
         try:
@@ -790,7 +803,7 @@ class FusedUpdate:
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             self._target_images()
-            self._w_ih(tar, False)
+            self._w_ihp(tar, False)
         cur.wait_stream(side)  # (captures below synchronise the device anyway; replays of the target graph run on `side` behind the packs)
 
         def cap_target():
@@ -910,28 +923,30 @@ class FusedUpdate:
             aux.wait_stream(torch.cuda.current_stream(dev))
         with (torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext()):
             st_x = _stream(dev)
-            # bias gradients: the kernel's per-workgroup partials, summed in two stages (see fused._EncoderTrain.backward)
-            pad = (-nblk) % 256
-            gp = gb_part if pad == 0 else torch.cat([gb_part, gb_part.new_empty((7, pad, 128)).fill_(0)], dim=1)
-            torch.sum(gp.view(7, -1, 256, 128).sum(dim=2), dim=1, out=flat.span(G, names[0] + ".bias", names[6] + ".bias").view(7, 128))
-            torch.sum(gb7_part, dim=0, out=flat.mem(G, names[7] + ".bias"))
             ws0 = torch.empty((ENC_WGRAD0_PARTS, 128, 64), dtype=torch.float32, device=dev)
             check(lib.mapf_encoder_wgrad0(_ptr(gz[0]), _ptr(obs_rows), 1, M, _ptr(scale), _ptr(ws0), st_x), "mapf_encoder_wgrad0")
-            # conv0: columns j = ci*9 + ky*3 + kx -> the weight's memory [co][ky][kx][ci]
-            flat.mem(G, names[0] + ".weight").copy_(ws0.sum(dim=0)[:, :54].view(128, 6, 3, 3).permute(0, 2, 3, 1))
-            g7 = flat.mem(G, names[7] + ".weight").view(16, 128)
-            _tall_tn_into(g7, gz7, acts[6].reshape(M * 49, 128))
-            g7.mul_(scale.view(torch.float32)[1])
+            # bias gradients from the backward kernel's per-workgroup partials, conv0's weight gradient from its slabs (columns
+            # j = ci*9 + ky*3 + kx -> the weight's memory [co][ky][kx][ci]): two small launches of this library
+            check(lib.mapf_encoder_small_grads(_ptr(gb_part), nblk, _ptr(flat.span(G, names[0] + ".bias", names[6] + ".bias")), _ptr(gb7_part), 4 * nblk,
+                                               _ptr(flat.mem(G, names[7] + ".bias")), _ptr(ws0), ENC_WGRAD0_PARTS, _ptr(flat.mem(G, names[0] + ".weight")),
+                                               st_x), "mapf_encoder_small_grads")
+            # the 1x1 head: [16, 128] = gz7^T acts6 over M * 49 positions (f16, the chain's loss scale taken out in fp32)
+            tall_tn_into(flat.mem(G, names[7] + ".weight").view(16, 128), gz7, acts[6].reshape(M * 49, 128), scale=scale)
         ws = torch.empty((ENC_WGRAD_PARTS, 128, 3, 3, 128), dtype=torch.float32, device=dev)
         for k in range(1, 7):
             check(lib.mapf_encoder_wgrad(_ptr(gz[k]), _ptr(acts[k - 1]), M, _ptr(scale), _ptr(ws), st), "mapf_encoder_wgrad")
-            torch.sum(ws, dim=0, out=flat.mem(G, names[k] + ".weight"))  # [co][ky][kx][ci] == the weight's channels_last memory
+            sum_parts_into([flat.mem(G, names[k] + ".weight")], [ws])  # [co][ky][kx][ci] == the weight's channels_last memory
+
+
+OWN_TALL_GEMM = os.environ.get("MAPF_OWN_TALL_GEMM", "1") != "0"  # (A/B runs)
 
 
 def _tall_tn_into(out, a, b, rows=8192):
-    """out[m, n] = a^T b for a [K, m], b [K, n] with K in the 10^5 .. 10^6 range (model._tall_tn), written in place: K is split into
-    batches of `rows` (bmm, 16-bit in / fp32 out) that are summed in fp32 straight into `out`.  (fp32 partial products: the
-    encoder's f16 operands carry a loss scale, and a 16-bit partial of 8192 rows also costs the gradient 2-3 digits.)"""
+    """out[m, n] = a^T b for a [K, m], b [K, n] with K in the 10^4 .. 10^6 range, written in place: this library's split-K kernel
+    (fused.tall_tn_into; fp32 partial slabs summed in partition order).  MAPF_OWN_TALL_GEMM=0: rounds 1-4's formulation -- K split into
+    batches of `rows` for a library bmm (16-bit in / fp32 out) whose fp32 partial products are summed into `out`."""
+    if OWN_TALL_GEMM:
+        return tall_tn_into(out, a, b)
     K, m = a.shape
     S = K // rows
     if S > 1:
@@ -941,3 +956,4 @@ def _tall_tn_into(out, a, b, rows=8192):
             out += torch.mm(a[S * rows:].t(), b[S * rows:], out_dtype=torch.float32)
     else:
         out.copy_(torch.mm(a.t(), b, out_dtype=torch.float32))
+    return out
