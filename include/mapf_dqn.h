@@ -240,7 +240,8 @@ int mapf_input_proj_rows(const uint16_t *latent_dev, int64_t num_rows, const int
  *     pointers), n a multiple of 4: the per-partition slabs of mapf_encoder_wgrad for up to six layers in one launch.
  *   mapf_encoder_small_grads: the encoder's bias gradients from mapf_encoder_backward's per-workgroup partials (gb_part [7][nblk][128]
  *     -> bias7_out [7][128]; gb7_part [rows7][16] -> bias1_out [16]) and conv0's weight gradient from mapf_encoder_wgrad0's slabs
- *     (ws0 [parts0][128][64], column ci*9 + ky*3 + kx -> w0_out [128][3][3][6], the weight's channels_last memory).
+ *     (ws0 [parts0][128][64], column ci*9 + ky*3 + kx -> w0_out [128][3][3][6], the weight's channels_last memory); scratch_dev:
+ *     MAPF_SMALL_GRADS_SCRATCH_ELEMS floats between the two stages of the bias sums.
  *   mapf_latent_grad_pack / _rows: g_lat[row] = W_ih^T d_gi[row] (bf16 [num_rows][768] -> bf16 [num_rows][784]): the gradient of the
  *     GRU's input projection w.r.t. the encoder's latents; W_ih f32 [768][784] packed once per weight change into
  *     MAPF_LATGRAD_PACKED_ELEMS bf16 (fragments of W_ih^T).  The forward projection is mapf_input_proj_rows without a list.
@@ -251,8 +252,9 @@ int mapf_tall_tn_plan(int64_t K, int m, int n, int *slabs_out, int *parts_out, i
 int mapf_tall_tn(const uint16_t *a_dev, int64_t lda, const uint16_t *b_dev, int64_t ldb, int64_t K, int m, int n, int f16, float *out_dev,
                  const uint32_t *scale_dev, int accumulate, float *ws_dev, int64_t ws_elems, int32_t *counters_dev, int num_counters, void *stream);
 int mapf_sum_parts(const float *const *parts_dev, float *const *out_dev, int groups, int P, int64_t n, const uint32_t *scale_dev, void *stream);
+#define MAPF_SMALL_GRADS_SCRATCH_ELEMS 65536 /* 8 x 64 x 128 floats */
 int mapf_encoder_small_grads(const float *gb_part_dev, int64_t nblk, float *bias7_out_dev, const float *gb7_part_dev, int64_t rows7,
-                             float *bias1_out_dev, const float *ws0_dev, int parts0, float *w0_out_dev, void *stream);
+                             float *bias1_out_dev, const float *ws0_dev, int parts0, float *w0_out_dev, float *scratch_dev, void *stream);
 int mapf_latent_grad_pack(const float *w_ih_dev, uint16_t *packed_dev, void *stream);
 int mapf_latent_grad_rows(const uint16_t *d_gi_dev, int64_t num_rows, const uint16_t *packed_dev, uint16_t *g_lat_dev, void *stream);
 

@@ -97,6 +97,17 @@ int mapf_load_envs(mapf_env_t *env, const int32_t *env_ids, int n, const int8_t 
  */
 int mapf_reset_envs(mapf_env_t *env, const uint8_t *mask_dev, float density, uint64_t seed, void *stream);
 
+/*
+ * Scenario generation off the caller's critical path (reference worker.py:422-428: an actor draws its next scenario when an episode
+ * ends -- but the scenario of (seed, environment, reset count + 1) does not depend on when it is drawn).  mapf_stage_next draws it
+ * AHEAD into a second copy of the scenario state, for every environment that has none staged for its next reset (on any stream,
+ * e.g. beside the policy's forward pass); from the first call on, mapf_reset_envs with the SAME (density, seed) no longer draws:
+ * the flagged environments take their staged scenario over in one copy launch -- bit for bit the scenario the direct reset would have
+ * drawn.  The caller orders the two (stage before the reset that consumes it, the next stage behind that reset); a reset that finds
+ * nothing staged raises a sticky error (mapf_check_status: MAPF_ERR_NOT_READY).  A different (density, seed) takes the direct path.
+ */
+int mapf_stage_next(mapf_env_t *env, float density, uint64_t seed, void *stream);
+
 /* Overwrite agent positions only (e.g. rewind to the start of an action tape); steps := 0. */
 int mapf_set_agents(mapf_env_t *env, const int16_t *agents_dev, void *stream);
 

@@ -205,6 +205,10 @@ int mapf_actor_iteration_tail(const mapf_actor_state *a, void *env, mapf_replay_
 int mapf_actor_log(int num_envs, const uint8_t *finished_dev, const uint8_t *done_dev, const uint8_t *stat_mask_dev,
                    uint8_t *log_dev, int log_size, int64_t *counters_dev, void *stream);
 
+/* Importance-sampling weights of a sampled batch (reference worker.py:165-166): weights[i] = (pri[i] / min pri) ^ -beta, computed in
+ * f64 like the reference's numpy, written as f32 [n]. */
+int mapf_replay_is_weights(const double *pri_dev, int n, double beta, float *weights_dev, void *stream);
+
 /*
  * GlobalBuffer.sample_batch (worker.py:106-184) minus the IS weights (a reduction the caller does on
  * pri_dev): tree sample + window gather.  Outputs (device):

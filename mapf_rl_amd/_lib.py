@@ -23,6 +23,7 @@ SYMBOLS = [
     ("mapf_load", _i, [_vp, _vp, _vp, _vp, _i, _vp]),
     ("mapf_set_agents", _i, [_vp, _vp, _vp]),
     ("mapf_reset_envs", _i, [_vp, _vp, _f, _u64, _vp]),
+    ("mapf_stage_next", _i, [_vp, _f, _u64, _vp]),
     ("mapf_build_navi", _i, [_vp, _vp]),
     ("mapf_step", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_observe", _i, [_vp, _vp, _vp, _vp, _vp]),
@@ -72,6 +73,7 @@ SYMBOLS = [
     ("mapf_actor_iteration_tail", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_float, ctypes.c_uint64, _vp]),
     ("mapf_actor_log", _i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     ("mapf_obs_changed", _i, [_vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp]),
+    ("mapf_replay_is_weights", _i, [_vp, _i, ctypes.c_double, _vp, _vp]),
     ("mapf_replay_sample", _i, [_vp, _vp, _i, _i] + [_vp] * 12),
     ("mapf_replay_update_priorities", _i, [_vp, _vp, _vp, _i, _vp, _vp]),
     # include/mapf_dqn.h
@@ -113,7 +115,7 @@ SYMBOLS = [
     ("mapf_tall_tn_plan", _i, [ctypes.c_int64, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_int64)]),
     ("mapf_tall_tn", _i, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int64, _i, _i, _i, _vp, _vp, _i, _vp, ctypes.c_int64, _vp, _i, _vp]),
     ("mapf_sum_parts", _i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, ctypes.c_int64, _vp, _vp]),
-    ("mapf_encoder_small_grads", _i, [_vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, _vp, _i, _vp, _vp]),
+    ("mapf_encoder_small_grads", _i, [_vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, _vp, _i, _vp, _vp, _vp]),
     ("mapf_latent_grad_pack", _i, [_vp, _vp, _vp]),
     ("mapf_latent_grad_rows", _i, [_vp, ctypes.c_int64, _vp, _vp, _vp]),
     # include/mapf_search.h

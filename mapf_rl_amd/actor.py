@@ -69,8 +69,10 @@ class VecActor:
     REUSE_LATENTS = True  # encode only the agents whose observation changed since the previous step (fused.LatentCache: exact)
     FUSED_TAIL = True     # exploration .. episode flush of an iteration as one library call (mapf_actor_iteration_tail)
 
+    STAGE_AHEAD = True    # the next scenario of every environment is drawn beside the policy's forward (mapf_stage_next); an episode end swaps it in
+
     def __init__(self, env: VecEnvironment, model, buffer, epsilons=None, max_steps=MAX_STEPS, seed=0, density=-1.0,
-                 keep_flushed=False, on_device_reset=True, weights_period=None):
+                 keep_flushed=False, on_device_reset=True, weights_period=None, stage_ahead=None):
         """weights_period (reference config.actor_update_steps = 400, worker.py:416-420: an actor pulls the learner's weights every
         400 steps and acts on that snapshot in between): None = act on `model` itself (always the newest weights); an integer =
         keep an own copy of the network, refreshed from `model` every that many steps -- the reference's semantics, and what keeps
@@ -97,6 +99,14 @@ class VecActor:
         self.explore_seed, self._explore_counter = (seed * 0x9E3779B1 + 12345) & 0xFFFFFFFFFFFFFFFF, 0
         self.last_policy_actions = self._act8 = self._state = self._state_key = None
         self.scenario_seed = seed * 1000003 + 17
+        # Scenario generation off the critical path (round 5; reference worker.py:422-428 draws at the episode's end): the scenario of
+        # (seed, environment, reset count) does not depend on WHEN it is drawn, so with one fixed seed per actor the next one of every
+        # environment is staged on a second stream beside the policy's forward pass, and the reset behind env.step is a copy.
+        # (Rounds 1-4 passed a new seed every iteration, which tied a scenario to the iteration its episode ended in.)
+        stage = self.STAGE_AHEAD if stage_ahead is None else stage_ahead
+        self._fixed_seed = bool(stage and on_device_reset and env.device.type == "cuda")
+        self._stage_stream = torch.cuda.Stream(device=env.device) if self._fixed_seed else None  # (None with _fixed_seed: the same scenarios, drawn at the reset -- tests)
+        self._stage_ev = None
         self.RD = env.obs_bits_row_dwords
         # replay rows are laid out for A = buffer.max_agents >= N agents: the N-agent bit row is a prefix of the
         # A-agent row (bit a*486 + ...), so local rows are simply allocated at the replay's width, zero padded
@@ -142,8 +152,32 @@ class VecActor:
         next step)."""
         comm, comm_packed = self.policy_inputs()
         self.pull_weights()
+        self.stage_scenarios()
         actions, q, hidden, comm = self.model.step_batch(self.obs, self.pos, self.hidden, comm, cache=self.latents)
         return self.act(actions, q, hidden, comm, comm_packed, actions_override)
+
+    def stage_scenarios(self):
+        """Next scenarios onto the staging stream: behind everything this stream has queued (the last iteration's reset moved the
+        environments' epochs), beside what it queues next (the policy's forward); `act` waits for it in front of its reset."""
+        if self._stage_stream is None:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        self._stage_stream.wait_stream(cur)
+        with torch.cuda.stream(self._stage_stream):
+            self.env.stage_next(self.density, self.scenario_seed)
+            ev = torch.cuda.Event()
+            ev.record(self._stage_stream)
+        self._stage_ev = ev
+
+    def _reset_seed(self):
+        """The seed of this iteration's reset: fixed while scenarios are staged ahead, a new one per iteration otherwise."""
+        if self._fixed_seed:
+            if self._stage_ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(self._stage_ev)
+                self._stage_ev = None
+            return self.scenario_seed
+        self.scenario_seed += 1
+        return self.scenario_seed
 
     def _tail_state(self, actions):
         """The mapf_actor_state struct of this actor (built once; rebuilt when a buffer it names was replaced)."""
@@ -197,12 +231,12 @@ class VecActor:
             assert hidden.dtype == torch.bfloat16 and hidden.is_contiguous() and q.is_contiguous() and q.dtype == torch.float32
             actions = actions.contiguous()
             state = self._tail_state(actions)
-            self.scenario_seed += 1
+            rseed = self._reset_seed()
             buf = self.buffer
             with (buf.lock if buf is not None else contextlib.nullcontext()):
                 check(lib.mapf_actor_iteration_tail(ctypes.byref(state), self.env._h, None if buf is None else buf._h, _ptr(actions), _ptr(q), _ptr(hidden),
                                                     _ptr(comm_packed), self.explore_seed, self._explore_counter, float(self.density),
-                                                    int(self.scenario_seed) & 0xFFFFFFFFFFFFFFFF, st), "mapf_actor_iteration_tail")
+                                                    int(rseed) & 0xFFFFFFFFFFFFFFFF, st), "mapf_actor_iteration_tail")
             self._explore_counter += 1
             self.obs, self.pos = self.env.obs, self.env.pos
             self.hidden = hidden
@@ -281,13 +315,13 @@ class VecActor:
         check(lib.mapf_actor_log(E, _ptr(self.finished), _ptr(done), _ptr(self.stat_mask), _ptr(self.stat_log), self.STAT_LOG,
                                  _ptr(self.counters), st), "mapf_actor_log")
         # Actor.reset (worker.py:422-428): fresh scenario, recurrent state cleared
-        self.scenario_seed += 1
-        if self.on_device_reset:   # mapf_reset_envs: generation + placement + navi in one launch, only where the mask is set
-            self.env.reset_envs(self.finished, self.density, self.scenario_seed)
+        rseed = self._reset_seed()
+        if self.on_device_reset:   # mapf_reset_envs: generation + placement + navi (or the staged scenario's hand-over), only where the mask is set
+            self.env.reset_envs(self.finished, self.density, rseed)
         else:                      # host generator + partial load (synchronises)
             ids_h = finished.bool().nonzero().view(-1).tolist()
             if ids_h:
-                maps, agents, goals, _ = generate_scenarios(len(ids_h), self.env.map_length, N, self.density, self.scenario_seed)
+                maps, agents, goals, _ = generate_scenarios(len(ids_h), self.env.map_length, N, self.density, rseed)
                 self.env.load_envs(ids_h, maps, agents, goals)
         # obs / pos / bits already hold what env.step wrote for the environments that go on: only the reset ones are re-observed
         self.obs, self.pos = self.env.observe(obs_bits_out=self.bits, mask=self.finished if self.on_device_reset else None)

@@ -47,6 +47,7 @@ namespace {
 constexpr int kStatusAction = 1;   // action outside [0,5)
 constexpr int kStatusOverlap = 2;  // two agents on one cell after a step
 constexpr int kStatusRange = 4;    // position outside the map in a device-side load
+constexpr int kStatusStage = 8;    // mapf_reset_envs in staged mode found no staged scenario for an environment's next epoch
 
 // LDS atomic OR on a bit row (uint64_t is `unsigned long` here; HIP's overload wants unsigned long long)
 __device__ __forceinline__ uint32_t lds_or(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
@@ -362,10 +363,15 @@ __device__ __forceinline__ int wave_sum(int v) {
 // ones; a BFS only for a cell of a new partition), and the N fields are built afterwards by navi_bfs_kernel on the flagged
 // environments, one wavefront per field, in parallel.  Same draws, same scenario, same fields either way.
 constexpr int RESET_CACHED_PARTS = 16;
-template <typename W, bool NAVI>
+// STAGE (mapf_stage_next, round 5): the scenario of (environment, epoch + 1) is drawn AHEAD into staging arrays -- map_rows / agents /
+// goals are then the staging ones, `st_epoch[e]` names the epoch the staged scenario belongs to (nothing is drawn while it is still the
+// next one), `st_need[e]` tells the field kernel behind this one whether the environment was re-drawn; the live epoch counter and the
+// step counter are not touched.  Same draws as the direct reset of that (seed, environment, epoch).
+template <typename W, bool NAVI, bool STAGE = false>
 __device__ __forceinline__ void reset_body(const int e, int E, int L, int N, const uint8_t *mask, float density, uint64_t seed,
                                            W *map_rows, int16_t *agents, int16_t *goals, NaviRec<W> *navi,
-                                           int32_t *steps, int32_t *epochs, int32_t *status) {
+                                           int32_t *steps, int32_t *epochs, int32_t *status, int32_t *st_epoch = nullptr,
+                                           uint8_t *st_need = nullptr) {
     const int lane = threadIdx.x;
     if (e >= E || (mask && !mask[e])) return;
     __shared__ W s_part[NAVI ? 1 : RESET_CACHED_PARTS][64];  // !NAVI: row masks of the partitions seen on the current map
@@ -373,8 +379,15 @@ __device__ __forceinline__ void reset_body(const int e, int E, int L, int N, con
     const bool in_map = row < L;
     const W lmask = (L == (int)(8 * sizeof(W))) ? ~(W)0 : (((W)1 << L) - 1);
     int epoch = 0;
-    if (lane == 0) epoch = atomicAdd(&epochs[e], 1) + 1;
-    epoch = __shfl(epoch, 0, 64);
+    if (STAGE) {
+        epoch = epochs[e] + 1;
+        const bool have = st_epoch[e] == epoch;
+        if (lane == 0) st_need[e] = have ? 0 : 1;
+        if (have) return;
+    } else {
+        if (lane == 0) epoch = atomicAdd(&epochs[e], 1) + 1;
+        epoch = __shfl(epoch, 0, 64);
+    }
     const uint64_t base = mix64(seed ^ mix64(((uint64_t)e << 32) | (uint32_t)epoch));
     bool ok = false;
     for (int attempt = 0; attempt < 64 && !ok; ++attempt) {
@@ -473,8 +486,52 @@ __device__ __forceinline__ void reset_body(const int e, int E, int L, int N, con
         if (ok && in_map) map_rows[(size_t)e * L + row] = obst;
     }
     if (lane == 0) {
-        if (ok) steps[e] = 0;
-        else atomicOr(status, kStatusRange);
+        if (STAGE) {
+            if (ok) st_epoch[e] = epoch;
+            else st_need[e] = 0, atomicOr(status, kStatusRange);
+        } else {
+            if (ok) steps[e] = 0;
+            else atomicOr(status, kStatusRange);
+        }
+    }
+}
+
+// the staged scenario of every environment that has none for its next epoch (see reset_body<.., STAGE>)
+template <typename W>
+__global__ void __launch_bounds__(64) stage_fill_kernel(int E, int L, int N, float density, uint64_t seed, W *st_map_rows, int16_t *st_agents,
+                                                        int16_t *st_goals, const int32_t *epochs, int32_t *status, int32_t *st_epoch,
+                                                        uint8_t *st_need) {
+    reset_body<W, false, true>((int)blockIdx.x, E, L, N, nullptr, density, seed, st_map_rows, st_agents, st_goals, nullptr, nullptr,
+                               const_cast<int32_t *>(epochs), status, st_epoch, st_need);
+}
+
+// mapf_reset_envs with a staged scenario: the flagged environments take theirs over -- map rows, positions, goals, navigation records
+// (16-byte chunks) -- and move on to the next epoch.  An environment without a staged scenario for its next epoch raises kStatusStage.
+template <typename W>
+__global__ void __launch_bounds__(256) stage_swap_kernel(int E, int L, int N, const uint8_t *mask, W *map_rows, int16_t *agents, int16_t *goals,
+                                                         NaviRec<W> *navi, int32_t *steps, int32_t *epochs, int32_t *status, const W *st_map_rows,
+                                                         const int16_t *st_agents, const int16_t *st_goals, const NaviRec<W> *st_navi,
+                                                         const int32_t *st_epoch) {
+    const int e = blockIdx.x, tid = threadIdx.x;
+    if (e >= E || (mask && !mask[e])) return;
+    const int epoch = epochs[e] + 1;
+    if (st_epoch[e] != epoch) {
+        if (tid == 0) atomicOr(status, kStatusStage);
+        return;
+    }
+    const size_t nrec = (size_t)N * L * sizeof(NaviRec<W>) / 16;
+    const uint4 *src = reinterpret_cast<const uint4 *>(st_navi + (size_t)e * N * L);
+    uint4 *dst = reinterpret_cast<uint4 *>(navi + (size_t)e * N * L);
+    for (size_t i = tid; i < nrec; i += 256) dst[i] = src[i];
+    for (int i = tid; i < L; i += 256) map_rows[(size_t)e * L + i] = st_map_rows[(size_t)e * L + i];
+    for (int i = tid; i < 2 * N; i += 256) {
+        agents[(size_t)e * N * 2 + i] = st_agents[(size_t)e * N * 2 + i];
+        goals[(size_t)e * N * 2 + i] = st_goals[(size_t)e * N * 2 + i];
+    }
+    __syncthreads();  // (every thread has read epochs[e])
+    if (tid == 0) {
+        epochs[e] = epoch;
+        steps[e] = 0;
     }
 }
 
@@ -597,6 +654,14 @@ struct mapf_env {
     int32_t *steps;
     int32_t *status;
     int32_t *epochs;  // per-environment reset counter (RNG stream of mapf_reset_envs)
+    // staged next scenarios (mapf_stage_next): allocated at its first call
+    void *st_map_rows = nullptr, *st_navi = nullptr;
+    int16_t *st_agents = nullptr, *st_goals = nullptr;
+    int32_t *st_epoch = nullptr;
+    uint8_t *st_need = nullptr;
+    bool staged = false;
+    float st_density = 0.f;
+    uint64_t st_seed = 0;
     bool loaded, navi_ready;
     float rtab[5];
     int tune_threads;  // 0 = default; MAPF_STEP_THREADS (tuning experiments only)
@@ -924,6 +989,12 @@ int mapf_destroy(mapf_env_t *h) {
     (void)hipFree(h->steps);
     (void)hipFree(h->status);
     (void)hipFree(h->epochs);
+    (void)hipFree(h->st_map_rows);
+    (void)hipFree(h->st_navi);
+    (void)hipFree(h->st_agents);
+    (void)hipFree(h->st_goals);
+    (void)hipFree(h->st_epoch);
+    (void)hipFree(h->st_need);
     delete h;
     return MAPF_OK;
 }
@@ -1013,10 +1084,72 @@ int mapf_load_envs(mapf_env_t *h, const int32_t *env_ids, int n, const int8_t *m
     return MAPF_OK;
 }
 
+int mapf_stage_next(mapf_env_t *h, float density, uint64_t seed, void *stream) {
+    if (!h || density >= 1.0f) return MAPF_ERR_INVALID_ARG;
+    DeviceGuard guard(h->device);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t E = h->E, L = h->L, N = h->N, wb = word_bytes(h);
+    if (!h->st_epoch) {  // first call: the staging arrays (a second copy of the scenario state) + "nothing staged"
+        hipError_t err = hipSuccess;
+        auto alloc = [&err](void **p, size_t bytes) {
+            if (err == hipSuccess) err = hipMalloc(p, bytes);
+        };
+        alloc(&h->st_map_rows, E * L * wb);
+        alloc(reinterpret_cast<void **>(&h->st_agents), E * N * 2 * sizeof(int16_t));
+        alloc(reinterpret_cast<void **>(&h->st_goals), E * N * 2 * sizeof(int16_t));
+        alloc(&h->st_navi, E * N * L * 4 * wb);
+        alloc(reinterpret_cast<void **>(&h->st_epoch), E * sizeof(int32_t));
+        alloc(reinterpret_cast<void **>(&h->st_need), E);
+        if (err == hipSuccess) err = hipMemsetAsync(h->st_epoch, 0, E * sizeof(int32_t), s);
+        if (err != hipSuccess) {
+            std::fprintf(stderr, "mapf_stage_next: %s\n", hipGetErrorString(err));
+            return MAPF_ERR_HIP;
+        }
+    } else if (h->staged && (h->st_seed != seed || h->st_density != density)) {
+        HIP_TRY(hipMemsetAsync(h->st_epoch, 0, E * sizeof(int32_t), s));  // another scenario stream: what is staged belongs to the old one
+    }
+    h->staged = true;
+    h->st_seed = seed;
+    h->st_density = density;
+    const long long fields = (long long)h->E * h->N;
+    if (h->wide) {
+        hipLaunchKernelGGL(stage_fill_kernel<uint64_t>, dim3(h->E), dim3(64), 0, s, h->E, h->L, h->N, density, seed, static_cast<uint64_t *>(h->st_map_rows),
+                           h->st_agents, h->st_goals, h->epochs, h->status, h->st_epoch, h->st_need);
+        hipLaunchKernelGGL(navi_bfs_kernel<uint64_t>, dim3(blocks_for(fields * 64, 256)), dim3(256), 0, s, h->E, h->L, h->N,
+                           static_cast<const uint64_t *>(h->st_map_rows), h->st_goals, static_cast<NaviRec<uint64_t> *>(h->st_navi), h->status,
+                           (const int32_t *)nullptr, h->st_need);
+    } else {
+        hipLaunchKernelGGL(stage_fill_kernel<uint32_t>, dim3(h->E), dim3(64), 0, s, h->E, h->L, h->N, density, seed, static_cast<uint32_t *>(h->st_map_rows),
+                           h->st_agents, h->st_goals, h->epochs, h->status, h->st_epoch, h->st_need);
+        hipLaunchKernelGGL(navi_bfs_kernel<uint32_t>, dim3(blocks_for(((fields + 1) / 2) * 64, 256)), dim3(256), 0, s, h->E, h->L, h->N,
+                           static_cast<const uint32_t *>(h->st_map_rows), h->st_goals, static_cast<NaviRec<uint32_t> *>(h->st_navi), h->status,
+                           (const int32_t *)nullptr, h->st_need);
+    }
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
 int mapf_reset_envs(mapf_env_t *h, const uint8_t *mask_dev, float density, uint64_t seed, void *stream) {
     if (!h || density >= 1.0f) return MAPF_ERR_INVALID_ARG;
     DeviceGuard guard(h->device);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (h->staged && h->st_seed == seed && h->st_density == density) {
+        // the flagged environments take over the scenario mapf_stage_next drew for their next epoch: one copy launch where the direct
+        // path below draws, places and floods N fields (~0.1 ms on the actor's critical path whenever an episode ended)
+        if (h->wide)
+            hipLaunchKernelGGL(stage_swap_kernel<uint64_t>, dim3(h->E), dim3(256), 0, s, h->E, h->L, h->N, mask_dev, static_cast<uint64_t *>(h->map_rows),
+                               h->agents, h->goals, static_cast<NaviRec<uint64_t> *>(h->navi), h->steps, h->epochs, h->status,
+                               static_cast<const uint64_t *>(h->st_map_rows), h->st_agents, h->st_goals,
+                               static_cast<const NaviRec<uint64_t> *>(h->st_navi), h->st_epoch);
+        else
+            hipLaunchKernelGGL(stage_swap_kernel<uint32_t>, dim3(h->E), dim3(256), 0, s, h->E, h->L, h->N, mask_dev, static_cast<uint32_t *>(h->map_rows),
+                               h->agents, h->goals, static_cast<NaviRec<uint32_t> *>(h->navi), h->steps, h->epochs, h->status,
+                               static_cast<const uint32_t *>(h->st_map_rows), h->st_agents, h->st_goals,
+                               static_cast<const NaviRec<uint32_t> *>(h->st_navi), h->st_epoch);
+        HIP_TRY(hipGetLastError());
+        if (!mask_dev) h->loaded = h->navi_ready = true;
+        return MAPF_OK;
+    }
     if (h->wide)
         hipLaunchKernelGGL(reset_kernel<uint64_t>, dim3(h->E), dim3(64), 0, s, h->E, h->L, h->N, mask_dev, density, seed,
                            static_cast<uint64_t *>(h->map_rows), h->agents, h->goals, static_cast<NaviRec<uint64_t> *>(h->navi),
@@ -1358,6 +1491,7 @@ int mapf_check_status(mapf_env_t *h, void *stream) {
     if (st & kStatusRange) return MAPF_ERR_INVALID_ARG;
     if (st & kStatusAction) return MAPF_ERR_ACTION;
     if (st & kStatusOverlap) return MAPF_ERR_OVERLAP;
+    if (st & kStatusStage) return MAPF_ERR_NOT_READY;
     return MAPF_OK;
 }
 

@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(T_THR) tall_tn_kernel(const uint16_t *__restri
             for (int j = 0; j < NT; ++j) finish(acc[i][j], m0 + 16 * (MT * wm + i) + li, n0 + 16 * (NT * wn + j) + 4 * lh);
         return;
     }
-    // partial slab -> workspace; tall_reduce_kernel (the next launch) adds the P partials in partition order.  (Round 5 first let the
+    // partial slab -> workspace; tall_sum_kernel (the next launch) adds the P partials in partition order.  (Round 5 first let the
     // last-arriving workgroup of a slab do it behind an agent-scope fence + counter: correct, and ~100 us slower -- every workgroup's
     // release fence writes its XCD's L2 back so that the other seven XCDs may read the slab.)
     constexpr int SLAB = S::SM * S::SN;
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(T_THR) tall_tn_kernel(const uint16_t *__restri
 }
 
 // out = [out +] scale * sum_p ws[slab][p]: grid (SM * SN / 1024, slabs); a thread owns one float4 of the slab
-__global__ void __launch_bounds__(256) tall_reduce_kernel(const float *__restrict__ ws, int P, int SM, int SN, int slabs_n, int m, int n,
+__global__ void __launch_bounds__(256) tall_sum_kernel(const float *__restrict__ ws, int P, int SM, int SN, int slabs_n, int m, int n,
                                                           float *__restrict__ out, const uint32_t *__restrict__ scale_bits, int accumulate) {
     const int slab = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x, row = c / (SN / 4), col = 4 * (c - (SN / 4) * row);
     const int mm = SM * (slab / slabs_n) + row, nn = SN * (slab % slabs_n) + col;
@@ -274,35 +274,68 @@ __global__ void __launch_bounds__(256) sum_conv0_kernel(const float *__restrict_
     const int co = i / 54, r = i - 54 * co, tap = r / 6, ci = r - 6 * tap;
     const float *src = ws0 + co * 64 + ci * 9 + tap;
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += src[(long long)p * (128 * 64)];
+    int p = 0;
+    for (; p + 16 <= P; p += 16) {  // sixteen loads in flight (one per iteration ran at a load latency per partition: 0.22 ms for 512)
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = src[(long long)(p + u) * (128 * 64)];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; p < P; ++p) s += src[(long long)p * (128 * 64)];
     out[i] = s;
 }
 
-// bias partials: gb_part [7][nblk][128] -> out7 [7][128]; gb7_part [rows7][16] -> out1 [16].  One workgroup per output row of 128
-// (and one for the 16): thread (c, s) sums every 2nd / 16th partial of column c, then the slices are added through LDS in slice order.
-__global__ void __launch_bounds__(256) sum_bias_kernel(const float *__restrict__ gb_part, long long nblk, float *__restrict__ out7,
-                                                       const float *__restrict__ gb7_part, long long rows7, float *__restrict__ out1) {
-    __shared__ float red[256];
-    const int tid = threadIdx.x;
-    if (blockIdx.x < 7) {
-        const int c = tid & 127, sl = tid >> 7;
-        const float *src = gb_part + (long long)blockIdx.x * nblk * 128 + c;
-        float s = 0.f;
-        for (long long b = sl; b < nblk; b += 2) s += src[b * 128];
-        red[tid] = s;
-        __syncthreads();
-        if (tid < 128) out7[blockIdx.x * 128 + tid] = red[tid] + red[tid + 128];
-    } else {
-        const int c = tid & 15, sl = tid >> 4;
-        float s = 0.f;
-        for (long long b = sl; b < rows7; b += 16) s += gb7_part[b * 16 + c];
-        red[tid] = s;
-        __syncthreads();
-        if (tid < 16) {
-            float t = 0.f;
-            for (int k = 0; k < 16; ++k) t += red[16 * k + tid];
-            out1[tid] = t;
-        }
+// bias partials, two stages (one workgroup per output row walking all partials took 0.9 ms at 6,000 partials: a load latency per two of them).
+// Stage 1, grid (8, BS): rows 0..6 = gb_part [7][nblk][128], row 7 = gb7_part [rows7][16] read as [rows7 / 8][128]; workgroup (r, s) adds
+// partials s, s + BS, ... of its row: thread (sub, quad) takes every 8th of those for 4 columns, eight loads in flight, then the 8
+// sub-sums are added through LDS in order -> scratch [8][BS][128].  Stage 2, grid 8: the BS slices in order -> the outputs.
+constexpr int BS = 64;
+__global__ void __launch_bounds__(256) sum_bias1_kernel(const float *__restrict__ gb_part, long long nblk, const float *__restrict__ gb7_part,
+                                                        long long rows7, float *__restrict__ scratch) {
+    __shared__ f32x4 red[256];
+    const int tid = threadIdx.x, quad = tid & 31, sub = tid >> 5, r = blockIdx.x, sl = blockIdx.y;
+    const long long n = r < 7 ? nblk : rows7 / 8;   // partial rows of 128 floats
+    const float *src = (r < 7 ? gb_part + (long long)r * nblk * 128 : gb7_part) + 4 * quad;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    long long b = sl + (long long)BS * sub;
+    const long long step = 8ll * BS;
+    for (; b + 7 * step < n; b += 8 * step) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(src + (b + u * step) * 128);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < n; b += step) s += *reinterpret_cast<const f32x4 *>(src + b * 128);
+    red[tid] = s;
+    __syncthreads();
+    if (sub == 0) {
+        f32x4 t = red[quad];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[32 * k + quad];
+        *reinterpret_cast<f32x4 *>(scratch + ((long long)r * BS + sl) * 128 + 4 * quad) = t;
+    }
+}
+__global__ void __launch_bounds__(128) sum_bias2_kernel(const float *__restrict__ scratch, const float *__restrict__ gb7_part, long long rows7,
+                                                        float *__restrict__ out7, float *__restrict__ out1) {
+    __shared__ float red[128];
+    const int c = threadIdx.x, r = blockIdx.x;
+    float s = 0.f;
+#pragma unroll 16
+    for (int k = 0; k < BS; ++k) s += scratch[((long long)r * BS + k) * 128 + c];
+    if (r < 7) {
+        out7[r * 128 + c] = s;
+        return;
+    }
+    // row 7: column c of the [rows7 / 8][128] view is column c & 15 of every 8th row (+ c >> 4) of gb7_part; the rows7 % 8 tail rows follow
+    red[c] = s;
+    __syncthreads();
+    if (c < 16) {
+        float t = 0.f;
+        for (int k = 0; k < 8; ++k) t += red[16 * k + c];
+        for (long long b = rows7 / 8 * 8; b < rows7; ++b) t += gb7_part[b * 16 + c];
+        out1[c] = t;
     }
 }
 
@@ -427,7 +460,7 @@ int mapf_tall_tn(const uint16_t *a_dev, int64_t lda, const uint16_t *b_dev, int6
     }
 #undef TALL_LAUNCH
     if (p.parts > 1)
-        hipLaunchKernelGGL(tall_reduce_kernel, dim3(p.sm * p.sn / 1024, p.slabs), dim3(256), 0, st, ws_dev, p.parts, p.sm, p.sn, (n + p.sn - 1) / p.sn, m, n,
+        hipLaunchKernelGGL(tall_sum_kernel, dim3(p.sm * p.sn / 1024, p.slabs), dim3(256), 0, st, ws_dev, p.parts, p.sm, p.sn, (n + p.sn - 1) / p.sn, m, n,
                            out_dev, scale_dev, accumulate);
     return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
 }
@@ -446,11 +479,13 @@ int mapf_sum_parts(const float *const *parts_dev, float *const *out_dev, int gro
 }
 
 int mapf_encoder_small_grads(const float *gb_part_dev, int64_t nblk, float *bias7_out_dev, const float *gb7_part_dev, int64_t rows7,
-                             float *bias1_out_dev, const float *ws0_dev, int parts0, float *w0_out_dev, void *stream) {
-    if (!gb_part_dev || !bias7_out_dev || !gb7_part_dev || !bias1_out_dev || !ws0_dev || !w0_out_dev || nblk < 0 || rows7 < 0 || parts0 < 1)
+                             float *bias1_out_dev, const float *ws0_dev, int parts0, float *w0_out_dev, float *scratch_dev, void *stream) {
+    if (!gb_part_dev || !bias7_out_dev || !gb7_part_dev || !bias1_out_dev || !ws0_dev || !w0_out_dev || !scratch_dev || nblk < 0 || rows7 < 0 || parts0 < 1)
         return MAPF_ERR_INVALID_ARG;
+    if (!aligned16(gb_part_dev) || !aligned16(gb7_part_dev) || !aligned16(scratch_dev)) return MAPF_ERR_INVALID_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(sum_bias_kernel, dim3(8), dim3(256), 0, st, gb_part_dev, (long long)nblk, bias7_out_dev, gb7_part_dev, (long long)rows7, bias1_out_dev);
+    hipLaunchKernelGGL(sum_bias1_kernel, dim3(8, BS), dim3(256), 0, st, gb_part_dev, (long long)nblk, gb7_part_dev, (long long)rows7, scratch_dev);
+    hipLaunchKernelGGL(sum_bias2_kernel, dim3(8), dim3(128), 0, st, scratch_dev, gb7_part_dev, (long long)rows7, bias7_out_dev, bias1_out_dev);
     hipLaunchKernelGGL(sum_conv0_kernel, dim3((128 * 54 + 255) / 256), dim3(256), 0, st, ws0_dev, parts0, w0_out_dev);
     return hipGetLastError() == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
 }

@@ -384,6 +384,21 @@ __global__ void __launch_bounds__(1024) flush_top_kernel(double *tree, int cap_l
 
 __global__ void state_reset_counter_kernel(int64_t *state) { state[2] = 0; }
 
+// importance-sampling weights of a sampled batch (reference worker.py:165-166): w = (p / min p) ^ -beta, f64 like numpy, one workgroup
+__global__ void __launch_bounds__(256) is_weights_kernel(const double *__restrict__ pri, int n, double beta, float *__restrict__ w) {
+    __shared__ double red[256];
+    double m = 1.0e300;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmin(m, pri[i]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmin(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    m = red[0];
+    for (int i = threadIdx.x; i < n; i += 256) w[i] = (float)pow(pri[i] / m, -beta);
+}
+
 }  // namespace
 
 struct mapf_replay {
@@ -692,6 +707,13 @@ int mapf_replay_add_many_env(mapf_replay_t *r, int num_envs, const int32_t *num_
     p.q = q_dev;
     p.td = nullptr;
     return flush(r, p, static_cast<hipStream_t>(stream));
+}
+
+int mapf_replay_is_weights(const double *pri_dev, int n, double beta, float *weights_dev, void *stream) {
+    if (!pri_dev || !weights_dev || n < 1) return MAPF_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(is_weights_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), pri_dev, n, beta, weights_dev);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
 }
 
 int mapf_replay_sample(mapf_replay_t *r, const double *uniforms_dev, int n, int unit_uniforms, int64_t *idx_dev, double *pri_dev,

@@ -134,7 +134,8 @@ class CurriculumActors:
         env = VecEnvironment(E, L, n, reward_fn=self.reward_fn, device=self.device)
         maps, agents, goals, _ = generate_scenarios(E, L, n, -1.0, seed=self.seed * 7919 + n * 131 + L)
         env.load(maps, agents, goals)
-        return VecActor(env, self.model, self.buffer, max_steps=self.max_steps, seed=self.seed + n * 1000 + L, density=-1.0)
+        # (stage_ahead off: the levels' resets are one merged launch inside the captured iteration, environment.MultiEnvironment)
+        return VecActor(env, self.model, self.buffer, max_steps=self.max_steps, seed=self.seed + n * 1000 + L, density=-1.0, stage_ahead=False)
 
     def sync_levels(self):
         """Create actors for new levels, drop actors of levels no longer in GlobalBuffer.level (worker.py:224)."""

@@ -123,6 +123,11 @@ class VecEnvironment:
               "mapf_reset_envs")
         self._keep_mask = m
 
+    def stage_next(self, density=-1.0, seed=0):
+        """Draws the NEXT scenario of every environment that has none staged (mapf_stage_next) on the current stream; from then on
+        `reset_envs` with the same (density, seed) hands the staged scenario over instead of drawing one.  Asynchronous."""
+        check(lib.mapf_stage_next(self._h, float(density), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream(self.device)), "mapf_stage_next")
+
     def set_agents(self, agents_pos, sync=True):
         """Overwrites the agent positions (rewind to the start of an action tape), steps := 0.  sync=False: asynchronous; the
         caller keeps `agents_pos` (an int16 device tensor, used as is) alive until the stream has consumed it."""

@@ -220,7 +220,7 @@ class GlobalBuffer:
                                          _ptr(action), _ptr(reward), _ptr(done), _ptr(steps), _ptr(bt), _ptr(old_ptr), _stream(d)),
                   "mapf_replay_sample")
             old_ptr = old_ptr[0]  # 0-dim device tensor: the ring pointer at sample time (worker.py:182); int(old_ptr) reads it
-        out["weights"].copy_(torch.pow(pri / pri.min(), -self.beta))  # worker.py:165-166
+        check(lib.mapf_replay_is_weights(_ptr(pri), B, float(self.beta), _ptr(out["weights"]), _stream(d)), "mapf_replay_is_weights")  # worker.py:165-166
         # (the gather kernel writes 0 / 1 bytes: the bool tensor is a view)
         return (obs.transpose(0, 1), action.unsqueeze(1), reward.unsqueeze(1), done.unsqueeze(1), steps.unsqueeze(1), bt, hidden,
                 comm.view(torch.bool).transpose(0, 1), idx, out["weights"].unsqueeze(1), old_ptr)

@@ -929,7 +929,7 @@ class FusedUpdate:
             # j = ci*9 + ky*3 + kx -> the weight's memory [co][ky][kx][ci]): two small launches of this library
             check(lib.mapf_encoder_small_grads(_ptr(gb_part), nblk, _ptr(flat.span(G, names[0] + ".bias", names[6] + ".bias")), _ptr(gb7_part), 4 * nblk,
                                                _ptr(flat.mem(G, names[7] + ".bias")), _ptr(ws0), ENC_WGRAD0_PARTS, _ptr(flat.mem(G, names[0] + ".weight")),
-                                               st_x), "mapf_encoder_small_grads")
+                                               _ptr(torch.empty(65536, dtype=torch.float32, device=dev)), st_x), "mapf_encoder_small_grads")
             # the 1x1 head: [16, 128] = gz7^T acts6 over M * 49 positions (f16, the chain's loss scale taken out in fp32)
             tall_tn_into(flat.mem(G, names[7] + ".weight").view(16, 128), gz7, acts[6].reshape(M * 49, 128), scale=scale)
         ws = torch.empty((ENC_WGRAD_PARTS, 128, 3, 3, 128), dtype=torch.float32, device=dev)

@@ -346,3 +346,34 @@ def test_actor_with_latent_reuse_records_the_same_episodes():
         actor.step()
         pulled = k > 3
         assert torch.equal(actor.model.adv.bias, net.adv.bias if pulled else before), k
+
+
+def test_actor_with_staged_scenarios_equals_the_actor_that_draws_at_the_reset():
+    """VecActor.STAGE_AHEAD: the next scenarios are drawn on a second stream beside the policy's forward pass and an episode end only
+    swaps them in.  The same actor with the staging stream taken away draws them at the reset: same episodes, same replay, bit for bit."""
+    import mapf_rl_amd as M
+    from mapf_rl_amd.actor import VecActor
+    from mapf_rl_amd.model import Network
+    from mapf_rl_amd.replay import GlobalBuffer
+
+    def run(staged):
+        torch.manual_seed(3)
+        E, L, N = 48, 12, 4
+        env = M.VecEnvironment(E, L, N)
+        maps, agents, goals, _ = M.generate_scenarios(E, L, N, 0.2, seed=5)
+        env.load(maps, agents, goals)
+        buf = GlobalBuffer(128, max_agents=6, init_set=(N, L), fixed_level=True)
+        actor = VecActor(env, Network().cuda(), buf, seed=1, density=0.2, max_steps=24)
+        if not staged:
+            actor._stage_stream = None
+        for _ in range(120):
+            actor.step()
+        torch.cuda.synchronize()
+        env.check_status()
+        return env.maps().clone(), env.agents_pos().clone(), env.goals_pos().clone(), actor.obs.clone(), buf.state(), buf.priority_tree.tree().clone(), actor.episodes
+
+    a, b = run(True), run(False)
+    assert a[6] > 100 and a[4] == b[4] and a[6] == b[6]
+    for x, y in zip(a[:4], b[:4]):
+        assert torch.equal(x, y)
+    assert torch.equal(a[5], b[5])

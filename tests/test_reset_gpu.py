@@ -123,3 +123,54 @@ def test_reset_kernel_matches_reference_statistics(N, L, E):
     env.reset_envs(None, -1.0, seed=23)
     env.check_status()
     GS.check(N, L, GS.batch_stats(_np(env.maps()), _np(env.agents_pos()), _np(env.goals_pos())))
+
+
+@pytest.mark.parametrize("E,L,N,rho", [(96, 32, 40, 0.3), (64, 40, 16, -1.0), (48, 64, 40, 0.3), (128, 10, 1, -1.0)])
+def test_staged_scenarios_are_the_direct_resets_scenarios(E, L, N, rho):
+    """Round 5 (mapf_stage_next): the scenario of (seed, environment, reset count) is drawn AHEAD -- on another stream, beside whatever
+    the caller runs -- and a reset only hands it over.  Two handles go through the same sequence of masked resets, one staging
+    ahead, one drawing at the reset: maps, starts, goals, navigation fields and step counters agree bit for bit after every round,
+    including environments reset in consecutive rounds, never reset, and a round with nothing flagged."""
+    import mapf_rl_amd as M
+
+    a, b = M.VecEnvironment(E, L, N), M.VecEnvironment(E, L, N)
+    side = torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+    rng = np.random.RandomState(E + L)
+    a.reset_envs(None, rho, seed=11)
+    b.reset_envs(None, rho, seed=11)
+    for rnd in range(7):
+        mask = torch.from_numpy((rng.random_sample(E) < (0.0 if rnd == 3 else 0.35)).astype(np.uint8)).cuda()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            a.stage_next(rho, seed=11)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        cur.wait_event(ev)
+        a.reset_envs(mask, rho, seed=11)      # hands the staged scenarios over
+        b.reset_envs(mask, rho, seed=11)      # draws them now
+        a.check_status()
+        b.check_status()
+        for name in ("maps", "agents_pos", "goals_pos", "navi_map"):
+            assert torch.equal(getattr(a, name)(), getattr(b, name)()), (rnd, name)
+    _check_invariants(_np(a.maps()), _np(a.agents_pos()), _np(a.goals_pos()), L, N)
+
+
+def test_reset_without_a_staged_scenario_is_reported():
+    """Two resets of one environment with a single staging call in between: the second finds nothing staged for its epoch -> sticky
+    MAPF_ERR_NOT_READY (the caller's ordering contract, include/mapf_env.h); another (density, seed) takes the direct path."""
+    import mapf_rl_amd as M
+    from mapf_rl_amd._lib import ERR_NOT_READY, MapfError
+
+    env = M.VecEnvironment(8, 16, 4)
+    env.reset_envs(None, 0.2, seed=3)
+    env.stage_next(0.2, seed=3)
+    mask = torch.ones(8, dtype=torch.uint8, device="cuda")
+    env.reset_envs(mask, 0.2, seed=3)
+    env.check_status()
+    env.reset_envs(mask, 0.2, seed=3)
+    with pytest.raises(MapfError) as ex:
+        env.check_status()
+    assert ex.value.status == ERR_NOT_READY
+    env.reset_envs(mask, 0.2, seed=4)        # not the staged stream: drawn directly
+    env.check_status()
