@@ -216,6 +216,67 @@ def out_of_cache_leg(M, dev, args, rank, steps=40, warmup=8):
     return out
 
 
+NOMINAL_GHZ = 2.4  # the clock the 2.5 PFLOP/s dense bf16 / f16 peak is quoted at (MI355X_MICROARCH.md)
+
+
+def encoder_clock_ghz(model, obs_flat, dev, seconds=2.0):
+    """The shader clock the chip HOLDS under the encoder kernel: delta s_memtime / delta s_memrealtime x 100 MHz, stamped once per
+    workgroup in the diagnostic build of the same kernel (mapf_rl_amd/libmapf_enc_clock.so: csrc/mapf_encoder.hip with -DMAPF_ENC_CLOCK;
+    in the product's kernel no stamp executes), after `seconds` of back-to-back launches on the bench's observations, median over
+    workgroups (MI355X_MICROARCH.md, DVFS give-back item 6).  Returns the keys it adds to `encoder_roofline`; {} without the library."""
+    import ctypes
+
+    import numpy as np
+    import torch
+
+    path = os.path.join(ROOT, "mapf_rl_amd", "libmapf_enc_clock.so")
+    if not os.path.exists(path):
+        return {"clock_note": "libmapf_enc_clock.so not built"}
+    try:
+        lib = ctypes.CDLL(path)
+        fwd, rd = lib.mapf_encoder_forward, lib.mapf_enc_clock_read
+        fwd.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        rd.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        wp, bp = model._packed.get(model.obs_encoder, model.weights_epoch)
+        obs = obs_flat.contiguous()
+        assert obs.dtype == torch.uint8
+        M = obs.shape[0]
+        lat = torch.empty((M, 784), dtype=torch.bfloat16, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        args = (ctypes.c_void_p(obs.data_ptr()), 0, M,  # (0 = MAPF_ENC_OBS_U8)
+                ctypes.c_void_p(wp.data_ptr()), ctypes.c_void_p(bp.data_ptr()), ctypes.c_void_p(lat.data_ptr()), st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        assert fwd(*args) == 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < seconds:  # back to back: the queue never runs dry (20 launches of ~10 ms per check)
+            for _ in range(20):
+                fwd(*args)
+            n += 20
+            if n % 100 == 0:  # (bounds the queue: ~1 s of launches ahead at most)
+                torch.cuda.current_stream(dev).synchronize()
+        e0.record()
+        for _ in range(5):
+            fwd(*args)
+        e1.record()
+        torch.cuda.synchronize()
+        nwg = min(8192, (M + 3) // 4)
+        buf = np.zeros((nwg, 2), dtype=np.uint64)
+        assert rd(buf.ctypes.data_as(ctypes.c_void_p), nwg) == 0
+        ok = buf[:, 1] > 0
+        ghz = float(np.median(buf[ok, 0].astype(np.float64) / buf[ok, 1].astype(np.float64))) * 0.1
+        ms = e0.elapsed_time(e1) / 5
+        flop = 2.0 * (49 * 128 * 54 + 6 * 49 * 128 * 1152 + 49 * 16 * 128) * M
+        ach = flop / (ms * 1e-3) / 1e12
+        return {"clock_ghz": ghz, "peak_at_clock": 2500.0 * ghz / NOMINAL_GHZ, "frac_at_clock": ach / (2500.0 * ghz / NOMINAL_GHZ),
+                "clock_build_kernel_avg_ms": ms, "clock_build_achieved": ach,
+                "clock_note": "median over %d workgroups of delta s_memtime / delta s_memrealtime x 100 MHz in the diagnostic build of the same kernel "
+                              "after %.1f s of back-to-back launches; frac_at_clock = that build's TFLOP/s over 2500 x clock / %.1f GHz" % (int(ok.sum()), seconds, NOMINAL_GHZ)}
+    except Exception as ex:  # the primary numbers stand
+        return {"clock_note": "clock measurement failed: %r" % (ex,)}
+
+
 def cpu_baseline(args, maps, agents, goals, tape, final_pos, E, T):
     """The oracle (C restatement with the reference's sequential semantics), in child processes without torch and without
     the GPU: one single-threaded, pinned process per usable host core (oracle/cpu_bench.py)."""
@@ -550,6 +611,7 @@ def main():
             torch.cuda.synchronize()
             enc_s = e0.elapsed_time(e1) * 1e-3 / 5
             enc_flop = 2.0 * (49 * 128 * 54 + 6 * 49 * 128 * 1152 + 49 * 16 * 128) * E * N  # 87.6 MFLOP per observation
+            enc_clock = encoder_clock_ghz(learner.model, obs_flat, dev)
             result.update({
                 "learner_updates_per_sec": 1.0 / dt_upd, "learner_ms_per_update": dt_upd * 1e3,
                 "learner_ms_per_update_all_observations": dt_upd_all * 1e3,
@@ -580,9 +642,12 @@ def main():
                 "train_loop_updates_per_sec": 1.0 / dt_train, "train_loop_env_steps_per_sec": world * E / dt_train,
                 "train_loop_ms_per_iter": dt_train * 1e3,
                 "train_loop_config": "one actor iteration (%d envs/GPU) + one learner update per iteration, the actor iteration on its own stream beside the update as in train.py (--overlap-actors)" % E,
-                "encoder_roofline": {"bound": "mfma", "kernel": "encoder_fwd_kernel", "achieved": enc_flop / enc_s / 1e12,
-                                     "peak": 2500.0, "unit": "TFLOP/s", "frac": enc_flop / enc_s / 1e12 / 2500.0,
-                                     "flop_per_launch": enc_flop, "kernel_avg_ms": enc_s * 1e3, "observations": E * N},
+                # the env-steps/s of the whole pipeline with a policy in the loop and agents moving (BASELINE metric "env steps/sec" as a
+                # system rate; `value` above is the env kernel alone): the tape-policy actor loop
+                "pipeline_env_steps_per_sec": world * E / dt_act_tape,
+                "encoder_roofline": dict({"bound": "mfma", "kernel": "encoder_fwd_kernel", "achieved": enc_flop / enc_s / 1e12,
+                                          "peak": 2500.0, "unit": "TFLOP/s", "frac": enc_flop / enc_s / 1e12 / 2500.0,
+                                          "flop_per_launch": enc_flop, "kernel_avg_ms": enc_s * 1e3, "observations": E * N}, **enc_clock),
             })
         except Exception as ex:  # the primary metric must still be reported
             result["dqn_error"] = repr(ex)[:300]

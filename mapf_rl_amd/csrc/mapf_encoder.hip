@@ -197,6 +197,10 @@ __device__ __forceinline__ void save_rows(const unsigned char *act, uint16_t *__
     }
 }
 
+#ifdef MAPF_ENC_CLOCK  // diagnostic build only (libmapf_enc_clock.so, bench.py's encoder_roofline.clock_ghz): per workgroup the shader-clock
+__device__ unsigned long long g_enc_clock[8192][2];  // cycles (s_memtime) and the 100 MHz reference ticks (s_memrealtime) it ran for
+#endif
+
 template <typename InT, bool SAVE, bool IDX = false>
 __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__restrict__ obs, long long M,
                                                           const uint16_t *__restrict__ wp, const float *__restrict__ bias,
@@ -211,6 +215,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
     if constexpr (IDX) M = min(M, (long long)*row_count);
     if constexpr (IDX)
         if ((long long)blockIdx.x * G >= M) return;
+#ifdef MAPF_ENC_CLOCK
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), ref0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) alone: the stamps are back before the first LDS wait is counted
+#endif
     __shared__ __attribute__((aligned(16))) unsigned char smem[ACT_BYTES + RAW_BYTES];
     unsigned char *const act = smem;
     const InT *const raw = reinterpret_cast<const InT *>(smem + ACT_BYTES);
@@ -413,7 +421,21 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
     if ((wg + gridDim.x) * G >= M) break;
     __syncthreads();  // every wave is done with the activation image before the next pass zeroes it
   }
+#ifdef MAPF_ENC_CLOCK
+    if (threadIdx.x == 0) {
+        const unsigned long long clk1 = __builtin_amdgcn_s_memtime(), ref1 = __builtin_amdgcn_s_memrealtime();
+        g_enc_clock[blockIdx.x & 8191][0] = clk1 - clk0;
+        g_enc_clock[blockIdx.x & 8191][1] = ref1 - ref0;
+    }
+#endif
 }
+
+#ifdef MAPF_ENC_CLOCK
+extern "C" int mapf_enc_clock_read(unsigned long long *out_host, int n) {  // [n][2] of the last launch's workgroups (n <= 8192)
+    if (!out_host || n < 1 || n > 8192) return -1;
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_enc_clock), sizeof(unsigned long long) * 2 * n) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // ---- weight packing: fp32 [co][ci][kh][kw] (contiguous) -> f16 MFMA A fragments, biases concatenated ----
 struct PackArgs {
