@@ -235,7 +235,11 @@ class FusedUpdate:
     GRAPH_MAX_AGENTS = 16       # replay rows wider than this are GPU-bound (no gain) and would need many more buckets
     GRAPH_ROW_STEP = 2048       # bucket of the entry count (== WGRAD_SPLIT: the weight-gradient GEMMs' K is padded to it anyway)
     GRAPH_UROW_STEP = 1024      # bucket of the distinct-observation count (the encoder kernels' batch)
-    GRAPH_CACHE = 24            # captured graphs kept per stage (an online entry holds ~0.1 MB per row of saved tensors); LRU beyond it
+    GRAPH_CACHE = 24            # captured graphs kept per stage; LRU beyond it
+    GRAPH_CACHE_BYTES = int(float(os.environ.get("MAPF_UPDATE_GRAPH_GB", "48")) * (1 << 30))  # ... and what their private pools may hold
+    # in all (an online entry pins its saved tensors -- ~0.1 MB per distinct observation row -- and its backward graphs: a moving
+    # curriculum that touches many (rows, distinct rows) buckets at 16 agents would otherwise pin tens of GB; advisor, round 4).
+    # `graph_captures` counts captures: a thrashing cache shows there.
 
     def __init__(self, learner):
         self.lr = learner
@@ -779,8 +783,13 @@ class FusedUpdate:
             same = [k for k in self._graphs if k[0] == stage]
             if len(same) >= self.GRAPH_CACHE:
                 del self._graphs[min(same, key=lambda k: self._graphs[k][2])]
+            # the byte bound: least recently used entries of any stage go until the new one fits (sizes: what the allocator's
+            # reserved memory grew by during an entry's captures -- its own and, for an online entry, its backward graphs')
+            while self._graphs and sum(e[3] for e in self._graphs.values()) > self.GRAPH_CACHE_BYTES:
+                del self._graphs[min(self._graphs, key=lambda k: self._graphs[k][2])]
+            before = torch.cuda.memory_reserved(self.dev)
             g, out = self._capture(pool, fn)
-            ent = [g, out, self._tick]
+            ent = [g, out, self._tick, max(0, torch.cuda.memory_reserved(self.dev) - before)]
             self._graphs[(stage, key)] = ent
         ent[2] = self._tick
         return ent[0], ent[1]
@@ -881,7 +890,11 @@ class FusedUpdate:
         ent = c_o.backward.get(lr_value)  # (kept with the online graph whose saved tensors it reads: evicted together)
         if ent is None:
             saved_step, saved_epoch = flat.step_host, lr.model.weights_epoch
+            before = torch.cuda.memory_reserved(dev)
             g_b, norm = self._capture("main", cap_backward)
+            ent_o = self._graphs.get(("online", key_o))
+            if ent_o is not None:
+                ent_o[3] += max(0, torch.cuda.memory_reserved(dev) - before)
             flat.step_host, lr.model.weights_epoch = saved_step, saved_epoch  # (a capture runs adam_step's Python without executing it)
             ent = c_o.backward[lr_value] = (g_b, norm)
         g_b, norm = ent
