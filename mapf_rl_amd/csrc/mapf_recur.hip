@@ -284,6 +284,9 @@ __device__ __forceinline__ void gru_pair(int cA, int cB, const GruInit &sA, cons
     const int lane = 16 * lh + lr;
     f32x4 ar[NT], az[NT], ani[NT], anh[NT];
     TRACE_POINT(20);
+    // (Tried, round 5: waves 4-7 -- the SIMD partners of 0-3 -- entering a cell 640 / 1280 / 1920 cycles late (s_sleep), and the partners at
+    // different issue priorities (s_setprio), so that one's MFMA chain would run under the other's pointwise math: 0.550 -> 0.544 / 0.546 /
+    // 0.554 ms per 4096 x 40 step, nothing at 18 x 192 x 40.  profiles/r05_recurrence_stagger.txt)
     gru_start<GI_GLOBAL>(sA, bsum, 16 * cA + 4 * lh, ar, az, ani, anh);
     if (!GI_GLOBAL) stream_mfma<KI, true>(ar, az, ani, wi, Xi, xirow, lane, gate_frags(Wi, cB, KI, lane));
     stream_mfma<8, true>(ar, az, anh, wf, Hin, H_ROW, lane, gate_frags(Wh, cB, 8, lane));
@@ -341,9 +344,6 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
     const int rot = blockIdx.x;  // workgroups walk the weight tiles in rotated order: they run in step, and would otherwise all
                                  // request the same cache lines at the same moment
 
-#ifdef MAPF_RECUR_PRIO  // experiment: the two waves of a SIMD (w, w + 4) at different issue priorities, so that one's MFMA chain runs under the other's pointwise math
-    if (MAPF_RECUR_PRIO == 1 ? w < 4 : w >= 4) __builtin_amdgcn_s_setprio(2);
-#endif
     TRACE_BEGIN();
     TRACE_POINT(30);
     // the weight stream (see stream_mfma): this wave's channel blocks / q|k|v tiles are the same in every phase of every step
@@ -522,8 +522,12 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
             // (32 k-slots x 16 agents) of ctx^T = v^T P^T once the k-slots are numbered  slot 8 lh + u  <->  j = 16 (2 kk + (u >> 2)) +
             // 4 lh + (u & 3); v^T's A operand reads its columns in the same numbering (two 8-byte reads).  Rounds 1-4 went through a
             // score image and a softmax image in LDS with a barrier behind each: 4.1 k of a step's ~30 k cycles per round at 40 agents.
-            for (int job = w; job < 2 * NT && !(MAPF_RECUR_ABLATE & 4); job += NTHR / 64) {
-                const int hd = job / NT, ti = job - NT * hd, i = 16 * ti + lr;
+            // (at one or two agent tiles there are only 2 / 4 (head, tile) pairs for 8 waves: two waves then share a pair, each repeating the
+            //  scores and the softmax and taking two of the four d-tiles of ctx -- SPLIT)
+            constexpr int SPLIT = NT <= 2 ? 2 : 1;
+            for (int job = w; job < 2 * NT * SPLIT && !(MAPF_RECUR_ABLATE & 4); job += NTHR / 64) {
+                const int half = job / (2 * NT), pair = job - 2 * NT * half;
+                const int hd = pair / NT, ti = pair - NT * hd, i = 16 * ti + lr;
                 f32x4 sc[NT];
                 {
                     bf16x8 qf[2];
@@ -572,15 +576,16 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                     pw[tj] = tj < NT ? make_uint2(pack2_bf16(sc[tj < NT ? tj : 0][0] * inv, sc[tj < NT ? tj : 0][1] * inv),
                                                   pack2_bf16(sc[tj < NT ? tj : 0][2] * inv, sc[tj < NT ? tj : 0][3] * inv))
                                      : make_uint2(0u, 0u);
-                if (hd == 0 && lh == 0) upd[i] = (i < N && __popcll(bits) > 1) ? 1 : 0;  // model.py:103
-                if (SAVE) {  // P rows (2 heads x NA agents x 64 slots = 128 B each; slots >= NA zero) -> global
+                if (hd == 0 && lh == 0 && half == 0) upd[i] = (i < N && __popcll(bits) > 1) ? 1 : 0;  // model.py:103
+                if (SAVE && half == 0) {  // P rows (2 heads x NA agents x 64 slots = 128 B each; slots >= NA zero) -> global
                     uint16_t *pd = sv.P + ((((long long)round * T + t) * E + e) * 2 + hd) * (NA * 64) + i * 64 + 4 * lh;
 #pragma unroll
                     for (int tj = 0; tj < 4; ++tj) *reinterpret_cast<uint2 *>(pd + 16 * tj) = pw[tj];
                 }
                 // ctx^T[d][i] = sum_j vT[d][j] P[i][j]: 4 d-tiles of this head -> CTX[agent][head*64 + d]
 #pragma unroll
-                for (int td = 0; td < 4; ++td) {
+                for (int tq = 0; tq < 4 / SPLIT; ++tq) {
+                    const int td = (4 / SPLIT) * half + tq;
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                     const unsigned char *vr = smem + OFF_VT + (hd * HD + 16 * td + lr) * VT_ROW + 8 * lh;
 #pragma unroll

@@ -63,20 +63,24 @@ def run(shapes):
     w = (torch.randn(548864, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
     b = torch.randn(3456, device="cuda", generator=g) * 0.1
 
-    def timed(fn, args, reps=8):
-        for _ in range(3):
-            rc = fn(*args)
+    def timed_all(calls, reps=8, rounds=4):
+        """calls {name: (fn, args)} -> {name: best ms}: the variants take turns (round robin, `rounds` times) so that none of them is
+        always the first one on a cold chip (a variant timed first read 4-7 % slower than the same code timed later)."""
+        best = {n: 1e9 for n in calls}
+        for n, (fn, args) in calls.items():
+            for _ in range(3):
+                assert fn(*args) == 0, n
         torch.cuda.synchronize()
-        best = 1e9
-        for _ in range(3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                fn(*args)
-            e1.record()
-            torch.cuda.synchronize()
-            best = min(best, e0.elapsed_time(e1) / reps)
-        return rc, best
+        for _ in range(rounds):
+            for n, (fn, args) in calls.items():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    fn(*args)
+                e1.record()
+                torch.cuda.synchronize()
+                best[n] = min(best[n], e0.elapsed_time(e1) / reps)
+        return best
 
     print("%-22s" % "shape" + "".join("%12s" % n for n in names))
     for T, E, N in shapes:
@@ -84,16 +88,14 @@ def run(shapes):
         h0 = (torch.randn((E, N, 256), device="cuda", generator=g) * 0.3).to(torch.bfloat16)
         comm = (torch.rand((T, E, N, N), device="cuda", generator=g) < 0.1).to(torch.uint8)
         comm |= torch.eye(N, device="cuda", dtype=torch.uint8)
-        outs, row, row_s, saved = {}, [], [], {}
+        outs, saved, calls, calls_s, keep = {}, {}, {}, {}, []
         for n in names:
             fn = libs[n].mapf_recurrent_infer
             fn.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p]
             out = torch.zeros((E, N, 256), dtype=torch.bfloat16, device="cuda")
             a0 = torch.zeros((T, E, 256), dtype=torch.bfloat16, device="cuda")
-            rc, ms = timed(fn, (gi.data_ptr(), h0.data_ptr(), comm.data_ptr(), w.data_ptr(), b.data_ptr(), T, E, N, out.data_ptr(), a0.data_ptr(), None, 0, st))
-            assert rc == 0, (n, rc)
+            calls[n] = (fn, (gi.data_ptr(), h0.data_ptr(), comm.data_ptr(), w.data_ptr(), b.data_ptr(), T, E, N, out.data_ptr(), a0.data_ptr(), None, 0, st))
             outs[n] = (out, a0)
-            row.append(ms)
             if T > 1:
                 R = T * E * N
                 sizes = [R * 256, R * 1024, 2 * R * 256, 2 * R * 384, 2 * R * 128, 2 * R * 64, 2 * R * 1024, 2 * T * E * 2 * 48 * 64]
@@ -103,10 +105,16 @@ def run(shapes):
                 ptrs = (ctypes.c_void_p * 8)(*[x.data_ptr() for x in bufs])
                 out2 = torch.zeros((E, N, 256), dtype=torch.bfloat16, device="cuda")
                 a02 = torch.zeros((T, E, 256), dtype=torch.bfloat16, device="cuda")
-                rc, ms = timed(fs, (gi.data_ptr(), h0.data_ptr(), comm.data_ptr(), w.data_ptr(), b.data_ptr(), T, E, N, out2.data_ptr(), a02.data_ptr(), ptrs, None, 0, st), 4)
-                assert rc == 0, (n, rc)
-                row_s.append(ms)
-                saved[n] = [x.float().abs().sum().item() for x in bufs] + [(out2.float() - out.float()).abs().max().item()]
+                calls_s[n] = (fs, (gi.data_ptr(), h0.data_ptr(), comm.data_ptr(), w.data_ptr(), b.data_ptr(), T, E, N, out2.data_ptr(), a02.data_ptr(), ptrs, None, 0, st))
+                keep.append((bufs, ptrs, out2, a02))
+        best = timed_all(calls)
+        row = [best[n] for n in names]
+        row_s = []
+        if calls_s:
+            best_s = timed_all(calls_s, reps=4)
+            row_s = [best_s[n] for n in names]
+            for n, (bufs, ptrs, out2, a02) in zip(names, keep):
+                saved[n] = [x.float().abs().sum().item() for x in bufs] + [(out2.float() - outs[n][0].float()).abs().max().item()]
         tag = "T=%d E=%d N=%d" % (T, E, N)
         print("%-22s" % tag + "".join("%9.3f ms" % v for v in row), flush=True)
         if row_s:
