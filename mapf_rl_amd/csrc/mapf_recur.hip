@@ -77,7 +77,17 @@ __shared__ int trace_lds_n;
 constexpr int NA = 16 * NT;
 constexpr int D = 256;           // hidden size (config.latent_dim)
 constexpr int HD = 64;           // attention head dim (comm output_dim)
-constexpr int NTHR = 512;        // 8 waves: twice the weight loads in flight per CU (the kernel is bound by the L2 -> CU weight stream)
+// MAPF_RECUR_WAVES: 8 (what is built) = two waves per SIMD with 256 registers each and the weight stream held one job ahead in registers.
+// 16 (round 5, A/B builds only: tools/micro/recur_multi.py) = four waves per SIMD with 128 registers each -- one channel block per wave,
+// fragments requested a k-step ahead -- so that the cells' pointwise math of one wave would run under the MFMAs of its three SIMD
+// partners.  Same bits; SLOWER: 0.560 -> 0.603 ms per 4096 x 40 step, 0.509 -> 0.533 per 18 x 192 x 40 pass (27-49 spilled registers at
+// three agent tiles; requesting 2 / 3 k-steps ahead: 0.64 / 0.73).  profiles/r05_recurrence_16waves.txt
+#ifndef MAPF_RECUR_WAVES
+#define MAPF_RECUR_WAVES 8
+#endif
+constexpr int NTHR = 64 * MAPF_RECUR_WAVES;
+constexpr int NWV = MAPF_RECUR_WAVES;
+static_assert(NWV == 8 || NWV == 16, "");
 
 // LDS image (bytes)
 constexpr int H_ROW = D * 2 + 32;          // 544
@@ -99,7 +109,6 @@ constexpr int OFF_RIDX = OFF_MB + NA * 2 * 4;  // global row of every agent at t
 constexpr int OFF_BSUM = OFF_RIDX + NA * 4;   // gate biases of both cells as the accumulators want them: [cell][r: b_ir + b_hr | z: b_iz + b_hz | b_in | b_hn][256] f32
 constexpr int LDS_BYTES = OFF_BSUM + 2 * 4 * 256 * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-static_assert(NTHR == 512, "gru_pair: a wave owns exactly two of the 16 channel blocks");
 static_assert(OFF_CTX % 16 == 0 && OFF_INFO % 16 == 0 && OFF_UPD % 16 == 0 && OFF_BSUM % 16 == 0 && LDS_BYTES % 16 == 0, "");
 
 // weight buffer (bf16 elements) and bias buffer (f32 elements), see mapf_dqn.h
@@ -303,6 +312,55 @@ __device__ __forceinline__ void gru_pair(int cA, int cB, const GruInit &sA, cons
     TRACE_POINT(24);
 }
 
+// ---- sixteen waves: the weight fragments of a k-step are requested one k-step ahead, nothing is held across phases ----
+// acc_g[n] += (gate tiles f.p[g] of a packed matrix) x X for KS k-steps
+#ifndef MAPF_RECUR_JIT_AHEAD
+#define MAPF_RECUR_JIT_AHEAD 1  // k-steps a fragment is requested ahead of its MFMAs
+#endif
+template <int KS>
+__device__ __forceinline__ void jit_mfma(f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], f32x4 (&acc2)[NT], const Frag3 &f, const unsigned char *X, int xrow,
+                                         int lane) {
+    const int lr = lane & 15, lh = lane >> 4;
+    constexpr int AH = MAPF_RECUR_JIT_AHEAD < KS ? MAPF_RECUR_JIT_AHEAD : KS - 1, RING = AH + 1;
+    bf16x8 a[RING][3];
+#pragma unroll
+    for (int k0 = 0; k0 < AH; ++k0)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) a[k0][g] = f.p[g][k0 * 64];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        if (kk + AH < KS) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) a[(kk + AH) % RING][g] = f.p[g][(kk + AH) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (the requests stay in front of this k-step's MFMAs, and no further ahead)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8 *>(X + (16 * n + lr) * xrow + (32 * kk + 8 * lh) * 2);
+            acc0[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk % RING][0], b, acc0[n], 0, 0, 0);
+            acc1[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk % RING][1], b, acc1[n], 0, 0, 0);
+            acc2[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk % RING][2], b, acc2[n], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// the cell for this wave's ONE channel block
+template <bool GI_GLOBAL, int KI>
+__device__ __forceinline__ void gru_one(int cA, const GruInit &sA, const uint16_t *__restrict__ Wi, const unsigned char *Xi, int xirow,
+                                        const uint16_t *__restrict__ Wh, const float *bsum, const unsigned char *Hin, unsigned char *Hout,
+                                        const int *upd, const int *ridx, int lr, int lh, uint16_t *__restrict__ gsave) {
+    const int lane = 16 * lh + lr;
+    f32x4 ar[NT], az[NT], ani[NT], anh[NT];
+    TRACE_POINT(20);
+    gru_start<GI_GLOBAL>(sA, bsum, 16 * cA + 4 * lh, ar, az, ani, anh);
+    if (!GI_GLOBAL) jit_mfma<KI>(ar, az, ani, gate_frags(Wi, cA, KI, lane), Xi, xirow, lane);
+    jit_mfma<8>(ar, az, anh, gate_frags(Wh, cA, 8, lane), Hin, H_ROW, lane);
+    TRACE_POINT(21);
+    gru_finish(cA, ar, az, ani, anh, Hin, Hout, upd, ridx, lr, lh, gsave);
+    TRACE_POINT(24);
+}
+
 // Barrier between two phases of a step.  The weight loads are loads from read-only, non-aliased memory: the instruction scheduler moves
 // them up across s_barrier (and then spills what it fetched early) unless the barrier is also a scheduling boundary.
 __device__ __forceinline__ void phase_sync(int id = 0) {
@@ -348,8 +406,10 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
     TRACE_POINT(30);
     // the weight stream (see stream_mfma): this wave's channel blocks / q|k|v tiles are the same in every phase of every step
     const int cA = (w + rot) & 15, cB = (w + 8 + rot) & 15, wq = (w + rot) & 7;
+#if MAPF_RECUR_WAVES == 8
     bf16x8 wf[8][3], wi[2][3];
     load_frags<8>(wf, gate_frags(W + W_HH, cA, 8, lane));  // first job: the recurrent cell's block cA; under way during the prologue
+#endif
 
     // What a step reads from global memory besides the weights: its mask bytes and the recurrent cell's input projection rows of this
     // lane's agents, for both channel blocks (from HBM -- 60 KB per 40-agent environment, by all workgroups at about the same time: a
@@ -374,7 +434,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
         }
         if (!(MAPF_RECUR_ABLATE & 1)) {
             gru_fetch_gi(sA, cA, gi, grow, lh);
-            gru_fetch_gi(sB, cB, gi, grow, lh);
+            if (NWV == 8) gru_fetch_gi(sB, cB, gi, grow, lh);
         }
     };
     fetch_inputs(e, 0);
@@ -466,9 +526,14 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                 atomicOr(&mb[2 * i + (j >> 5)], 1u << (j & 31));
             }
         // ---------------- recurrent GRU cell: Hc -> Hn (the barrier behind it also publishes the mask bits) ----------------
+#if MAPF_RECUR_WAVES == 8
         if (!(MAPF_RECUR_ABLATE & 1))
             gru_pair<true, 2>(cA, cB, sA, sB, wf, wi, nullptr, nullptr, 0, W + W_HH, bsum, Hc, Hn, nullptr, ridx, lr, lh, SAVE ? sv.g1 : nullptr,
                               frag3(W + W_QKV, wq, wq + 8, wq + 16, 8, lane));
+#else
+        if (!(MAPF_RECUR_ABLATE & 1))
+            gru_one<true, 2>(cA, sA, nullptr, nullptr, 0, W + W_HH, bsum, Hc, Hn, nullptr, ridx, lr, lh, SAVE ? sv.g1 : nullptr);
+#endif
         phase_sync(2);
         {
             unsigned char *tmp = Hc;
@@ -482,6 +547,26 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
             bias = bias_arg + opaque0;
             if (SAVE) save_hidden(sv.hr + (long long)round * RTOT * D, Hc);
             // q | k | v = W_qkv h + b: 24 output tiles of 16
+            auto store_qkv = [&](int tile, const f32x4 (&acc)[NT]) {  // tile 0..7 q, 8..15 k, 16..23 v (16 channels each)
+                const int g = tile >> 3, c0 = 16 * (tile & 7) + 4 * lh;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int agent = 16 * n + lr;
+                    const uint32_t p01 = pack2_bf16(acc[n][0], acc[n][1]), p23 = pack2_bf16(acc[n][2], acc[n][3]);
+                    if (g < 2) {  // q (channels 0..127) and k (128..255): [agent][channel]
+                        *reinterpret_cast<uint2 *>(smem + OFF_QK + agent * QK_ROW + (128 * g + c0) * 2) = make_uint2(p01, p23);
+                    } else {      // v transposed: row (head, d) = c0 + r, column = agent
+                        uint16_t *vt = reinterpret_cast<uint16_t *>(smem + OFF_VT + c0 * VT_ROW) + agent;
+                        vt[0] = (uint16_t)(p01 & 0xFFFFu);
+                        vt[VT_ROW / 2] = (uint16_t)(p01 >> 16);
+                        vt[2 * (VT_ROW / 2)] = (uint16_t)(p23 & 0xFFFFu);
+                        vt[3 * (VT_ROW / 2)] = (uint16_t)(p23 >> 16);
+                    }
+                    if (SAVE && ridx[agent] >= 0)
+                        *reinterpret_cast<uint2 *>(sv.qkv + ((long long)round * RTOT + ridx[agent]) * 384 + 128 * g + c0) = make_uint2(p01, p23);
+                }
+            };
+#if MAPF_RECUR_WAVES == 8
             if (!(MAPF_RECUR_ABLATE & 2)) {  // (one job per wave)
                 f32x4 acc[3][NT];  // tiles wq (q), wq + 8 (k), wq + 16 (v)
 #pragma unroll
@@ -493,29 +578,21 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                 stream_mfma<8, true>(acc[0], acc[1], acc[2], wf, Hc, H_ROW, lane, gate_frags(W + U_HH, cA, 8, lane));  // next: the update cell
                 load_frags<2>(wi, gate_frags(W + U_IH, cA, 2, lane));
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const int agent = 16 * n + lr, c0 = 16 * wq + 4 * lh;
-                    // q (channels 0..127) and k (128..255): [agent][channel]
-                    *reinterpret_cast<uint2 *>(smem + OFF_QK + agent * QK_ROW + c0 * 2) =
-                        make_uint2(pack2_bf16(acc[0][n][0], acc[0][n][1]), pack2_bf16(acc[0][n][2], acc[0][n][3]));
-                    *reinterpret_cast<uint2 *>(smem + OFF_QK + agent * QK_ROW + (128 + c0) * 2) =
-                        make_uint2(pack2_bf16(acc[1][n][0], acc[1][n][1]), pack2_bf16(acc[1][n][2], acc[1][n][3]));
-                    // v transposed: row (head, d) = c0 + r, column = agent
-                    const uint32_t p01 = pack2_bf16(acc[2][n][0], acc[2][n][1]), p23 = pack2_bf16(acc[2][n][2], acc[2][n][3]);
-                    uint16_t *vt = reinterpret_cast<uint16_t *>(smem + OFF_VT + c0 * VT_ROW) + agent;
-                    vt[0] = (uint16_t)(p01 & 0xFFFFu);
-                    vt[VT_ROW / 2] = (uint16_t)(p01 >> 16);
-                    vt[2 * (VT_ROW / 2)] = (uint16_t)(p23 & 0xFFFFu);
-                    vt[3 * (VT_ROW / 2)] = (uint16_t)(p23 >> 16);
-                    if (SAVE && ridx[agent] >= 0) {
-                        uint16_t *qs = sv.qkv + ((long long)round * RTOT + ridx[agent]) * 384 + c0;
-                        *reinterpret_cast<uint2 *>(qs) = make_uint2(pack2_bf16(acc[0][n][0], acc[0][n][1]), pack2_bf16(acc[0][n][2], acc[0][n][3]));
-                        *reinterpret_cast<uint2 *>(qs + 128) = make_uint2(pack2_bf16(acc[1][n][0], acc[1][n][1]), pack2_bf16(acc[1][n][2], acc[1][n][3]));
-                        *reinterpret_cast<uint2 *>(qs + 256) = make_uint2(p01, p23);
-                    }
-                }
+                store_qkv(wq, acc[0]);
+                store_qkv(wq + 8, acc[1]);
+                store_qkv(wq + 16, acc[2]);
             }
+#else
+            for (int j = w; j < 24 && !(MAPF_RECUR_ABLATE & 2); j += NWV) {  // (waves 0..7: two tiles, 8..15: one -- two of each kind per SIMD)
+                const int tile = (j + rot) % 24;
+                f32x4 acc[NT];
+                const float4 b4 = *reinterpret_cast<const float4 *>(bias + B_QKV + 16 * tile + 4 * lh);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = f32x4{b4.x, b4.y, b4.z, b4.w};
+                gemm16<8>(acc, W + W_QKV, tile, Hc, H_ROW, lane);
+                store_qkv(tile, acc);
+            }
+#endif
             phase_sync(3);
             // Attention of one (head, agent tile) per wave, entirely in registers.  S^T = k q^T: an accumulator lane then holds, for ITS
             // agent i = 16 ti + lr, the scores of the partners j = 16 tj + 4 lh + r -- which is, tile pair by tile pair, the B operand
@@ -618,10 +695,16 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
             }
             phase_sync(7);
             // update cell: Hc -> Hn where the agent has a partner
+#if MAPF_RECUR_WAVES == 8
             if (!(MAPF_RECUR_ABLATE & 16))  // behind it: the second round's q|k|v, or the next step's recurrent cell (a wasted fetch at the last step of the last environment)
                 gru_pair<false, 2>(cA, cB, sA, sB, wf, wi, W + U_IH, smem + OFF_INFO, INFO_ROW, W + U_HH, bsum + 1024, Hc, Hn, upd, ridx, lr, lh,
                                    SAVE ? sv.g2 + (long long)round * RTOT * 1024 : nullptr,
                                    round == 0 ? frag3(W + W_QKV, wq, wq + 8, wq + 16, 8, lane) : gate_frags(W + W_HH, cA, 8, lane));
+#else
+            if (!(MAPF_RECUR_ABLATE & 16))
+                gru_one<false, 2>(cA, sA, W + U_IH, smem + OFF_INFO, INFO_ROW, W + U_HH, bsum + 1024, Hc, Hn, upd, ridx, lr, lh,
+                                  SAVE ? sv.g2 + (long long)round * RTOT * 1024 : nullptr);
+#endif
             phase_sync(8);
             unsigned char *tmp = Hc;
             Hc = Hn;
