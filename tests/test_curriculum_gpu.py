@@ -138,3 +138,41 @@ def test_graph_replayed_actor_iterations_interleaved_with_learner_updates(update
         assert abs(float(tree[0]) - float(leaves.sum())) < 1e-6 * float(tree[0])
     finally:
         FusedUpdate.GRAPH = saved
+
+
+def test_actors_on_the_learners_own_module_leave_the_graph_when_its_weights_change():
+    """Advisor, round 4: with weights_period=None the actors act on the learner's module itself; a captured iteration reads the packed
+    weight images and cached latents of the last directly issued iteration, so replaying it after an optimizer step would mix stale
+    encoder / recurrence weights with the live head.  The graph is keyed on the acting weights (epoch + every parameter's address and
+    version): while they stand still iterations are replayed, after any change one is issued directly, re-packing the images and
+    re-encoding every observation."""
+    import config
+    from mapf_rl_amd.curriculum import CurriculumActors
+    from mapf_rl_amd.model import Network
+    from mapf_rl_amd.replay import GlobalBuffer
+
+    def make(model):
+        buf = GlobalBuffer(512, max_agents=6, init_set=(1, 10), max_map_length=40, pass_rate=0.9)
+        buf.stat_dict = {k: [] for k in [(2, 10), (4, 15)]}
+        return CurriculumActors(model, buf, envs_per_level=64, seed=3, max_steps=24, reward_fn=config.reward_fn, weights_period=None)
+
+    torch.manual_seed(1)
+    model = Network().cuda()
+    cur = make(model)
+    for _ in range(8):
+        cur.step()
+    r0 = cur.graph_replays
+    assert r0 >= 4
+    with torch.no_grad():                       # "an optimizer step": every parameter moves, in place
+        for p in model.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    model.weights_epoch += 1
+    cur.step()
+    assert cur.graph_replays == r0              # issued directly, not replayed
+    rows = sum(a.E * a.N for a in cur.actors.values())
+    assert cur.latents.last_encoded() == rows   # ... with every observation re-encoded under the new weights (no stale latent survives)
+    cur.step()
+    assert cur.graph_replays == r0 + 1          # replayed again from then on
+    torch.cuda.synchronize()
+    for a in cur.actors.values():
+        a.env.check_status()
