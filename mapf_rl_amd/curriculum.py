@@ -327,14 +327,14 @@ class CurriculumActors:
         dev = self.device
         cur = torch.cuda.current_stream(dev)
         cur.synchronize()
-        from .fused import no_gc_during_capture, warm_up_gemm_library
+        from .fused import capture_mode, no_gc_during_capture, warm_up_gemm_library
 
         if self._cap_stream is None:
             self._cap_stream = torch.cuda.Stream(device=dev)
             warm_up_gemm_library(self._cap_stream)
         g = torch.cuda.CUDAGraph()
         with no_gc_during_capture(), torch.cuda.stream(self._cap_stream):
-            g.capture_begin()
+            g.capture_begin(capture_error_mode=capture_mode())
             try:
                 self._iteration()
             finally:

@@ -35,6 +35,15 @@ def warm_up_gemm_library(stream):
     stream.synchronize()
 
 
+def capture_mode():
+    """Error mode of a stream capture: "global" (PyTorch's default: an unsafe runtime call from ANY thread invalidates the capture) on a
+    single rank; "thread_local" once a process group exists -- its watchdog thread queries the events of collectives from outside
+    (hipEventQuery), which a global-mode capture on the main thread must not be failed by."""
+    import torch.distributed as dist
+
+    return "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+
+
 @contextlib.contextmanager
 def no_gc_during_capture():
     """Keeps Python's cyclic garbage collector from running while a stream is being captured.  A collection that happens to fall into

@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from ._lib import check, lib
-from .fused import (no_gc_during_capture, warm_up_gemm_library, ENC_OBS_PER_BLOCK, ENC_WGRAD0_PARTS, ENC_WGRAD_PARTS, RECUR_NARROW_AGENTS, RECUR_WEIGHT_ELEMS, PackedEncoder,
+from .fused import (capture_mode, no_gc_during_capture, warm_up_gemm_library, ENC_OBS_PER_BLOCK, ENC_WGRAD0_PARTS, ENC_WGRAD_PARTS, RECUR_NARROW_AGENTS, RECUR_WEIGHT_ELEMS, PackedEncoder,
                     PackedRecurrence, pack_encoder_backward, recurrence_params, rows_buffer, ENC_ELEMENT, INPROJ_PACKED_ELEMS, LATGRAD_PACKED_ELEMS,
                     input_proj_rows, latent_grad_rows, sum_parts_into, tall_tn_into)
 
@@ -764,7 +764,7 @@ class FusedUpdate:
         self._capturing = True
         try:
             with no_gc_during_capture(), torch.cuda.stream(self._cap_stream):
-                g.capture_begin(pool=self._pools.get(pool))
+                g.capture_begin(pool=self._pools.get(pool), capture_error_mode=capture_mode())
                 try:
                     out = fn()
                 finally:
