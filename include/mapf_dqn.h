@@ -233,9 +233,8 @@ int mapf_input_proj_rows(const uint16_t *latent_dev, int64_t num_rows, const int
  *   mapf_tall_tn: out[m][n] (f32, row-major, ld n) = [accumulate ? out : 0] + scale * sum_k a[k][m] b[k][n]; a [K][lda], b [K][ldb]
  *     16-bit (bf16, or f16 when f16 != 0), m, n, lda, ldb multiples of 8, 16-byte aligned; scale = the float at scale_dev[1]
  *     (the encoder chain's 1 / loss scale, include above) or 1 when NULL.  K is split into mapf_tall_tn_plan's `parts` partitions
- *     whose partial slabs go through ws_dev (>= mapf_tall_tn_plan's ws_elems floats, at most 2^18 floats + one slab per output slab) and are
- *     summed in partition order by the last workgroup of a slab (counters_dev: >= slabs int32, zero on entry, zero again on exit):
- *     deterministic, one launch.
+ *     whose partial slabs go through ws_dev (>= mapf_tall_tn_plan's ws_elems floats) and are summed in partition order by a second,
+ *     small launch: deterministic.  (An agent-scope fence + last-arriver sum inside the one launch cost 100 us per product.)
  *   mapf_sum_parts: out_dev[g][i] = scale * sum_p parts_dev[g][p * n + i] for `groups` <= 8 pointer pairs (HOST arrays of device
  *     pointers), n a multiple of 4: the per-partition slabs of mapf_encoder_wgrad for up to six layers in one launch.
  *   mapf_encoder_small_grads: the encoder's bias gradients from mapf_encoder_backward's per-workgroup partials (gb_part [7][nblk][128]
@@ -250,7 +249,7 @@ int mapf_input_proj_rows(const uint16_t *latent_dev, int64_t num_rows, const int
 #define MAPF_LATGRAD_PACKED_ELEMS 602112
 int mapf_tall_tn_plan(int64_t K, int m, int n, int *slabs_out, int *parts_out, int64_t *ws_elems_out);
 int mapf_tall_tn(const uint16_t *a_dev, int64_t lda, const uint16_t *b_dev, int64_t ldb, int64_t K, int m, int n, int f16, float *out_dev,
-                 const uint32_t *scale_dev, int accumulate, float *ws_dev, int64_t ws_elems, int32_t *counters_dev, int num_counters, void *stream);
+                 const uint32_t *scale_dev, int accumulate, float *ws_dev, int64_t ws_elems, void *stream);
 int mapf_sum_parts(const float *const *parts_dev, float *const *out_dev, int groups, int P, int64_t n, const uint32_t *scale_dev, void *stream);
 #define MAPF_SMALL_GRADS_SCRATCH_ELEMS 65536 /* 8 x 64 x 128 floats */
 int mapf_encoder_small_grads(const float *gb_part_dev, int64_t nblk, float *bias7_out_dev, const float *gb7_part_dev, int64_t rows7,

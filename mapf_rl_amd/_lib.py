@@ -113,7 +113,7 @@ SYMBOLS = [
     ("mapf_to_bf16", _i, [_vp, _vp, ctypes.c_int64, _vp]),
     ("mapf_zero_rows", _i, [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, ctypes.c_int64, ctypes.c_int64, _vp]),
     ("mapf_tall_tn_plan", _i, [ctypes.c_int64, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_int64)]),
-    ("mapf_tall_tn", _i, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int64, _i, _i, _i, _vp, _vp, _i, _vp, ctypes.c_int64, _vp, _i, _vp]),
+    ("mapf_tall_tn", _i, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int64, _i, _i, _i, _vp, _vp, _i, _vp, ctypes.c_int64, _vp]),
     ("mapf_sum_parts", _i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, ctypes.c_int64, _vp, _vp]),
     ("mapf_encoder_small_grads", _i, [_vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64, _vp, _vp, _i, _vp, _vp, _vp]),
     ("mapf_latent_grad_pack", _i, [_vp, _vp, _vp]),

@@ -6,8 +6,7 @@
 //   mapf_tall_tn     weight gradients  dW[m][n] = sum_k dY[k][m] X[k][n]  with K = 10^4 .. 10^6 rows and a small output (the GRU cells,
 //                    q|k|v, W_O, the input projection, the encoder's 1x1 head): both operands stored row-major with K as the ROW index,
 //                    so both MFMA fragments come out of LDS through the transposing read (ds_read_b64_tr_b16); split over K into
-//                    partitions whose fp32 partial slabs are summed -- in partition order, deterministically -- by whichever workgroup of
-//                    a slab finishes last (no second launch);
+//                    partitions whose fp32 partial slabs a second, small launch sums in partition order (deterministic);
 //   mapf_sum_parts   out[i] = scale * sum_p parts[p][i]: the encoder's per-partition weight-gradient slabs (6 layers in one launch),
 //                    its bias partials, conv0's slab with the column -> [co][ky][kx][ci] permutation;
 //   mapf_proj_rows   y[row] = W x[row] for all rows, W a packed fragment image: the GRU's input projection W_ih (768 x 784) forward --
@@ -436,12 +435,11 @@ int mapf_tall_tn_plan(int64_t K, int m, int n, int *slabs_out, int *parts_out, i
 }
 
 int mapf_tall_tn(const uint16_t *a_dev, int64_t lda, const uint16_t *b_dev, int64_t ldb, int64_t K, int m, int n, int f16, float *out_dev,
-                 const uint32_t *scale_dev, int accumulate, float *ws_dev, int64_t ws_elems, int32_t *counters_dev, int num_counters, void *stream) {
+                 const uint32_t *scale_dev, int accumulate, float *ws_dev, int64_t ws_elems, void *stream) {
     if (K < 0 || m < 1 || n < 1 || !out_dev || (K > 0 && (!a_dev || !b_dev)) || lda < m || ldb < n) return MAPF_ERR_INVALID_ARG;
     if ((lda & 7) || (ldb & 7) || (m & 7) || (n & 7) || !aligned16(a_dev) || !aligned16(b_dev) || !aligned16(out_dev) || !aligned16(ws_dev))
         return MAPF_ERR_INVALID_ARG;
     const TallPlan p = tall_plan(K, m, n);
-    (void)counters_dev, (void)num_counters;  // (kept in the signature: round 5's first, fenced single-launch reduction used them)
     if (p.parts > 1 && (!ws_dev || ws_elems < (int64_t)p.slabs * p.parts * p.sm * p.sn))
         return MAPF_ERR_INVALID_ARG;
     const dim3 grid((n + p.sn - 1) / p.sn, (m + p.sm - 1) / p.sm, p.parts);

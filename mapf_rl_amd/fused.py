@@ -132,7 +132,7 @@ def mm_rows(x, w, transpose_w=True):
 
 
 # ---- this library's own dense products / reductions for the learner (csrc/mapf_gemm.hip) ----
-_TALL_WS = {}  # (device index, stream) -> (workspace f32, counters i32): launches on one stream are serial, streams must not share
+_TALL_WS = {}  # (device index, stream) -> workspace f32: launches on one stream are serial, streams must not share
 
 
 def _tall_ws(dev):
@@ -140,13 +140,13 @@ def _tall_ws(dev):
     ws = _TALL_WS.get(key)
     if ws is None:
         # per output slab at most 2 MiB of partial slabs + one (mapf_tall_tn_plan); the widest output here, 768 x 784, has 42 slabs: 128 MiB
-        ws = _TALL_WS[key] = (torch.empty(32 << 20, dtype=torch.float32, device=dev), torch.zeros(256, dtype=torch.int32, device=dev))
+        ws = _TALL_WS[key] = torch.empty(32 << 20, dtype=torch.float32, device=dev)
     return ws
 
 
 def prepare_tall_ws(dev, streams):
     """Allocates the workspaces of `streams` now -- outside any capture: a workspace first touched while a stream is capturing would come
-    from the capture's private pool, and its zeroed counters would be a memset node (see update.FusedUpdate._plan_rows)."""
+    from the capture's private pool."""
     for s in streams:
         if s is not None:
             with torch.cuda.stream(s):
@@ -155,15 +155,15 @@ def prepare_tall_ws(dev, streams):
 
 def tall_tn_into(out, a, b, scale=None, accumulate=False):
     """out[m, n] (f32, contiguous) = [out +] scale * a^T b for 16-bit a [K, m], b [K, n] (rows may be strided views) with K in the
-    10^4 .. 10^6 range: mapf_tall_tn -- split over K, fp32 partial slabs summed in partition order by the last workgroup of a slab.
+    10^4 .. 10^6 range: mapf_tall_tn -- split over K, fp32 partial slabs summed in partition order by a second small launch.
     scale: the int32 [2] tensor of mapf_encoder_backward (bits of 1 / loss scale at [1]) or None."""
     K, m = a.shape
     n = b.shape[1]
     assert b.shape[0] == K and out.shape == (m, n) and out.is_contiguous() and out.dtype == torch.float32 and a.dtype == b.dtype
     assert a.stride(1) == 1 and b.stride(1) == 1
-    ws, cnt = _tall_ws(a.device)
+    ws = _tall_ws(a.device)
     check(lib.mapf_tall_tn(_ptr(a), a.stride(0) if K > 1 else m, _ptr(b), b.stride(0) if K > 1 else n, K, m, n, int(a.dtype == torch.float16), _ptr(out),
-                           _ptr(scale), int(accumulate), _ptr(ws), ws.numel(), _ptr(cnt), cnt.numel(), _stream(a.device)), "mapf_tall_tn")
+                           _ptr(scale), int(accumulate), _ptr(ws), ws.numel(), _stream(a.device)), "mapf_tall_tn")
     return out
 
 
