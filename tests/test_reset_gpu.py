@@ -174,3 +174,34 @@ def test_reset_without_a_staged_scenario_is_reported():
     assert ex.value.status == ERR_NOT_READY
     env.reset_envs(mask, 0.2, seed=4)        # not the staged stream: drawn directly
     env.check_status()
+
+
+def test_staged_resets_at_the_full_baseline_size():
+    """BASELINE config 2's launch (4096 environments, 32x32, 40 agents): three rounds of staged resets with a third of the
+    environments flagged each time -- the invariants the reference guarantees by construction for every environment, navigation
+    fields equal to the oracle's on a sample, step counters zeroed exactly where flagged, and no environment left without a staged
+    scenario (sticky status clean)."""
+    import mapf_rl_amd as M
+
+    E, L, N = 4096, 32, 40
+    env = M.VecEnvironment(E, L, N)
+    env.reset_envs(None, 0.3, seed=21)
+    rng = np.random.RandomState(9)
+    acts = torch.zeros((E, N), dtype=torch.int8, device="cuda")
+    for rnd in range(3):
+        env.stage_next(0.3, seed=21)
+        env.step(acts)                                   # every environment's step counter moves to 1
+        mask = torch.from_numpy((rng.random_sample(E) < 0.33).astype(np.uint8)).cuda()
+        before = _np(env.maps())
+        env.reset_envs(mask, 0.3, seed=21)
+        env.check_status()
+        steps = _np(env.steps())
+        after = _np(env.maps())
+        m = _np(mask).astype(bool)
+        assert np.all(steps[m] == 0) and np.all(steps[~m] >= 1)   # step counters zeroed exactly where flagged
+        assert np.array_equal(after[~m], before[~m])     # unflagged environments untouched
+        assert (after[m] != before[m]).reshape(m.sum(), -1).any(axis=1).mean() > 0.99   # flagged ones re-drawn
+    maps, agents, goals = _np(env.maps()), _np(env.agents_pos()), _np(env.goals_pos())
+    _check_invariants(maps[:512], agents[:512], goals[:512], L, N)
+    sample = np.arange(0, E, 64)
+    assert np.array_equal(_np(env.navi_map())[sample], oracle.navi_batch(maps[sample], goals[sample]))
