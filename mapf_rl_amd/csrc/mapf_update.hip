@@ -54,6 +54,7 @@ struct PlanMarkArgs {
 __global__ void __launch_bounds__(128) plan_mark_kernel(PlanMarkArgs p) {
     __shared__ unsigned long long s_ballot[2];
     __shared__ int s_key[128], s_last[128], s_ord[128], s_cnt[128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_m[128 * 128];
     const int b = blockIdx.x, j = threadIdx.x, wv = j >> 6, T = p.T, N = p.N;
     const long long last = p.steps[b] + (p.extra ? (long long)p.extra[b] : 0) - 1;
     unsigned long long r0 = 0, r1 = 0;
@@ -64,7 +65,17 @@ __global__ void __launch_bounds__(128) plan_mark_kernel(PlanMarkArgs p) {
             r0 = N >= 64 ? ~0ull : ((1ull << N) - 1ull);
             r1 = N > 64 ? (N >= 128 ? ~0ull : ((1ull << (N - 64)) - 1ull)) : 0ull;
         } else if (t <= last) {
-            const uint8_t *m = p.comm + (long long)b * p.sB + (long long)t * p.sT;
+            // the step's mask goes to LDS first: the closure below reads ~2 x |needed| of its bytes per thread, one after the other --
+            // from global memory that was a load latency each (round 5: 170 -> ~25 us per launch at 40 agents)
+            const uint8_t *mg = p.comm + (long long)b * p.sB + (long long)t * p.sT;
+            const int NN = N * N;
+            if ((reinterpret_cast<uintptr_t>(mg) & 3) == 0 && (NN & 3) == 0) {
+                for (int i = j; i < NN / 4; i += 128) reinterpret_cast<uint32_t *>(s_m)[i] = reinterpret_cast<const uint32_t *>(mg)[i];
+            } else {
+                for (int i = j; i < NN; i += 128) s_m[i] = mg[i];
+            }
+            __syncthreads();
+            const uint8_t *m = s_m;
             for (int round = 0; round < 2; ++round) {  // i needed and i reads j  =>  j needed (two attention rounds per step)
                 bool v = false;
                 for (unsigned long long w = r0; w != 0 && j < N; w &= w - 1) v |= m[(__ffsll((long long)w) - 1) * N + j] != 0;
@@ -142,18 +153,30 @@ __global__ void __launch_bounds__(256) obs_dup_kernel(ObsDupArgs p) {
     for (long long w = (long long)blockIdx.x * 4 + wv; w < total; w += (long long)gridDim.x * 4) {
         const int j = (int)(w % p.N), b = (int)(w / p.N);
         const int st = p.slot_t[(size_t)b * p.N + j], so = p.slot_o[(size_t)b * p.N + j];
-        // the steps at which this agent is needed form a prefix 0 .. nt - 1 (the needed set only shrinks going forward)
-        int nt = 0, no = 0;
-        for (int t = 0; t < p.T; ++t) nt += (st >= 0 && st < p.nact_t[(size_t)t * p.B + b]) ? 1 : 0;
-        for (int t = 0; t < p.To; ++t) no += (so >= 0 && so < p.nact_o[(size_t)t * p.B + b]) ? 1 : 0;
+        // the steps at which this agent is needed form a prefix 0 .. nt - 1 (the needed set only shrinks going forward): lane t looks at
+        // step t (one load latency for the whole window; a loop over the steps paid one per step -- round 5)
+        const bool need_t = lane < p.T && st >= 0 && st < p.nact_t[(size_t)lane * p.B + b];
+        const bool need_o = lane < p.To && so >= 0 && so < p.nact_o[(size_t)lane * p.B + b];
+        const int nt = __popcll(__ballot(need_t)), no = __popcll(__ballot(need_o));
         const uint16_t *base = p.obs + (long long)b * p.o_sB + (long long)j * 486;
-        for (int t = 0; t < nt; ++t) {  // (wave-uniform trip count)
-            const uint32_t *row = reinterpret_cast<const uint32_t *>(base + (long long)t * p.o_sT);
-            unsigned long long h = 0;
-            for (int d = lane; d < 243; d += 64) h += mix64u(((unsigned long long)row[d] << 8) ^ (unsigned long long)d);
+        for (int t0 = 0; t0 < nt; t0 += 4) {  // (wave-uniform trip count; the rows of four steps are requested together)
+            uint32_t v[4][4];
 #pragma unroll
-            for (int s2 = 32; s2 > 0; s2 >>= 1) h += __shfl_xor(h, s2, 64);
-            if (lane == 0) s_hash[wv][t] = h;
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t *row = reinterpret_cast<const uint32_t *>(base + (long long)(t0 + u < nt ? t0 + u : t0) * p.o_sT);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[u][q] = lane + 64 * q < 243 ? row[lane + 64 * q] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                unsigned long long h = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (lane + 64 * q < 243) h += mix64u(((unsigned long long)v[u][q] << 8) ^ (unsigned long long)(lane + 64 * q));
+#pragma unroll
+                for (int s2 = 32; s2 > 0; s2 >>= 1) h += __shfl_xor(h, s2, 64);
+                if (lane == 0 && t0 + u < nt) s_hash[wv][t0 + u] = h;
+            }
         }
         int distinct_t = 0, distinct_o = 0;
         for (int t = 0; t < p.T; ++t) {
