@@ -497,17 +497,31 @@ def main():
                 actor.step(actions_override=heuristic_actions(actor.obs, gen).long())
             torch.cuda.synchronize()
 
+            pull_s = [0.0]  # the snapshot refresh of every timed_actor call in turn, seconds: [0] = the latest
+
             def timed_actor(tape, iters):
                 """ms per actor iteration + share of agent rows the encoder saw (an unchanged observation keeps its latent)."""
                 enc = 0
                 for _ in range(60):  # untimed: let the population of moving / standing agents settle under this policy (steady state: >= 50)
                     actor.step(actions_override=heuristic_actions(actor.obs, gen).long() if tape else None)
+                # the snapshot refresh (one iteration in weights_period = 400: load_state_dict + re-packing the weight images) is timed
+                # by itself below and charged at 1/400 per iteration, wherever the iteration counter happens to stand in this window
+                # (rounds 2-5 left that to chance: the greedy window fell on iteration 400 and carried a whole refresh over 12 iterations)
+                actor._since_pull = 1
                 torch.cuda.synchronize()
                 t_ = time.perf_counter()
                 for _ in range(iters):
                     actor.step(actions_override=heuristic_actions(actor.obs, gen).long() if tape else None)
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t_) / iters
+                if actor.weights_period is not None:
+                    actor._since_pull = actor.weights_period
+                    t_ = time.perf_counter()
+                    actor.step(actions_override=heuristic_actions(actor.obs, gen).long() if tape else None)
+                    torch.cuda.synchronize()
+                    pull_s[0] = max(time.perf_counter() - t_ - dt, 0.0)  # (with the latent cache: + every row encoded once again)
+                    pull_s.append(pull_s[0])
+                    dt += pull_s[0] / actor.weights_period
                 if actor.latents is not None:  # (a second, untimed pass for the statistic: reading the device counter synchronises)
                     for _ in range(4):
                         actor.step(actions_override=heuristic_actions(actor.obs, gen).long() if tape else None)
@@ -578,6 +592,8 @@ def main():
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
+            pulls_before = actor._since_pull
+            pull_greedy = pull_s[2] if len(pull_s) > 2 else pull_s[0]  # (the train loop's actor iteration is the greedy one)
             t1 = time.perf_counter()
             for _ in range(args.train_iters):
                 train_iteration()
@@ -586,6 +602,9 @@ def main():
             if world > 1:
                 dist.barrier()
             dt_train = (time.perf_counter() - t1) / args.train_iters
+            if actor._since_pull < pulls_before + args.train_iters:  # a refresh fell inside the window: charged below like the actor loops'
+                dt_train -= pull_greedy / args.train_iters
+            dt_train += pull_greedy / actor.weights_period
             env.check_status()
             if world > 1:
                 tt = torch.tensor([dt_upd, dt_act, dt_train, dt_upd_all, dt_act_tape, dt_act_all], dtype=torch.float64, device=dev)
@@ -629,6 +648,7 @@ def main():
                     N, "flat-bucket RCCL all-reduce x%d (synchronous data parallel: this is the job's update rate, global batch %d)" % (
                         world, 192 * world) if world > 1 else "1 GPU"),
                 "actor_loop_env_steps_per_sec": world * E / dt_act, "actor_loop_ms_per_iter": dt_act * 1e3,
+                "actor_weights_refresh_ms": pull_s[2] * 1e3 if len(pull_s) > 2 else None,
                 "actor_loop_rows_encoded_fraction": enc_greedy,
                 "actor_loop_tape_policy_env_steps_per_sec": world * E / dt_act_tape, "actor_loop_tape_policy_ms_per_iter": dt_act_tape * 1e3,
                 "actor_loop_tape_policy_rows_encoded_fraction": enc_tape,
@@ -638,7 +658,7 @@ def main():
                                    "agents move: actor_loop_* = the network's own greedy actions (random-init weights: most agents stand), "
                                    "actor_loop_tape_policy_* = the bench tape's 80 %% heuristic-following actions executed instead, "
                                    "actor_loop_every_row_* = every agent row through the encoder every step (round 2's loop)",
-                "actor_loop_config": "Network.step_batch (bf16) + mapf_step + local-buffer recording + episode flush into the device replay, %d envs x %d agents per GPU; weights snapshot pulled every %d iterations (config.actor_update_steps)" % (E, N, ref_config.actor_update_steps),
+                "actor_loop_config": "Network.step_batch (bf16) + mapf_step + local-buffer recording + episode flush into the device replay, %d envs x %d agents per GPU; weights snapshot pulled every %d iterations (config.actor_update_steps; timed by itself -- actor_weights_refresh_ms -- and charged at 1/%d per iteration)" % (E, N, ref_config.actor_update_steps, ref_config.actor_update_steps),
                 "train_loop_updates_per_sec": 1.0 / dt_train, "train_loop_env_steps_per_sec": world * E / dt_train,
                 "train_loop_ms_per_iter": dt_train * 1e3,
                 "train_loop_config": "one actor iteration (%d envs/GPU) + one learner update per iteration, the actor iteration on its own stream beside the update as in train.py (--overlap-actors)" % E,
