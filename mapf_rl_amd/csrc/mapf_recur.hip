@@ -110,6 +110,25 @@ constexpr int OFF_BSUM = OFF_RIDX + NA * 4;   // gate biases of both cells as th
 constexpr int LDS_BYTES = OFF_BSUM + 2 * 4 * 256 * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(OFF_CTX % 16 == 0 && OFF_INFO % 16 == 0 && OFF_UPD % 16 == 0 && OFF_BSUM % 16 == 0 && LDS_BYTES % 16 == 0, "");
+// TWO environments per workgroup (round 5, recurrent_infer_kernel<false, true>; the one-step launches of the actor, where a CU has many
+// environments to walk): every weight fragment a wave fetches serves both environments' MFMAs -- a step is bound by the L2 -> CU weight
+// stream (1.8 MB per environment step at 64 B/clk), this halves it.  Two of the images above do not fit in 160 KB, so per environment only
+//   [ H a | H b | v^T ]   (H a / H b: hidden state, current and next, trading places as above)
+// is kept and the rest lives in bytes that are dead at the time:
+//   q | k      in the NEXT-state buffer (dead between a cell and the update cell behind it; same 544-byte rows),
+//   ctx        over the q half of the same rows: the wave of a (head, agent tile) is the only reader of that tile's q of that head, and has
+//              it in registers before its first ctx store (one wave per (head, tile) in this mode, whatever NT),
+//   info       over the first NA rows of v^T (dead between the attention and the next q|k|v; the slots >= NA of those rows, which the
+//              attention multiplies by P = 0, are zeroed again in front of the next q|k|v: 0 x garbage could be 0 x Inf).
+constexpr int P_OFF_VT = 2 * H_BYTES;
+constexpr int P_ENV = P_OFF_VT + 128 * VT_ROW;
+constexpr int P_OFF_UPD = 2 * P_ENV;                 // [2][64] int
+constexpr int P_OFF_MB = P_OFF_UPD + 2 * 64 * 4;     // [2][NA][2] words
+constexpr int P_OFF_RIDX = P_OFF_MB + 2 * NA * 2 * 4;
+constexpr int P_OFF_BSUM = P_OFF_RIDX + 2 * NA * 4;
+constexpr int P_LDS_BYTES = P_OFF_BSUM + 2 * 4 * 256 * 4;
+static_assert(P_LDS_BYTES <= 160 * 1024, "LDS budget (two environments)");
+static_assert(P_ENV % 16 == 0 && P_OFF_BSUM % 16 == 0 && QK_ROW == H_ROW && INFO_ROW == VT_ROW, "");
 
 // weight buffer (bf16 elements) and bias buffer (f32 elements), see mapf_dqn.h
 constexpr int W_HH = 0, W_QKV = W_HH + 768 * 256, W_O = W_QKV + 384 * 256, U_IH = W_O + 64 * 128, U_HH = U_IH + 768 * 64;
@@ -181,7 +200,7 @@ __device__ __forceinline__ void load_frags(bf16x8 (&a)[KS][3], const Frag3 &f) {
 }
 
 // acc_g[n] += a[kk][g] x X for all k-steps; with RELOAD every k-step's fragments are replaced by `next`'s once used
-template <int KS, bool RELOAD>
+template <int KS, bool RELOAD, bool PIN = false>
 __device__ __forceinline__ void stream_mfma(f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], f32x4 (&acc2)[NT], bf16x8 (&a)[KS][3], const unsigned char *X,
                                             int xrow, int lane, const Frag3 &next) {
     const int lr = lane & 15, lh = lane >> 4;
@@ -198,6 +217,8 @@ __device__ __forceinline__ void stream_mfma(f32x4 (&acc0)[NT], f32x4 (&acc1)[NT]
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < 3; ++g) a[kk][g] = next.p[g][kk * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        } else if (PIN) {  // (two environments: the first one's k-steps stay in order too, or all their activation reads are hoisted to the top)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -283,32 +304,51 @@ __device__ __forceinline__ void gru_finish(int cblk, const f32x4 (&ar)[NT], cons
     }
 }
 
-// The cell for the wave's two channel blocks cA, cB.  On entry wf holds W_h's gate tiles of cA (and wi W_i's, KI k-steps, when the
+// The cell for the wave's two channel blocks cA, cB, of NE environments (2: the weight fragments of a block serve both environments'
+// MFMAs before the next block's replace them).  On entry wf holds W_h's gate tiles of cA (and wi W_i's, KI k-steps, when the
 // input projection is computed here); on exit wf holds `next` (wi is spent).  sA / sB: the blocks' input projection rows (GI_GLOBAL).
-template <bool GI_GLOBAL, int KI>
-__device__ __forceinline__ void gru_pair(int cA, int cB, const GruInit &sA, const GruInit &sB, bf16x8 (&wf)[8][3], bf16x8 (&wi)[KI][3],
-                                         const uint16_t *__restrict__ Wi, const unsigned char *Xi, int xirow, const uint16_t *__restrict__ Wh,
-                                         const float *bsum, const unsigned char *Hin, unsigned char *Hout, const int *upd, const int *ridx, int lr,
-                                         int lh, uint16_t *__restrict__ gsave, const Frag3 &next) {
+// (Tried with two environments: block cB's input projection rows requested inside the cell, into the registers block cA's had just left --
+// four GruInit at once cost spills at three agent tiles.  Slower at every shape: the rows come from HBM, and the second request wave pays
+// its latency again: 0.585 -> 0.629 ms at 4096 x 40, 0.328 -> 0.362 at 4096 x 24.)
+template <bool GI_GLOBAL, int KI, int NE>
+__device__ __forceinline__ void gru_pair(int cA, int cB, const GruInit (&sA)[NE], const GruInit (&sB)[NE], bf16x8 (&wf)[8][3], bf16x8 (&wi)[KI][3],
+                                         const uint16_t *__restrict__ Wi, const unsigned char *const (&Xi)[NE], int xirow,
+                                         const uint16_t *__restrict__ Wh, const float *bsum, const unsigned char *const (&Hin)[NE],
+                                         unsigned char *const (&Hout)[NE], const int *const (&upd)[NE], const int *const (&ridx)[NE], int lr, int lh,
+                                         uint16_t *__restrict__ gsave, const Frag3 &next) {
     const int lane = 16 * lh + lr;
     f32x4 ar[NT], az[NT], ani[NT], anh[NT];
     TRACE_POINT(20);
     // (Tried, round 5: waves 4-7 -- the SIMD partners of 0-3 -- entering a cell 640 / 1280 / 1920 cycles late (s_sleep), and the partners at
     // different issue priorities (s_setprio), so that one's MFMA chain would run under the other's pointwise math: 0.550 -> 0.544 / 0.546 /
     // 0.554 ms per 4096 x 40 step, nothing at 18 x 192 x 40.  profiles/r05_recurrence_stagger.txt)
-    gru_start<GI_GLOBAL>(sA, bsum, 16 * cA + 4 * lh, ar, az, ani, anh);
-    if (!GI_GLOBAL) stream_mfma<KI, true>(ar, az, ani, wi, Xi, xirow, lane, gate_frags(Wi, cB, KI, lane));
-    stream_mfma<8, true>(ar, az, anh, wf, Hin, H_ROW, lane, gate_frags(Wh, cB, 8, lane));
-    TRACE_POINT(21);
-    gru_finish(cA, ar, az, ani, anh, Hin, Hout, upd, ridx, lr, lh, gsave);
-    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < NE; ++s) {
+        gru_start<GI_GLOBAL>(sA[s], bsum, 16 * cA + 4 * lh, ar, az, ani, anh);
+        if (s == NE - 1) {
+            if (!GI_GLOBAL) stream_mfma<KI, true>(ar, az, ani, wi, Xi[s], xirow, lane, gate_frags(Wi, cB, KI, lane));
+            stream_mfma<8, true>(ar, az, anh, wf, Hin[s], H_ROW, lane, gate_frags(Wh, cB, 8, lane));
+        } else {
+            if (!GI_GLOBAL) stream_mfma<KI, false, true>(ar, az, ani, wi, Xi[s], xirow, lane, next);
+            stream_mfma<8, false, true>(ar, az, anh, wf, Hin[s], H_ROW, lane, next);
+        }
+        if (s == 0) TRACE_POINT(21);
+        gru_finish(cA, ar, az, ani, anh, Hin[s], Hout[s], upd[s], ridx[s], lr, lh, gsave);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     TRACE_POINT(22);
-    gru_start<GI_GLOBAL>(sB, bsum, 16 * cB + 4 * lh, ar, az, ani, anh);
-    if (!GI_GLOBAL) stream_mfma<KI, false>(ar, az, ani, wi, Xi, xirow, lane, next);
-    stream_mfma<8, true>(ar, az, anh, wf, Hin, H_ROW, lane, next);
-    TRACE_POINT(23);
-    gru_finish(cB, ar, az, ani, anh, Hin, Hout, upd, ridx, lr, lh, gsave);
-    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < NE; ++s) {
+        gru_start<GI_GLOBAL>(sB[s], bsum, 16 * cB + 4 * lh, ar, az, ani, anh);
+        if (!GI_GLOBAL) stream_mfma<KI, false, (NE > 1)>(ar, az, ani, wi, Xi[s], xirow, lane, next);
+        if (s == NE - 1)
+            stream_mfma<8, true>(ar, az, anh, wf, Hin[s], H_ROW, lane, next);
+        else
+            stream_mfma<8, false, true>(ar, az, anh, wf, Hin[s], H_ROW, lane, next);
+        if (s == 0) TRACE_POINT(23);
+        gru_finish(cB, ar, az, ani, anh, Hin[s], Hout[s], upd[s], ridx[s], lr, lh, gsave);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     TRACE_POINT(24);
 }
 
@@ -371,25 +411,29 @@ __device__ __forceinline__ void phase_sync(int id = 0) {
     TRACE_POINT(id + 100);
 }
 
-template <bool SAVE>
+template <bool SAVE, bool PAIR>
 __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t *__restrict__ gi, const uint16_t *__restrict__ h0,
                                                                   const uint8_t *__restrict__ comm, const uint16_t *__restrict__ W,
                                                                   const float *__restrict__ bias, int T, int E, int N_arg,
                                                                   uint16_t *__restrict__ h_out, uint16_t *__restrict__ agent0_out,
                                                                   RecurSave sv, const int32_t *__restrict__ rowidx, long long nrows,
                                                                   const int4 *__restrict__ envtab) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    // NE environments side by side in this workgroup (PAIR: two, see the LDS map; never with SAVE, envtab or sixteen waves)
+    constexpr int NE = PAIR ? 2 : 1;
+    static_assert(!(PAIR && SAVE) && !(PAIR && NWV != 8), "");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PAIR ? P_LDS_BYTES : LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lh = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction; said so, its tiles' addresses stay in scalar registers
-    // Persistent over environments (round 5): workgroup b steps environments b, b + gridDim.x, ...: the LDS fill, the bias sums and the
+    // Persistent over environments (round 5): workgroup b steps environments b, b + gridDim.x, ... (PAIR: the pairs 2 b | 2 b + 1,
+    // 2 (b + gridDim.x) | ...): the LDS fill, the bias sums and the
     // first weight fragments are paid once per workgroup instead of once per environment, and a CU never waits for a new workgroup to
     // be placed.  (envtab launches keep one environment per workgroup: their agent counts differ.)
-    int e = blockIdx.x;
+    int e = NE * blockIdx.x;
     // envtab (mapf_recurrent_infer_multi: one step of environments of DIFFERENT agent counts -- the curriculum's levels -- in one
     // launch): per environment {agents, first row of its agents in gi / h0 / h_out, byte offset of its mask in comm, -}
     int n_env = N_arg, n_real = N_arg;
-    long long hrow0 = (long long)blockIdx.x * N_arg, coff = 0;
-    if (envtab != nullptr) {
+    long long hrow0 = (long long)e * N_arg, coff = 0;
+    if (!PAIR && envtab != nullptr) {
         const int4 d = envtab[e];
         n_env = __builtin_amdgcn_readfirstlane(d.x);
         hrow0 = __builtin_amdgcn_readfirstlane(d.y);
@@ -397,8 +441,11 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
         n_real = __builtin_amdgcn_readfirstlane(d.w);
         if (n_real <= 0) n_real = n_env;
     }
-    const int N = n_env;   // agent rows this workgroup steps
+    const int N = n_env;   // agent rows this workgroup steps (per environment)
     const int NR = n_real;  // ... of which every NR consecutive ones are one environment (their masks [NR][NR] back to back): see below
+    // agents of environment e + s: N, or 0 when E is odd and the last pair has no second member (all of its rows are then padding rows:
+    // computed like real agents, never loaded or stored)
+    auto agents = [&](int s) { return (!PAIR || e + s < E) ? N : 0; };
     const int rot = blockIdx.x;  // workgroups walk the weight tiles in rotated order: they run in step, and would otherwise all
                                  // request the same cache lines at the same moment
 
@@ -416,58 +463,94 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
     // one-step launch waited 18 k cycles for them behind its prologue).  Requested before anything else of the step; step 0's before
     // the prologue.  The mask bytes first: vmcnt retires in order, requested behind the input projection they would wait for it.
     constexpr int CI = (NA * NA + NTHR - 1) / NTHR;
-    uint8_t cbyte[CI];
-    GruInit sA, sB;
-    auto fetch_inputs = [&](int ee, int t) {
-        const long long row0 = envtab ? hrow0 : ((long long)t * E + ee) * N;
-        const uint8_t *comm_t = comm + (envtab ? coff : ((long long)t * E + ee) * N * N);
+    uint8_t cbyte[NE][CI];
+    GruInit sA[NE], sB[NE];
+    auto fetch_inputs = [&](int t) {
 #pragma unroll
-        for (int q = 0; q < CI; ++q) {
-            const int idx = tid + q * NTHR;
-            cbyte[q] = idx < N * NR ? comm_t[idx] : (uint8_t)0;
-        }
-        int grow[NT];
+        for (int s = 0; s < NE; ++s) {
+            const int Ns = agents(s);
+            const uint8_t *comm_t = comm + (envtab ? coff : ((long long)t * E + e + s) * N * N);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int a = 16 * n + lr;
-            grow[n] = a < N ? (rowidx ? rowidx[row0 + a] : (int)(row0 + a)) : -1;
+            for (int q = 0; q < CI; ++q) {
+                const int idx = tid + q * NTHR;
+                cbyte[s][q] = idx < Ns * NR ? comm_t[idx] : (uint8_t)0;
+            }
         }
-        if (!(MAPF_RECUR_ABLATE & 1)) {
-            gru_fetch_gi(sA, cA, gi, grow, lh);
-            if (NWV == 8) gru_fetch_gi(sB, cB, gi, grow, lh);
+#pragma unroll
+        for (int s = 0; s < NE; ++s) {
+            const int Ns = agents(s);
+            const long long row0 = envtab ? hrow0 : ((long long)t * E + e + s) * N;
+            int grow[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int a = 16 * n + lr;
+                grow[n] = a < Ns ? (rowidx ? rowidx[row0 + a] : (int)(row0 + a)) : -1;
+            }
+            if (!(MAPF_RECUR_ABLATE & 1)) {
+                gru_fetch_gi(sA[s], cA, gi, grow, lh);
+                if (NWV == 8) gru_fetch_gi(sB[s], cB, gi, grow, lh);
+            }
         }
     };
-    fetch_inputs(e, 0);
+    fetch_inputs(0);
     // initial hidden rows of an environment: 32 chunks of 16 B per agent, HP per thread, through registers into the LDS image
     constexpr int HP = (NA * 32 + NTHR - 1) / NTHR;
-    uint4 hpre[HP];
-    auto fetch_h0 = [&](long long first_row) {
+    uint4 hpre[NE][HP];
+    auto fetch_h0 = [&]() {
 #pragma unroll
-        for (int q = 0; q < HP; ++q) {
-            const int i = tid + q * NTHR, a = i >> 5, ch = i & 31;
-            hpre[q] = make_uint4(0, 0, 0, 0);
-            if (h0 != nullptr && a < N) hpre[q] = *reinterpret_cast<const uint4 *>(h0 + (first_row + a) * D + ch * 8);
+        for (int s = 0; s < NE; ++s)
+#pragma unroll
+            for (int q = 0; q < HP; ++q) {
+                const int i = tid + q * NTHR, a = i >> 5, ch = i & 31;
+                hpre[s][q] = make_uint4(0, 0, 0, 0);
+                if (h0 != nullptr && a < agents(s)) hpre[s][q] = *reinterpret_cast<const uint4 *>(h0 + (hrow0 + (long long)s * N + a) * D + ch * 8);
+            }
+    };
+    // LDS images of environment s (see the maps above)
+    auto envb = [&](int s) -> unsigned char * { return smem + (PAIR ? s * P_ENV : 0); };
+    unsigned char *Hc_[NE], *Hn_[NE];
+#pragma unroll
+    for (int s = 0; s < NE; ++s) Hc_[s] = envb(s), Hn_[s] = envb(s) + H_BYTES;
+    auto Hcur = [&](int s) -> unsigned char * { return Hc_[s]; };
+    auto Hnxt = [&](int s) -> unsigned char * { return Hn_[s]; };
+    auto swap_states = [&]() {
+#pragma unroll
+        for (int s = 0; s < NE; ++s) {
+            unsigned char *tmp = Hc_[s];
+            Hc_[s] = Hn_[s];
+            Hn_[s] = tmp;
         }
     };
-    auto store_h0 = [&](unsigned char *H) {  // rows >= N keep what they hold (zeros, or the padding rows' own bounded trajectory)
+    auto QKp = [&](int s) -> unsigned char * { return PAIR ? Hnxt(s) : smem + OFF_QK; };
+    auto VTp = [&](int s) -> unsigned char * { return PAIR ? envb(s) + P_OFF_VT : smem + OFF_VT; };
+    auto CTXp = [&](int s) -> unsigned char * { return PAIR ? Hnxt(s) : smem + OFF_CTX; };
+    auto INFOp = [&](int s) -> unsigned char * { return PAIR ? envb(s) + P_OFF_VT : smem + OFF_INFO; };
+    constexpr int CTX_ROW_ = PAIR ? QK_ROW : CTX_ROW;
+    auto updp = [&](int s) -> int * { return reinterpret_cast<int *>(smem + (PAIR ? P_OFF_UPD + s * 256 : OFF_UPD)); };
+    auto mbp = [&](int s) -> uint32_t * { return reinterpret_cast<uint32_t *>(smem + (PAIR ? P_OFF_MB + s * NA * 8 : OFF_MB)); };
+    auto ridxp = [&](int s) -> int * { return reinterpret_cast<int *>(smem + (PAIR ? P_OFF_RIDX + s * NA * 4 : OFF_RIDX)); };
+    auto store_h0 = [&]() {  // rows >= N keep what they hold (zeros, or the padding rows' own bounded trajectory)
 #pragma unroll
-        for (int q = 0; q < HP; ++q) {
-            const int i = tid + q * NTHR, a = i >> 5, ch = i & 31;
-            if (a < N) *reinterpret_cast<uint4 *>(H + a * H_ROW + ch * 16) = hpre[q];
-        }
+        for (int s = 0; s < NE; ++s)
+#pragma unroll
+            for (int q = 0; q < HP; ++q) {
+                const int i = tid + q * NTHR, a = i >> 5, ch = i & 31;
+                if (a < agents(s)) *reinterpret_cast<uint4 *>(Hcur(s) + a * H_ROW + ch * 16) = hpre[s][q];
+            }
     };
-    fetch_h0(hrow0);
+    fetch_h0();
     // (Tried and dropped, round 5: pulling the NEXT environment's input lines into L2 ahead of time -- one dword per 128-byte line,
     // either by every wave in front of the last update cell, or by waves 6-7, idle in the attention phase.  The first made the cell's
     // own weight reloads wait for HBM (vmcnt retires in order): 0.62 -> 0.68 ms per 4096 x 40 step; the second cost 200 more spilled
     // registers in a kernel that sits at its 256-register ceiling: 0.93 ms.  Holding the rows themselves in registers across the cell:
-    // 300 spills.  What is kept: the persistent loop, and the initial hidden rows through registers in front of the LDS fill --
-    // 0.61 -> 0.55 ms.  profiles/r05_recurrence_ab_persistent.txt)
+    // 300 spills.  Workgroups starting spread over a 15 .. 60 us window, so that their per-environment input bursts do not coincide:
+    // -1 .. -2 % at 40 agents, +2 .. +15 % at 24 / 16 / 6.  What is kept: the persistent loop, and the initial hidden rows through
+    // registers in front of the LDS fill -- 0.61 -> 0.55 ms.  profiles/r05_recurrence_ab_persistent.txt)
 
     // hidden state of this environment (rows >= N stay zero: they are computed like real agents and never stored)
-    for (int i = tid; i < LDS_BYTES / 16; i += NTHR) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < (PAIR ? P_LDS_BYTES : LDS_BYTES) / 16; i += NTHR) reinterpret_cast<uint4 *>(smem)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    float *bsum = reinterpret_cast<float *>(smem + OFF_BSUM);
+    float *bsum = reinterpret_cast<float *>(smem + (PAIR ? P_OFF_BSUM : OFF_BSUM));
     for (int i = tid; i < 2 * 256; i += NTHR) {  // same sums, same order as the accumulators used to start from
         const int cell = i >> 8, c = i & 255;
         const float *bi = bias + (cell ? UB_IH : B_IH), *bh = bias + (cell ? UB_HH : B_HH);
@@ -477,21 +560,18 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
         d[512] = bi[512 + c];
         d[768] = bh[512 + c];
     }
-    store_h0(smem + OFF_H0);
+    store_h0();
     __syncthreads();
 
     TRACE_POINT(31);
-    unsigned char *Hc = smem + OFF_H0, *Hn = smem + OFF_H1;
-    int *upd = reinterpret_cast<int *>(smem + OFF_UPD);
-    uint32_t *mb = reinterpret_cast<uint32_t *>(smem + OFF_MB);
-    int *ridx = reinterpret_cast<int *>(smem + OFF_RIDX);
     const float scale = 0.125f;  // 1 / sqrt(64)
 
     // Rows of gi and of the saved tensors: dense (rowidx == nullptr) -- agent a of (step t, environment e) is row (t E + e) N + a of
     // T E N rows -- or compact: rowidx [T][E][N] names the row of every entry that matters among `nrows` rows, -1 for the others
     // (include/mapf_dqn.h: mapf_plan_rows' gidx; such an agent gets no input projection and nothing of it is saved).
     const long long RTOT = rowidx ? nrows : (long long)T * E * N;
-    auto save_hidden = [&](uint16_t *dst, const unsigned char *H) {  // the step's rows of 256 bf16 from an LDS hidden image
+    auto save_hidden = [&](uint16_t *dst, const unsigned char *H) {  // the step's rows of 256 bf16 from an LDS hidden image (SAVE: one environment)
+        const int *ridx = ridxp(0);
         for (int i = tid; i < N * 32; i += NTHR) {
             const int a = i >> 5, ch = i & 31, row = ridx[a];
             if (row >= 0) *reinterpret_cast<uint4 *>(dst + (long long)row * D + ch * 8) = *reinterpret_cast<const uint4 *>(H + a * H_ROW + ch * 16);
@@ -508,79 +588,110 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
         asm volatile("" : "+s"(opaque0));
         const uint16_t *__restrict__ W = W_arg + opaque0;
         const float *__restrict__ bias = bias_arg + opaque0;
-        const long long row0 = envtab ? hrow0 : ((long long)t * E + e) * N;  // first dense row of this (step, environment)
         // ---------------- this step's communication mask -> bit rows in LDS (the softmax loops must not touch global memory:
         // 120 dependent byte loads per row made the first version 10x slower than its MFMAs) ----------------
-        if (tid < NA * 2) mb[tid] = 0u;
-        if (tid < NA) ridx[tid] = tid < N ? (rowidx ? rowidx[row0 + tid] : (int)(row0 + tid)) : -1;
+#pragma unroll
+        for (int s = 0; s < NE; ++s) {
+            const long long row0 = envtab ? hrow0 : ((long long)t * E + e + s) * N;  // first dense row of this (step, environment)
+            if (tid < NA * 2) mbp(s)[tid] = 0u;
+            if (tid < NA) ridxp(s)[tid] = tid < agents(s) ? (rowidx ? rowidx[row0 + tid] : (int)(row0 + tid)) : -1;
+        }
         phase_sync(1);
-        if (SAVE) save_hidden(sv.hin0, Hc);
+        if (SAVE) save_hidden(sv.hin0, Hcur(0));
         // (mapf_recurrent_infer_multi packs several small environments of one level into one workgroup -- their agents' rows are
         // consecutive everywhere, and the weights, which is what a step streams, are fetched once for all of them: row i = agent i % NR
         // of environment i / NR reads that environment's mask row, its partners are the columns of that environment: a block-diagonal
         // mask.  NR == N: one environment, the plain case.)
 #pragma unroll
-        for (int q = 0; q < CI; ++q)
-            if (cbyte[q] != 0) {
-                const int idx = tid + q * NTHR, i = idx / NR, j = (i / NR) * NR + (idx - i * NR);
-                atomicOr(&mb[2 * i + (j >> 5)], 1u << (j & 31));
-            }
-        // ---------------- recurrent GRU cell: Hc -> Hn (the barrier behind it also publishes the mask bits) ----------------
+        for (int s = 0; s < NE; ++s) {
+            uint32_t *mb = mbp(s);
+#pragma unroll
+            for (int q = 0; q < CI; ++q)
+                if (cbyte[s][q] != 0) {
+                    const int idx = tid + q * NTHR, i = idx / NR, j = (i / NR) * NR + (idx - i * NR);
+                    atomicOr(&mb[2 * i + (j >> 5)], 1u << (j & 31));
+                }
+        }
+        // ---------------- recurrent GRU cell: current -> next state (the barrier behind it also publishes the mask bits) ----------------
+        const unsigned char *Hin[NE], *Xi[NE];
+        unsigned char *Hout[NE];
+        const int *updv[NE], *noupd[NE], *ridxv[NE];
+#pragma unroll
+        for (int s = 0; s < NE; ++s) {
+            Hin[s] = Hcur(s);
+            Hout[s] = Hnxt(s);
+            Xi[s] = nullptr;
+            noupd[s] = nullptr;
+            updv[s] = updp(s);
+            ridxv[s] = ridxp(s);
+        }
 #if MAPF_RECUR_WAVES == 8
         if (!(MAPF_RECUR_ABLATE & 1))
-            gru_pair<true, 2>(cA, cB, sA, sB, wf, wi, nullptr, nullptr, 0, W + W_HH, bsum, Hc, Hn, nullptr, ridx, lr, lh, SAVE ? sv.g1 : nullptr,
-                              frag3(W + W_QKV, wq, wq + 8, wq + 16, 8, lane));
+            gru_pair<true, 2, NE>(cA, cB, sA, sB, wf, wi, nullptr, Xi, 0, W + W_HH, bsum, Hin, Hout, noupd, ridxv, lr, lh, SAVE ? sv.g1 : nullptr,
+                                  frag3(W + W_QKV, wq, wq + 8, wq + 16, 8, lane));
 #else
         if (!(MAPF_RECUR_ABLATE & 1))
-            gru_one<true, 2>(cA, sA, nullptr, nullptr, 0, W + W_HH, bsum, Hc, Hn, nullptr, ridx, lr, lh, SAVE ? sv.g1 : nullptr);
+            gru_one<true, 2>(cA, sA[0], nullptr, nullptr, 0, W + W_HH, bsum, Hin[0], Hout[0], nullptr, ridxv[0], lr, lh, SAVE ? sv.g1 : nullptr);
 #endif
         phase_sync(2);
-        {
-            unsigned char *tmp = Hc;
-            Hc = Hn;
-            Hn = tmp;
-        }
-        // ---------------- two communication rounds (shared weights): Hc -> Hn -> swap ----------------
+        swap_states();
+        // ---------------- two communication rounds (shared weights): current -> next -> swap ----------------
         for (int round = 0; round < 2; ++round) {
             asm volatile("" : "+s"(opaque0));  // (both rounds read the same weights: without this the second round's loads are "the first round's
             W = W_arg + opaque0;               //  values", kept in registers across the whole round)
             bias = bias_arg + opaque0;
-            if (SAVE) save_hidden(sv.hr + (long long)round * RTOT * D, Hc);
+            if (SAVE) save_hidden(sv.hr + (long long)round * RTOT * D, Hcur(0));
             // q | k | v = W_qkv h + b: 24 output tiles of 16
-            auto store_qkv = [&](int tile, const f32x4 (&acc)[NT]) {  // tile 0..7 q, 8..15 k, 16..23 v (16 channels each)
+            auto store_qkv = [&](int s, int tile, const f32x4 (&acc)[NT]) {  // tile 0..7 q, 8..15 k, 16..23 v (16 channels each)
                 const int g = tile >> 3, c0 = 16 * (tile & 7) + 4 * lh;
+                unsigned char *QK = QKp(s), *VT = VTp(s);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const int agent = 16 * n + lr;
                     const uint32_t p01 = pack2_bf16(acc[n][0], acc[n][1]), p23 = pack2_bf16(acc[n][2], acc[n][3]);
                     if (g < 2) {  // q (channels 0..127) and k (128..255): [agent][channel]
-                        *reinterpret_cast<uint2 *>(smem + OFF_QK + agent * QK_ROW + (128 * g + c0) * 2) = make_uint2(p01, p23);
+                        *reinterpret_cast<uint2 *>(QK + agent * QK_ROW + (128 * g + c0) * 2) = make_uint2(p01, p23);
                     } else {      // v transposed: row (head, d) = c0 + r, column = agent
-                        uint16_t *vt = reinterpret_cast<uint16_t *>(smem + OFF_VT + c0 * VT_ROW) + agent;
+                        uint16_t *vt = reinterpret_cast<uint16_t *>(VT + c0 * VT_ROW) + agent;
                         vt[0] = (uint16_t)(p01 & 0xFFFFu);
                         vt[VT_ROW / 2] = (uint16_t)(p01 >> 16);
                         vt[2 * (VT_ROW / 2)] = (uint16_t)(p23 & 0xFFFFu);
                         vt[3 * (VT_ROW / 2)] = (uint16_t)(p23 >> 16);
                     }
-                    if (SAVE && ridx[agent] >= 0)
-                        *reinterpret_cast<uint2 *>(sv.qkv + ((long long)round * RTOT + ridx[agent]) * 384 + 128 * g + c0) = make_uint2(p01, p23);
+                    if (SAVE && ridxp(0)[agent] >= 0)
+                        *reinterpret_cast<uint2 *>(sv.qkv + ((long long)round * RTOT + ridxp(0)[agent]) * 384 + 128 * g + c0) = make_uint2(p01, p23);
                 }
             };
-#if MAPF_RECUR_WAVES == 8
-            if (!(MAPF_RECUR_ABLATE & 2)) {  // (one job per wave)
-                f32x4 acc[3][NT];  // tiles wq (q), wq + 8 (k), wq + 16 (v)
-#pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    const float4 b4 = *reinterpret_cast<const float4 *>(bias + B_QKV + 16 * (wq + 8 * g) + 4 * lh);
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) acc[g][n] = f32x4{b4.x, b4.y, b4.z, b4.w};
+            if (PAIR) {  // the previous round's info lay over the first NA rows of v^T: their agent slots >= NA are zero again before P meets them
+                constexpr int ZW = (128 - 2 * NA) / 16;  // 16-byte words per row
+                for (int i = tid; i < NE * NA * ZW; i += NTHR) {
+                    const int s = i / (NA * ZW), r = (i - s * NA * ZW) / ZW, q = i - (s * NA + r) * ZW;
+                    *reinterpret_cast<uint4 *>(VTp(s) + r * VT_ROW + 2 * NA + 16 * q) = make_uint4(0, 0, 0, 0);
                 }
-                stream_mfma<8, true>(acc[0], acc[1], acc[2], wf, Hc, H_ROW, lane, gate_frags(W + U_HH, cA, 8, lane));  // next: the update cell
-                load_frags<2>(wi, gate_frags(W + U_IH, cA, 2, lane));
-                __builtin_amdgcn_sched_barrier(0);
-                store_qkv(wq, acc[0]);
-                store_qkv(wq + 8, acc[1]);
-                store_qkv(wq + 16, acc[2]);
+            }
+#if MAPF_RECUR_WAVES == 8
+            if (!(MAPF_RECUR_ABLATE & 2)) {  // (one job per wave and environment)
+#pragma unroll
+                for (int s = 0; s < NE; ++s) {
+                    f32x4 acc[3][NT];  // tiles wq (q), wq + 8 (k), wq + 16 (v)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        const float4 b4 = *reinterpret_cast<const float4 *>(bias + B_QKV + 16 * (wq + 8 * g) + 4 * lh);
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) acc[g][n] = f32x4{b4.x, b4.y, b4.z, b4.w};
+                    }
+                    if (s == NE - 1) {
+                        stream_mfma<8, true>(acc[0], acc[1], acc[2], wf, Hcur(s), H_ROW, lane, gate_frags(W + U_HH, cA, 8, lane));  // next: the update cell
+                        load_frags<2>(wi, gate_frags(W + U_IH, cA, 2, lane));
+                    } else {
+                        stream_mfma<8, false, true>(acc[0], acc[1], acc[2], wf, Hcur(s), H_ROW, lane, gate_frags(W + U_HH, cA, 8, lane));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    store_qkv(s, wq, acc[0]);
+                    store_qkv(s, wq + 8, acc[1]);
+                    store_qkv(s, wq + 16, acc[2]);
+                    if (s != NE - 1) __builtin_amdgcn_sched_barrier(0);
+                }
             }
 #else
             for (int j = w; j < 24 && !(MAPF_RECUR_ABLATE & 2); j += NWV) {  // (waves 0..7: two tiles, 8..15: one -- two of each kind per SIMD)
@@ -589,8 +700,8 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                 const float4 b4 = *reinterpret_cast<const float4 *>(bias + B_QKV + 16 * tile + 4 * lh);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[n] = f32x4{b4.x, b4.y, b4.z, b4.w};
-                gemm16<8>(acc, W + W_QKV, tile, Hc, H_ROW, lane);
-                store_qkv(tile, acc);
+                gemm16<8>(acc, W + W_QKV, tile, Hcur(0), H_ROW, lane);
+                store_qkv(0, tile, acc);
             }
 #endif
             phase_sync(3);
@@ -600,28 +711,34 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
             // 4 lh + (u & 3); v^T's A operand reads its columns in the same numbering (two 8-byte reads).  Rounds 1-4 went through a
             // score image and a softmax image in LDS with a barrier behind each: 4.1 k of a step's ~30 k cycles per round at 40 agents.
             // (at one or two agent tiles there are only 2 / 4 (head, tile) pairs for 8 waves: two waves then share a pair, each repeating the
-            //  scores and the softmax and taking two of the four d-tiles of ctx -- SPLIT)
-            constexpr int SPLIT = NT <= 2 ? 2 : 1;
-            for (int job = w; job < 2 * NT * SPLIT && !(MAPF_RECUR_ABLATE & 4); job += NTHR / 64) {
-                const int half = job / (2 * NT), pair = job - 2 * NT * half;
+            //  scores and the softmax and taking two of the four d-tiles of ctx -- SPLIT; not with two environments, whose ctx replaces q)
+            constexpr int SPLIT = (NT <= 2 && !PAIR) ? 2 : 1;
+            constexpr int JOBS1 = 2 * NT * SPLIT;  // per environment
+            for (int job = w; job < NE * JOBS1 && !(MAPF_RECUR_ABLATE & 4); job += NTHR / 64) {
+                const int s = NE == 1 ? 0 : job / JOBS1, job1 = job - s * JOBS1;
+                const int half = job1 / (2 * NT), pair = job1 - 2 * NT * half;
                 const int hd = pair / NT, ti = pair - NT * hd, i = 16 * ti + lr;
+                const int Ns = agents(s);
+                const unsigned char *QK = QKp(s), *VT = VTp(s);
+                unsigned char *CTX = CTXp(s);
+                const uint32_t *mb = mbp(s);
                 f32x4 sc[NT];
                 {
                     bf16x8 qf[2];
 #pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) qf[kk] = *reinterpret_cast<const bf16x8 *>(smem + OFF_QK + i * QK_ROW + (hd * HD + 32 * kk + 8 * lh) * 2);
+                    for (int kk = 0; kk < 2; ++kk) qf[kk] = *reinterpret_cast<const bf16x8 *>(QK + i * QK_ROW + (hd * HD + 32 * kk + 8 * lh) * 2);
 #pragma unroll
                     for (int tj = 0; tj < NT; ++tj) {
                         sc[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk) {
-                            const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(smem + OFF_QK + (16 * tj + lr) * QK_ROW + (128 + hd * HD + 32 * kk + 8 * lh) * 2);
+                            const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(QK + (16 * tj + lr) * QK_ROW + (128 + hd * HD + 32 * kk + 8 * lh) * 2);
                             sc[tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], sc[tj], 0, 0, 0);
                         }
                     }
                 }
                 // masked softmax over the row (model.py:75-78): columns without a mask bit (incl. j >= N) read -1e9; rows i >= N come out 0
-                const uint64_t bits = i < N ? ((uint64_t)mb[2 * i] | ((uint64_t)mb[2 * i + 1] << 32)) : 0ull;  // bits >= N are 0
+                const uint64_t bits = i < Ns ? ((uint64_t)mb[2 * i] | ((uint64_t)mb[2 * i + 1] << 32)) : 0ull;  // bits >= N are 0
                 float mx = -3.0e38f;
 #pragma unroll
                 for (int tj = 0; tj < NT; ++tj) {
@@ -646,14 +763,14 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                     }
                 sum += __shfl_xor(sum, 16);
                 sum += __shfl_xor(sum, 32);
-                const float inv = i < N ? 1.f / sum : 0.f;
+                const float inv = i < Ns ? 1.f / sum : 0.f;
                 uint2 pw[4];
 #pragma unroll
                 for (int tj = 0; tj < 4; ++tj)
                     pw[tj] = tj < NT ? make_uint2(pack2_bf16(sc[tj < NT ? tj : 0][0] * inv, sc[tj < NT ? tj : 0][1] * inv),
                                                   pack2_bf16(sc[tj < NT ? tj : 0][2] * inv, sc[tj < NT ? tj : 0][3] * inv))
                                      : make_uint2(0u, 0u);
-                if (hd == 0 && lh == 0 && half == 0) upd[i] = (i < N && __popcll(bits) > 1) ? 1 : 0;  // model.py:103
+                if (hd == 0 && lh == 0 && half == 0) updp(s)[i] = (i < Ns && __popcll(bits) > 1) ? 1 : 0;  // model.py:103
                 if (SAVE && half == 0) {  // P rows (2 heads x NA agents x 64 slots = 128 B each; slots >= NA zero) -> global
                     uint16_t *pd = sv.P + ((((long long)round * T + t) * E + e) * 2 + hd) * (NA * 64) + i * 64 + 4 * lh;
 #pragma unroll
@@ -664,7 +781,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                 for (int tq = 0; tq < 4 / SPLIT; ++tq) {
                     const int td = (4 / SPLIT) * half + tq;
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    const unsigned char *vr = smem + OFF_VT + (hd * HD + 16 * td + lr) * VT_ROW + 8 * lh;
+                    const unsigned char *vr = VT + (hd * HD + 16 * td + lr) * VT_ROW + 8 * lh;
 #pragma unroll
                     for (int kk = 0; kk < (NT + 1) / 2; ++kk) {
                         const uint2 alo = *reinterpret_cast<const uint2 *>(vr + 64 * kk), ahi = *reinterpret_cast<const uint2 *>(vr + 64 * kk + 32);
@@ -673,59 +790,69 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
                     }
                     const uint2 v = make_uint2(pack2_bf16(acc[0], acc[1]), pack2_bf16(acc[2], acc[3]));
-                    *reinterpret_cast<uint2 *>(smem + OFF_CTX + i * CTX_ROW + (hd * HD + 16 * td + 4 * lh) * 2) = v;
-                    if (SAVE && ridx[i] >= 0)
-                        *reinterpret_cast<uint2 *>(sv.ctx + ((long long)round * RTOT + ridx[i]) * 128 + hd * HD + 16 * td + 4 * lh) = v;
+                    *reinterpret_cast<uint2 *>(CTX + i * CTX_ROW_ + (hd * HD + 16 * td + 4 * lh) * 2) = v;
+                    if (SAVE && ridxp(0)[i] >= 0)
+                        *reinterpret_cast<uint2 *>(sv.ctx + ((long long)round * RTOT + ridxp(0)[i]) * 128 + hd * HD + 16 * td + 4 * lh) = v;
                 }
             }
             phase_sync(6);
-            // info = W_O ctx (no bias): 4 output tiles, K = 128
-            for (int ot = w; ot < 4 && !(MAPF_RECUR_ABLATE & 8); ot += NTHR / 64) {
+            // info = W_O ctx (no bias): 4 output tiles per environment, K = 128
+            for (int j = w; j < 4 * NE && !(MAPF_RECUR_ABLATE & 8); j += NTHR / 64) {
+                const int s = NE == 1 ? 0 : j >> 2, ot = NE == 1 ? j : j & 3;
                 f32x4 acc[NT];
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-                gemm16<4>(acc, W + W_O, ot, smem + OFF_CTX, CTX_ROW, lane);
+                gemm16<4>(acc, W + W_O, ot, CTXp(s), CTX_ROW_, lane);
+                unsigned char *INFO = INFOp(s);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const uint2 v = make_uint2(pack2_bf16(acc[n][0], acc[n][1]), pack2_bf16(acc[n][2], acc[n][3]));
-                    *reinterpret_cast<uint2 *>(smem + OFF_INFO + (16 * n + lr) * INFO_ROW + (16 * ot + 4 * lh) * 2) = v;
-                    if (SAVE && ridx[16 * n + lr] >= 0)
-                        *reinterpret_cast<uint2 *>(sv.info + ((long long)round * RTOT + ridx[16 * n + lr]) * 64 + 16 * ot + 4 * lh) = v;
+                    *reinterpret_cast<uint2 *>(INFO + (16 * n + lr) * INFO_ROW + (16 * ot + 4 * lh) * 2) = v;
+                    if (SAVE && ridxp(0)[16 * n + lr] >= 0)
+                        *reinterpret_cast<uint2 *>(sv.info + ((long long)round * RTOT + ridxp(0)[16 * n + lr]) * 64 + 16 * ot + 4 * lh) = v;
                 }
             }
             phase_sync(7);
-            // update cell: Hc -> Hn where the agent has a partner
+            // update cell: current -> next state where the agent has a partner
+#pragma unroll
+            for (int s = 0; s < NE; ++s) {
+                Hin[s] = Hcur(s);
+                Hout[s] = Hnxt(s);
+                Xi[s] = INFOp(s);
+            }
 #if MAPF_RECUR_WAVES == 8
             if (!(MAPF_RECUR_ABLATE & 16))  // behind it: the second round's q|k|v, or the next step's recurrent cell (a wasted fetch at the last step of the last environment)
-                gru_pair<false, 2>(cA, cB, sA, sB, wf, wi, W + U_IH, smem + OFF_INFO, INFO_ROW, W + U_HH, bsum + 1024, Hc, Hn, upd, ridx, lr, lh,
-                                   SAVE ? sv.g2 + (long long)round * RTOT * 1024 : nullptr,
-                                   round == 0 ? frag3(W + W_QKV, wq, wq + 8, wq + 16, 8, lane) : gate_frags(W + W_HH, cA, 8, lane));
+                gru_pair<false, 2, NE>(cA, cB, sA, sB, wf, wi, W + U_IH, Xi, INFO_ROW, W + U_HH, bsum + 1024, Hin, Hout, updv, ridxv, lr, lh,
+                                       SAVE ? sv.g2 + (long long)round * RTOT * 1024 : nullptr,
+                                       round == 0 ? frag3(W + W_QKV, wq, wq + 8, wq + 16, 8, lane) : gate_frags(W + W_HH, cA, 8, lane));
 #else
             if (!(MAPF_RECUR_ABLATE & 16))
-                gru_one<false, 2>(cA, sA, W + U_IH, smem + OFF_INFO, INFO_ROW, W + U_HH, bsum + 1024, Hc, Hn, upd, ridx, lr, lh,
+                gru_one<false, 2>(cA, sA[0], W + U_IH, Xi[0], INFO_ROW, W + U_HH, bsum + 1024, Hin[0], Hout[0], updv[0], ridxv[0], lr, lh,
                                   SAVE ? sv.g2 + (long long)round * RTOT * 1024 : nullptr);
 #endif
             phase_sync(8);
-            unsigned char *tmp = Hc;
-            Hc = Hn;
-            Hn = tmp;
+            swap_states();
         }
-        if (agent0_out != nullptr && tid < 32)  // agent 0's state after this step (model.py:248)
-            *reinterpret_cast<uint4 *>(agent0_out + ((long long)t * E + e) * D + tid * 8) = *reinterpret_cast<const uint4 *>(Hc + tid * 16);
+#pragma unroll
+        for (int s = 0; s < NE; ++s)
+            if (agent0_out != nullptr && tid < 32 && agents(s) > 0)  // agent 0's state after this step (model.py:248)
+                *reinterpret_cast<uint4 *>(agent0_out + ((long long)t * E + e + s) * D + tid * 8) = *reinterpret_cast<const uint4 *>(Hcur(s) + tid * 16);
         if (++t >= T) break;
-        fetch_inputs(e, t);  // the next step's (step 0's were requested in front of the prologue)
+        fetch_inputs(t);  // the next step's (step 0's were requested in front of the prologue)
     }
-    for (int i = tid; i < N * 32; i += NTHR) {
-        const int a = i >> 5, ch = i & 31;
-        *reinterpret_cast<uint4 *>(h_out + (hrow0 + a) * D + ch * 8) = *reinterpret_cast<const uint4 *>(Hc + a * H_ROW + ch * 16);
-    }
-    if (envtab != nullptr || e + G >= E) break;
-    e += G;
+#pragma unroll
+    for (int s = 0; s < NE; ++s)
+        for (int i = tid; i < agents(s) * 32; i += NTHR) {
+            const int a = i >> 5, ch = i & 31;
+            *reinterpret_cast<uint4 *>(h_out + (hrow0 + (long long)s * N + a) * D + ch * 8) = *reinterpret_cast<const uint4 *>(Hcur(s) + a * H_ROW + ch * 16);
+        }
+    if (envtab != nullptr || e + NE * G >= E) break;
+    e += NE * G;
     hrow0 = (long long)e * N_arg;
-    fetch_inputs(e, 0);
-    fetch_h0(hrow0);
+    fetch_inputs(0);
+    fetch_h0();
     __syncthreads();  // every row of the finished environment is on its way out before the next one's rows replace it
-    store_h0(Hc);     // (the first barrier of the step publishes them)
+    store_h0();       // (the first barrier of the step publishes them)
     }
     TRACE_POINT(32);
     TRACE_END();
@@ -742,6 +869,25 @@ inline int persistent_grid(int E) {
         return n;
     }();
     return (cus > 0 && E > cus) ? cus : E;
+}
+// Two environments per workgroup (recurrent_infer_kernel<false, true>): builds for one and two agent tiles only, and only when there are
+// more environments than CUs -- below that a launch lasts as long as ONE workgroup's steps, which a second environment lengthens (a pair's
+// step takes ~1.4 x an environment's).  At three agent tiles the pair kernel is slower than two single steps (0.585 against 0.535 ms at
+// 4096 x 40: 128 spilled registers, and its cells are bound by the LDS reads of the activations, which pairing does not share; see
+// HISTORY.md).  MAPF_RECUR_PAIR=0 (A/B runs): never.
+constexpr bool PAIR_BUILT = NT <= 2 && NWV == 8;
+inline int recur_cus() { return persistent_grid(1 << 30); }  // CU count, or 0 with MAPF_RECUR_PERSIST=0 / unknown
+inline bool pair_launch(int E) {
+    static const int on = [] {
+        const char *v = std::getenv("MAPF_RECUR_PAIR");
+        return (v != nullptr && v[0] == '0') ? 0 : 1;
+    }();
+    const int cus = recur_cus();
+    return PAIR_BUILT && on && cus > 0 && cus < (1 << 30) && E > cus;
+}
+inline int pair_grid(int E) {
+    const int cus = recur_cus(), pairs = (E + 1) / 2;
+    return pairs < cus ? pairs : cus;
 }
 
 #define HIP_TRY(expr)                                                                        \
@@ -784,8 +930,16 @@ int RECUR_ENTRY(mapf_recurrent_infer)(const uint16_t *gi_dev, const uint16_t *h0
     if (N > NA)  // 49..128 agents: csrc/mapf_recur_wide.hip
         return mapf_recur_wide_forward(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, nullptr,
                                        static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(recurrent_infer_kernel<false>, dim3(persistent_grid(E)), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
-                       weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, RecurSave{}, row_index_dev, (long long)num_rows, (const int4 *)nullptr);
+#if MAPF_RECUR_WAVES == 8 && MAPF_RECUR_NT <= 2
+    if (pair_launch(E))
+        hipLaunchKernelGGL((recurrent_infer_kernel<false, true>), dim3(pair_grid(E)), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev,
+                           comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, RecurSave{}, row_index_dev, (long long)num_rows,
+                           (const int4 *)nullptr);
+    else
+#endif
+        hipLaunchKernelGGL((recurrent_infer_kernel<false, false>), dim3(persistent_grid(E)), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev,
+                           comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, RecurSave{}, row_index_dev, (long long)num_rows,
+                           (const int4 *)nullptr);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }
@@ -812,7 +966,7 @@ int RECUR_ENTRY(mapf_recurrent_forward_save)(const uint16_t *gi_dev, const uint1
     if (N > NA)
         return mapf_recur_wide_forward(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, &sv,
                                        static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(recurrent_infer_kernel<true>, dim3(persistent_grid(E)), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
+    hipLaunchKernelGGL((recurrent_infer_kernel<true, false>), dim3(persistent_grid(E)), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
                        weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, sv, row_index_dev, (long long)num_rows, (const int4 *)nullptr);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
@@ -828,7 +982,7 @@ extern "C" int mapf_recurrent_infer_multi(const uint16_t *gi_dev, const uint16_t
         (reinterpret_cast<uintptr_t>(bias_dev) & 15) || (reinterpret_cast<uintptr_t>(h_out_dev) & 15) || (reinterpret_cast<uintptr_t>(envtab_dev) & 15))
         return MAPF_ERR_INVALID_ARG;
     if (E == 0) return MAPF_OK;
-    hipLaunchKernelGGL(recurrent_infer_kernel<false>, dim3(E), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
+    hipLaunchKernelGGL((recurrent_infer_kernel<false, false>), dim3(E), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
                        weights_dev, bias_dev, 1, E, 1, h_out_dev, (uint16_t *)nullptr, RecurSave{}, (const int32_t *)nullptr, 0ll,
                        reinterpret_cast<const int4 *>(envtab_dev));
     HIP_TRY(hipGetLastError());

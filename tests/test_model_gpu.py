@@ -157,6 +157,37 @@ def test_fused_recurrence_kernel_matches_module_path(E, N, T):
         assert torch.allclose(x, y, rtol=3e-2, atol=3e-2), float((x - y).abs().max())
 
 
+@pytest.mark.parametrize("E,N,T", [(600, 6, 1), (601, 16, 1), (515, 1, 2), (700, 24, 1), (529, 32, 3), (513, 17, 1), (2049, 5, 1)])
+def test_two_environments_per_workgroup_step_like_one(E, N, T):
+    """With more environments than CUs, the <= 32-agent builds of mapf_recurrent_infer step TWO environments per workgroup (the weight
+    fragments a wave fetches serve both: csrc/mapf_recur.hip, recurrent_infer_kernel<false, true>), q | k, ctx and info living in LDS
+    bytes that are dead at the time.  Same bits as the one-environment launches the same call makes for <= 256 environments: hidden
+    states and agent-0 states, with and without an initial state, odd environment counts (a pair without a second member) included."""
+    from mapf_rl_amd import fused
+
+    g = torch.Generator(device="cuda").manual_seed(E + N)
+    w = (torch.randn(fused.RECUR_WEIGHT_ELEMS, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(fused.RECUR_BIAS_ELEMS, device="cuda", generator=g) * 0.1
+    gi = (torch.randn((T, E, N, 768), device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    h0 = (torch.randn((E, N, 256), device="cuda", generator=g) * 0.3).to(torch.bfloat16)
+    comm = torch.rand((T, E, N, N), device="cuda", generator=g) < 0.3
+    comm |= torch.eye(N, dtype=torch.bool, device="cuda")
+    comm[:, 3] = False  # (a zero-padded row: nobody is updated)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert E > cus, "the launch under test needs more environments than CUs"
+    for start in (h0, None):
+        whole, a_whole = fused.recurrent_infer(gi, start, comm, w, b, want_agent0=True)
+        parts, a_parts = [], []
+        for lo in range(0, E, 200):  # <= CUs: one environment per workgroup
+            hi = min(E, lo + 200)
+            h, a = fused.recurrent_infer(gi[:, lo:hi], None if start is None else start[lo:hi], comm[:, lo:hi], w, b, want_agent0=True)
+            parts.append(h)
+            a_parts.append(a)
+        assert not whole.isnan().any()
+        assert torch.equal(whole, torch.cat(parts, 0))
+        assert torch.equal(a_whole, torch.cat(a_parts, 1))
+
+
 @pytest.mark.parametrize("B,T,N", [(6, 5, 7), (3, 16, 40), (4, 3, 48), (5, 2, 1), (4, 6, 16), (3, 4, 17), (3, 5, 32), (2, 3, 33), (3, 4, 24),  # <= 16 / <= 32: csrc/mapf_recur*_nt1.hip / _nt2.hip
                                    (3, 4, 64), (2, 3, 100), (2, 5, 128), (3, 2, 49)])  # > 48: csrc/mapf_recur_wide*.hip
 def test_bptt_kernels_match_pytorch_recurrence(B, T, N):
