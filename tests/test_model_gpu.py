@@ -188,6 +188,40 @@ def test_two_environments_per_workgroup_step_like_one(E, N, T):
         assert torch.equal(a_whole, torch.cat(a_parts, 1))
 
 
+@pytest.mark.parametrize("E,N", [(320, 5), (600, 20)])
+def test_policy_step_of_many_small_environments_equals_its_halves(E, N):
+    """Network.step_batch over more environments than CUs (where the recurrence steps two environments per workgroup) returns, for every
+    environment, the bits it returns when the same environments are stepped in groups of <= 160 (one environment per workgroup):
+    actions, Q-values, hidden states -- and stays within the module path's tolerance."""
+    from mapf_rl_amd.model import Network
+
+    torch.manual_seed(E + N)
+    net = Network().cuda()
+    g = torch.Generator(device="cuda").manual_seed(E)
+    obs = (torch.rand((E, N, 6, 9, 9), device="cuda", generator=g) < 0.3).to(torch.uint8)
+    comm = torch.rand((E, N, N), device="cuda", generator=g) < 0.3
+    comm |= torch.eye(N, dtype=torch.bool, device="cuda")
+    hidden = (torch.randn((E * N, 256), device="cuda", generator=g) * 0.3).to(torch.bfloat16)
+    pos = torch.zeros((E, N, 2), dtype=torch.int16, device="cuda")
+    assert E > torch.cuda.get_device_properties(0).multi_processor_count
+    whole = net.step_batch(obs, pos, hidden, comm)
+    whole = [x.clone() for x in whole[:3]]
+    parts = []
+    for lo in range(0, E, 160):
+        hi = min(E, lo + 160)
+        r = net.step_batch(obs[lo:hi].contiguous(), pos[lo:hi].contiguous(), hidden[lo * N:hi * N].contiguous(), comm[lo:hi].contiguous())
+        parts.append([x.clone() for x in r[:3]])
+    for k in range(3):
+        assert torch.equal(whole[k].reshape(E, -1), torch.cat([p[k].reshape(-1, whole[k].numel() // E) for p in parts], 0)), k
+    Network.FUSED_RECURRENCE = False
+    try:
+        ref = net.step_batch(obs, pos, hidden, comm)
+    finally:
+        Network.FUSED_RECURRENCE = True
+    assert torch.allclose(whole[1].float(), ref[1].float(), rtol=3e-2, atol=3e-2)
+    assert torch.allclose(whole[2].float(), ref[2].float(), rtol=3e-2, atol=3e-2)
+
+
 @pytest.mark.parametrize("B,T,N", [(6, 5, 7), (3, 16, 40), (4, 3, 48), (5, 2, 1), (4, 6, 16), (3, 4, 17), (3, 5, 32), (2, 3, 33), (3, 4, 24),  # <= 16 / <= 32: csrc/mapf_recur*_nt1.hip / _nt2.hip
                                    (3, 4, 64), (2, 3, 100), (2, 5, 128), (3, 2, 49)])  # > 48: csrc/mapf_recur_wide*.hip
 def test_bptt_kernels_match_pytorch_recurrence(B, T, N):
