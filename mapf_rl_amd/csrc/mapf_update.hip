@@ -326,10 +326,23 @@ __global__ void __launch_bounds__(256) plan_rows_kernel(PlanRowsArgs p) {
         __syncthreads();
     }
     int next = s_red[0];  // first distinct row of this window (identical in every thread)
+    // this position's duplicate flags of all steps, requested at once instead of one dependent global load per step of the loop below
+    // (one workgroup per window: nothing else hides the latency)
+    __shared__ short s_t0[MAPF_PLAN_MAX_STEPS][128];
+    if (tid < 128) {
+        int t0s[MAPF_PLAN_MAX_STEPS];
+#pragma unroll
+        for (int t = 0; t < MAPF_PLAN_MAX_STEPS; ++t) {
+            t0s[t] = t;
+            if (t < T && tid < s_nact[t]) t0s[t] = p.dup[((size_t)t * B + b) * N + s_ord[tid]];
+        }
+#pragma unroll
+        for (int t = 0; t < MAPF_PLAN_MAX_STEPS; ++t) s_t0[t][tid] = (short)t0s[t];
+    }
+    __syncthreads();
     for (int t = 0; t < T; ++t) {
         const int na = s_nact[t];
-        int t0 = t;
-        if (tid < na) t0 = p.dup[((size_t)t * B + b) * N + s_ord[tid]];
+        const int t0 = tid < 128 ? s_t0[t][tid] : t;
         if (tid < 128) s_flag[tid] = (tid < na) && t0 >= t;
         __syncthreads();
         if (tid < na) {
