@@ -145,7 +145,8 @@ int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M
  *   hidden = GRUCell(latent_t, hidden)                                   (reference model.py:186-189 / :244)
  *   2 x: info = MultiHeadAttention(hidden, comm_mask_t); hidden = where(partners > 1, GRUCell(info, hidden), hidden)
  *                                                                        (CommBlock, model.py:99-135)
- * with one workgroup per environment keeping the hidden states in LDS across all steps.  No autograd.
+ * with a workgroup keeping an environment's hidden states in LDS across all steps (one workgroup per CU walks its share of the
+ * environments; with more environments than CUs and N <= 32, two environments side by side per workgroup).  No autograd.
  *   gi_dev      bf16 [T][E][N][768]  the GRU's input projection W_ih latent (no bias), one GEMM done by the caller
  *   h0_dev      bf16 [E][N][256] or NULL (zeros: episode start)
  *   comm_dev    u8   [T][E][N][N]    communication masks (non-zero = j talks to i)

@@ -2,7 +2,7 @@
 // and the no-gradient `bootstrap` of the target network, model.py:242-249 called from worker.py:300-303):
 //     hidden = GRUCell(latent, hidden);  2 x [ info = MultiHeadAttention(hidden, comm_mask);
 //                                              hidden = where(has_partner, GRUCell(info, hidden), hidden) ]
-// for T consecutive steps, ONE workgroup per environment (see include/mapf_dqn.h: mapf_recurrent_infer).
+// for T consecutive steps, an environment (or two, see the LDS maps) at a time per workgroup (see include/mapf_dqn.h: mapf_recurrent_infer).
 //
 // Everything after the GRU's input projection is independent between environments (attention only mixes the <= 48
 // agents of one environment), so a workgroup keeps its environment's hidden states in LDS for all T steps and only

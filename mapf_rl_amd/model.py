@@ -492,7 +492,7 @@ class Network(nn.Module):
             if comm_mask is None:
                 comm_mask = comm_mask_from_pos(pos)
             if self.FUSED_RECURRENCE and latent.is_cuda and latent.dtype == torch.bfloat16 and N <= RECUR_MAX_AGENTS:
-                # GRU cell + both communication rounds in one kernel, one workgroup per environment (csrc/mapf_recur.hip)
+                # GRU cell + both communication rounds in one kernel, an environment's states in one workgroup's LDS (csrc/mapf_recur.hip)
                 hidden = self._recur_kernel(latent.view(1, E, N, ENC_FEATURES), hidden, comm_mask.unsqueeze(0), False, gi=gi_cached)[0]
                 hidden = hidden.view(E * N, self.latent_dim)
             else:
