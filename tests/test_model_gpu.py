@@ -188,6 +188,31 @@ def test_two_environments_per_workgroup_step_like_one(E, N, T):
         assert torch.equal(a_whole, torch.cat(a_parts, 1))
 
 
+@pytest.mark.parametrize("E,N", [(4096, 40), (4096, 6), (4095, 24)])
+def test_recurrence_at_full_size_treats_environments_independently(E, N):
+    """BASELINE config 2's actor batch (4096 environments x 40 agents) and two smaller-agent batches of the same size: an environment's
+    new hidden states do not depend on where it stands in the batch (which workgroup walks it, which environment shares the workgroup,
+    the order in which that workgroup's waves fetch the weight tiles) -- the batch in reversed order returns the reversed result, bit for
+    bit -- and an environment stepped alone returns the same bits."""
+    from mapf_rl_amd import fused
+
+    g = torch.Generator(device="cuda").manual_seed(N)
+    w = (torch.randn(fused.RECUR_WEIGHT_ELEMS, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(fused.RECUR_BIAS_ELEMS, device="cuda", generator=g) * 0.1
+    gi = (torch.randn((1, E, N, 768), device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+    h0 = (torch.randn((E, N, 256), device="cuda", generator=g) * 0.3).to(torch.bfloat16)
+    comm = torch.rand((1, E, N, N), device="cuda", generator=g) < 0.15
+    comm |= torch.eye(N, dtype=torch.bool, device="cuda")
+    out, a0 = fused.recurrent_infer(gi, h0, comm, w, b, want_agent0=True)
+    rev, a0r = fused.recurrent_infer(gi.flip(1).contiguous(), h0.flip(0).contiguous(), comm.flip(1).contiguous(), w, b, want_agent0=True)
+    assert not out.isnan().any()
+    assert torch.equal(out, rev.flip(0)) and torch.equal(a0, a0r.flip(1))
+    assert torch.equal(a0[0], out[:, 0])  # agent 0's state after the step is row 0 of its environment
+    for e in (0, 1, E // 2, E - 1):
+        one, _ = fused.recurrent_infer(gi[:, e:e + 1].contiguous(), h0[e:e + 1].contiguous(), comm[:, e:e + 1].contiguous(), w, b)
+        assert torch.equal(one[0], out[e]), e
+
+
 @pytest.mark.parametrize("E,N", [(320, 5), (600, 20)])
 def test_policy_step_of_many_small_environments_equals_its_halves(E, N):
     """Network.step_batch over more environments than CUs (where the recurrence steps two environments per workgroup) returns, for every
