@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Runs a few actor-loop iterations (Network.step_batch + mapf_step + recording) at the config-2 shape for
+"""Runs a few actor-loop iterations (Network.step_batch + mapf_step + recording) at the config-2 shape (NAGENTS / NENVS / MAPLEN: another) for
 rocprofv3 (kernel breakdown of the end-to-end env-steps/s)."""
 import os
 import sys
@@ -12,11 +12,11 @@ import mapf_rl_amd as M  # noqa: E402
 from mapf_rl_amd.actor import VecActor  # noqa: E402
 from mapf_rl_amd.model import Network  # noqa: E402
 
-N, E = 40, 4096
+N, E, L = int(os.environ.get("NAGENTS", 40)), int(os.environ.get("NENVS", 4096)), int(os.environ.get("MAPLEN", 32))
 torch.manual_seed(0)
 model = Network().cuda()
-maps, agents, goals, _ = M.generate_scenarios(E, 32, N, 0.3, seed=1)
-env = M.VecEnvironment(E, 32, N)
+maps, agents, goals, _ = M.generate_scenarios(E, L, N, 0.3, seed=1)
+env = M.VecEnvironment(E, L, N)
 env.load(maps, agents, goals)
 actor = VecActor(env, model, None, seed=0, density=0.3)
 import time
