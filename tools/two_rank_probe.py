@@ -106,6 +106,8 @@ def main():
         # the collective in isolation (GPU otherwise idle): a host tensor of the gradient buffer's size, then the device buffer itself
         hostbuf = torch.ones(learner.bucket.flat.numel(), dtype=torch.float32)
         for name, t in (("host_tensor", hostbuf), ("device_tensor", learner.bucket.flat)):
+            if name == "host_tensor" and dist.get_backend() == "nccl":  # (RCCL has no host path)
+                continue
             ts = []
             for _ in range(6):
                 torch.cuda.synchronize()
