@@ -212,6 +212,27 @@ int mapf_recurrent_forward_save(const uint16_t *gi_dev, const uint16_t *h0_dev, 
 int mapf_recurrent_backward(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev,
                             const uint16_t *weights_t_dev, int T, int E, int N, void *const *out_dev,
                             const int32_t *row_index_dev, int64_t num_rows, void *stream);
+/*
+ * The same three entry points over TILES of several training windows (round 5): with agent0_stride = S > 0 (N <= 48, else
+ * MAPF_ERR_UNSUPPORTED) an "environment" of N agent rows stands for ceil(N / S) windows of S rows each, lying back to back -- rows
+ * k S .. k S + S - 1 are window k's agents, its agent 0 in row k S -- whose masks in comm_dev [T][E][N][N] are block-diagonal (no entry
+ * between two windows; mapf_plan_rows writes them so for compact widths 4 and 8).  agent0_out_dev / d_agent0_dev are then
+ * [T][E][ceil(N / S)][256]: one agent-0 row per window.  Everything else as above, row by row the same bits as one window per
+ * environment: a workgroup streams the 1.1 MB of weights once per step whatever the rows of its tile hold, so a batch of 192 windows
+ * of <= 8 agents becomes 96 workgroups -- and the online and the target network's recurrences of an update, 192 workgroups each on 256
+ * CUs before, run side by side (reference: the same Network.forward per window, model.py:220-249).  agent0_stride = 0: the plain
+ * entry points above.  bsum: one row per tile ([E][MAPF_RECUR_BSUM_ELEMS] with the E passed here).
+ */
+int mapf_recurrent_infer_packed(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
+                                const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev,
+                                const int32_t *row_index_dev, int64_t num_rows, int agent0_stride, void *stream);
+int mapf_recurrent_forward_save_packed(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
+                                       const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev,
+                                       uint16_t *const *save_dev, const int32_t *row_index_dev, int64_t num_rows, int agent0_stride,
+                                       void *stream);
+int mapf_recurrent_backward_packed(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev,
+                                   const uint16_t *weights_t_dev, int T, int E, int N, void *const *out_dev, const int32_t *row_index_dev,
+                                   int64_t num_rows, int agent0_stride, void *stream);
 
 /*
  * Input projection of the recurrent cell for the ACTOR's step (reference model.py:191: the W_ih x half of `self.recurrent(latent, hidden)`;
@@ -307,6 +328,9 @@ int mapf_window_relevance(const uint8_t *comm_dev, const int64_t *steps_dev, int
  *   h0_c bf16 [B][Nc][256] from hidden f16 (or bf16) [B*N][256]; row_src int64 [num_rows] element offset of every row's observation
  *   in the bf16 observations (window b, step t at obs + b * obs_stride_b + t * obs_stride_t elements, [N][486] contiguous) and
  *   obs_rows bf16 [num_rows][486] the rows themselves (both optional; num_rows = sum of cnt, known to the caller).
+ * Nc = 4 or 8 (every nag <= Nc, B a multiple of K = 16 / Nc): K consecutive windows share a 16-row tile of the recurrence kernels
+ * (mapf_recurrent_*_packed with agent0_stride = Nc and E = B / K): gidx and h0_c as above -- [T][B][Nc] IS [T][B / K][16] --, and
+ * comm_c u8 [T][B / K][16][16] block-diagonal, window b in rows and columns (b % K) Nc .. of tile b / K.
  */
 #define MAPF_PLAN_MAX_STEPS 20
 int mapf_plan_mark(const uint8_t *comm_dev, int64_t stride_b, int64_t stride_t, const int64_t *steps_dev, const float *extra_steps_dev,

@@ -83,6 +83,9 @@ SYMBOLS = [
     ("mapf_recurrent_infer_multi", _i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     ("mapf_recurrent_forward_save", _i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, ctypes.POINTER(_vp), _vp, ctypes.c_int64, _vp]),
     ("mapf_recurrent_backward", _i, [ctypes.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(_vp), _vp, ctypes.c_int64, _vp]),
+    ("mapf_recurrent_infer_packed", _i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, ctypes.c_int64, _i, _vp]),
+    ("mapf_recurrent_forward_save_packed", _i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, ctypes.POINTER(_vp), _vp, ctypes.c_int64, _i, _vp]),
+    ("mapf_recurrent_backward_packed", _i, [ctypes.POINTER(_vp), _vp, _vp, _vp, _i, _i, _i, ctypes.POINTER(_vp), _vp, ctypes.c_int64, _i, _vp]),
     ("mapf_comm_mask", _i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     ("mapf_q_head", _i, [_vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_input_proj_pack", _i, [_vp, _vp, _vp]),

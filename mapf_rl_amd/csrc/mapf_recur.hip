@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
                                                                   const float *__restrict__ bias, int T, int E, int N_arg,
                                                                   uint16_t *__restrict__ h_out, uint16_t *__restrict__ agent0_out,
                                                                   RecurSave sv, const int32_t *__restrict__ rowidx, long long nrows,
-                                                                  const int4 *__restrict__ envtab) {
+                                                                  const int4 *__restrict__ envtab, int a0s) {
     // NE environments side by side in this workgroup (PAIR: two, see the LDS map; never with SAVE, envtab or sixteen waves)
     constexpr int NE = PAIR ? 2 : 1;
     static_assert(!(PAIR && SAVE) && !(PAIR && NWV != 8), "");
@@ -833,10 +833,18 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_infer_kernel(const uint16_t
             phase_sync(8);
             swap_states();
         }
+        // agent 0's state after this step (model.py:248).  a0s > 0: the environment is a TILE of several windows of a0s agent rows each
+        // (block-diagonal masks: include/mapf_dqn.h, mapf_recurrent_infer_packed) -- rows 0, a0s, 2 a0s, ... are their agents 0
+        {
+            const int K = a0s > 0 ? (N + a0s - 1) / a0s : 1;
 #pragma unroll
-        for (int s = 0; s < NE; ++s)
-            if (agent0_out != nullptr && tid < 32 && agents(s) > 0)  // agent 0's state after this step (model.py:248)
-                *reinterpret_cast<uint4 *>(agent0_out + ((long long)t * E + e + s) * D + tid * 8) = *reinterpret_cast<const uint4 *>(Hcur(s) + tid * 16);
+            for (int s = 0; s < NE; ++s)
+                if (agent0_out != nullptr && tid < 32 * K && agents(s) > 0) {
+                    const int k = tid >> 5, c = tid & 31;
+                    *reinterpret_cast<uint4 *>(agent0_out + (((long long)t * E + e + s) * K + k) * D + c * 8) =
+                        *reinterpret_cast<const uint4 *>(Hcur(s) + (k * a0s) * H_ROW + c * 16);
+                }
+        }
         if (++t >= T) break;
         fetch_inputs(t);  // the next step's (step 0's were requested in front of the prologue)
     }
@@ -910,22 +918,26 @@ extern "C" {
 #define RECUR_ENTRY(name) __attribute__((visibility("hidden"))) RECUR_PASTE(name, MAPF_RECUR_SUFFIX)
 #endif
 
-int RECUR_ENTRY(mapf_recurrent_infer)(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
+int RECUR_ENTRY(mapf_recurrent_infer_packed)(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
                          const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev, const int32_t *row_index_dev,
-                         int64_t num_rows, void *stream) {
+                         int64_t num_rows, int agent0_stride, void *stream) {
     if (T < 1 || E < 0 || N < 1 || N > MAPF_RECUR_MAX_AGENTS || !gi_dev || !comm_dev || !weights_dev || !bias_dev || !h_out_dev)
         return MAPF_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(gi_dev) & 7) || (reinterpret_cast<uintptr_t>(h0_dev) & 15) || (reinterpret_cast<uintptr_t>(weights_dev) & 15) ||
         (reinterpret_cast<uintptr_t>(bias_dev) & 15) || (reinterpret_cast<uintptr_t>(h_out_dev) & 15) ||
         (reinterpret_cast<uintptr_t>(agent0_out_dev) & 15))
         return MAPF_ERR_INVALID_ARG;
+    if (agent0_stride < 0 || agent0_stride > N) return MAPF_ERR_INVALID_ARG;
     if (E == 0) return MAPF_OK;
     if (row_index_dev && (N > NA || num_rows < 1)) return MAPF_ERR_UNSUPPORTED;  // compact rows: the <= 48-agent kernels only
+    if (agent0_stride > 0 && N > MAPF_RECUR_NARROW_AGENTS) return MAPF_ERR_UNSUPPORTED;  // tiles of several windows: the <= 48-agent kernels only
 #if MAPF_RECUR_NT == 3
     if (N <= MAPF_RECUR_SMALL_AGENTS)  // one agent tile: the same kernel built for 16 agents (a third of the MFMA / LDS work per step)
-        return mapf_recurrent_infer_nt1(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, row_index_dev, num_rows, stream);
+        return mapf_recurrent_infer_packed_nt1(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, row_index_dev, num_rows,
+                                               agent0_stride, stream);
     if (N <= 2 * MAPF_RECUR_SMALL_AGENTS)  // two tiles
-        return mapf_recurrent_infer_nt2(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, row_index_dev, num_rows, stream);
+        return mapf_recurrent_infer_packed_nt2(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, row_index_dev, num_rows,
+                                               agent0_stride, stream);
 #endif
     if (N > NA)  // 49..128 agents: csrc/mapf_recur_wide.hip
         return mapf_recur_wide_forward(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, nullptr,
@@ -934,43 +946,60 @@ int RECUR_ENTRY(mapf_recurrent_infer)(const uint16_t *gi_dev, const uint16_t *h0
     if (pair_launch(E))
         hipLaunchKernelGGL((recurrent_infer_kernel<false, true>), dim3(pair_grid(E)), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev,
                            comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, RecurSave{}, row_index_dev, (long long)num_rows,
-                           (const int4 *)nullptr);
+                           (const int4 *)nullptr, agent0_stride);
     else
 #endif
         hipLaunchKernelGGL((recurrent_infer_kernel<false, false>), dim3(persistent_grid(E)), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev,
                            comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, RecurSave{}, row_index_dev, (long long)num_rows,
-                           (const int4 *)nullptr);
+                           (const int4 *)nullptr, agent0_stride);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }
 
-int RECUR_ENTRY(mapf_recurrent_forward_save)(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
+int RECUR_ENTRY(mapf_recurrent_forward_save_packed)(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
                                 const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev,
-                                uint16_t *const *save_dev, const int32_t *row_index_dev, int64_t num_rows, void *stream) {
+                                uint16_t *const *save_dev, const int32_t *row_index_dev, int64_t num_rows, int agent0_stride, void *stream) {
     if (T < 1 || E < 0 || N < 1 || N > MAPF_RECUR_MAX_AGENTS || !gi_dev || !comm_dev || !weights_dev || !bias_dev || !h_out_dev ||
         !agent0_out_dev || !save_dev)
         return MAPF_ERR_INVALID_ARG;
     for (int i = 0; i < 8; ++i)
         if (!save_dev[i] || (reinterpret_cast<uintptr_t>(save_dev[i]) & 15)) return MAPF_ERR_INVALID_ARG;
+    if (agent0_stride < 0 || agent0_stride > N) return MAPF_ERR_INVALID_ARG;
     if (E == 0) return MAPF_OK;
     const RecurSave sv{save_dev[0], save_dev[1], save_dev[2], save_dev[3], save_dev[4], save_dev[5], save_dev[6], save_dev[7]};
     if (row_index_dev && (N > NA || num_rows < 1)) return MAPF_ERR_UNSUPPORTED;
+    if (agent0_stride > 0 && N > MAPF_RECUR_NARROW_AGENTS) return MAPF_ERR_UNSUPPORTED;
 #if MAPF_RECUR_NT == 3
     if (N <= MAPF_RECUR_SMALL_AGENTS)
-        return mapf_recurrent_forward_save_nt1(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, save_dev, row_index_dev,
-                                               num_rows, stream);
+        return mapf_recurrent_forward_save_packed_nt1(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, save_dev,
+                                                      row_index_dev, num_rows, agent0_stride, stream);
     if (N <= 2 * MAPF_RECUR_SMALL_AGENTS)
-        return mapf_recurrent_forward_save_nt2(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, save_dev, row_index_dev,
-                                               num_rows, stream);
+        return mapf_recurrent_forward_save_packed_nt2(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, save_dev,
+                                                      row_index_dev, num_rows, agent0_stride, stream);
 #endif
     if (N > NA)
         return mapf_recur_wide_forward(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, &sv,
                                        static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL((recurrent_infer_kernel<true, false>), dim3(persistent_grid(E)), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
-                       weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, sv, row_index_dev, (long long)num_rows, (const int4 *)nullptr);
+                       weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, sv, row_index_dev, (long long)num_rows, (const int4 *)nullptr, agent0_stride);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }
+
+#if MAPF_RECUR_NT == 3
+int mapf_recurrent_infer(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev, const float *bias_dev,
+                         int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev, const int32_t *row_index_dev, int64_t num_rows,
+                         void *stream) {
+    return mapf_recurrent_infer_packed(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, row_index_dev, num_rows, 0, stream);
+}
+
+int mapf_recurrent_forward_save(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
+                                const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev,
+                                uint16_t *const *save_dev, const int32_t *row_index_dev, int64_t num_rows, void *stream) {
+    return mapf_recurrent_forward_save_packed(gi_dev, h0_dev, comm_dev, weights_dev, bias_dev, T, E, N, h_out_dev, agent0_out_dev, save_dev, row_index_dev,
+                                              num_rows, 0, stream);
+}
+#endif
 
 #if MAPF_RECUR_NT == 1
 // One step of E environments of DIFFERENT agent counts (each <= 16) in one launch: the policy recurrence of all active curriculum
@@ -984,7 +1013,7 @@ extern "C" int mapf_recurrent_infer_multi(const uint16_t *gi_dev, const uint16_t
     if (E == 0) return MAPF_OK;
     hipLaunchKernelGGL((recurrent_infer_kernel<false, false>), dim3(E), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gi_dev, h0_dev, comm_dev,
                        weights_dev, bias_dev, 1, E, 1, h_out_dev, (uint16_t *)nullptr, RecurSave{}, (const int32_t *)nullptr, 0ll,
-                       reinterpret_cast<const int4 *>(envtab_dev));
+                       reinterpret_cast<const int4 *>(envtab_dev), 0);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }

@@ -228,6 +228,7 @@ struct BwdArgs {
     int T, E, N;
     const int32_t *rowidx;    // [T][E][N] compact rows (see csrc/mapf_recur.hip) or nullptr: dense
     long long nrows;
+    int a0s;                  // > 0: the environment is a tile of several windows of a0s agent rows each; dA0 [T][E][N / a0s][256] -> rows 0, a0s, ...
 };
 
 __device__ __forceinline__ void unpack8(const uint4 v, float (&f)[8]) {
@@ -358,13 +359,16 @@ __global__ void __launch_bounds__(NTHR, 1) recurrent_bwd_kernel(BwdArgs A) {
         const long long row0 = ((long long)t * E + e) * N;
         // ---- external gradient of agent 0's state after step t; partner counts of this step's mask ----
         if (tid < 64) {
-            const uint2 g = *reinterpret_cast<const uint2 *>(A.dA0 + ((long long)t * E + e) * D + tid * 4);
-            uint2 *cell = reinterpret_cast<uint2 *>(DH + tid * 8);
-            float a[4], b[4];
-            unpack4(*cell, a);
-            unpack4(g, b);
-            const float o[4] = {a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
-            *cell = pack4(o);
+            const int K = A.a0s > 0 ? (N + A.a0s - 1) / A.a0s : 1;
+            for (int k = 0; k < K; ++k) {
+                const uint2 g = *reinterpret_cast<const uint2 *>(A.dA0 + (((long long)t * E + e) * K + k) * D + tid * 4);
+                uint2 *cell = reinterpret_cast<uint2 *>(DH + (k * A.a0s) * H_ROW + tid * 8);
+                float a[4], b[4];
+                unpack4(*cell, a);
+                unpack4(g, b);
+                const float o[4] = {a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
+                *cell = pack4(o);
+            }
         } else if (tid < 128) {
             upd[tid - 64] = 0;
         } else if (tid < 192) {
@@ -617,9 +621,9 @@ extern "C" {
 #define RECUR_ENTRY(name) __attribute__((visibility("hidden"))) RECUR_PASTE(name, MAPF_RECUR_SUFFIX)
 #endif
 
-int RECUR_ENTRY(mapf_recurrent_backward)(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev,
+int RECUR_ENTRY(mapf_recurrent_backward_packed)(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev,
                             const uint16_t *weights_t_dev, int T, int E, int N, void *const *out_dev, const int32_t *row_index_dev,
-                            int64_t num_rows, void *stream) {
+                            int64_t num_rows, int agent0_stride, void *stream) {
     if (T < 1 || E < 0 || N < 1 || N > MAPF_RECUR_MAX_AGENTS || !saved_dev || !comm_dev || !d_agent0_dev || !weights_t_dev || !out_dev)
         return MAPF_ERR_INVALID_ARG;
     for (int i = 0; i < 8; ++i)
@@ -627,12 +631,16 @@ int RECUR_ENTRY(mapf_recurrent_backward)(const uint16_t *const *saved_dev, const
     for (int i = 0; i < 7; ++i)
         if (!out_dev[i] || (reinterpret_cast<uintptr_t>(out_dev[i]) & 15)) return MAPF_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(d_agent0_dev) & 15) || (reinterpret_cast<uintptr_t>(weights_t_dev) & 15)) return MAPF_ERR_INVALID_ARG;
+    if (agent0_stride < 0 || agent0_stride > N) return MAPF_ERR_INVALID_ARG;
     if (E == 0) return MAPF_OK;
+    if (agent0_stride > 0 && N > MAPF_RECUR_NARROW_AGENTS) return MAPF_ERR_UNSUPPORTED;  // tiles of several windows: the <= 48-agent kernels only
 #if MAPF_RECUR_NT == 3
     if (N <= MAPF_RECUR_SMALL_AGENTS)  // one agent tile: the same kernel built for 16 agents (and what the forward of these shapes saved)
-        return mapf_recurrent_backward_nt1(saved_dev, comm_dev, d_agent0_dev, weights_t_dev, T, E, N, out_dev, row_index_dev, num_rows, stream);
+        return mapf_recurrent_backward_packed_nt1(saved_dev, comm_dev, d_agent0_dev, weights_t_dev, T, E, N, out_dev, row_index_dev, num_rows, agent0_stride,
+                                                  stream);
     if (N <= 2 * MAPF_RECUR_SMALL_AGENTS)  // two tiles
-        return mapf_recurrent_backward_nt2(saved_dev, comm_dev, d_agent0_dev, weights_t_dev, T, E, N, out_dev, row_index_dev, num_rows, stream);
+        return mapf_recurrent_backward_packed_nt2(saved_dev, comm_dev, d_agent0_dev, weights_t_dev, T, E, N, out_dev, row_index_dev, num_rows, agent0_stride,
+                                                  stream);
 #endif
     BwdArgs a;
     a.hin0 = saved_dev[0];
@@ -658,6 +666,7 @@ int RECUR_ENTRY(mapf_recurrent_backward)(const uint16_t *const *saved_dev, const
     a.N = N;
     a.rowidx = row_index_dev;
     a.nrows = num_rows;
+    a.a0s = agent0_stride;
     if (row_index_dev && (N > NA || num_rows < 1)) return MAPF_ERR_UNSUPPORTED;  // compact rows: the <= 48-agent kernels only
     if (N > NA) {  // 49..128 agents: csrc/mapf_recur_wide_bwd.hip
         RecurBwdArgs b{};
@@ -673,6 +682,10 @@ int RECUR_ENTRY(mapf_recurrent_backward)(const uint16_t *const *saved_dev, const
 }
 
 #if MAPF_RECUR_NT == 3
+int mapf_recurrent_backward(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev, const uint16_t *weights_t_dev, int T,
+                            int E, int N, void *const *out_dev, const int32_t *row_index_dev, int64_t num_rows, void *stream) {
+    return mapf_recurrent_backward_packed(saved_dev, comm_dev, d_agent0_dev, weights_t_dev, T, E, N, out_dev, row_index_dev, num_rows, 0, stream);
+}
 }  // extern "C"
 #endif
 #ifdef MAPF_RECUR_TRACE

@@ -42,23 +42,25 @@ struct RecurBwdArgs {
 // csrc/mapf_recur_nt1.hip / mapf_recur_bwd_nt1.hip (and _nt2): csrc/mapf_recur.hip / mapf_recur_bwd.hip compiled for one agent tile (N <= 16:
 // the reference's own training shapes and every curriculum level) and for two (N <= 32).  Same arguments as the C ABI entry points that dispatch to them; the
 // attention weights P of the saved state are laid out for 16 (32) agent rows per (step, environment) by these pairs.
-int mapf_recurrent_infer_nt1(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev, const float *bias_dev,
-                             int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev, const int32_t *row_index_dev, int64_t num_rows,
-                             void *stream);
-int mapf_recurrent_forward_save_nt1(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
-                                    const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev, uint16_t *const *save_dev,
-                                    const int32_t *row_index_dev, int64_t num_rows, void *stream);
-int mapf_recurrent_backward_nt1(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev, const uint16_t *weights_t_dev,
-                                int T, int E, int N, void *const *out_dev, const int32_t *row_index_dev, int64_t num_rows, void *stream);
+int mapf_recurrent_infer_packed_nt1(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
+                                    const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev, const int32_t *row_index_dev,
+                                    int64_t num_rows, int agent0_stride, void *stream);
+int mapf_recurrent_forward_save_packed_nt1(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
+                                           const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev,
+                                           uint16_t *const *save_dev, const int32_t *row_index_dev, int64_t num_rows, int agent0_stride, void *stream);
+int mapf_recurrent_backward_packed_nt1(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev,
+                                       const uint16_t *weights_t_dev, int T, int E, int N, void *const *out_dev, const int32_t *row_index_dev,
+                                       int64_t num_rows, int agent0_stride, void *stream);
 
-int mapf_recurrent_infer_nt2(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev, const float *bias_dev,
-                             int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev, const int32_t *row_index_dev, int64_t num_rows,
-                             void *stream);
-int mapf_recurrent_forward_save_nt2(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
-                                    const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev, uint16_t *const *save_dev,
-                                    const int32_t *row_index_dev, int64_t num_rows, void *stream);
-int mapf_recurrent_backward_nt2(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev, const uint16_t *weights_t_dev,
-                                int T, int E, int N, void *const *out_dev, const int32_t *row_index_dev, int64_t num_rows, void *stream);
+int mapf_recurrent_infer_packed_nt2(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
+                                    const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev, const int32_t *row_index_dev,
+                                    int64_t num_rows, int agent0_stride, void *stream);
+int mapf_recurrent_forward_save_packed_nt2(const uint16_t *gi_dev, const uint16_t *h0_dev, const uint8_t *comm_dev, const uint16_t *weights_dev,
+                                           const float *bias_dev, int T, int E, int N, uint16_t *h_out_dev, uint16_t *agent0_out_dev,
+                                           uint16_t *const *save_dev, const int32_t *row_index_dev, int64_t num_rows, int agent0_stride, void *stream);
+int mapf_recurrent_backward_packed_nt2(const uint16_t *const *saved_dev, const uint8_t *comm_dev, const uint16_t *d_agent0_dev,
+                                       const uint16_t *weights_t_dev, int T, int E, int N, void *const *out_dev, const int32_t *row_index_dev,
+                                       int64_t num_rows, int agent0_stride, void *stream);
 
 // csrc/mapf_recur_wide.hip: forward for 48 < N <= 128 (sv == nullptr: inference, nothing saved).  Returns a MAPF_* status.
 int mapf_recur_wide_forward(const uint16_t *gi, const uint16_t *h0, const uint8_t *comm, const uint16_t *W, const float *bias, int T, int E,

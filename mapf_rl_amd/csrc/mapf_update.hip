@@ -242,6 +242,19 @@ __global__ void __launch_bounds__(256) plan_masks_kernel(PlanRowsArgs p) {
     if (t < T) {
         const int na = p.nact[(size_t)t * B + b];
         const uint8_t *src = p.comm + (long long)b * p.c_sB + (long long)t * p.c_sT;
+        if (Nc < 16) {
+            // Nc = 4 or 8: 16 / Nc windows share a 16 x 16 mask tile, block-diagonally (mapf_recurrent_*_packed): this window writes its Nc
+            // rows of tile b / K over all 16 columns -- zeros outside its own block
+            const int K = 16 / Nc, k = b % K;
+            uint8_t *dst = p.comm_c + ((size_t)t * (B / K) + b / K) * 256 + (size_t)k * Nc * 16;
+            for (int idx = tid; idx < Nc * 16; idx += 256) {
+                const int i = idx >> 4, jj = (idx & 15) - k * Nc;  // jj: the column as a position of this window
+                uint8_t v = (uint8_t)(i == jj);
+                if (jj >= 0 && jj < Nc && i < na && jj < na) v = src[(long long)s_ord[i] * N + s_ord[jj]] != 0;
+                dst[idx] = v;
+            }
+            return;
+        }
         uint8_t *dst = p.comm_c + ((size_t)t * B + b) * Nc * Nc;
         for (int idx = tid; idx < Nc * Nc; idx += 256) {
             const int i = idx / Nc, j = idx - i * Nc;
@@ -813,8 +826,9 @@ int mapf_plan_rows(int T, int B, int N, int Nc, const int16_t *order_dev, const 
                    const uint16_t *obs_bf16_dev, int64_t obs_stride_b, int64_t obs_stride_t, int32_t *gidx_dev, uint8_t *comm_c_dev, uint16_t *h0_c_dev,
                    int64_t num_rows, int64_t *row_src_dev, uint16_t *obs_rows_dev, const uint8_t *dup_dev, const int32_t *ucnt_dev, int32_t *umap_dev,
                    int32_t *row_tbp_dev, void *stream) {
-    if (T < 1 || T > MAPF_PLAN_MAX_STEPS || B < 0 || N < 1 || N > 128 || Nc < 16 || Nc > 128 || (Nc & 15) || !order_dev || !nact_dev || !cnt_dev || !nag_dev ||
-        !comm_dev || !hidden_dev || !gidx_dev || !comm_c_dev || !h0_c_dev)
+    const bool tiled = (Nc == 4 || Nc == 8) && B % (16 / Nc) == 0;  // several windows per 16-row tile (see plan_masks_kernel)
+    if (T < 1 || T > MAPF_PLAN_MAX_STEPS || B < 0 || N < 1 || N > 128 || (!tiled && (Nc < 16 || Nc > 128 || (Nc & 15))) || !order_dev || !nact_dev || !cnt_dev ||
+        !nag_dev || !comm_dev || !hidden_dev || !gidx_dev || !comm_c_dev || !h0_c_dev)
         return MAPF_ERR_INVALID_ARG;
     if (obs_rows_dev && (!obs_bf16_dev || !row_src_dev || num_rows < 0 || (obs_stride_b % 2) || (obs_stride_t % 2) ||
                          (reinterpret_cast<uintptr_t>(obs_bf16_dev) & 3) || (reinterpret_cast<uintptr_t>(obs_rows_dev) & 3)))
@@ -998,7 +1012,7 @@ int mapf_obs_dup(int T, int To, int B, int N, const uint16_t *obs_bf16_dev, int6
 
 int mapf_dedup_sum(int T, int B, int Nc, int64_t rows, int row_bytes, const int32_t *gidx_dev, const int32_t *umap_dev, const int32_t *row_tbp_dev,
                    const void *d_rows_dev, void *d_unique_dev, void *stream) {
-    if (T < 1 || T > 64 || B < 1 || Nc < 16 || rows < 0 || row_bytes < 16 || (row_bytes & 15) || !gidx_dev || !umap_dev || !row_tbp_dev || !d_rows_dev || !d_unique_dev)
+    if (T < 1 || T > 64 || B < 1 || Nc < 1 || rows < 0 || row_bytes < 16 || (row_bytes & 15) || !gidx_dev || !umap_dev || !row_tbp_dev || !d_rows_dev || !d_unique_dev)
         return MAPF_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(d_rows_dev) & 15) || (reinterpret_cast<uintptr_t>(d_unique_dev) & 15)) return MAPF_ERR_INVALID_ARG;
     if (rows == 0) return MAPF_OK;

@@ -231,6 +231,7 @@ class FusedUpdate:
     # consumer of a tensor a later capture placed there.  Hence three pools: "main" (pack, online, backward: the saved tensors of an
     # online graph live until its backward graph has run, and only `head` runs in between), "head", and "side" (target, prefetch:
     # nothing of theirs outlives its graph; their results land in buffers allocated outside any capture).
+    TILE_WINDOWS = os.environ.get("MAPF_TILE_WINDOWS", "1") != "0"  # several few-agent windows per recurrence tile (_compact_width; the variable: A/B runs)
     GRAPH = os.environ.get("MAPF_UPDATE_GRAPH", "1") != "0"   # (the variable: A/B runs of train.py)
     GRAPH_MAX_AGENTS = 16       # replay rows wider than this are GPU-bound (no gain) and would need many more buckets
     GRAPH_ROW_STEP = 2048       # bucket of the entry count (== WGRAD_SPLIT: the weight-gradient GEMMs' K is padded to it anyway)
@@ -377,14 +378,32 @@ class FusedUpdate:
         h = pl["host"].numpy()
         for k, p in enumerate((pl["online"], pl["target"])):
             p.rows = int(h[2 * k].sum())
-            p.nc = 16 * max(1, -(-int(h[2 * k + 1].max()) // 16))
+            p.nc = self._compact_width(int(h[2 * k + 1].max()), p.B)
             p.urows = int(h[4 + k].sum()) if p.dup is not None else p.rows
             p.true_rows, p.true_urows = p.rows, p.urows
             if padded:
-                p.nc = 16 * max(1, -(-p.N // 16))
+                p.nc = self._compact_width(p.N, p.B)
                 p.rows = _round_up(p.rows, self.GRAPH_ROW_STEP)
                 p.urows = _round_up(p.urows, self.GRAPH_UROW_STEP) if p.dup is not None else p.rows
         return pl
+
+    def _compact_width(self, agents, B):
+        """Agent positions per window in the compact numbering: a multiple of 16 (the recurrence kernels' agent tile) -- or, for windows
+        of <= 4 / <= 8 agents that matter, 4 / 8: four / two consecutive windows then share a tile (`TILE_WINDOWS`; include/mapf_dqn.h:
+        mapf_plan_rows, mapf_recurrent_*_packed), and a batch of 192 six-agent windows is 96 workgroups per recurrence launch instead
+        of 192 -- the online and the target network's launches, which met on 256 CUs one behind the other, run side by side."""
+        if self.TILE_WINDOWS:
+            for w in (4, 8):
+                if agents <= w and B % (16 // w) == 0:
+                    return w
+        return 16 * max(1, -(-agents // 16))
+
+    @staticmethod
+    def _tile(p):
+        """(environments, agent rows per environment, agent-0 stride) the recurrence kernels are launched with for window set p."""
+        if p.nc < 16:
+            return p.B // (16 // p.nc), 16, p.nc
+        return p.B, p.nc, 0
 
     def _plan_rows(self, p, v, padded=False):
         """`mapf_plan_rows` for one window set.  padded: the launch sizes are buckets >= the real counts; the index tables are
@@ -394,7 +413,7 @@ class FusedUpdate:
         st = _stream(dev)
         T, B, N, Nc = p.T, p.B, p.N, p.nc
         p.gidx = torch.empty((T, B, Nc), dtype=torch.int32, device=dev)
-        p.comm_c = torch.empty((T, B, Nc, Nc), dtype=torch.uint8, device=dev)
+        p.comm_c = torch.empty((T, B, Nc, Nc) if Nc >= 16 else (T, B // (16 // Nc), 16, 16), dtype=torch.uint8, device=dev)
         p.h0_c = torch.empty((B, Nc, 256), dtype=torch.bfloat16, device=dev)
         # the observations to encode: every row, or -- with the duplicate flags -- the distinct ones (umap: entry -> distinct row)
         p.obs_rows = rows_buffer((), max(p.urows, 1), (6, 9, 9), torch.bfloat16, dev)
@@ -453,8 +472,9 @@ class FusedUpdate:
             gi_rows, gi = gi, torch.empty((T, B, Nc, 768), dtype=torch.bfloat16, device=dev)
             check(lib.mapf_rows_scatter(_ptr(gi_rows), _ptr(p.gidx), _ptr(gi), T * B * Nc, 1536, 1, st), "mapf_rows_scatter")
         h_out = torch.empty((B, Nc, 256), dtype=torch.bfloat16, device=dev)
-        check(lib.mapf_recurrent_infer(_ptr(gi), _ptr(p.h0_c), _ptr(p.comm_c), _ptr(w), _ptr(b), T, B, Nc, _ptr(h_out), _ptr(a0),
-                                       _ptr(p.gidx) if compact else None, p.rows if compact else 0, st), "mapf_recurrent_infer")
+        E_, N_, stride = self._tile(p)
+        check(lib.mapf_recurrent_infer_packed(_ptr(gi), _ptr(p.h0_c), _ptr(p.comm_c), _ptr(w), _ptr(b), T, E_, N_, _ptr(h_out), _ptr(a0),
+                                              _ptr(p.gidx) if compact else None, p.rows if compact else 0, stride, st), "mapf_recurrent_infer_packed")
         return a0
 
     def _expand(self, x_u, p):
@@ -549,8 +569,9 @@ class FusedUpdate:
         h_out = torch.empty((B, Nc, 256), dtype=bf, device=dev)
         c.a0 = self._out(c, "a0", (To, B, 256), bf)
         c.sp = _ptr_array(c.saves)
-        check(lib.mapf_recurrent_forward_save(_ptr(gi), _ptr(po.h0_c), _ptr(po.comm_c), _ptr(c.w_rec), _ptr(c.b_rec), To, B, Nc, _ptr(h_out), _ptr(c.a0), c.sp,
-                                              c.ridx, c.nrows, st), "mapf_recurrent_forward_save")
+        E_, N_, stride = self._tile(po)
+        check(lib.mapf_recurrent_forward_save_packed(_ptr(gi), _ptr(po.h0_c), _ptr(po.comm_c), _ptr(c.w_rec), _ptr(c.b_rec), To, E_, N_, _ptr(h_out),
+                                                     _ptr(c.a0), c.sp, c.ridx, c.nrows, stride, st), "mapf_recurrent_forward_save_packed")
 
     def _head(self, c, v, To, Tt, batch):
         """Dueling heads, TD error, priorities, loss and their gradients; then the priority write-back."""
@@ -592,8 +613,9 @@ class FusedUpdate:
                       rows_buffer((2,), R, (768,), bf, dev), rows_buffer((2,), R, (768,), bf, dev),
                       rows_buffer((2,), R, (64,), bf, dev), rows_buffer((2,), R, (384,), bf, dev),
                       torch.empty((B, 2432), dtype=torch.float32, device=dev)]
-        check(lib.mapf_recurrent_backward(c.sp, _ptr(po.comm_c), _ptr(c.d_a0), _ptr(c.wt), To, B, Nc, _ptr_array(outs_b), c.ridx, c.nrows, st),
-              "mapf_recurrent_backward")
+        E_, N_, stride = self._tile(po)  # (bsum: one row per tile, E_ of its B rows)
+        check(lib.mapf_recurrent_backward_packed(c.sp, _ptr(po.comm_c), _ptr(c.d_a0), _ptr(c.wt), To, E_, N_, _ptr_array(outs_b), c.ridx, c.nrows, stride, st),
+              "mapf_recurrent_backward_packed")
         if compact and R > M and not c.padded:  # rows M..R of every GEMM operand (both rounds of the [2, R, w] tensors)
             ops = [saves[0], saves[2][0], saves[2][1], saves[4][0], saves[4][1], saves[5][0], saves[5][1], outs_b[1], outs_b[2][0], outs_b[2][1],
                    outs_b[3][0], outs_b[3][1], outs_b[4][0], outs_b[4][1], outs_b[5][0], outs_b[5][1]]
@@ -630,7 +652,7 @@ class FusedUpdate:
             _tall_tn_into(flat.mem(G, "comm.update_cell.weight_hh"), d_gh2.view(2 * R, 768), hrf, rows_k)
             bias_names = ("recurrent.bias_ih", "recurrent.bias_hh", "comm.self_attn.W_Q.bias", "comm.self_attn.W_K.bias", "comm.self_attn.W_V.bias",
                           "comm.update_cell.bias_ih", "comm.update_cell.bias_hh")
-            check(lib.mapf_recurrent_bias_grads(_ptr(bsum), B, _ptr_array([flat.mem(G, k) for k in bias_names]), st_x), "mapf_recurrent_bias_grads")
+            check(lib.mapf_recurrent_bias_grads(_ptr(bsum), E_, _ptr_array([flat.mem(G, k) for k in bias_names]), st_x), "mapf_recurrent_bias_grads")
         # ---- input projection ----
         if compact:
             d_gi_rows = d_gi1[:M]

@@ -366,3 +366,60 @@ def test_input_projection_kernel_for_all_rows_and_for_a_row_list(R):
     out.fill_(7.0)
     input_proj_rows(x, wp, out, lst, torch.zeros(1, dtype=torch.int32, device="cuda"))
     assert bool((out == 7.0).all())
+
+
+@pytest.mark.parametrize("B,S,T", [(6, 8, 3), (8, 4, 2), (4, 8, 18)])
+def test_tiles_of_several_windows_step_like_one_window_per_environment(B, S, T):
+    """mapf_recurrent_{infer,forward_save,backward}_packed with agent0_stride = S: 16 / S windows of S agents share a 16-row tile under a
+    block-diagonal mask.  Row by row the same bits as one window per environment (plain entry points, E = B, N = S): hidden states,
+    agent-0 states, every saved row tensor, every row gradient; the per-tile bias column sums add up to the per-window ones."""
+    import ctypes
+
+    from mapf_rl_amd import fused
+    from mapf_rl_amd._lib import lib, check
+
+    K, dev, bf = 16 // S, torch.device("cuda"), torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(B * 100 + S)
+    w = (torch.randn(fused.RECUR_WEIGHT_ELEMS, device=dev, generator=g) * 0.05).to(bf)
+    wt = (torch.randn(fused.RECUR_WEIGHT_ELEMS, device=dev, generator=g) * 0.05).to(bf)
+    bias = torch.randn(fused.RECUR_BIAS_ELEMS, device=dev, generator=g) * 0.1
+    gi = (torch.randn((T, B, S, 768), device=dev, generator=g) * 0.5).to(bf)
+    h0 = (torch.randn((B, S, 256), device=dev, generator=g) * 0.3).to(bf)
+    comm = (torch.rand((T, B, S, S), device=dev, generator=g) < 0.4) | torch.eye(S, dtype=torch.bool, device=dev)
+    comm[:, 1, 2] = torch.eye(S, dtype=torch.bool, device=dev)[2]  # an agent without partners
+    comm = comm.to(torch.uint8).contiguous()
+    tiles = torch.zeros((T, B // K, 16, 16), dtype=torch.uint8, device=dev)
+    for b in range(B):
+        k = b % K
+        tiles[:, b // K, k * S:(k + 1) * S, k * S:(k + 1) * S] = comm[:, b]
+    d_a0 = (torch.randn((T, B, 256), device=dev, generator=g) * 0.1).to(bf)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    R = T * B * S
+
+    def run(E, N, masks, stride):
+        saves = [torch.zeros(s_, dtype=bf, device=dev) for s_ in ((R, 256), (R, 1024), (2, R, 256), (2, R, 384), (2, R, 128), (2, R, 64), (2, R, 1024),
+                                                                 (2, T * B, 2, 48, 64))]
+        outs = [torch.zeros(s_, dtype=bf, device=dev) for s_ in ((R, 768), (R, 768), (2, R, 768), (2, R, 768), (2, R, 64), (2, R, 384))]
+        outs.append(torch.zeros((E, 2432), dtype=torch.float32, device=dev))
+        h_out, a0 = torch.zeros((B, S, 256), dtype=bf, device=dev), torch.zeros((T, B, 256), dtype=bf, device=dev)
+        h_inf, a_inf = torch.zeros_like(h_out), torch.zeros_like(a0)
+        sp = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in saves])
+        op = (ctypes.c_void_p * 7)(*[t.data_ptr() for t in outs])
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        check(lib.mapf_recurrent_infer_packed(p(gi), p(h0), p(masks), p(w), p(bias), T, E, N, p(h_inf), p(a_inf), None, 0, stride, st), "infer")
+        check(lib.mapf_recurrent_forward_save_packed(p(gi), p(h0), p(masks), p(w), p(bias), T, E, N, p(h_out), p(a0), sp, None, 0, stride, st), "save")
+        check(lib.mapf_recurrent_backward_packed(sp, p(masks), p(d_a0), p(wt), T, E, N, op, None, 0, stride, st), "bwd")
+        torch.cuda.synchronize()
+        return h_inf, a_inf, h_out, a0, saves[:7], outs
+
+    plain = run(B, S, comm, 0)
+    tiled = run(B // K, 16, tiles, S)
+    for k in range(4):
+        assert not plain[k].isnan().any()
+        assert torch.equal(plain[k], tiled[k]), k
+    assert torch.equal(plain[0], plain[2]) and torch.equal(plain[1], plain[3])  # (inference == training forward)
+    for k, (a, b_) in enumerate(zip(plain[4], tiled[4])):
+        assert torch.equal(a, b_), ("saved", k)
+    for k in range(6):
+        assert plain[5][k].abs().sum() > 0 and torch.equal(plain[5][k], tiled[5][k]), ("row gradient", k)
+    assert torch.allclose(plain[5][6].sum(0), tiled[5][6].sum(0), rtol=1e-3, atol=1e-3)
