@@ -313,6 +313,48 @@ def test_fused_update_equals_autograd_update(tag):
         assert torch.allclose(s0[k], s1[k], rtol=0, atol=2.5e-4), k
 
 
+@pytest.mark.parametrize("tag", ["b6", "upd"])
+def test_windows_sharing_a_recurrence_tile_give_the_same_update(tag):
+    """FusedUpdate.TILE_WINDOWS: two (four) windows of <= 8 (<= 4) agents that matter share a 16-row tile of the recurrence kernels under a
+    block-diagonal mask (mapf_plan_rows at compact width 8 / 4, mapf_recurrent_*_packed).  Row by row the kernels compute the same bits,
+    so Q-values, TD errors, loss and every weight gradient are IDENTICAL to one window per tile; the recurrence's bias gradients are sums
+    over tiles instead of windows (same terms, another order)."""
+    from mapf_rl_amd.update import FusedUpdate
+
+    if tag == "upd":
+        z = H.load_npz("dqn_update.npz")
+        mk = lambda: _batch(z, "cuda", torch.bfloat16)
+    else:
+        z = H.load_npz("dqn_big.npz")
+        mk = lambda: BG.batch(z, tag, "cuda", torch.bfloat16)
+    res, widths = {}, {}
+    try:
+        for tiles in (False, True):
+            FusedUpdate.TILE_WINDOWS = tiles
+            lr = _models("cuda")
+            grads = _grads_of(lr)
+            batch = mk()
+            pl = lr._fused._finish_plan(lr._fused.plan(batch))
+            widths[tiles] = (pl["online"].nc, pl["target"].nc, pl["online"].B)
+            out = lr.update(batch)
+            torch.cuda.synchronize()
+            res[tiles] = (out, grads)
+    finally:
+        FusedUpdate.TILE_WINDOWS = True
+    assert widths[False][0] == 16 and widths[False][1] == 16
+    if widths[True][2] % 2 == 0:
+        assert widths[True][0] < 16 and widths[True][1] < 16, widths  # (the case must exercise what it names)
+    (o0, g0), (o1, g1) = res[False], res[True]
+    for k in ("td", "q", "q_next"):
+        assert torch.equal(o0[k], o1[k]), k
+    assert float(o0["loss"]) == float(o1["loss"])
+    for k in g0:
+        if "bias" in k and ("recurrent" in k or "comm" in k):
+            assert torch.allclose(g0[k], g1[k], rtol=2e-3, atol=1e-5 + 1e-3 * float(g0[k].abs().max())), k
+        else:
+            assert torch.equal(g0[k], g1[k]), k
+
+
 def test_fused_update_pruning_is_dead_code_elimination():
     """The same fused update with every observation of the window encoded (Network.PRUNE_UNREACHABLE = False: mapf_plan_mark's
     mark_all) and with only the entries that can reach agent 0's Q-value: same TD errors and gradients up to the order of sums."""
