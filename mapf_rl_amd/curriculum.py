@@ -126,7 +126,17 @@ class CurriculumActors:
         self.obs_all = self.latents = self.multi = self._graph = self._cap_stream = None
         self._warm = self.graph_replays = 0
         self.tick = torch.zeros(1, dtype=torch.int64, device=self.device)  # iteration counter on the device (exploration / scenario streams)
+        self.policy_override = None
         self.sync_levels()
+
+    def set_policy_override(self, fn):
+        """bench.py / tests (the counterpart of VecActor.step(actions_override=...)): `fn(obs_all u8 [rows, 6, 9, 9]) -> int64 [rows]` gives
+        the action every agent row executes instead of the network's greedy one (the network's forward runs all the same; agent 0 of an
+        environment still explores on top, worker.py:380-382).  Capturable torch operations only -- it becomes part of the replayed
+        iteration; None = the policy's own actions again."""
+        self.policy_override = fn
+        self._graph = None
+        self._warm = 0
 
     def _make(self, key):
         n, L = key
@@ -269,6 +279,8 @@ class CurriculumActors:
         # policy: change detection, encoder on the changed rows, projection GEMM, ONE recurrence launch, Q head, arg-max
         self.model.step_levels([(a.E, a.N, a.pos, a.hidden, None) for a in acts], self.obs_all, self.latents, hidden_out=self.hidden_new,
                                packed_inplace=True, merged=(self.rtab, c["comm"], self.hidden_all), q_out=c["q"], act_out=c["act"])
+        if self.policy_override is not None:
+            c["act"].copy_(self.policy_override(self.obs_all))
         # worker.py:380-382: agent 0 of every environment explores (its level's own stream: seed, base counter + tick, index in the level)
         check(lib.mapf_actor_explore_multi(Et, _ptr(self.envtab), _ptr(self.aux), _ptr(c["act"]), _ptr(c["policy"]), _ptr(c["act8"]), _ptr(c["eps"]),
                                            _ptr(self.tick), st), "mapf_actor_explore_multi")
@@ -294,6 +306,7 @@ class CurriculumActors:
         from .actor import _ptr, _stream
         from .fused import comm_mask
 
+        assert self.policy_override is None, "policy_override: merged launches only (levels of <= 16 agents)"
         acts = list(self.actors.values())
         inputs = [comm_mask(a.pos, packed_words=a.CW, out_mask=cm, out_packed=pk) for a, (cm, pk, _) in zip(acts, self._views)]
         outs = self.model.step_levels([(a.E, a.N, a.pos, a.hidden, cm) for a, (cm, _) in zip(acts, inputs)], self.obs_all, self.latents,
@@ -327,11 +340,12 @@ class CurriculumActors:
         dev = self.device
         cur = torch.cuda.current_stream(dev)
         cur.synchronize()
-        from .fused import capture_mode, no_gc_during_capture, warm_up_gemm_library
+        from .fused import capture_mode, no_gc_during_capture
 
         if self._cap_stream is None:
+            # (no library warm-up: the captured iteration contains no library GEMM since round 5 -- every product in it is a kernel of
+            # this library, tests/test_curriculum_gpu.py replays it from a fresh process)
             self._cap_stream = torch.cuda.Stream(device=dev)
-            warm_up_gemm_library(self._cap_stream)
         g = torch.cuda.CUDAGraph()
         with no_gc_during_capture(), torch.cuda.stream(self._cap_stream):
             g.capture_begin(capture_error_mode=capture_mode())

@@ -89,6 +89,10 @@ class FlatGradBucket:
     split = None       # element index where the encoder's gradients end (None: one piece)
     pieces = 0         # collectives issued by the last exchange (tests)
     _pending = ()
+    # bench.py / tools: a list that begin() / finish() append to -- ("begin", host seconds, None, None) per piece issued,
+    # ("finish", host seconds, HIP event in front of the waits, HIP event behind the division) per exchange; the two events sit on the
+    # update's stream, so their distance is the EXPOSED part of the exchange (what travelled beside the backward chain does not show)
+    timing = None
 
     def _world(self, group=None):
         import torch.distributed as dist
@@ -109,6 +113,19 @@ class FlatGradBucket:
 
         if not (exchanging(group) and hi > lo):
             return
+        if self.timing is not None:
+            import time
+
+            t0 = time.perf_counter()
+            try:
+                return self._begin(lo, hi, group)
+            finally:
+                self.timing.append(("begin", time.perf_counter() - t0, None, None))
+        return self._begin(lo, hi, group)
+
+    def _begin(self, lo, hi, group=None):
+        import torch.distributed as dist
+
         if self._host_staged(group):
             if getattr(self, "_stage", None) is None or self._stage.numel() != self.flat.numel():
                 self._stage = torch.empty(self.flat.numel(), dtype=self.flat.dtype, pin_memory=True)
@@ -124,6 +141,14 @@ class FlatGradBucket:
 
         w = self._world(group)
         self.pieces = len(self._pending)
+        timed = self.timing is not None and (self._pending or w > 1)
+        if timed:
+            import time
+
+            t0, e0, e1 = time.perf_counter(), None, None
+            if self.flat.is_cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream(self.flat.device))
         for work in self._pending:
             if isinstance(work, tuple):  # host-staged piece: wait for its copy, reduce on the host, hand it back on this stream
                 lo, hi, ev = work
@@ -135,6 +160,10 @@ class FlatGradBucket:
         self._pending = ()
         if w > 1:
             self.flat.div_(w)
+        if timed:
+            if e1 is not None:
+                e1.record(torch.cuda.current_stream(self.flat.device))
+            self.timing.append(("finish", time.perf_counter() - t0, e0, e1))
 
     def all_reduce_mean(self, group=None):
         n = self.flat.numel()
@@ -155,9 +184,9 @@ class _FlatView:
     def zero(self):
         self.flat.zero_()
 
-    pieces, _pending = 0, ()
-    _world, begin, finish, all_reduce_mean, _host_staged = (FlatGradBucket._world, FlatGradBucket.begin, FlatGradBucket.finish, FlatGradBucket.all_reduce_mean,
-                                                             FlatGradBucket._host_staged)
+    pieces, _pending, timing = 0, (), None
+    _world, begin, _begin, finish, all_reduce_mean, _host_staged = (FlatGradBucket._world, FlatGradBucket.begin, FlatGradBucket._begin, FlatGradBucket.finish,
+                                                                     FlatGradBucket.all_reduce_mean, FlatGradBucket._host_staged)
 
 
 class Learner:
@@ -300,6 +329,7 @@ class Learner:
             batch = self._sample()
         if self._fused is not None and self._fused.usable(batch):
             out = self._fused.run(batch, plan if isinstance(plan, dict) else None, own_batch)
+            self.last_path = "fused"
             self.counter += 1
             self._last = (out["loss"], out["grad_norm"])
             if self.counter % TARGET_SYNC == 0:                                                  # worker.py:336-338
@@ -309,7 +339,9 @@ class Learner:
         if isinstance(plan, dict):
             plan = None
         fallback = self._fused is not None  # a batch outside the fused kernels' limits on a Learner that was built for them
+        self.last_path = "autograd"
         if fallback:
+            self._say_fallback(batch)
             # ONE optimizer state whichever path takes a step: torch's Adam runs on the flat buffers' own moment tensors (views), at
             # the step count and learning rate the fused path is at, and the count moves on afterwards
             flat = self._fused.flat
@@ -382,6 +414,22 @@ class Learner:
             self.save()
         return dict(loss=loss.detach(), td=td.detach(), priorities=priorities, grad_norm=grad_norm.detach(), q=q.detach(),
                     q_next=q_next)
+
+    last_path = None   # "fused" | "autograd": which path the last update took (bench.py: learner_path)
+    _fallback_said = ()
+
+    def _say_fallback(self, batch):
+        """A Learner built for the hand-written kernels whose batch leaves their shape limits runs through PyTorch (autograd, library
+        GEMMs): correct, several times slower -- said ONCE per (shape, reason) on stderr, never silently."""
+        import sys
+
+        obs = batch[0]
+        why = self._fused.why_not(batch)
+        key = (tuple(obs.shape[:3]), why)
+        if key not in self._fallback_said:
+            self._fallback_said = tuple(self._fallback_said) + (key,)
+            print("mapf_rl_amd.learner: update on a batch of shape B x T x A = %s leaves the fused path (%s): running it through "
+                  "PyTorch autograd" % (" x ".join(str(v) for v in obs.shape[:3]), why), file=sys.stderr, flush=True)
 
     def _drop_prefetch(self):
         """Forget the batch sampled ahead (it carries no network output, so a weight change does not invalidate it; for callers

@@ -497,6 +497,22 @@ class FusedUpdate:
         return (obs.is_cuda and obs.dim() == 6 and obs.shape[2] <= 128 and FORWARD_STEPS < obs.shape[1] <= 20 and Network.FUSED_TRAINING and
                 Network.FUSED_INFERENCE and Network.FUSED_BPTT and Network.FUSED_RECURRENCE and Network.FAST_RECURRENCE)
 
+    def why_not(self, batch):
+        """Why `usable(batch)` is False, in words (Learner._say_fallback)."""
+        from .model import Network
+
+        obs = batch[0]
+        if not obs.is_cuda:
+            return "the batch is not on a HIP device"
+        if obs.dim() != 6:
+            return "observations are not [B, T, A, 6, 9, 9]"
+        if obs.shape[2] > 128:
+            return "%d agents per window: the recurrence kernels hold at most 128" % obs.shape[2]
+        if not FORWARD_STEPS < obs.shape[1] <= 20:
+            return "windows of %d steps: the kernels take %d..20" % (obs.shape[1], FORWARD_STEPS + 1)
+        off = [k for k in ("FUSED_TRAINING", "FUSED_INFERENCE", "FUSED_BPTT", "FUSED_RECURRENCE", "FAST_RECURRENCE") if not getattr(Network, k)]
+        return "Network.%s switched off" % ", ".join(off) if off else "usable"
+
     # ---- stages (each is a fixed launch sequence for given sizes: issued one after the other, or captured once per bucket) ----
     def _target_images(self):
         """Packed weight images of the target network (re-packed when its parameters changed; in place: captured graphs hold them)."""
@@ -776,9 +792,10 @@ class FusedUpdate:
             self.lr._side.synchronize()
         if self._cap_stream is None:
             self._cap_stream = torch.cuda.Stream(device=dev)
-            warm_up_gemm_library(self._cap_stream)
-            if self.lr._side is not None:
-                warm_up_gemm_library(self.lr._side)  # (the capture forks onto it)
+            if not OWN_TALL_GEMM:  # (the A/B formulation with library products: hipBLASLt must have made its handle before a capture)
+                warm_up_gemm_library(self._cap_stream)
+                if self.lr._side is not None:
+                    warm_up_gemm_library(self.lr._side)  # (the capture forks onto it)
         from .fused import prepare_tall_ws
 
         prepare_tall_ws(dev, (self._cap_stream, self.lr._side))

@@ -5,6 +5,7 @@ import os
 import socket
 import sys
 
+import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -64,30 +65,40 @@ def _rank_main(rank, world, port, root, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
 
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from mapf_rl_amd.curriculum import LevelTable
 
     t = LevelTable((1, 10))
-    # rank 0 alone would promote (200/200), rank 1 alone would not (150/200): pooled 350/400 = 87.5 % -> nobody promotes
+    # the even ranks alone would promote (200/200), the odd ranks alone would not (150/200): pooled 87.5 % -> nobody promotes
     for i in range(200):
-        t.record((1, 10), rank == 0 or i < 150)
+        t.record((1, 10), rank % 2 == 0 or i < 150)
     pooled = t.pooled_counts(torch.device("cpu"))
     t.advance(pooled, t.WINDOW * world)
     first = (dict(pooled), list(t.levels))
-    # now rank 1 catches up: pooled 390/400 -> both promote, to the same level set
+    # now the odd ranks catch up: pooled 97.5 % -> every rank promotes, to the same level set
     for i in range(200):
-        t.record((1, 10), rank == 0 or i < 190)
+        t.record((1, 10), rank % 2 == 0 or i < 190)
     pooled = t.pooled_counts(torch.device("cpu"))
     t.advance(pooled, t.WINDOW * world)
-    ret[rank] = (first, dict(pooled), sorted(t.levels), t.done(t.pooled_counts(torch.device("cpu")), t.WINDOW * world))
+    # the control plane of train.py: three flags MAX-reduced asynchronously on host tensors, read one decision period later
+    mine = torch.tensor([int(rank == world - 1), 0, int(rank == 0)], dtype=torch.int32)
+    work = dist.all_reduce(mine, op=dist.ReduceOp.MAX, async_op=True)
+    work.wait()
+    ret[rank] = (first, dict(pooled), sorted(t.levels), t.done(t.pooled_counts(torch.device("cpu")), t.WINDOW * world), mine.tolist())
     dist.destroy_process_group()
 
 
-def test_two_ranks_take_identical_decisions():
+@pytest.mark.parametrize("world", [2, 8])
+def test_n_ranks_take_identical_decisions(world):
+    """2 ranks, and 8 (the node's size, BASELINE configs[3]): pooled level windows and reduced control flags give every rank the same
+    promotion / start / stop decisions whatever its own episodes say."""
     mgr = mp.get_context("spawn").Manager()
     ret = mgr.dict()
-    mp.spawn(_rank_main, args=(2, _free_port(), ROOT, ret), nprocs=2, join=True)
-    assert ret[0] == ret[1]
-    first, pooled, levels, done = ret[0]
-    assert first[0][(1, 10)] == (350, 400) and first[1] == [(1, 10)]
-    assert pooled[(1, 10)] == (390, 400) and levels == [(1, 15), (2, 10)] and done is False
+    mp.spawn(_rank_main, args=(world, _free_port(), ROOT, ret), nprocs=world, join=True)
+    assert all(ret[r] == ret[0] for r in range(world))
+    first, pooled, levels, done, flags = ret[0]
+    h = world // 2
+    assert first[0][(1, 10)] == (350 * h, 400 * h) and first[1] == [(1, 10)]
+    assert pooled[(1, 10)] == (390 * h, 400 * h) and levels == [(1, 15), (2, 10)] and done is False
+    assert flags == [1, 0, 1]

@@ -121,24 +121,34 @@ def test_train_two_ranks_stop_together(tmp_path):
     assert len(os.listdir(str(tmp_path / "models"))) >= 1
 
 
+def _bench_env():
+    env = dict(os.environ, PYTHONPATH=ROOT, MAPF_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MAPF_BENCH_FAULT"):
+        env.pop(k, None)
+    return env
+
+
+SMALL_BENCH = ["--steps", "5", "--warmup", "2", "--envs", "256", "--dist-backend", "gloo", "--no-cpu-baseline", "--dqn-updates", "6",
+               "--dqn-actor-iters", "4", "--train-iters", "8", "--curriculum-envs", "64", "--curriculum-iters", "20", "--ref-shape-updates", "10",
+               "--ref-shape-warmup", "12"]
+
+
 def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` without a launcher starts the two ranks itself (fresh child processes, before it touches the
-    GPU) and forwards rank 0's JSON line; here both ranks share GPU 0 over gloo (MAPF_BENCH_SHARE_GPU=1, the single-GPU rehearsal
-    of the driver's N-GPU command)."""
+    GPU) and forwards rank 0's JSON lines; here both ranks share GPU 0 over gloo (MAPF_BENCH_SHARE_GPU=1, the single-GPU rehearsal
+    of the driver's N-GPU command).  Several ranks: the headline line first (`partial`), the complete line last."""
     import json
 
-    env = dict(os.environ, PYTHONPATH=ROOT, MAPF_BENCH_SHARE_GPU="1")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
-        env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--envs", "256", "--dist-backend", "gloo",
-           "--no-cpu-baseline", "--dqn-updates", "6", "--dqn-actor-iters", "4", "--train-iters", "8"]
-    out = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL_BENCH
+    out = subprocess.run(cmd, cwd=str(tmp_path), env=_bench_env(), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    r = json.loads(lines[0])
+    assert len(lines) == 2
+    h, r = json.loads(lines[0]), json.loads(lines[-1])
+    assert h["partial"] is True and "partial" not in r and "dqn_error" not in r
+    assert h["value"] == r["value"] and h["roofline"]["frac"] == r["roofline"]["frac"] and "learner_updates_per_sec" not in h
     assert r["n_gpus"] == 2 and "dist.get_world_size()=2" in r["config"]["parallelism"] and r["steps"] == 5
-    assert r["value"] > 0 and r["learner_updates_per_sec"] > 0 and "flat-bucket" in r["learner_config"]
+    assert r["value"] > 0 and r["learner_updates_per_sec"] > 0 and "flat-bucket" in r["learner_config"] and r["learner_path"] == "fused"
     # the timed region is stretched to >= ~12 ms by repeating the K-step tape; the pruning spread over ranks is reported
     assert r["timed_repeats"] >= 1 and r["timed_region_ms"] >= 10.0
     assert abs(r["value"] - 2 * 256 * 5 * r["timed_repeats"] / (r["timed_region_ms"] * 1e-3)) <= 1e-6 * r["value"]
@@ -147,8 +157,60 @@ def test_bench_launches_its_own_ranks(tmp_path):
     rf = r["roofline"]
     assert rf["envs_out_of_cache"] >= 4 * 256 and rf["working_set_out_of_cache_bytes"] >= 2 * (256 << 20)
     assert 0 < rf["frac_out_of_cache"] < 1 and 0 < rf["frac"] < 1.2
+    # who took part, on what, and what the exchange cost per update (per-N visibility)
+    mr = r["multi_rank"]
+    assert mr["backend"] == "gloo" and mr["world_size"] == 2 and [x["rank"] for x in mr["ranks_seen"]] == [0, 1]
+    assert mr["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "rccl_version" in mr
+    assert r["learner_exchange_pieces_per_update"] == 2 and r["learner_exchange_begin_ms"] >= 0 and r["learner_exchange_finish_ms"] > 0
     # the interleaved loop costs what its two halves cost (round-4 review: 410 ms beside a 14 ms update and a 4 ms actor iteration --
     # stalls inside PyTorch's gloo path for device tensors, profiles/r05_two_rank_probe.md; the exchange is host-staged through one
     # persistent pinned buffer now, learner.FlatGradBucket._host_staged)
     assert r["train_loop_ms_per_iter"] <= 1.5 * (r["learner_ms_per_update"] + r["actor_loop_ms_per_iter"]), (
         r["train_loop_ms_per_iter"], r["learner_ms_per_update"], r["actor_loop_ms_per_iter"])
+    assert r["train_loop_tape_policy_ms_per_iter"] <= 1.5 * (r["learner_ms_per_update"] + r["actor_loop_tape_policy_ms_per_iter"])
+    # the reference's own training shape: graph-replayed update on the curriculum actors' replay, the captured actor iteration
+    assert r["learner_ref_shape_path"] == "fused" and r["learner_ref_shape_ms_per_update"] > 0 and r["learner_ref_shape_graph_replays"] == 10
+    assert r["curriculum_actor_iter_ms"] > 0 and r["curriculum_actor_graph_replays"] == 20 and r["train_loop_ref_shape_ms_per_iter"] > 0
+
+
+def test_bench_rank_fault_ends_the_job_with_the_headline_out(tmp_path):
+    """A rank that raises inside a secondary leg (here rank 1, at the start of the learner leg, while rank 0 walks into the leg's
+    first collective) leaves the job at once: non-zero exit within seconds, never a hang until the driver's deadline -- and the
+    headline line is already on stdout."""
+    import json
+    import time
+
+    env = dict(_bench_env(), MAPF_BENCH_FAULT="1:learner")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-out-of-cache"] + SMALL_BENCH
+    t0 = time.time()
+    out = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    dt = time.time() - t0
+    assert out.returncode == 1
+    assert "injected fault at stage 'learner' on rank 1" in out.stderr and "leaving the job (exit 13)" in out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    h = json.loads(lines[0])
+    assert h["partial"] is True and h["metric"] == "env_steps_per_sec" and h["value"] > 0 and h["roofline"]["frac"] > 0 and h["n_gpus"] == 2
+    # (bounded by the legs in front of the fault, not by a timeout: the whole two-rank command takes ~1-2 minutes when it succeeds)
+    assert dt < 240, dt
+    m = [l for l in out.stderr.splitlines() if "ending the other ranks" in l]
+    assert m, out.stderr[-1500:]
+
+
+def test_one_rank_bench_prints_one_line(tmp_path):
+    """The driver's N=1 command shape: exactly ONE JSON line, with the reference-training-shape keys and the moving-policy train loop."""
+    import json
+
+    env = _bench_env()
+    env.pop("MAPF_BENCH_SHARE_GPU")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + [a for a in SMALL_BENCH if a not in ("--dist-backend", "gloo")]
+    out = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert "partial" not in r and "multi_rank" not in r and "dqn_error" not in r and r["n_gpus"] == 1
+    for k in ("learner_ref_shape_ms_per_update", "learner_ref_shape_graph_captures", "curriculum_actor_iter_ms", "train_loop_tape_policy_ms_per_iter",
+              "train_loop_tape_policy_updates_per_sec", "train_loop_ref_shape_updates_per_sec", "learner_path", "pipeline_env_steps_per_sec"):
+        assert k in r, k
+    assert r["learner_path"] == "fused" and r["learner_ref_shape_path"] == "fused"

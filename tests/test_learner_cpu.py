@@ -71,52 +71,76 @@ def _free_port():
     return p
 
 
-def _rank_main(rank, world, port, root, ret):
+def _tiled(full, reps):
+    """The golden batch repeated `reps` times along B (a larger batch with the same per-sample values: its mean loss -- and so its
+    gradient -- equals the golden's, which keeps the single-rank reference pinned to the reference's own numbers)."""
+    if reps == 1:
+        return full
+    B, A = full[0].shape[0], full[0].shape[2]
+    rep = lambda v: torch.cat([v] * reps, dim=0) if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B else v
+    out = tuple(rep(v) for v in full)
+    return out[:6] + (torch.cat([full[6].view(B, A, 256)] * reps, dim=0).reshape(-1, 256),) + out[7:]
+
+
+def _rank_main(rank, world, port, root, ret, reps):
     sys.path.insert(0, root)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
 
-    torch.set_num_threads(2)
+    torch.set_num_threads(1 if world > 2 else 2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from tests import helpers as H2
-    from tests.test_learner_cpu import _batch, _models
+    from tests.test_learner_cpu import _batch, _models, _tiled
 
     z = H2.load_npz("dqn_update.npz")
-    full = _batch(z)
+    full = _tiled(_batch(z), reps)
     B = full[0].shape[0]
-    half = B // world
-    sl = slice(rank * half, (rank + 1) * half)
+    share = B // world
+    assert share * world == B
+    sl = slice(rank * share, (rank + 1) * share)
     A = full[0].shape[2]
-    part = tuple(v[sl] if torch.is_tensor(v) and v.shape[0] == B else v for v in full)
+    part = tuple(v[sl] if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B else v for v in full)
     part = part[:6] + (full[6].view(B, A, 256)[sl].reshape(-1, 256),) + part[7:]
     lr = _models()
+    lr.bucket.timing = []
     lr.update(part)
     out = {k: v.detach().clone() for k, v in lr.model.state_dict().items() if k in ("adv.bias", "state.weight", "recurrent.bias_hh")}
     out["flat"] = lr.bucket.flat.clone()
     out["pieces"] = lr.bucket.pieces   # the exchange went out as recurrence + head first, encoder second (learner.FlatGradBucket)
+    out["timing"] = [(r[0], r[1] >= 0.0) for r in lr.bucket.timing]
     ret[rank] = out
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_equals_single_rank():
-    """N ranks with disjoint equal batch shards == 1 rank with the concatenated batch."""
+@pytest.mark.parametrize("world,reps", [(2, 1), (8, 4)])
+def test_n_rank_gloo_equals_single_rank(world, reps):
+    """N ranks with disjoint equal batch shards == 1 rank with the concatenated batch -- at 2 ranks on the golden
+    batch itself (3 windows per rank), at 8 ranks (the node's size: BASELINE configs[3]) on the golden batch four times over (24
+    windows, 3 per rank): the launcher-independent part of an 8-rank update -- two collectives per exchange, the division by the world
+    size, identical parameters on every rank."""
     z = H.load_npz("dqn_update.npz")
     lr = _models()
     # single-rank reference on the whole batch but with the per-shard mean semantics (equal shard sizes)
-    lr.update(_batch(z))
+    out1 = lr.update(_tiled(_batch(z), reps))
+    assert abs(float(out1["loss"]) - float(z["loss"])) <= 1e-5 * max(1, abs(float(z["loss"])))  # (tiling keeps the golden's mean loss)
     single = lr.bucket.flat.clone()
     mgr = mp.get_context("spawn").Manager()
     ret = mgr.dict()
     port = _free_port()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    mp.spawn(_rank_main, args=(2, port, root, ret), nprocs=2, join=True)
-    f0, f1 = ret[0]["flat"], ret[1]["flat"]
-    assert torch.equal(f0, f1)  # identical averaged gradients on both ranks
-    assert ret[0]["pieces"] == ret[1]["pieces"] == 2 and lr.bucket.pieces == 0   # two collectives per exchange; none on one rank
+    mp.spawn(_rank_main, args=(world, port, root, ret, reps), nprocs=world, join=True)
+    f0 = ret[0]["flat"]
+    for r in range(1, world):
+        assert torch.equal(f0, ret[r]["flat"])  # identical averaged gradients on every rank
+    assert all(ret[r]["pieces"] == 2 for r in range(world)) and lr.bucket.pieces == 0   # two collectives per exchange; none on one rank
+    # the exchange's timing records (bench.py: learner_exchange_*): one per piece issued, one per exchange finished
+    assert all(ret[r]["timing"] == [("begin", True), ("begin", True), ("finish", True)] for r in range(world))
     # clip_grad_norm_ scales in place only above 40; the norm here is ~0.6, so the buckets hold raw averaged grads
     assert torch.allclose(f0, single, rtol=1e-4, atol=1e-6), (f0 - single).abs().max()
     for k in ("adv.bias", "state.weight", "recurrent.bias_hh"):
-        assert torch.allclose(ret[0][k], ret[1][k]) and torch.allclose(ret[0][k], lr.model.state_dict()[k], rtol=1e-4, atol=2e-6)
+        for r in range(1, world):
+            assert torch.equal(ret[0][k], ret[r][k])
+        assert torch.allclose(ret[0][k], lr.model.state_dict()[k], rtol=1e-4, atol=2e-6)
 
 
 def test_double_q_is_online_argmax_target_value():
