@@ -81,6 +81,7 @@ def parse_args(argv=None):
     ap.add_argument("--dqn-actor-iters", type=int, default=12)
     ap.add_argument("--train-iters", type=int, default=10, help="interleaved actor-step + learner-update iterations")
     ap.add_argument("--no-ref-shape", action="store_true", help="skip the legs at the reference's own training shape (B 192 x T 18 x <= 6 agents)")
+    ap.add_argument("--only-ref-shape", action="store_true", help="of the secondary legs, run only those at the reference's training shape (diagnostics)")
     ap.add_argument("--curriculum-envs", type=int, default=1024, help="environments per active curriculum level (train.py's default)")
     ap.add_argument("--curriculum-iters", type=int, default=200, help="timed curriculum actor iterations")
     ap.add_argument("--ref-shape-updates", type=int, default=100, help="timed updates at the reference's training shape (and train-loop pairs)")
@@ -559,7 +560,7 @@ def main():
     # ---- system rates of the same pipeline (BASELINE metric: "env steps/sec + learner updates/sec") ----
     if not args.no_dqn:
         for name, leg in (("dqn legs (BASELINE configs[1] shape)", dqn_legs), ("reference-training-shape legs", ref_shape_legs)):
-            if leg is ref_shape_legs and args.no_ref_shape:
+            if (leg is ref_shape_legs and args.no_ref_shape) or (leg is dqn_legs and args.only_ref_shape):
                 continue
             try:
                 result.update(leg(M, args, env, dev, rank, world, dist, gen))
@@ -733,7 +734,9 @@ def dqn_legs(M, args, env, dev, rank, world, dist, gen):
         rows_enc = rows_enc_min = rows_enc_max = int(pl["online"].urows)  # the online encoder's batch of this rank's probe window
     # interleaved: the loop train.py runs (one update per actor iteration; the actor iteration on its own stream beside the
     # update, the replay ordered by the learner's two events -- train.py --overlap-actors, its default)
-    astream = torch.cuda.Stream(device=dev)
+    from mapf_rl_amd.streams import role_stream
+
+    astream = role_stream(dev, "actors")  # (one stream per role in the process: mapf_rl_amd/streams.py)
 
     def train_iteration(tape):
         if learner.replay_released is not None:
@@ -955,7 +958,9 @@ def ref_shape_legs(M, args, env, dev, rank, world, dist, gen):
         pl = fu._finish_plan(fu.plan(probe))
         rows_enc = (int(pl["online"].urows), int(pl["online"].rows))
     # ---- the pair train.py runs: one curriculum actor iteration on its own stream beside every update ----
-    astream = torch.cuda.Stream(device=dev)
+    from mapf_rl_amd.streams import role_stream
+
+    astream = role_stream(dev, "actors")  # (one stream per role in the process: mapf_rl_amd/streams.py)
 
     def train_iteration():
         if learner.replay_released is not None:

@@ -139,6 +139,17 @@ int mapf_encoder_backward(const uint16_t *g_latent_dev, const uint16_t *latent_d
 #define MAPF_ENC_WGRAD_SLABS 2 /* internal: input-channel halves of the output, one workgroup each per partition */
 int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M, const uint32_t *grad_scale_dev, float *partial_dev,
                        void *stream);
+/*
+ * The same for `layers` (<= 8) layers in ONE launch -- the encoder's six 3x3 layers of an update (reference model.py:30-42 x 3 ResBlocks,
+ * worker.py:316): layer l reads gz_dev + l * gz_layer_stride and in_dev + l * in_layer_stride (elements; the slices of
+ * mapf_encoder_backward's gz and mapf_encoder_forward_save's acts lie that far apart), the observations of every layer are split into
+ * `parts` (<= MAPF_ENC_WGRAD_PARTS; 128 / layers keeps the launch at one workgroup per CU) partitions, and partial_dev is
+ * fp32 [layers][parts][128][3][3][128]: layer l's weight gradient is the sum of its `parts` slabs (mapf_sum_parts takes the six sums in
+ * one launch).  Same arithmetic per partition as mapf_encoder_wgrad; the partition boundaries -- and with them the fp32 summation
+ * order -- follow `parts`.
+ */
+int mapf_encoder_wgrad_multi(const uint16_t *gz_dev, int64_t gz_layer_stride, const uint16_t *in_dev, int64_t in_layer_stride, int layers,
+                             int parts, int64_t M, const uint32_t *grad_scale_dev, float *partial_dev, void *stream);
 
 /*
  * Inference recurrence behind the encoder (csrc/mapf_recur.hip): for T steps and E environments of N <= 48 agents

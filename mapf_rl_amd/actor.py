@@ -28,6 +28,7 @@ import torch
 from . import environment as _envmod
 from ._lib import check, lib
 from .environment import VecEnvironment, generate_scenarios
+from .streams import role_stream as _role_stream
 
 
 def _ptr(t):
@@ -105,7 +106,7 @@ class VecActor:
         # (Rounds 1-4 passed a new seed every iteration, which tied a scenario to the iteration its episode ended in.)
         stage = self.STAGE_AHEAD if stage_ahead is None else stage_ahead
         self._fixed_seed = bool(stage and on_device_reset and env.device.type == "cuda")
-        self._stage_stream = torch.cuda.Stream(device=env.device) if self._fixed_seed else None  # (None with _fixed_seed: the same scenarios, drawn at the reset -- tests)
+        self._stage_stream = _role_stream(env.device, "actor_stage") if self._fixed_seed else None  # (None with _fixed_seed: the same scenarios, drawn at the reset -- tests)
         self._stage_ev = None
         self.RD = env.obs_bits_row_dwords
         # replay rows are laid out for A = buffer.max_agents >= N agents: the N-agent bit row is a prefix of the
@@ -172,6 +173,11 @@ class VecActor:
     def _reset_seed(self):
         """The seed of this iteration's reset: fixed while scenarios are staged ahead, a new one per iteration otherwise."""
         if self._fixed_seed:
+            if self._stage_ev is None and self._stage_stream is not None:
+                # a reset that step() did not prepare (act() called directly, or a staging call that failed before its event): stage here,
+                # in front of the reset -- once a handle has staged, a reset of the same (density, seed) without a staged scenario is
+                # the sticky MAPF_ERR_NOT_READY (advisor, round 5: the contract was implicit in step())
+                self.stage_scenarios()
             if self._stage_ev is not None:
                 torch.cuda.current_stream(self.device).wait_event(self._stage_ev)
                 self._stage_ev = None

@@ -1102,7 +1102,20 @@ int mapf_stage_next(mapf_env_t *h, float density, uint64_t seed, void *stream) {
         alloc(reinterpret_cast<void **>(&h->st_need), E);
         if (err == hipSuccess) err = hipMemsetAsync(h->st_epoch, 0, E * sizeof(int32_t), s);
         if (err != hipSuccess) {
+            // nothing half-allocated survives: a later call starts over (st_epoch is the "staging arrays exist" test above), and the
+            // handle stays in direct-draw mode (h->staged untouched)
             std::fprintf(stderr, "mapf_stage_next: %s\n", hipGetErrorString(err));
+            (void)hipFree(h->st_map_rows);
+            (void)hipFree(h->st_navi);
+            (void)hipFree(h->st_agents);
+            (void)hipFree(h->st_goals);
+            (void)hipFree(h->st_epoch);
+            (void)hipFree(h->st_need);
+            h->st_map_rows = h->st_navi = nullptr;
+            h->st_agents = h->st_goals = nullptr;
+            h->st_epoch = nullptr;
+            h->st_need = nullptr;
+            (void)hipGetLastError();
             return MAPF_ERR_HIP;
         }
     } else if (h->staged && (h->st_seed != seed || h->st_density != density)) {

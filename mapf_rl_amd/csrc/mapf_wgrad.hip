@@ -99,17 +99,28 @@ __device__ __forceinline__ el8 tr_read2(const unsigned char *p0, const unsigned 
     return u.v;
 }
 
+// Workgroup id -> (layer, partition, slab): ids 16 g + r, r < 8 (slab 0) and 16 g + 8 + r (slab 1) are the two slabs of pair 8 g + r
+// and land on the same XCD (id mod 8); pair = layer * parts + partition.  One layer with MAPF_ENC_WGRAD_PARTS partitions is
+// mapf_encoder_wgrad; `layers` layers whose gz / input arrays lie `gz_stride` / `in_stride` elements apart, with parts = 128 / layers,
+// is mapf_encoder_wgrad_multi: ONE round of workgroups (<= 256, one per CU -- the kernel holds 104 KB of LDS) does the six 3x3 layers of
+// the encoder, and each workgroup writes its 295 KB partial slab once per launch instead of once per layer (at the few thousand
+// observations of a few-agent update that write, 75 MB per layer with 128 partitions, was most of a 54 us launch).
 __global__ void __launch_bounds__(NTHR) encoder_wgrad_kernel(const uint16_t *__restrict__ gz, const uint16_t *__restrict__ ain, long long M,
-                                                           float *__restrict__ ws, const uint32_t *__restrict__ grad_scale) {
+                                                           float *__restrict__ ws, const uint32_t *__restrict__ grad_scale, int parts,
+                                                           int layers, long long gz_stride, long long in_stride) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-    const int slab = slot % SLABS, part = (slot / SLABS) * 8 + xcd;
+    const int id = blockIdx.x;
+    const int slab = (id >> 3) & 1, pair = (id >> 4) * 8 + (id & 7);
+    const int layer = pair / parts, part = pair - layer * parts;
+    if (layer >= layers) return;  // (the grid is rounded up to whole groups of 16)
     const int chalf = w & 1, nq = w >> 1;  // this wave's 64 output channels / 16 input channels of the slab
+    gz += layer * gz_stride;
+    ain += layer * in_stride;
 
     // observations of this partition -> a stream of IR image rows in nblk blocks of 8
-    const long long per = (M + MAPF_ENC_WGRAD_PARTS - 1) / MAPF_ENC_WGRAD_PARTS;
+    const long long per = (M + parts - 1) / parts;
     const long long ob0 = per * part;
     long long nobl = M - ob0;
     nobl = nobl < 0 ? 0 : (nobl > per ? per : nobl);
@@ -287,7 +298,7 @@ __global__ void __launch_bounds__(NTHR) encoder_wgrad_kernel(const uint16_t *__r
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the asm MFMAs are opaque to hipcc's hazard padding: let the last ones retire
     // (gz carries the backward chain's loss scale: taken out here, in fp32)
     const float inv_scale = grad_scale ? __uint_as_float(grad_scale[1]) : 1.f;
-    float *out = ws + (long long)part * (128 * 9 * 128);
+    float *out = ws + (long long)pair * (128 * 9 * 128);
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -323,7 +334,24 @@ int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M
     if ((M + MAPF_ENC_WGRAD_PARTS - 1) / MAPF_ENC_WGRAD_PARTS > (1 << 18)) return MAPF_ERR_INVALID_ARG;  // int element offsets inside a partition
     // every partition writes its slab (zeros when it has no observations), so the caller's sum is always defined
     hipLaunchKernelGGL(encoder_wgrad_kernel, dim3(SLABS * MAPF_ENC_WGRAD_PARTS), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gz_dev,
-                       in_dev, (long long)M, partial_dev, grad_scale_dev);
+                       in_dev, (long long)M, partial_dev, grad_scale_dev, MAPF_ENC_WGRAD_PARTS, 1, 0LL, 0LL);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
+int mapf_encoder_wgrad_multi(const uint16_t *gz_dev, int64_t gz_layer_stride, const uint16_t *in_dev, int64_t in_layer_stride, int layers,
+                             int parts, int64_t M, const uint32_t *grad_scale_dev, float *partial_dev, void *stream) {
+    if (M < 0 || !partial_dev || layers < 1 || layers > 8 || parts < 1 || parts > MAPF_ENC_WGRAD_PARTS || (M > 0 && (!gz_dev || !in_dev)))
+        return MAPF_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(gz_dev) & 15) || (reinterpret_cast<uintptr_t>(in_dev) & 15) ||
+        (reinterpret_cast<uintptr_t>(partial_dev) & 15) || (gz_layer_stride & 7) || (in_layer_stride & 7))
+        return MAPF_ERR_INVALID_ARG;
+    if (layers > 1 && (gz_layer_stride < M * 6272 || in_layer_stride < M * 6272)) return MAPF_ERR_INVALID_ARG;  // layers may not overlap
+    if ((M + parts - 1) / parts > (1 << 18)) return MAPF_ERR_INVALID_ARG;  // int element offsets inside a partition
+    const int pairs = layers * parts, groups = (pairs + 7) / 8;
+    // every (layer, partition) writes its slab (zeros when it has no observations), so the caller's sum is always defined
+    hipLaunchKernelGGL(encoder_wgrad_kernel, dim3(16 * groups), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gz_dev, in_dev,
+                       (long long)M, partial_dev, grad_scale_dev, parts, layers, (long long)gz_layer_stride, (long long)in_layer_stride);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }

@@ -345,7 +345,9 @@ class CurriculumActors:
         if self._cap_stream is None:
             # (no library warm-up: the captured iteration contains no library GEMM since round 5 -- every product in it is a kernel of
             # this library, tests/test_curriculum_gpu.py replays it from a fresh process)
-            self._cap_stream = torch.cuda.Stream(device=dev)
+            from .streams import role_stream
+
+            self._cap_stream = role_stream(dev, "capture_actors")
         g = torch.cuda.CUDAGraph()
         with no_gc_during_capture(), torch.cuda.stream(self._cap_stream):
             g.capture_begin(capture_error_mode=capture_mode())

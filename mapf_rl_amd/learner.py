@@ -239,7 +239,12 @@ class Learner:
         self.prefetch = bool(prefetch) and buffer is not None and self.device.type == "cuda"
         # (a plain second stream.  PyTorch maps `priority` to a stream pool by clamp(-priority, 0, max-1): a positive value does NOT make a
         # lower-priority HIP stream, so rounds 3-4's `priority=1` was the default pool all along and the knob is gone.)
-        self._side = torch.cuda.Stream(device=self.device) if self.prefetch else None
+        # (MAPF_LEARNER_STREAM_PRIORITY=-1: a high-priority second stream, for callers that run update() on a high-priority stream of
+        # their own beside actors on a normal one -- train.py --learner-priority, tools/micro/train_loop_overlap.py)
+        # ONE second stream per device, whoever builds learners (streams.py: streams are multiplexed onto four hardware queues)
+        from .streams import role_stream
+
+        self._side = role_stream(self.device, "learner_side", int(os.environ.get("MAPF_LEARNER_STREAM_PRIORITY", "0"))) if self.prefetch else None
         self._pre = None
 
     def current_lr(self):

@@ -218,14 +218,17 @@ class FusedUpdate:
     # is fixed except for its row counts (how many observations can reach agent 0's Q-value, how many of those are distinct), which
     # differ from batch to batch.  Graph mode rounds them UP to buckets and pads: the kernels run on bucket-sized buffers whose
     # padding rows are harmless by construction (their gradient is exactly zero, see _plan_rows / _online_forward / _backward), so a
-    # handful of captured graphs covers every batch.  An update is five graph launches over static interface buffers:
-    #   target   (side stream)  mapf_plan_rows + the target network's forward on the target window     -> a0_tg        [key: target buckets]
-    #   online   (main stream)  weight packs + mapf_plan_rows + forward-save of the online network     -> a0, saved    [key: online buckets]
-    #   head     (main)         dueling heads, TD error, loss, priorities, priority write-back                          [one graph]
-    #   prefetch (side)         next prioritized sample + its plan (closure marks, duplicate flags, counts -> pinned)   [one graph]
-    #   backward (main)         BPTT, weight gradients, encoder backward, clip + Adam                                   [key: online buckets, lr]
-    # with ordinary events between them (the actors' replay gate in front of `head`, `replay_released` behind `prefetch`), so the
-    # overlap of actors and learner (train.py) is what it was.
+    # handful of captured graphs covers every batch.  An update is eight graph launches over static interface buffers (round 6; five
+    # in rounds 4-5):
+    #   pack     (side stream)  the online network's weight images, behind the last optimizer step                 [one graph]
+    #   rows_t, rows_o (main)   mapf_plan_rows of the target / online window set (beside `pack`)                   [key: target / online buckets]
+    #   target   (side)         the target network's forward on the target window                -> a0_tg        [kept with rows_t]
+    #   online   (main)         forward-save of the online network                               -> a0, saved    [kept with rows_o]
+    #   head     (main)         dueling heads, TD error, loss, priorities                                         [one graph]
+    #   prefetch (side)         priority write-back, next prioritized sample + its plan (closure marks, duplicate flags, counts -> pinned)
+    #   backward (main)         BPTT, weight gradients, encoder backward, clip + Adam                              [kept with rows_o; key: lr]
+    # with ordinary events between them (the actors' replay gate in front of `prefetch`, `replay_released` behind it), so the
+    # overlap of actors and learner (train.py) is what it was -- except that the main stream no longer waits for the actors at all.
     # Memory.  Captures allocate from private pools, and a capture may reuse whatever an EARLIER capture of its pool has freed -- its
     # temporaries.  That is only sound if no graph that still writes such a temporary is replayed between the producer and the
     # consumer of a tensor a later capture placed there.  Hence three pools: "main" (pack, online, backward: the saved tensors of an
@@ -235,7 +238,7 @@ class FusedUpdate:
     GRAPH = os.environ.get("MAPF_UPDATE_GRAPH", "1") != "0"   # (the variable: A/B runs of train.py)
     GRAPH_MAX_AGENTS = 16       # replay rows wider than this are GPU-bound (no gain) and would need many more buckets
     GRAPH_ROW_STEP = 2048       # bucket of the entry count (== WGRAD_SPLIT: the weight-gradient GEMMs' K is padded to it anyway)
-    GRAPH_UROW_STEP = 1024      # bucket of the distinct-observation count (the encoder kernels' batch)
+    GRAPH_UROW_STEP = int(os.environ.get("MAPF_GRAPH_UROW_STEP", "1024"))  # bucket of the distinct-observation count (the encoder kernels' batch; the variable: A/B runs)
     GRAPH_CACHE = 24            # captured graphs kept per stage; LRU beyond it
     GRAPH_CACHE_BYTES = int(float(os.environ.get("MAPF_UPDATE_GRAPH_GB", "48")) * (1 << 30))  # ... and what their private pools may hold
     # in all (an online entry pins its saved tensors -- ~0.1 MB per distinct observation row -- and its backward graphs: a moving
@@ -791,7 +794,9 @@ class FusedUpdate:
         if self.lr._side is not None:
             self.lr._side.synchronize()
         if self._cap_stream is None:
-            self._cap_stream = torch.cuda.Stream(device=dev)
+            from .streams import role_stream
+
+            self._cap_stream = role_stream(dev, "capture_learner")
             if not OWN_TALL_GEMM:  # (the A/B formulation with library products: hipBLASLt must have made its handle before a capture)
                 warm_up_gemm_library(self._cap_stream)
                 if self.lr._side is not None:
@@ -814,21 +819,34 @@ class FusedUpdate:
         self.graph_captures += 1
         return g, out
 
+    _update_tick = 0   # `_tick` at the start of the update in flight: entries used since are not evicted
+
+    def _pool_bytes(self):
+        """Bytes the allocator holds in blocks that are in use (captures allocate from private pools: their blocks stay 'active' for the
+        graph's lifetime, whether the pool grew or reused a block an earlier capture's temporary had freed -- reserved-memory growth,
+        round 5's measure, reads 0 for the latter)."""
+        return int(torch.cuda.memory_stats(self.dev).get("active_bytes.all.current", 0))
+
     def _graph(self, stage, key, pool, fn):
         """The captured graph of `stage` for `key` (captured now if new).  Returns (graph, what fn returned at capture time)."""
         self._tick += 1
         ent = self._graphs.get((stage, key))
         if ent is None:
-            same = [k for k in self._graphs if k[0] == stage]
+            same = [k for k in self._graphs if k[0] == stage and self._graphs[k][2] < self._update_tick]
             if len(same) >= self.GRAPH_CACHE:
                 del self._graphs[min(same, key=lambda k: self._graphs[k][2])]
             # the byte bound: least recently used entries of any stage go until the new one fits (sizes: what the allocator's
             # reserved memory grew by during an entry's captures -- its own and, for an online entry, its backward graphs')
-            while self._graphs and sum(e[3] for e in self._graphs.values()) > self.GRAPH_CACHE_BYTES:
-                del self._graphs[min(self._graphs, key=lambda k: self._graphs[k][2])]
-            before = torch.cuda.memory_reserved(self.dev)
+            # (never an entry THIS update has already fetched -- `_update_tick`: its pack / target / online graphs are in flight and its
+            # backward capture is still to be accounted to the online entry; advisor, round 5)
+            while sum(e[3] for e in self._graphs.values()) > self.GRAPH_CACHE_BYTES:
+                old = [k for k, e in self._graphs.items() if e[2] < self._update_tick]
+                if not old:
+                    break
+                del self._graphs[min(old, key=lambda k: self._graphs[k][2])]
+            before = self._pool_bytes()
             g, out = self._capture(pool, fn)
-            ent = [g, out, self._tick, max(0, torch.cuda.memory_reserved(self.dev) - before)]
+            ent = [g, out, self._tick, max(0, self._pool_bytes() - before)]
             self._graphs[(stage, key)] = ent
         ent[2] = self._tick
         return ent[0], ent[1]
@@ -836,6 +854,7 @@ class FusedUpdate:
     def _run_graphed(self, batch, pl):
         """One update as five graph replays (see the class comment).  `batch` / `pl` are the static slot and its static plan."""
         lr, dev, flat = self.lr, self.dev, self.flat
+        self._update_tick = self._tick + 1
         self._plan_sizes(pl, padded=True)
         v, po, pt = pl["views"], pl["online"], pl["target"]
         B, To, Tt = v["B"], po.T, pt.T
@@ -854,10 +873,30 @@ class FusedUpdate:
             self._w_ihp(tar, False)
         cur.wait_stream(side)  # (captures below synchronise the device anyway; replays of the target graph run on `side` behind the packs)
 
+        ROWS = ("gidx", "comm_c", "h0_c", "obs_rows", "umap", "row_tbp")
+
+        def cap_rows(p):
+            """`mapf_plan_rows` of one window set as a graph of its own: both sets' row tables are built on the main stream BEFORE
+            the two networks' forward passes fork (round 5 had each at the head of its forward graph, where the online set's
+            plan_rows_kernel ran beside the target network's encoder and took 110 us instead of 20:
+            profiles/r05_update6_graph_timeline_tiles.md).  The forward graph of the same key is kept WITH this entry (`c.fwd`): it
+            reads the tensors this capture allocated, so the two are evicted together."""
+            def fn():
+                c = _Ctx()
+                self._plan_rows(p, v, padded=True)
+                c.rows = tuple(getattr(p, k) for k in ROWS)
+                c.fwd = None
+                return c
+            return fn
+
+        def use_rows(p, c):
+            for k, t in zip(ROWS, c.rows):
+                setattr(p, k, t)
+
         def cap_target():
             c = _Ctx()
             c.static, c.padded = True, True
-            self._plan_rows(pt, v, padded=True)
+            use_rows(pt, c_rt)
             self._target_forward(c, pt, (c_p.wp, c_p.bp, c_p.w_rec, c_p.b_rec))
             return c
 
@@ -871,20 +910,34 @@ class FusedUpdate:
             c.static, c.padded = True, True
             c.wp, c.bp, c.w_rec, c.b_rec, c.wt, c.wpt = c_p.wp, c_p.bp, c_p.w_rec, c_p.b_rec, c_p.wt, c_p.wpt
             c.backward = {}
-            self._plan_rows(po, v, padded=True)
+            use_rows(po, c_ro)
             self._online_forward(c, po)
-            c.po = (po.gidx, po.comm_c, po.h0_c, po.obs_rows, po.umap, po.row_tbp)  # (kept alive: the backward graph reads them)
             return c
 
         self._prealloc(B, To, Tt)
-        # the online network's weight images first, on this stream, before the side stream may read them (double-DQN's arg-max)
+        # the online network's weight images (six pack launches behind the last optimizer step) on the SECOND stream, beside the two
+        # window sets' row tables on this one -- neither needs the other; both forward passes wait for both
+        # (captures happen with THIS stream current -- _capture drains it and the second one first -- replays go where they belong)
         g_k, c_p = self._graph("pack", (), "main", cap_pack)
-        g_k.replay()
-        side.wait_stream(cur)
+        g_rt, c_rt = self._graph("rows_t", key_t, "side", cap_rows(pt))
+        g_ro, c_ro = self._graph("rows_o", key_o, "main", cap_rows(po))
+        if c_rt.fwd is None or c_ro.fwd is None:  # (new buckets: the row tables must exist on the device before a forward is captured on them)
+            g_k.replay(), g_rt.replay(), g_ro.replay()
+            if c_rt.fwd is None:
+                c_rt.fwd = self._capture_into(("rows_t", key_t), "side", cap_target)
+            if c_ro.fwd is None:
+                c_ro.fwd = self._capture_into(("rows_o", key_o), "main", cap_online)
+        (g_t, c_t), (g_o, c_o) = c_rt.fwd, c_ro.fwd
+        # second stream: packs, the target set's row table, the target network's forward; this stream: the online set's row table,
+        # then -- behind the packs -- the online network's forward (the critical path: it starts ~60 us into the update)
+        g_ro.replay()  # (first: the host's launches reach the GPU in this order, and this stream's chain is the critical one)
         with torch.cuda.stream(side):
-            g_t, c_t = self._graph("target", key_t, "side", cap_target)
+            g_k.replay()
+            packed = torch.cuda.Event()
+            packed.record(side)
+            g_rt.replay()
             g_t.replay()
-        g_o, c_o = self._graph("online", key_o, "main", cap_online)
+        cur.wait_event(packed)
         g_o.replay()
         cur.wait_stream(side)
 
@@ -893,17 +946,17 @@ class FusedUpdate:
             c.static, c.padded = True, True
             c.a0, c.a0_tg, c.a0_on2 = c_o.a0, c_t.a0_tg, c_t.a0_on2
             self._head(c, v, To, Tt, batch)
-            self._write_priorities(c, batch)
             return c
 
         # (its own memory pool: this graph runs BETWEEN the online graph and its backward graph, whose saved tensors live in pool "main" --
         # a temporary of this capture may not alias what a later capture keeps there across graphs)
-        g_h, c_h = self._graph("head", shape + flags, "head", cap_head)
-        if lr.replay_gate is not None:  # (actors on their own stream: their last episode flush precedes this update's replay operations)
-            cur.wait_event(lr.replay_gate)
+        g_h, c_h = self._graph("head", shape + flags, "head", cap_head)  # (a0 / a0_tg / a0_on2 are static interface buffers: any bucket's)
         g_h.replay()
 
         def cap_prefetch():
+            # the priority write-back (a 40 us sum-tree walk) leads the side stream's stage: round 5 had it in the head graph, i.e. on
+            # the main stream between the loss and the backward-through-time kernel
+            self._write_priorities(c_h, batch)
             lr._launch_prefetch()
             return lr._pre
 
@@ -911,17 +964,24 @@ class FusedUpdate:
 
         side.wait_stream(cur)
         with torch.cuda.stream(side):
+            if lr.replay_gate is not None:  # (actors on their own stream: their last episode flush precedes this update's replay operations)
+                side.wait_event(lr.replay_gate)
             # (keyed by what the NEXT batch's plan bakes in: the switches as they are now)
             g_p, pre = self._graph("prefetch", shape + (bool(Network.PRUNE_UNREACHABLE), bool(self.DEDUP)), "side", cap_prefetch)
             g_p.replay()
             pre_ready = torch.cuda.Event()
             pre_ready.record(side)
+            # this update's results, copied out of the static interface buffers (the caller may keep them across updates): on this stream,
+            # beside the backward stage -- they were four serial copy launches at the end of the chain
+            outs, prio, loss = c_h.outs.clone(), c_h.prio.clone(), c_h.loss.clone()
+            out_ready = torch.cuda.Event()
+            out_ready.record(side)
         pre[1]["event"] = pre_ready
         lr._pre = pre
         lr.replay_released = pre_ready
 
         def cap_backward():
-            (po.gidx, po.comm_c, po.h0_c, po.obs_rows, po.umap, po.row_tbp) = c_o.po
+            use_rows(po, c_ro)
             c_o.d_a0 = c_h.d_a0
             norm = self._backward(c_o, po, lr_value)
             return norm
@@ -929,11 +989,7 @@ class FusedUpdate:
         ent = c_o.backward.get(lr_value)  # (kept with the online graph whose saved tensors it reads: evicted together)
         if ent is None:
             saved_step, saved_epoch = flat.step_host, lr.model.weights_epoch
-            before = torch.cuda.memory_reserved(dev)
-            g_b, norm = self._capture("main", cap_backward)
-            ent_o = self._graphs.get(("online", key_o))
-            if ent_o is not None:
-                ent_o[3] += max(0, torch.cuda.memory_reserved(dev) - before)
+            g_b, norm = self._capture_into(("rows_o", key_o), "main", cap_backward)
             flat.step_host, lr.model.weights_epoch = saved_step, saved_epoch  # (a capture runs adam_step's Python without executing it)
             ent = c_o.backward[lr_value] = (g_b, norm)
         g_b, norm = ent
@@ -949,10 +1005,21 @@ class FusedUpdate:
             flat.step_host += 1
             lr.model.weights_epoch += 1
             norm = norm.clone()
-        cur.wait_event(pre_ready)
+        cur.wait_event(out_ready)  # (behind pre_ready on the same stream: the next batch is sampled and planned, the results are copied)
         self.graph_replays += 1
-        outs, prio, loss = c_h.outs.clone(), c_h.prio.clone(), c_h.loss.clone()
         return dict(loss=loss[0], td=outs[2].view(B, 1), priorities=prio, grad_norm=norm, q=outs[0].view(B, 1), q_next=outs[1].view(B, 1))
+
+    def _capture_into(self, entry_key, pool, fn):
+        """A capture whose graph is kept INSIDE the cache entry `entry_key` (a forward graph with its row tables, a backward graph with
+        its forward): its bytes are accounted to that entry, it is evicted with it."""
+        before = self._pool_bytes()
+        g, out = self._capture(pool, fn)
+        ent = self._graphs.get(entry_key)
+        if ent is not None:
+            ent[3] += max(0, self._pool_bytes() - before)
+        return g, out
+
+    WGRAD_MERGED = os.environ.get("MAPF_WGRAD_MERGED", "1") != "0"  # (the variable: A/B runs)
 
     def _encoder_backward(self, obs_rows, M, acts, lat, bits, g_lat, wpt, aux=None):
         """aux: a second stream for what only needs the backward-data kernel's outputs besides the six 3x3 weight-gradient launches
@@ -984,6 +1051,19 @@ class FusedUpdate:
                                                _ptr(torch.empty(65536, dtype=torch.float32, device=dev)), st_x), "mapf_encoder_small_grads")
             # the 1x1 head: [16, 128] = gz7^T acts6 over M * 49 positions (f16, the chain's loss scale taken out in fp32)
             tall_tn_into(flat.mem(G, names[7] + ".weight").view(16, 128), gz7, acts[6].reshape(M * 49, 128), scale=scale)
+        if self.WGRAD_MERGED and gz.stride(0) == acts.stride(0) == M * 6272:
+            # the six 3x3 layers' weight gradients in ONE launch (one workgroup per CU: 6 x 21 partitions x 2 slabs) and one sum -- six
+            # serial (wgrad 54-75 us, sum 12-17 us) pairs were the last 400 us of a 6-agent update's chain
+            # (profiles/r05_update6_graph_timeline_tiles.md), most of each launch the write of 128 partial slabs
+            # (21 partitions per layer = 252 workgroups, one round.  A resident workgroup takes its CU's whole register file, so the
+            # side branch's small launches -- conv0's weight gradient, bias sums, the 1x1 head -- run once the round ends; leaving 16 / 40 /
+            # 64 CUs free for them -- 20 / 18 / 16 partitions -- measured the same update time: profiles/r06_update6_wgrad_parts.txt)
+            P = int(os.environ.get("MAPF_WGRAD_PARTS", str(ENC_WGRAD_PARTS // 6)))
+            ws = torch.empty((6, P, 128, 3, 3, 128), dtype=torch.float32, device=dev)
+            check(lib.mapf_encoder_wgrad_multi(_ptr(gz[1]), gz.stride(0), _ptr(acts[0]), acts.stride(0), 6, P, M, _ptr(scale), _ptr(ws), st),
+                  "mapf_encoder_wgrad_multi")
+            sum_parts_into([flat.mem(G, names[k] + ".weight") for k in range(1, 7)], [ws[k - 1] for k in range(1, 7)])
+            return
         ws = torch.empty((ENC_WGRAD_PARTS, 128, 3, 3, 128), dtype=torch.float32, device=dev)
         for k in range(1, 7):
             check(lib.mapf_encoder_wgrad(_ptr(gz[k]), _ptr(acts[k - 1]), M, _ptr(scale), _ptr(ws), st), "mapf_encoder_wgrad")

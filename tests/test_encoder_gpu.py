@@ -301,6 +301,44 @@ def test_wgrad_kernel_against_fp32(M):
     assert torch.equal(ws2, ws * 2.0 ** -9)
 
 
+@pytest.mark.parametrize("M,layers,parts", [(1, 6, 21), (2, 6, 21), (161, 6, 21), (1000, 6, 21), (3267, 6, 21), (700, 3, 42), (50, 1, 128), (333, 8, 16)])
+def test_wgrad_multi_layer_launch_against_fp32_and_the_single_layer_launch(M, layers, parts):
+    """mapf_encoder_wgrad_multi -- `layers` 3x3 layers in ONE launch, `parts` observation partitions per layer -- against the fp32
+    weight gradient of every layer and against mapf_encoder_wgrad on the same operands (with parts = 128 and one layer: the same
+    launch, bit for bit); layers a stride apart that is larger than the arrays (the rows_buffer bucket); the loss-scale word."""
+    from mapf_rl_amd._lib import ERR_INVALID_ARG, check, lib
+
+    g = torch.Generator(device="cuda").manual_seed(7 * M + layers)
+    pad = 3  # observations of slack between two layers' arrays
+    S = (M + pad) * 6272
+    gz = (torch.randn((layers, M + pad, 7, 7, 128), device="cuda", generator=g) * (torch.rand((layers, M + pad, 7, 7, 128), device="cuda", generator=g) < 0.5)).to(torch.float16)
+    a = torch.relu(torch.randn((layers, M + pad, 7, 7, 128), device="cuda", generator=g)).to(torch.float16)
+    ws = torch.full((layers, parts, 128, 3, 3, 128), float("nan"), dtype=torch.float32, device="cuda")
+    check(lib.mapf_encoder_wgrad_multi(gz.data_ptr(), S, a.data_ptr(), S, layers, parts, M, None, ws.data_ptr(), None), "mapf_encoder_wgrad_multi")
+    assert torch.isfinite(ws).all()
+    one = torch.empty((128, 128, 3, 3, 128), dtype=torch.float32, device="cuda")
+    for l in range(layers):
+        got = ws[l].sum(0).permute(0, 3, 1, 2)                                  # [co, ci, ky, kx]
+        ref = torch.nn.grad.conv2d_weight(a[l, :M].float().permute(0, 3, 1, 2), (128, 128, 3, 3), gz[l, :M].float().permute(0, 3, 1, 2), padding=1)
+        assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), (l, float((got - ref).abs().max()))
+        check(lib.mapf_encoder_wgrad(gz[l].data_ptr(), a[l].data_ptr(), M, None, one.data_ptr(), None), "mapf_encoder_wgrad")
+        if parts == 128:
+            assert torch.equal(ws[l], one)
+        else:
+            assert float((ws[l].sum(0) - one.sum(0)).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    scale = torch.tensor([0.0, 2.0 ** -9], dtype=torch.float32, device="cuda")
+    ws2 = torch.full_like(ws, float("nan"))
+    check(lib.mapf_encoder_wgrad_multi(gz.data_ptr(), S, a.data_ptr(), S, layers, parts, M, scale.data_ptr(), ws2.data_ptr(), None), "mapf_encoder_wgrad_multi")
+    assert torch.equal(ws2, ws * 2.0 ** -9)
+    # argument checks: layers that would overlap, a stride that breaks the 16-byte alignment, counts out of range
+    if layers > 1:
+        assert lib.mapf_encoder_wgrad_multi(gz.data_ptr(), M * 6272 - 8, a.data_ptr(), S, layers, parts, M, None, ws.data_ptr(), None) == ERR_INVALID_ARG
+    assert lib.mapf_encoder_wgrad_multi(gz.data_ptr(), S + 4, a.data_ptr(), S, layers, parts, M, None, ws.data_ptr(), None) == ERR_INVALID_ARG
+    assert lib.mapf_encoder_wgrad_multi(gz.data_ptr(), S, a.data_ptr(), S, 9, parts, M, None, ws.data_ptr(), None) == ERR_INVALID_ARG
+    assert lib.mapf_encoder_wgrad_multi(gz.data_ptr(), S, a.data_ptr(), S, layers, 129, M, None, ws.data_ptr(), None) == ERR_INVALID_ARG
+    assert lib.mapf_encoder_wgrad_multi(gz.data_ptr(), S, a.data_ptr(), S, layers, 0, M, None, ws.data_ptr(), None) == ERR_INVALID_ARG
+
+
 def test_training_step_is_bitwise_repeatable():
     """No atomics anywhere in the fused training path (bias and weight gradients are per-workgroup / per-partition
     partial sums added in a fixed order): two runs give bit-identical latents and parameter gradients."""

@@ -193,8 +193,9 @@ def test_bench_rank_fault_ends_the_job_with_the_headline_out(tmp_path):
     assert h["partial"] is True and h["metric"] == "env_steps_per_sec" and h["value"] > 0 and h["roofline"]["frac"] > 0 and h["n_gpus"] == 2
     # (bounded by the legs in front of the fault, not by a timeout: the whole two-rank command takes ~1-2 minutes when it succeeds)
     assert dt < 240, dt
-    m = [l for l in out.stderr.splitlines() if "ending the other ranks" in l]
-    assert m, out.stderr[-1500:]
+    # (rank 0 either gets ended by the launcher or -- over gloo -- sees its peer's connection drop inside the all-reduce and leaves the
+    # same way by itself)
+    assert "rank exit codes" in out.stderr and ("ending the other ranks" in out.stderr or "[13, 13]" in out.stderr), out.stderr[-1500:]
 
 
 def test_one_rank_bench_prints_one_line(tmp_path):

@@ -327,9 +327,12 @@ def test_graph_replayed_update_follows_the_eager_update(double_q):
     # the whole run: same sampling stream, nearly the same priorities -> nearly the same batches; Adam steps are +-lr per element
     num = sum(float((x - y).pow(2).sum()) for x, y in zip(p_e, p_g))
     den = sum(float((x - p0).pow(2).sum()) for x, p0 in zip(p_e, run(False, 0)[1]))
-    # the two runs moved the parameters the same way: difference << distance travelled (Adam turns every sign flip of a near-zero
-    # gradient into +-lr, so this is a coarse bound; the per-tensor gradient check above is the sharp one)
-    assert num <= 0.1 * den, (num, den)
+    # the two runs moved the parameters the same way: difference < distance travelled.  A COARSE bound -- Adam turns every sign flip
+    # of a near-zero gradient into +-lr and the sampled batches follow the priorities, so two EAGER runs that differ only in the
+    # summation order of the encoder's weight gradients (20 instead of 21 partitions) already sit at 0.17 of the distance travelled,
+    # where graph against eager reads 0.003 .. 0.17 depending on that order (tools/micro/graph_eager_drift.py,
+    # profiles/r06_graph_eager_drift.txt); the per-tensor gradient check above is the sharp one, a broken stage gives >= 1 here
+    assert num <= 0.5 * den, (num, den)
     for o in o_g:
         assert all(bool(torch.isfinite(v).all()) for v in o.values())
     leaves = t_g[-buf_leaves(t_g):]

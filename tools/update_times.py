@@ -47,7 +47,7 @@ for graph in (False, True):
     for prune in (False, True):
         Network.PRUNE_UNREACHABLE = prune
         lr._drop_prefetch()
-        for _ in range(40 if graph else 3):  # (graph mode: the buckets this replay produces get captured)
+        for _ in range(int(os.environ.get("WARM", "40")) if graph else 3):  # (graph mode: the buckets this replay produces get captured)
             lr.update()
         torch.cuda.synchronize()
         c0 = lr._fused.graph_captures

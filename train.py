@@ -59,9 +59,11 @@ def main(argv=None):
                     "update_priorities (worker.py:190-199) keeps working")
     ap.add_argument("--updates-per-iter", type=float, default=1.0, help="learner updates per actor iteration once training started")
     ap.add_argument("--max-updates", type=int, default=config.training_times)
-    ap.add_argument("--minutes", type=float, default=0.0, help="stop after this many minutes (0 = until --max-updates / curriculum done)")
-    ap.add_argument("--interval", type=float, default=30.0, help="statistics interval in seconds (train.py:39)")
-    ap.add_argument("--learning-starts", type=int, default=config.learning_starts)
+    ap.add_argument("--minutes", type=float, default=0.0, help="stop after this many minutes (0 = until --max-updates / curriculum done); several ranks: "
+                    "acted on up to 2 x --decide-every actor iterations late (the flag is reduced one decision period, read the next)")
+    ap.add_argument("--interval", type=float, default=30.0, help="statistics interval in seconds (train.py:39); several ranks: same lag as --minutes")
+    ap.add_argument("--learning-starts", type=int, default=config.learning_starts, help="transitions in EVERY rank's replay before updates start "
+                    "(several ranks: same lag as --minutes)")
     ap.add_argument("--batch-size", type=int, default=config.batch_size)
     ap.add_argument("--dist-backend", default="nccl", help="nccl = RCCL; gloo only for the CPU-side multi-rank tests")
     ap.add_argument("--double-q", action="store_true", default=bool(getattr(config, "double_q", False)),
@@ -145,7 +147,9 @@ def main(argv=None):
     # (beyond 48 agents the actors' recurrence runs in the wide kernels, whole-CU workgroups for milliseconds: beside them the update's
     # chain of small launches starves -- measured, see --overlap-actors)
     overlap = ((n_agents if fixed else config.max_num_agetns) <= 48) if a.overlap_actors < 0 else bool(a.overlap_actors)
-    astream = torch.cuda.Stream(device=dev) if overlap else None
+    from mapf_rl_amd.streams import role_stream
+
+    astream = role_stream(dev, "actors") if overlap else None
 
     def actor_step():
         if astream is None:
@@ -168,7 +172,9 @@ def main(argv=None):
     # one decision period.  The only blocking control-plane collective left is the pooled level statistics, once per interval.
     ctrl, K = None, 1
     if dist is not None:
-        ctrl = dist.new_group(backend="gloo") if a.dist_backend == "nccl" else dist.group.WORLD
+        # (a group of its own whatever carries the gradients: with --dist-backend gloo the flags would otherwise share the WORLD group
+        # with the host-staged gradient pieces, and correctness would hang on every rank issuing both in the same order)
+        ctrl = dist.new_group(backend="gloo")
         K = max(1, a.decide_every)
     cpu = torch.device("cpu")
     pending = None
