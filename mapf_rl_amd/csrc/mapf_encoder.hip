@@ -37,6 +37,9 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+#ifndef MAPF_ENC_NT_SAVE  // diagnostic builds only (tools/micro/enc_ablate.py): 1 = the saved-activation copies leave as non-temporal stores
+#define MAPF_ENC_NT_SAVE 0
+#endif
 #ifndef MAPF_ENC_ABLATE  // diagnostic builds only (tools/micro/enc_ablate.py): 1 = no saved-activation copies, 2 = no ReLU sign words, 4 = 16 consecutive LDS rows per position tile, 8 = conv0 without its input gather (zeros), 64 = conv0 gathering one tile's window for all tiles, 16 = no LDS zero fill, 32 = no 1x1 head
 #define MAPF_ENC_ABLATE 0
 #endif
@@ -97,6 +100,16 @@ __device__ __forceinline__ uint16_t f32_to_el_bits(float f) {
 }
 __device__ __forceinline__ uint16_t raw_to_el(uint8_t v) { return __builtin_bit_cast(uint16_t, (_Float16)(float)v); }  // exact for 0..255
 __device__ __forceinline__ uint16_t raw_to_el(uint16_t v) { return f32_to_el_bits(bf16_bits_to_f32(v)); }            // bf16 input
+
+// one 16-byte chunk of a saved activation tensor (written once here, read ~2 ms later by the weight-gradient kernels)
+__device__ __forceinline__ void save_store(uint4 *p, const uint4 &v) {
+#if MAPF_ENC_NT_SAVE
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4 *>(p));
+#else
+    *p = v;
+#endif
+}
 
 // relu(acc + bias) for the 4 consecutive channels of one lane, packed to 4 elements (v_med3_f32 = ReLU and range clamp in one)
 __device__ __forceinline__ uint2 pack_relu(const f32x4 &a, const float4 &b) {
@@ -177,7 +190,7 @@ __device__ __forceinline__ void conv3x3(const unsigned char *act, const el8 *__r
                 const int o = rowi / 49, q = rowi - 49 * o, y = q / 7, x = q - 7 * y;
                 cv = *reinterpret_cast<const uint4 *>(act + (64 * o + 8 * y + x + 9) * ROWB + ch * 16);
             }
-            if (COPY && !(MAPF_ENC_ABLATE & 1) && t % 36 == 22) reinterpret_cast<uint4 *>(cdst)[cc] = cv;
+            if (COPY && !(MAPF_ENC_ABLATE & 1) && t % 36 == 22) save_store(reinterpret_cast<uint4 *>(cdst) + cc, cv);
             acc[0][n] = el_mfma(ar[s % RA][0], br[t % RB], acc[0][n]);
             acc[1][n] = el_mfma(ar[s % RA][1], br[t % RB], acc[1][n]);
             __builtin_amdgcn_sched_barrier(0);
@@ -193,7 +206,7 @@ __device__ __forceinline__ void save_rows(const unsigned char *act, uint16_t *__
     for (int c = tid; c < total; c += NTHREADS) {
         const int rowi = c >> 4, ch = c & 15;
         const int o = rowi / 49, q = rowi - 49 * o, y = q / 7, x = q - 7 * y;
-        reinterpret_cast<uint4 *>(dst)[c] = *reinterpret_cast<const uint4 *>(act + (64 * o + 8 * y + x + 9) * ROWB + ch * 16);
+        save_store(reinterpret_cast<uint4 *>(dst) + c, *reinterpret_cast<const uint4 *>(act + (64 * o + 8 * y + x + 9) * ROWB + ch * 16));
     }
 }
 

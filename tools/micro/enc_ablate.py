@@ -11,7 +11,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-MODES = [0, 1, 2, 3, 4, 8, 64]
+# round 6: MODES from the environment (default: the round-4 set); mode 1000 = no ablation, saved activations through NON-TEMPORAL stores
+MODES = [int(m) for m in os.environ.get("MODES", "0,1,2,3,4,8,64").split(",")]
 
 
 def so(mode):
@@ -20,14 +21,15 @@ def so(mode):
 
 def build():
     for m in MODES:
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-mllvm", "-pragma-unroll-threshold=262144", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-                               "-DMAPF_ENC_ABLATE=%d" % m, os.path.join(ROOT, "mapf_rl_amd", "csrc", "mapf_encoder.hip"), "-o", so(m)])
+        flags = ["-DMAPF_ENC_ABLATE=0", "-DMAPF_ENC_NT_SAVE=1"] if m == 1000 else ["-DMAPF_ENC_ABLATE=%d" % m]
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-mllvm", "-pragma-unroll-threshold=262144", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include")] +
+                              flags + [os.path.join(ROOT, "mapf_rl_amd", "csrc", "mapf_encoder.hip"), "-o", so(m)])
 
 
 def run():
     import torch
 
-    M = 122880
+    M = int(os.environ.get("ROWS", "122880"))
     obs = (torch.rand((M, 6, 9, 9), device="cuda") < 0.3).to(torch.uint8)
     w = (torch.randn(894976, device="cuda") * 0.03).to(torch.bfloat16)
     b = torch.zeros(912, dtype=torch.float32, device="cuda")
@@ -35,7 +37,7 @@ def run():
     acts = torch.empty((7, M, 49, 128), dtype=torch.bfloat16, device="cuda")
     bits = torch.empty((7, M, 49, 4), dtype=torch.int32, device="cuda")
     vp = ctypes.c_void_p
-    for m in MODES:
+    for m in MODES * int(os.environ.get("TURNS", "1")):  # (TURNS > 1: the modes in turns -- the first library of a process runs on a cold chip)
         lib = ctypes.CDLL(so(m))
         for name in ("mapf_encoder_forward", "mapf_encoder_forward_save"):
             fn = getattr(lib, name)
@@ -51,7 +53,7 @@ def run():
                 fn(*args)
             e1.record()
             torch.cuda.synchronize()
-            print("ablate=%d  %-26s %.3f ms" % (m, name, e0.elapsed_time(e1) / 5), flush=True)
+            print("rows=%d ablate=%d  %-26s %.3f ms  (%.1f ns per observation)" % (M, m, name, e0.elapsed_time(e1) / 5, e0.elapsed_time(e1) / 5 * 1e6 / M), flush=True)
 
 
 if __name__ == "__main__":

@@ -6,6 +6,8 @@ own stream beside every graph-replayed update -- under different stream arrangem
   MODE=alow      learner normal, actors on a LOW-priority HIP stream (hipStreamCreateWithPriority, through torch.cuda.ExternalStream)
   MODE=mask:<n>  actors on a stream restricted to the first <n> CUs of every XCD pair ... (hipExtStreamCreateWithCUMask)
   MODE=serial    no second stream for the actors: strictly alternating
+  MODE=free      the actors do not flush into the replay and are not ordered against the update at all (the potential of splitting
+                 the captured iteration in front of its episode flush)
 Usage: MODE=... python tools/micro/train_loop_overlap.py [envs_per_level] [pairs]"""
 import ctypes
 import os
@@ -70,7 +72,18 @@ with torch.cuda.stream(main):
         from mapf_rl_amd.streams import role_stream
         astream = role_stream(dev, "actors")
 
+    if MODE == "free":
+        # the POTENTIAL of an actor iteration that is not ordered against the learner's replay operations at all: the actors stop
+        # flushing episodes (the learner keeps sampling what the replay holds), so nothing needs ordering
+        cur.buffer = None
+        cur._graph, cur._warm = None, 0
+
     def pair():
+        if MODE == "free":
+            with torch.cuda.stream(astream):
+                cur.step()
+            learner.update()
+            return
         if astream is None:
             cur.step()
             learner.update()

@@ -76,8 +76,12 @@ def main(argv=None):
                     "40-agent level: 63.6 -> 69.7 updates/s), 0 beyond (40x40 / 64 agents: 106.7 -> 61.3 updates/s, 64x64 / 128 agents: no change)")
     ap.add_argument("--decide-every", type=int, default=16, help="several ranks: actor iterations between two decision points (start of training, "
                     "statistics, stop); the flags are reduced asynchronously on host tensors and read one period later")
-    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=0, help="initial weights, exploration and scenario streams")
     a = ap.parse_args(argv)
+    if a.seed:  # (--seed 0 = the module-level seeds above: the runs of rounds 1-5)
+        torch.manual_seed(a.seed)
+        np.random.seed(a.seed)
+        random.seed(a.seed)
     fixed = a.agents is not None or a.map is not None
     n_agents = a.agents if a.agents is not None else config.num_agents
     map_len = a.map if a.map is not None else config.map_length
