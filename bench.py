@@ -325,7 +325,7 @@ def cpu_baseline(args, maps, agents, goals, tape, final_pos, E, T):
         f = os.path.join(td, "sample.npz")
         np.savez(f, maps=maps[:S], agents=agents[:S], goals=goals[:S], tape=tape[:, :S].cpu().numpy())
         out = subprocess.run([sys.executable, "-m", "oracle.cpu_bench", f, str(args.cpu_seconds)],
-                             cwd=ROOT, capture_output=True, text=True, timeout=900)
+                             cwd=ROOT, capture_output=True, text=True, timeout=max(120.0, 6 * args.cpu_seconds))
     assert out.returncode == 0, out.stderr[-2000:]
     cb = json.loads(out.stdout.strip().splitlines()[-1])
     # trajectories must be identical to the GPU's before any number is reported
@@ -442,9 +442,17 @@ def main():
 
     # ---- CPU baseline (rank 0) BEFORE the process group exists: the other ranks then sleep in the rendezvous instead of
     # spinning on their GPUs / holding host cores while the oracle processes are being timed ----
-    cpu = None
+    cpu = cpu_err = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, maps, agents, goals, tape, final_pos_first_pass, E, T)
+        try:
+            cpu = cpu_baseline(args, maps, agents, goals, tape, final_pos_first_pass, E, T)
+        except Exception as ex:
+            # reported in the line (`cpu_baseline_error`), never fatal: on several ranks the others are waiting in the rendezvous for
+            # this rank, and a job that dies here prints nothing at all
+            import traceback
+
+            traceback.print_exc()
+            cpu_err = repr(ex)[:400]
     ranks_seen = None
     if world > 1:
         import datetime
@@ -544,6 +552,8 @@ def main():
 
     if cpu is not None:
         result["cpu_baseline"] = cpu
+    if cpu_err is not None:
+        result["cpu_baseline_error"] = cpu_err
     if world > 1:
         result["multi_rank"] = multi_rank_info(torch, dist, ranks_seen, args)
         if rank == 0:

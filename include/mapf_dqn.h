@@ -146,10 +146,30 @@ int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M
  * `parts` (<= MAPF_ENC_WGRAD_PARTS; 128 / layers keeps the launch at one workgroup per CU) partitions, and partial_dev is
  * fp32 [layers][parts][128][3][3][128]: layer l's weight gradient is the sum of its `parts` slabs (mapf_sum_parts takes the six sums in
  * one launch).  Same arithmetic per partition as mapf_encoder_wgrad; the partition boundaries -- and with them the fp32 summation
- * order -- follow `parts`.
+ * order -- follow `parts`.  valid_rows_dev: see the `_bounded` entry points below (NULL = all M observations).
  */
 int mapf_encoder_wgrad_multi(const uint16_t *gz_dev, int64_t gz_layer_stride, const uint16_t *in_dev, int64_t in_layer_stride, int layers,
-                             int parts, int64_t M, const uint32_t *grad_scale_dev, float *partial_dev, void *stream);
+                             int parts, int64_t M, const int32_t *valid_rows_dev, const uint32_t *grad_scale_dev, float *partial_dev,
+                             void *stream);
+/*
+ * Row counts from DEVICE memory (`_bounded` entry points; `valid_rows_dev` of mapf_encoder_wgrad_multi may be NULL = M).  The learner's
+ * graph-replayed update (reference worker.py:287-338 replayed from captured launches) runs its kernels on bucket-sized buffers -- the
+ * number of distinct observations of a batch rounded up to 1,024 -- and knows the true count only on the device: these variants take it
+ * from `valid_rows_dev` (int32 [1], clamped to 0..M) and compute nothing for the rows behind it.  M stays the ALLOCATED row count (the
+ * launch grid, the stride between the saved layers).  What the skipped rows' owners leave behind where other kernels read all M rows
+ * or all workgroups' partials: zeros in `latent_dev`, in layer 6 of `acts_dev`, in `gz7_dev`, in the bias partials; everything else of
+ * those rows (layers 0-5 of acts / gz, the ReLU words) is left untouched and must only be read through the same bound
+ * (mapf_encoder_wgrad_multi / mapf_encoder_wgrad0_bounded partition the valid rows only).  `latent_dev` must be 16-byte aligned here.
+ */
+int mapf_encoder_forward_bounded(const void *obs_dev, int obs_dtype, int64_t M, const int32_t *valid_rows_dev, const uint16_t *packed_dev,
+                                 const float *bias_dev, uint16_t *latent_dev, void *stream);
+int mapf_encoder_forward_save_bounded(const void *obs_dev, int obs_dtype, int64_t M, const int32_t *valid_rows_dev, const uint16_t *packed_dev,
+                                      const float *bias_dev, uint16_t *latent_dev, uint16_t *acts_dev, uint32_t *relu_bits_dev, void *stream);
+int mapf_encoder_backward_bounded(const uint16_t *g_latent_dev, const uint16_t *latent_dev, int64_t M, const int32_t *valid_rows_dev,
+                                  const uint32_t *relu_bits_dev, const uint16_t *packed_bwd_dev, uint16_t *gz_dev, float *gbias_partial_dev,
+                                  uint16_t *gz7_dev, float *gb7_partial_dev, uint32_t *grad_scale_dev, void *stream);
+int mapf_encoder_wgrad0_bounded(const uint16_t *gz0_dev, const void *obs_dev, int obs_dtype, int64_t M, const int32_t *valid_rows_dev,
+                                const uint32_t *grad_scale_dev, float *partial_dev, void *stream);
 
 /*
  * Inference recurrence behind the encoder (csrc/mapf_recur.hip): for T steps and E environments of N <= 48 agents
@@ -347,6 +367,10 @@ int mapf_window_relevance(const uint8_t *comm_dev, const int64_t *steps_dev, int
 int mapf_plan_mark(const uint8_t *comm_dev, int64_t stride_b, int64_t stride_t, const int64_t *steps_dev, const float *extra_steps_dev,
                    int T, int B, int N, int mark_all, uint8_t *rel_dev, int16_t *slot_dev, int16_t *order_dev, int32_t *nact_dev, int32_t *cnt_dev, int32_t *nag_dev,
                    int32_t *ucnt_dev, void *stream);
+/* totals_dev[k] = sum over the B windows of counts_dev[k][b] for k < rows: the batch totals of mapf_plan_mark / mapf_obs_dup's per-window
+ * counts (entries online, agents online, entries target, agents target, distinct online, distinct target) -- what the `_bounded` encoder
+ * entry points read as their row count.  counts_dev int32 [rows][B], totals_dev int32 [rows]; rows <= 16. */
+int mapf_plan_totals(const int32_t *counts_dev, int rows, int B, int32_t *totals_dev, void *stream);
 int mapf_plan_rows(int T, int B, int N, int Nc, const int16_t *order_dev, const int32_t *nact_dev, const int32_t *cnt_dev,
                    const int32_t *nag_dev, const uint8_t *comm_dev, int64_t comm_stride_b, int64_t comm_stride_t,
                    const uint16_t *hidden_dev, int hidden_is_bf16, const uint16_t *obs_bf16_dev, int64_t obs_stride_b, int64_t obs_stride_t,

@@ -100,7 +100,12 @@ SYMBOLS = [
     ("mapf_encoder_wgrad0", _i, [_vp, _vp, _i, ctypes.c_int64, _vp, _vp, _vp]),
     ("mapf_encoder_backward", _i, [_vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_encoder_wgrad", _i, [_vp, _vp, ctypes.c_int64, _vp, _vp, _vp]),
-    ("mapf_encoder_wgrad_multi", _i, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, _i, _i, ctypes.c_int64, _vp, _vp, _vp]),
+    ("mapf_encoder_wgrad_multi", _i, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, _i, _i, ctypes.c_int64, _vp, _vp, _vp, _vp]),
+    ("mapf_encoder_forward_bounded", _i, [_vp, _i, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp]),
+    ("mapf_encoder_forward_save_bounded", _i, [_vp, _i, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("mapf_encoder_backward_bounded", _i, [_vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("mapf_encoder_wgrad0_bounded", _i, [_vp, _vp, _i, ctypes.c_int64, _vp, _vp, _vp, _vp]),
+    ("mapf_plan_totals", _i, [_vp, _i, _i, _vp, _vp]),
     ("mapf_encoder_forward_save", _i, [_vp, _i, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_plan_mark", _i, [_vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_obs_dup", _i, [_i, _i, _i, _i, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

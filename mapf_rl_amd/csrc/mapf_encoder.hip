@@ -228,6 +228,28 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
     if constexpr (IDX) M = min(M, (long long)*row_count);
     if constexpr (IDX)
         if ((long long)blockIdx.x * G >= M) return;
+    // not IDX, row_count given (mapf_encoder_forward[_save]_bounded): only the first *row_count <= M observations are computed -- the
+    // learner's graph-replayed update launches on bucket-sized buffers and hands the true count over in device memory.  M stays the
+    // allocated row count (the stride between the saved layers).  The rows this workgroup owns but does not compute read as zeros where
+    // OTHER kernels read all M rows (the latents; the last saved layer, an operand of the 1x1 layer's weight-gradient product).
+    long long Mv = M;
+    if constexpr (!IDX) {
+        if (row_count != nullptr) {
+            const long long cnt = (long long)*row_count;
+            Mv = cnt < M ? (cnt < 0 ? 0 : cnt) : M;
+            const long long o0 = (long long)blockIdx.x * G;
+            const long long z0 = o0 > Mv ? o0 : Mv, z1 = o0 + G < M ? o0 + G : M;
+            if (z1 > z0) {
+                uint4 *lz = reinterpret_cast<uint4 *>(out + z0 * 784);
+                for (long long i = threadIdx.x; i < (z1 - z0) * 98; i += NTHREADS) lz[i] = make_uint4(0, 0, 0, 0);
+                if constexpr (SAVE) {
+                    uint4 *sz = reinterpret_cast<uint4 *>(save + (6 * M + z0) * 6272);
+                    for (long long i = threadIdx.x; i < (z1 - z0) * 784; i += NTHREADS) sz[i] = make_uint4(0, 0, 0, 0);
+                }
+            }
+            if (o0 >= Mv) return;
+        }
+    }
 #ifdef MAPF_ENC_CLOCK
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), ref0 = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) alone: the stamps are back before the first LDS wait is counted
@@ -253,8 +275,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_fwd_kernel(const InT *__r
     const uint16_t *const wpz = wp + z;
     const float *const biasz = bias + z;
     const long long obs0 = wg * G;
-    const long long left = M - obs0;
-    const int nobs = left < G ? (int)left : G;  // >= 1 by the grid size
+    const long long left = Mv - obs0;
+    const int nobs = left < G ? (int)left : G;  // >= 1 by the grid size (and the early return above)
 
     // ---- zero the activation image (its border rows must be zero; they are never written afterwards) ----
     if (!(MAPF_ENC_ABLATE & 16))
@@ -591,7 +613,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
                                                                   const uint16_t *__restrict__ wpt, uint16_t *__restrict__ gz,
                                                                   float *__restrict__ gb_part, const uint16_t *__restrict__ latent,
                                                                   uint16_t *__restrict__ gz7_out, float *__restrict__ gb7_part,
-                                                                  uint32_t *__restrict__ grad_scale) {
+                                                                  uint32_t *__restrict__ grad_scale, const int32_t *__restrict__ valid_rows) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[ACT_BYTES + GZ7_BYTES];
     unsigned char *const act = smem;
     const unsigned char *const raw = smem + ACT_BYTES;
@@ -599,7 +621,28 @@ __global__ void __launch_bounds__(NTHREADS, 2) encoder_bwd_kernel(const uint16_t
     const int tid = threadIdx.x, lane = tid & 63, cb = tid >> 6;
     const int lr = lane & 15, lh = lane >> 4;
     const long long obs0 = (long long)blockIdx.x * G;
-    const long long left = M - obs0;
+    // valid_rows (mapf_encoder_backward_bounded): only the first *valid_rows <= M observations carry a gradient (see encoder_fwd_kernel);
+    // M stays the allocated row count (layer stride).  What this workgroup owns but skips reads as zeros where other kernels read all M
+    // rows or all workgroups' partials: gz7_out, the bias partials.
+    long long Mv = M;
+    if (valid_rows != nullptr) {
+        const long long cnt = (long long)*valid_rows;
+        Mv = cnt < M ? (cnt < 0 ? 0 : cnt) : M;
+        if (HEAD) {
+            const long long z0 = obs0 > Mv ? obs0 : Mv, z1 = obs0 + G < M ? obs0 + G : M;
+            if (z1 > z0) {
+                uint4 *gzz = reinterpret_cast<uint4 *>(gz7_out + z0 * (49 * 16));
+                for (long long i = tid; i < (z1 - z0) * 98; i += NTHREADS) gzz[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+        if (obs0 >= Mv) {
+            if (HEAD && blockIdx.x == 0 && tid == 0) grad_scale[1] = __float_as_uint(1.f / grad_scale_from_max(grad_scale[0]));
+            for (int i = tid; i < 7 * 128; i += NTHREADS) gb_part[((long long)(i >> 7) * gridDim.x + blockIdx.x) * 128 + (i & 127)] = 0.f;
+            if (HEAD && lane < 16) gb7_part[((long long)blockIdx.x * 4 + cb) * 16 + lane] = 0.f;
+            return;
+        }
+    }
+    const long long left = Mv - obs0;
     const int nobs = left < G ? (int)left : G;
 
     // HEAD: the chain runs on gradients times `scale`; bias partials are divided by it again here, the weight-gradient kernels
@@ -805,13 +848,15 @@ int mapf_encoder_pack(const float *const *w_dev, const float *const *b_dev, int 
 }
 
 static int encoder_launch(const void *obs_dev, int obs_dtype, int64_t M, const uint16_t *packed_dev, const float *bias_dev,
-                          uint16_t *latent_dev, uint16_t *save_dev, uint32_t *bits_dev, bool save, void *stream) {
+                          uint16_t *latent_dev, uint16_t *save_dev, uint32_t *bits_dev, bool save, void *stream,
+                          const int32_t *valid_rows_dev = nullptr) {
     if (M < 0 || !packed_dev || !bias_dev || (M > 0 && (!obs_dev || !latent_dev || (save && (!save_dev || !bits_dev))))) return MAPF_ERR_INVALID_ARG;
     if (obs_dtype != MAPF_ENC_OBS_U8 && obs_dtype != MAPF_ENC_OBS_BF16) return MAPF_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(obs_dev) & 3) || (reinterpret_cast<uintptr_t>(packed_dev) & 15) ||
         (reinterpret_cast<uintptr_t>(bias_dev) & 15) || (reinterpret_cast<uintptr_t>(latent_dev) & 1) ||
         (reinterpret_cast<uintptr_t>(save_dev) & 15) || (reinterpret_cast<uintptr_t>(bits_dev) & 15))
         return MAPF_ERR_INVALID_ARG;
+    if (valid_rows_dev && ((reinterpret_cast<uintptr_t>(latent_dev) & 15) || (reinterpret_cast<uintptr_t>(valid_rows_dev) & 3))) return MAPF_ERR_INVALID_ARG;
     if (M == 0) return MAPF_OK;
     const long long blocks = (M + G - 1) / G;
     if (blocks > 0x7FFFFFFFLL) return MAPF_ERR_INVALID_ARG;
@@ -820,13 +865,13 @@ static int encoder_launch(const void *obs_dev, int obs_dtype, int64_t M, const u
     const uint8_t *o8 = static_cast<const uint8_t *>(obs_dev);
     const uint16_t *o16 = static_cast<const uint16_t *>(obs_dev);
     if (obs_dtype == MAPF_ENC_OBS_U8 && !save)
-        hipLaunchKernelGGL((encoder_fwd_kernel<uint8_t, false>), grid, block, 0, st, o8, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev, (const int32_t *)nullptr, (const int32_t *)nullptr);
+        hipLaunchKernelGGL((encoder_fwd_kernel<uint8_t, false>), grid, block, 0, st, o8, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev, (const int32_t *)nullptr, valid_rows_dev);
     else if (obs_dtype == MAPF_ENC_OBS_U8)
-        hipLaunchKernelGGL((encoder_fwd_kernel<uint8_t, true>), grid, block, 0, st, o8, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev, (const int32_t *)nullptr, (const int32_t *)nullptr);
+        hipLaunchKernelGGL((encoder_fwd_kernel<uint8_t, true>), grid, block, 0, st, o8, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev, (const int32_t *)nullptr, valid_rows_dev);
     else if (!save)
-        hipLaunchKernelGGL((encoder_fwd_kernel<uint16_t, false>), grid, block, 0, st, o16, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev, (const int32_t *)nullptr, (const int32_t *)nullptr);
+        hipLaunchKernelGGL((encoder_fwd_kernel<uint16_t, false>), grid, block, 0, st, o16, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev, (const int32_t *)nullptr, valid_rows_dev);
     else
-        hipLaunchKernelGGL((encoder_fwd_kernel<uint16_t, true>), grid, block, 0, st, o16, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev, (const int32_t *)nullptr, (const int32_t *)nullptr);
+        hipLaunchKernelGGL((encoder_fwd_kernel<uint16_t, true>), grid, block, 0, st, o16, (long long)M, packed_dev, bias_dev, latent_dev, save_dev, bits_dev, (const int32_t *)nullptr, valid_rows_dev);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }
@@ -857,6 +902,18 @@ int mapf_encoder_forward_save(const void *obs_dev, int obs_dtype, int64_t M, con
     return encoder_launch(obs_dev, obs_dtype, M, packed_dev, bias_dev, latent_dev, acts_dev, relu_bits_dev, true, stream);
 }
 
+int mapf_encoder_forward_bounded(const void *obs_dev, int obs_dtype, int64_t M, const int32_t *valid_rows_dev, const uint16_t *packed_dev,
+                                 const float *bias_dev, uint16_t *latent_dev, void *stream) {
+    if (!valid_rows_dev) return MAPF_ERR_INVALID_ARG;
+    return encoder_launch(obs_dev, obs_dtype, M, packed_dev, bias_dev, latent_dev, nullptr, nullptr, false, stream, valid_rows_dev);
+}
+
+int mapf_encoder_forward_save_bounded(const void *obs_dev, int obs_dtype, int64_t M, const int32_t *valid_rows_dev, const uint16_t *packed_dev,
+                                      const float *bias_dev, uint16_t *latent_dev, uint16_t *acts_dev, uint32_t *relu_bits_dev, void *stream) {
+    if (!valid_rows_dev) return MAPF_ERR_INVALID_ARG;
+    return encoder_launch(obs_dev, obs_dtype, M, packed_dev, bias_dev, latent_dev, acts_dev, relu_bits_dev, true, stream, valid_rows_dev);
+}
+
 int mapf_encoder_pack_bwd(const float *const *w_dev, int weights_nhwc, uint16_t *packed_bwd_dev, void *stream) {
     if (!w_dev || !packed_bwd_dev || (reinterpret_cast<uintptr_t>(packed_bwd_dev) & 15)) return MAPF_ERR_INVALID_ARG;
     PackArgs pa;
@@ -882,14 +939,14 @@ int mapf_encoder_backward_data(const uint16_t *gz7_dev, int64_t M, const uint32_
     const long long blocks = (M + G - 1) / G;
     if (blocks > 0x7FFFFFFFLL) return MAPF_ERR_INVALID_ARG;
     hipLaunchKernelGGL(encoder_bwd_kernel<false>, dim3((unsigned)blocks), dim3(NTHREADS), 0, static_cast<hipStream_t>(stream), gz7_dev,
-                       (long long)M, relu_bits_dev, packed_bwd_dev, gz_dev, gbias_partial_dev, nullptr, nullptr, nullptr, nullptr);
+                       (long long)M, relu_bits_dev, packed_bwd_dev, gz_dev, gbias_partial_dev, nullptr, nullptr, nullptr, nullptr, (const int32_t *)nullptr);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }
 
-int mapf_encoder_backward(const uint16_t *g_latent_dev, const uint16_t *latent_dev, int64_t M, const uint32_t *relu_bits_dev,
-                          const uint16_t *packed_bwd_dev, uint16_t *gz_dev, float *gbias_partial_dev, uint16_t *gz7_dev,
-                          float *gb7_partial_dev, uint32_t *grad_scale_dev, void *stream) {
+static int encoder_backward_launch(const uint16_t *g_latent_dev, const uint16_t *latent_dev, int64_t M, const int32_t *valid_rows_dev,
+                                   const uint32_t *relu_bits_dev, const uint16_t *packed_bwd_dev, uint16_t *gz_dev, float *gbias_partial_dev,
+                                   uint16_t *gz7_dev, float *gb7_partial_dev, uint32_t *grad_scale_dev, void *stream) {
     if (M < 0 || !packed_bwd_dev || !grad_scale_dev || (reinterpret_cast<uintptr_t>(grad_scale_dev) & 3) ||
         (M > 0 && (!g_latent_dev || !latent_dev || !relu_bits_dev || !gz_dev || !gbias_partial_dev || !gz7_dev || !gb7_partial_dev)))
         return MAPF_ERR_INVALID_ARG;
@@ -909,9 +966,25 @@ int mapf_encoder_backward(const uint16_t *g_latent_dev, const uint16_t *latent_d
     hipLaunchKernelGGL(grad_absmax_kernel, dim3((unsigned)(chunks < 256 * 512 ? (chunks + 255) / 256 : 512)), dim3(256), 0, st,
                        reinterpret_cast<const uint4 *>(g_latent_dev), chunks, grad_scale_dev);
     hipLaunchKernelGGL(encoder_bwd_kernel<true>, dim3((unsigned)blocks), dim3(NTHREADS), 0, st, g_latent_dev,
-                       (long long)M, relu_bits_dev, packed_bwd_dev, gz_dev, gbias_partial_dev, latent_dev, gz7_dev, gb7_partial_dev, grad_scale_dev);
+                       (long long)M, relu_bits_dev, packed_bwd_dev, gz_dev, gbias_partial_dev, latent_dev, gz7_dev, gb7_partial_dev, grad_scale_dev,
+                       valid_rows_dev);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
+}
+
+int mapf_encoder_backward(const uint16_t *g_latent_dev, const uint16_t *latent_dev, int64_t M, const uint32_t *relu_bits_dev,
+                          const uint16_t *packed_bwd_dev, uint16_t *gz_dev, float *gbias_partial_dev, uint16_t *gz7_dev,
+                          float *gb7_partial_dev, uint32_t *grad_scale_dev, void *stream) {
+    return encoder_backward_launch(g_latent_dev, latent_dev, M, nullptr, relu_bits_dev, packed_bwd_dev, gz_dev, gbias_partial_dev, gz7_dev,
+                                   gb7_partial_dev, grad_scale_dev, stream);
+}
+
+int mapf_encoder_backward_bounded(const uint16_t *g_latent_dev, const uint16_t *latent_dev, int64_t M, const int32_t *valid_rows_dev,
+                                  const uint32_t *relu_bits_dev, const uint16_t *packed_bwd_dev, uint16_t *gz_dev, float *gbias_partial_dev,
+                                  uint16_t *gz7_dev, float *gb7_partial_dev, uint32_t *grad_scale_dev, void *stream) {
+    if (!valid_rows_dev || (reinterpret_cast<uintptr_t>(valid_rows_dev) & 3)) return MAPF_ERR_INVALID_ARG;
+    return encoder_backward_launch(g_latent_dev, latent_dev, M, valid_rows_dev, relu_bits_dev, packed_bwd_dev, gz_dev, gbias_partial_dev, gz7_dev,
+                                   gb7_partial_dev, grad_scale_dev, stream);
 }
 
 }  // extern "C"

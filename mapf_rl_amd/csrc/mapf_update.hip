@@ -821,6 +821,27 @@ int mapf_plan_mark(const uint8_t *comm_dev, int64_t stride_b, int64_t stride_t, 
     return MAPF_OK;
 }
 
+__global__ void __launch_bounds__(256) plan_totals_kernel(const int32_t *__restrict__ counts, int B, int32_t *__restrict__ totals) {
+    __shared__ int s_red[256];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    int part = 0;
+    for (int b = tid; b < B; b += 256) part += counts[(size_t)k * B + b];
+    s_red[tid] = part;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (tid < d) s_red[tid] += s_red[tid + d];
+        __syncthreads();
+    }
+    if (tid == 0) totals[k] = s_red[0];
+}
+
+int mapf_plan_totals(const int32_t *counts_dev, int rows, int B, int32_t *totals_dev, void *stream) {
+    if (!counts_dev || !totals_dev || rows < 1 || rows > 16 || B < 0) return MAPF_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(plan_totals_kernel, dim3(rows), dim3(256), 0, static_cast<hipStream_t>(stream), counts_dev, B, totals_dev);
+    HIP_TRY(hipGetLastError());
+    return MAPF_OK;
+}
+
 int mapf_plan_rows(int T, int B, int N, int Nc, const int16_t *order_dev, const int32_t *nact_dev, const int32_t *cnt_dev, const int32_t *nag_dev,
                    const uint8_t *comm_dev, int64_t comm_stride_b, int64_t comm_stride_t, const uint16_t *hidden_dev, int hidden_is_bf16,
                    const uint16_t *obs_bf16_dev, int64_t obs_stride_b, int64_t obs_stride_t, int32_t *gidx_dev, uint8_t *comm_c_dev, uint16_t *h0_c_dev,

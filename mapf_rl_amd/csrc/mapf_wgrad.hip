@@ -107,7 +107,8 @@ __device__ __forceinline__ el8 tr_read2(const unsigned char *p0, const unsigned 
 // observations of a few-agent update that write, 75 MB per layer with 128 partitions, was most of a 54 us launch).
 __global__ void __launch_bounds__(NTHR) encoder_wgrad_kernel(const uint16_t *__restrict__ gz, const uint16_t *__restrict__ ain, long long M,
                                                            float *__restrict__ ws, const uint32_t *__restrict__ grad_scale, int parts,
-                                                           int layers, long long gz_stride, long long in_stride) {
+                                                           int layers, long long gz_stride, long long in_stride,
+                                                           const int32_t *__restrict__ valid_rows) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,6 +119,10 @@ __global__ void __launch_bounds__(NTHR) encoder_wgrad_kernel(const uint16_t *__r
     const int chalf = w & 1, nq = w >> 1;  // this wave's 64 output channels / 16 input channels of the slab
     gz += layer * gz_stride;
     ain += layer * in_stride;
+    if (valid_rows != nullptr) {  // only the first *valid_rows <= M observations carry a gradient: they are what is partitioned
+        const long long cnt = (long long)*valid_rows;
+        M = cnt < M ? (cnt < 0 ? 0 : cnt) : M;
+    }
 
     // observations of this partition -> a stream of IR image rows in nblk blocks of 8
     const long long per = (M + parts - 1) / parts;
@@ -334,13 +339,15 @@ int mapf_encoder_wgrad(const uint16_t *gz_dev, const uint16_t *in_dev, int64_t M
     if ((M + MAPF_ENC_WGRAD_PARTS - 1) / MAPF_ENC_WGRAD_PARTS > (1 << 18)) return MAPF_ERR_INVALID_ARG;  // int element offsets inside a partition
     // every partition writes its slab (zeros when it has no observations), so the caller's sum is always defined
     hipLaunchKernelGGL(encoder_wgrad_kernel, dim3(SLABS * MAPF_ENC_WGRAD_PARTS), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gz_dev,
-                       in_dev, (long long)M, partial_dev, grad_scale_dev, MAPF_ENC_WGRAD_PARTS, 1, 0LL, 0LL);
+                       in_dev, (long long)M, partial_dev, grad_scale_dev, MAPF_ENC_WGRAD_PARTS, 1, 0LL, 0LL, (const int32_t *)nullptr);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }
 
 int mapf_encoder_wgrad_multi(const uint16_t *gz_dev, int64_t gz_layer_stride, const uint16_t *in_dev, int64_t in_layer_stride, int layers,
-                             int parts, int64_t M, const uint32_t *grad_scale_dev, float *partial_dev, void *stream) {
+                             int parts, int64_t M, const int32_t *valid_rows_dev, const uint32_t *grad_scale_dev, float *partial_dev,
+                             void *stream) {
+    if (reinterpret_cast<uintptr_t>(valid_rows_dev) & 3) return MAPF_ERR_INVALID_ARG;
     if (M < 0 || !partial_dev || layers < 1 || layers > 8 || parts < 1 || parts > MAPF_ENC_WGRAD_PARTS || (M > 0 && (!gz_dev || !in_dev)))
         return MAPF_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(gz_dev) & 15) || (reinterpret_cast<uintptr_t>(in_dev) & 15) ||
@@ -351,7 +358,8 @@ int mapf_encoder_wgrad_multi(const uint16_t *gz_dev, int64_t gz_layer_stride, co
     const int pairs = layers * parts, groups = (pairs + 7) / 8;
     // every (layer, partition) writes its slab (zeros when it has no observations), so the caller's sum is always defined
     hipLaunchKernelGGL(encoder_wgrad_kernel, dim3(16 * groups), dim3(NTHR), 0, static_cast<hipStream_t>(stream), gz_dev, in_dev,
-                       (long long)M, partial_dev, grad_scale_dev, parts, layers, (long long)gz_layer_stride, (long long)in_layer_stride);
+                       (long long)M, partial_dev, grad_scale_dev, parts, layers, (long long)gz_layer_stride, (long long)in_layer_stride,
+                       valid_rows_dev);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
 }

@@ -70,11 +70,16 @@ __device__ __forceinline__ uint32_t bf16_to_el_bits(uint32_t h) {  // observatio
 
 template <typename InT>
 __global__ void __launch_bounds__(NTHR, 2) conv0_wgrad_kernel(const uint16_t *__restrict__ gz, const InT *__restrict__ obs, long long M,
-                                                            float *__restrict__ ws, const uint32_t *__restrict__ grad_scale) {
+                                                            float *__restrict__ ws, const uint32_t *__restrict__ grad_scale,
+                                                            const int32_t *__restrict__ valid_rows) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int part = blockIdx.x;
+    if (valid_rows != nullptr) {  // (mapf_encoder_wgrad0_bounded: only the first *valid_rows <= M observations carry a gradient)
+        const long long cnt = (long long)*valid_rows;
+        M = cnt < M ? (cnt < 0 ? 0 : cnt) : M;
+    }
     const long long per = (M + PARTS - 1) / PARTS;
     const long long ob0 = per * part;
     long long nob = M - ob0;
@@ -226,8 +231,8 @@ __global__ void __launch_bounds__(NTHR, 2) conv0_wgrad_kernel(const uint16_t *__
 
 extern "C" {
 
-int mapf_encoder_wgrad0(const uint16_t *gz0_dev, const void *obs_dev, int obs_dtype, int64_t M, const uint32_t *grad_scale_dev,
-                        float *partial_dev, void *stream) {
+static int wgrad0_launch(const uint16_t *gz0_dev, const void *obs_dev, int obs_dtype, int64_t M, const int32_t *valid_rows_dev,
+                         const uint32_t *grad_scale_dev, float *partial_dev, void *stream) {
     if (M < 0 || !partial_dev || (M > 0 && (!gz0_dev || !obs_dev))) return MAPF_ERR_INVALID_ARG;
     if (obs_dtype != MAPF_ENC_OBS_U8 && obs_dtype != MAPF_ENC_OBS_BF16) return MAPF_ERR_INVALID_ARG;
     // u8 observations are fetched two bytes at a time (486 bytes each: every observation starts on an even address iff the base does)
@@ -238,12 +243,23 @@ int mapf_encoder_wgrad0(const uint16_t *gz0_dev, const void *obs_dev, int obs_dt
     // every partition writes its slab (zeros when it has no observations), so the caller's sum is always defined
     if (obs_dtype == MAPF_ENC_OBS_U8)
         hipLaunchKernelGGL(conv0_wgrad_kernel<uint8_t>, dim3(PARTS), dim3(NTHR), 0, st, gz0_dev, static_cast<const uint8_t *>(obs_dev),
-                           (long long)M, partial_dev, grad_scale_dev);
+                           (long long)M, partial_dev, grad_scale_dev, valid_rows_dev);
     else
         hipLaunchKernelGGL(conv0_wgrad_kernel<uint16_t>, dim3(PARTS), dim3(NTHR), 0, st, gz0_dev, static_cast<const uint16_t *>(obs_dev),
-                           (long long)M, partial_dev, grad_scale_dev);
+                           (long long)M, partial_dev, grad_scale_dev, valid_rows_dev);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
+}
+
+int mapf_encoder_wgrad0(const uint16_t *gz0_dev, const void *obs_dev, int obs_dtype, int64_t M, const uint32_t *grad_scale_dev,
+                        float *partial_dev, void *stream) {
+    return wgrad0_launch(gz0_dev, obs_dev, obs_dtype, M, nullptr, grad_scale_dev, partial_dev, stream);
+}
+
+int mapf_encoder_wgrad0_bounded(const uint16_t *gz0_dev, const void *obs_dev, int obs_dtype, int64_t M, const int32_t *valid_rows_dev,
+                                const uint32_t *grad_scale_dev, float *partial_dev, void *stream) {
+    if (!valid_rows_dev || (reinterpret_cast<uintptr_t>(valid_rows_dev) & 3)) return MAPF_ERR_INVALID_ARG;
+    return wgrad0_launch(gz0_dev, obs_dev, obs_dtype, M, valid_rows_dev, grad_scale_dev, partial_dev, stream);
 }
 
 }  // extern "C"

@@ -346,13 +346,14 @@ class FusedUpdate:
             if self._splan is None or self._splan["shape"] != (T, B, N):
                 self._splan = dict(shape=(T, B, N), po=WindowPlan(T - FORWARD_STEPS, B, N, dev), pt=WindowPlan(T, B, N, dev),
                                    counts=torch.empty((6, B), dtype=torch.int32, device=dev), dup=torch.empty((T, B, N), dtype=torch.uint8, device=dev),
-                                   host=torch.empty((6, B), dtype=torch.int32, pin_memory=True))
+                                   host=torch.empty((6, B), dtype=torch.int32, pin_memory=True), totals=torch.zeros(8, dtype=torch.int32, device=dev))
             sp = self._splan
-            po, pt, counts, host = sp["po"], sp["pt"], sp["counts"], sp["host"]
+            po, pt, counts, host, totals = sp["po"], sp["pt"], sp["counts"], sp["host"], sp["totals"]
         else:
             po, pt = WindowPlan(T - FORWARD_STEPS, B, N, dev), WindowPlan(T, B, N, dev)
             counts = torch.empty((6, B), dtype=torch.int32, device=dev)  # cnt online, nag online, cnt target, nag target, distinct online, distinct target
             host = torch.empty((6, B), dtype=torch.int32, pin_memory=True)
+            totals = None
         cm = v["comm"]
         mark_all = 0 if flags[0] else 1  # 1: encode every observation up to the window's last step, like the reference
         for k, (p, extra) in enumerate(((po, None), (pt, v["steps"]))):
@@ -367,12 +368,16 @@ class FusedUpdate:
             check(lib.mapf_obs_dup(T, po.T, B, N, _ptr(obs), obs.stride(0), obs.stride(1), _ptr(po.slot), _ptr(pt.slot), _ptr(po.nact), _ptr(pt.nact),
                                    _ptr(dup), _ptr(po.ucnt), _ptr(pt.ucnt), st), "mapf_obs_dup")
         po.dup = pt.dup = dup
+        if totals is not None:
+            # the batch totals stay on the device too: the bucket-sized launches of a graph-replayed update read their true row counts
+            # from here (include/mapf_dqn.h: the `_bounded` encoder entry points) -- [2 k] entries, [4 + k] distinct observations of set k
+            check(lib.mapf_plan_totals(_ptr(counts), 6, B, _ptr(totals), st), "mapf_plan_totals")
         host.copy_(counts, non_blocking=True)
         ev = None
         if not self._capturing:  # (inside a capture the event is recorded behind the graph's replay, _run_graphed)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
-        return dict(views=v, online=po, target=pt, counts=counts, host=host, event=ev, static=static, flags=flags)
+        return dict(views=v, online=po, target=pt, counts=counts, host=host, event=ev, static=static, flags=flags, totals=totals)
 
     def _plan_sizes(self, pl, padded=False):
         """Host side of the plan: row totals and the compact width of both window sets (waits for the count copy -- long finished
@@ -384,10 +389,14 @@ class FusedUpdate:
             p.nc = self._compact_width(int(h[2 * k + 1].max()), p.B)
             p.urows = int(h[4 + k].sum()) if p.dup is not None else p.rows
             p.true_rows, p.true_urows = p.rows, p.urows
+            p.valid_rows = None  # device-side count of the rows the encoder kernels have to compute (bucket-sized launches only)
             if padded:
                 p.nc = self._compact_width(p.N, p.B)
                 p.rows = _round_up(p.rows, self.GRAPH_ROW_STEP)
                 p.urows = _round_up(p.urows, self.GRAPH_UROW_STEP) if p.dup is not None else p.rows
+                if self.BOUNDED_ROWS and pl.get("totals") is not None:
+                    i = (4 + k) if p.dup is not None else 2 * k
+                    p.valid_rows = pl["totals"][i:i + 1]
         return pl
 
     def _compact_width(self, agents, B):
@@ -468,7 +477,10 @@ class FusedUpdate:
         st = _stream(dev)
         wp, bp, w, b = images
         lat = rows_buffer((), p.urows, (784,), torch.bfloat16, dev)
-        check(lib.mapf_encoder_forward(_ptr(p.obs_rows), 1, p.urows, _ptr(wp), _ptr(bp), _ptr(lat), st), "mapf_encoder_forward")
+        if getattr(p, "valid_rows", None) is not None:
+            check(lib.mapf_encoder_forward_bounded(_ptr(p.obs_rows), 1, p.urows, _ptr(p.valid_rows), _ptr(wp), _ptr(bp), _ptr(lat), st), "mapf_encoder_forward_bounded")
+        else:
+            check(lib.mapf_encoder_forward(_ptr(p.obs_rows), 1, p.urows, _ptr(wp), _ptr(bp), _ptr(lat), st), "mapf_encoder_forward")
         gi = self._expand(input_proj_rows(lat, self._w_ihp(net, own), out=rows_buffer((), p.urows, (768,), torch.bfloat16, dev)), p)  # [rows, 768]
         compact = Nc <= RECUR_NARROW_AGENTS  # the <= 48-agent kernels read / write the rows that exist (gidx); the wide ones are dense
         if not compact:
@@ -489,6 +501,9 @@ class FusedUpdate:
               "mapf_rows_scatter")
         return out
 
+    # graph mode: the encoder kernels of a bucket-sized launch compute the TRUE number of distinct observations only (read from device
+    # memory), not the bucket (the variable: A/B runs)
+    BOUNDED_ROWS = os.environ.get("MAPF_BOUNDED_ROWS", "1") != "0"
     DEDUP = True  # encode the distinct observations of a batch only (mapf_obs_dup: same agent, consecutive steps, same 486 values)
 
     # ------------------------------------------------------------------ the update
@@ -554,8 +569,13 @@ class FusedUpdate:
         c.acts = rows_buffer((7,), Mu, (7, 7, 128), ENC_ELEMENT, dev)
         c.lat = rows_buffer((), Mu, (784,), bf, dev)
         c.bits = rows_buffer((7,), Mu, (49, 4), torch.int32, dev)
-        check(lib.mapf_encoder_forward_save(_ptr(po.obs_rows), 1, Mu, _ptr(c.wp), _ptr(c.bp), _ptr(c.lat), _ptr(c.acts), _ptr(c.bits), st),
-              "mapf_encoder_forward_save")
+        c.valid_rows = getattr(po, "valid_rows", None)
+        if c.valid_rows is not None:
+            check(lib.mapf_encoder_forward_save_bounded(_ptr(po.obs_rows), 1, Mu, _ptr(c.valid_rows), _ptr(c.wp), _ptr(c.bp), _ptr(c.lat), _ptr(c.acts),
+                                                        _ptr(c.bits), st), "mapf_encoder_forward_save_bounded")
+        else:
+            check(lib.mapf_encoder_forward_save(_ptr(po.obs_rows), 1, Mu, _ptr(c.wp), _ptr(c.bp), _ptr(c.lat), _ptr(c.acts), _ptr(c.bits), st),
+                  "mapf_encoder_forward_save")
         gi_rows = self._expand(input_proj_rows(c.lat, self._on_w_ihp, out=rows_buffer((), Mu, (768,), bf, dev)), po)
         c.compact = compact = Nc <= RECUR_NARROW_AGENTS
         # rows of the recurrence's saved tensors / gradient outputs: the M rows that exist (compact: the <= 48-agent kernels address
@@ -696,7 +716,7 @@ class FusedUpdate:
         if aux is None:
             _tall_tn_into(flat.mem(G, "recurrent.weight_ih"), d_gi_rows, c.lat, rows=4096)
         # ---- encoder: backward-data chain in one kernel, then the weight-gradient kernels ----
-        self._encoder_backward(po.obs_rows, Mu, c.acts, c.lat, c.bits, g_lat, c.wpt, aux)
+        self._encoder_backward(po.obs_rows, Mu, c.acts, c.lat, c.bits, g_lat, c.wpt, aux, getattr(c, "valid_rows", None))
         if aux is not None:
             cur_s.wait_stream(aux)
         if ex and self._capturing:
@@ -885,6 +905,9 @@ class FusedUpdate:
                 c = _Ctx()
                 self._plan_rows(p, v, padded=True)
                 c.rows = tuple(getattr(p, k) for k in ROWS)
+                # THIS update's true row count, copied out of the plan's totals: the prefetch stage overwrites those with the next
+                # batch's while this update's backward stage is still to read them
+                c.valid = p.valid_rows.clone() if p.valid_rows is not None else None
                 c.fwd = None
                 return c
             return fn
@@ -892,6 +915,7 @@ class FusedUpdate:
         def use_rows(p, c):
             for k, t in zip(ROWS, c.rows):
                 setattr(p, k, t)
+            p.valid_rows = c.valid
 
         def cap_target():
             c = _Ctx()
@@ -1021,7 +1045,7 @@ class FusedUpdate:
 
     WGRAD_MERGED = os.environ.get("MAPF_WGRAD_MERGED", "1") != "0"  # (the variable: A/B runs)
 
-    def _encoder_backward(self, obs_rows, M, acts, lat, bits, g_lat, wpt, aux=None):
+    def _encoder_backward(self, obs_rows, M, acts, lat, bits, g_lat, wpt, aux=None, valid=None):
         """aux: a second stream for what only needs the backward-data kernel's outputs besides the six 3x3 weight-gradient launches
         (bias sums, conv0's and the 1x1 head's weight gradients: ~0.15 ms of small launches at few agents); the caller joins it."""
         dev, flat = self.dev, self.flat
@@ -1034,8 +1058,13 @@ class FusedUpdate:
         # the chain's gradients are f16 times a power-of-two loss scale S picked from max |g_lat| (include/mapf_dqn.h);
         # scale[1] = the bits of 1 / S, which the weight-gradient kernels multiply their partial sums by
         scale = torch.empty(2, dtype=torch.int32, device=dev)
-        check(lib.mapf_encoder_backward(_ptr(g_lat), _ptr(lat), M, _ptr(bits), _ptr(wpt), _ptr(gz), _ptr(gb_part), _ptr(gz7), _ptr(gb7_part),
-                                        _ptr(scale), st), "mapf_encoder_backward")
+        # valid: the true observation count on the device (bucket-sized launches of a graph-replayed update; rows behind it are skipped)
+        if valid is not None:
+            check(lib.mapf_encoder_backward_bounded(_ptr(g_lat), _ptr(lat), M, _ptr(valid), _ptr(bits), _ptr(wpt), _ptr(gz), _ptr(gb_part), _ptr(gz7),
+                                                    _ptr(gb7_part), _ptr(scale), st), "mapf_encoder_backward_bounded")
+        else:
+            check(lib.mapf_encoder_backward(_ptr(g_lat), _ptr(lat), M, _ptr(bits), _ptr(wpt), _ptr(gz), _ptr(gb_part), _ptr(gz7), _ptr(gb7_part),
+                                            _ptr(scale), st), "mapf_encoder_backward")
         names = ["obs_encoder.0", "obs_encoder.2.block1", "obs_encoder.2.block2", "obs_encoder.3.block1", "obs_encoder.3.block2",
                  "obs_encoder.4.block1", "obs_encoder.4.block2", "obs_encoder.5"]
         if aux is not None:
@@ -1043,7 +1072,10 @@ class FusedUpdate:
         with (torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext()):
             st_x = _stream(dev)
             ws0 = torch.empty((ENC_WGRAD0_PARTS, 128, 64), dtype=torch.float32, device=dev)
-            check(lib.mapf_encoder_wgrad0(_ptr(gz[0]), _ptr(obs_rows), 1, M, _ptr(scale), _ptr(ws0), st_x), "mapf_encoder_wgrad0")
+            if valid is not None:
+                check(lib.mapf_encoder_wgrad0_bounded(_ptr(gz[0]), _ptr(obs_rows), 1, M, _ptr(valid), _ptr(scale), _ptr(ws0), st_x), "mapf_encoder_wgrad0_bounded")
+            else:
+                check(lib.mapf_encoder_wgrad0(_ptr(gz[0]), _ptr(obs_rows), 1, M, _ptr(scale), _ptr(ws0), st_x), "mapf_encoder_wgrad0")
             # bias gradients from the backward kernel's per-workgroup partials, conv0's weight gradient from its slabs (columns
             # j = ci*9 + ky*3 + kx -> the weight's memory [co][ky][kx][ci]): two small launches of this library
             check(lib.mapf_encoder_small_grads(_ptr(gb_part), nblk, _ptr(flat.span(G, names[0] + ".bias", names[6] + ".bias")), _ptr(gb7_part), 4 * nblk,
@@ -1051,7 +1083,7 @@ class FusedUpdate:
                                                _ptr(torch.empty(65536, dtype=torch.float32, device=dev)), st_x), "mapf_encoder_small_grads")
             # the 1x1 head: [16, 128] = gz7^T acts6 over M * 49 positions (f16, the chain's loss scale taken out in fp32)
             tall_tn_into(flat.mem(G, names[7] + ".weight").view(16, 128), gz7, acts[6].reshape(M * 49, 128), scale=scale)
-        if self.WGRAD_MERGED and gz.stride(0) == acts.stride(0) == M * 6272:
+        if (self.WGRAD_MERGED or valid is not None) and gz.stride(0) == acts.stride(0) == M * 6272:
             # the six 3x3 layers' weight gradients in ONE launch (one workgroup per CU: 6 x 21 partitions x 2 slabs) and one sum -- six
             # serial (wgrad 54-75 us, sum 12-17 us) pairs were the last 400 us of a 6-agent update's chain
             # (profiles/r05_update6_graph_timeline_tiles.md), most of each launch the write of 128 partial slabs
@@ -1060,7 +1092,7 @@ class FusedUpdate:
             # 64 CUs free for them -- 20 / 18 / 16 partitions -- measured the same update time: profiles/r06_update6_wgrad_parts.txt)
             P = int(os.environ.get("MAPF_WGRAD_PARTS", str(ENC_WGRAD_PARTS // 6)))
             ws = torch.empty((6, P, 128, 3, 3, 128), dtype=torch.float32, device=dev)
-            check(lib.mapf_encoder_wgrad_multi(_ptr(gz[1]), gz.stride(0), _ptr(acts[0]), acts.stride(0), 6, P, M, _ptr(scale), _ptr(ws), st),
+            check(lib.mapf_encoder_wgrad_multi(_ptr(gz[1]), gz.stride(0), _ptr(acts[0]), acts.stride(0), 6, P, M, _ptr(valid), _ptr(scale), _ptr(ws), st),
                   "mapf_encoder_wgrad_multi")
             sum_parts_into([flat.mem(G, names[k] + ".weight") for k in range(1, 7)], [ws[k - 1] for k in range(1, 7)])
             return

@@ -314,7 +314,7 @@ def test_wgrad_multi_layer_launch_against_fp32_and_the_single_layer_launch(M, la
     gz = (torch.randn((layers, M + pad, 7, 7, 128), device="cuda", generator=g) * (torch.rand((layers, M + pad, 7, 7, 128), device="cuda", generator=g) < 0.5)).to(torch.float16)
     a = torch.relu(torch.randn((layers, M + pad, 7, 7, 128), device="cuda", generator=g)).to(torch.float16)
     ws = torch.full((layers, parts, 128, 3, 3, 128), float("nan"), dtype=torch.float32, device="cuda")
-    check(lib.mapf_encoder_wgrad_multi(gz.data_ptr(), S, a.data_ptr(), S, layers, parts, M, None, ws.data_ptr(), None), "mapf_encoder_wgrad_multi")
+    check(lib.mapf_encoder_wgrad_multi(gz.data_ptr(), S, a.data_ptr(), S, layers, parts, M, None, None, ws.data_ptr(), None), "mapf_encoder_wgrad_multi")
     assert torch.isfinite(ws).all()
     one = torch.empty((128, 128, 3, 3, 128), dtype=torch.float32, device="cuda")
     for l in range(layers):
@@ -328,15 +328,98 @@ def test_wgrad_multi_layer_launch_against_fp32_and_the_single_layer_launch(M, la
             assert float((ws[l].sum(0) - one.sum(0)).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
     scale = torch.tensor([0.0, 2.0 ** -9], dtype=torch.float32, device="cuda")
     ws2 = torch.full_like(ws, float("nan"))
-    check(lib.mapf_encoder_wgrad_multi(gz.data_ptr(), S, a.data_ptr(), S, layers, parts, M, scale.data_ptr(), ws2.data_ptr(), None), "mapf_encoder_wgrad_multi")
+    check(lib.mapf_encoder_wgrad_multi(gz.data_ptr(), S, a.data_ptr(), S, layers, parts, M, None, scale.data_ptr(), ws2.data_ptr(), None), "mapf_encoder_wgrad_multi")
     assert torch.equal(ws2, ws * 2.0 ** -9)
     # argument checks: layers that would overlap, a stride that breaks the 16-byte alignment, counts out of range
     if layers > 1:
-        assert lib.mapf_encoder_wgrad_multi(gz.data_ptr(), M * 6272 - 8, a.data_ptr(), S, layers, parts, M, None, ws.data_ptr(), None) == ERR_INVALID_ARG
-    assert lib.mapf_encoder_wgrad_multi(gz.data_ptr(), S + 4, a.data_ptr(), S, layers, parts, M, None, ws.data_ptr(), None) == ERR_INVALID_ARG
-    assert lib.mapf_encoder_wgrad_multi(gz.data_ptr(), S, a.data_ptr(), S, 9, parts, M, None, ws.data_ptr(), None) == ERR_INVALID_ARG
-    assert lib.mapf_encoder_wgrad_multi(gz.data_ptr(), S, a.data_ptr(), S, layers, 129, M, None, ws.data_ptr(), None) == ERR_INVALID_ARG
-    assert lib.mapf_encoder_wgrad_multi(gz.data_ptr(), S, a.data_ptr(), S, layers, 0, M, None, ws.data_ptr(), None) == ERR_INVALID_ARG
+        assert lib.mapf_encoder_wgrad_multi(gz.data_ptr(), M * 6272 - 8, a.data_ptr(), S, layers, parts, M, None, None, ws.data_ptr(), None) == ERR_INVALID_ARG
+    assert lib.mapf_encoder_wgrad_multi(gz.data_ptr(), S + 4, a.data_ptr(), S, layers, parts, M, None, None, ws.data_ptr(), None) == ERR_INVALID_ARG
+    assert lib.mapf_encoder_wgrad_multi(gz.data_ptr(), S, a.data_ptr(), S, 9, parts, M, None, None, ws.data_ptr(), None) == ERR_INVALID_ARG
+    assert lib.mapf_encoder_wgrad_multi(gz.data_ptr(), S, a.data_ptr(), S, layers, 129, M, None, None, ws.data_ptr(), None) == ERR_INVALID_ARG
+    assert lib.mapf_encoder_wgrad_multi(gz.data_ptr(), S, a.data_ptr(), S, layers, 0, M, None, None, ws.data_ptr(), None) == ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("M,valid", [(64, 64), (64, 37), (64, 1), (64, 0), (1000, 555), (4096, 3267), (13, 20)])
+def test_bounded_entry_points_equal_the_plain_ones_on_the_valid_rows(M, valid):
+    """The `_bounded` encoder entry points (row count read from device memory; the learner's bucket-sized launches) against the plain
+    ones run on exactly `valid` rows: forward / forward_save give the same latents, saved activations and ReLU words on the valid rows
+    and zeros in the latents and in the last saved layer behind them; backward gives the same gz / gz7 on the valid rows, zeros in gz7
+    behind them and the same bias sums; the weight-gradient kernels give the plain kernels' sums -- with every row behind the bound
+    poisoned (NaN operands) to prove that nothing reads them."""
+    from mapf_rl_amd._lib import ERR_INVALID_ARG, check, lib
+    from mapf_rl_amd import fused as F
+
+    net = _net(5)
+    wp, bp = F.PackedEncoder().get(net.obs_encoder)
+    wpt = F.pack_encoder_backward(net.obs_encoder)
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + valid)
+    V = min(valid, M)
+    obs = (torch.rand((M, 6, 9, 9), device="cuda", generator=g) < 0.3).to(torch.bfloat16)
+    cnt = torch.tensor([valid], dtype=torch.int32, device="cuda")
+    nan16 = lambda shape: torch.full(shape, float("nan"), dtype=torch.float16, device="cuda")
+    lat_b = torch.full((M, 784), float("nan"), dtype=torch.bfloat16, device="cuda")
+    acts_b, bits_b = nan16((7, M, 49, 128)), torch.full((7, M, 49, 4), -1, dtype=torch.int32, device="cuda")
+    check(lib.mapf_encoder_forward_save_bounded(obs.data_ptr(), 1, M, cnt.data_ptr(), wp.data_ptr(), bp.data_ptr(), lat_b.data_ptr(), acts_b.data_ptr(),
+                                                bits_b.data_ptr(), None), "mapf_encoder_forward_save_bounded")
+    lat_i = torch.full((M, 784), float("nan"), dtype=torch.bfloat16, device="cuda")
+    check(lib.mapf_encoder_forward_bounded(obs.data_ptr(), 1, M, cnt.data_ptr(), wp.data_ptr(), bp.data_ptr(), lat_i.data_ptr(), None), "mapf_encoder_forward_bounded")
+    assert torch.equal(lat_b[V:], torch.zeros_like(lat_b[V:])) and torch.equal(lat_i[V:], torch.zeros_like(lat_i[V:]))
+    assert torch.equal(acts_b[6, V:], torch.zeros_like(acts_b[6, V:]))
+    if V:
+        lat_p = torch.empty((V, 784), dtype=torch.bfloat16, device="cuda")
+        acts_p, bits_p = torch.empty((7, V, 49, 128), dtype=torch.float16, device="cuda"), torch.empty((7, V, 49, 4), dtype=torch.int32, device="cuda")
+        check(lib.mapf_encoder_forward_save(obs.data_ptr(), 1, V, wp.data_ptr(), bp.data_ptr(), lat_p.data_ptr(), acts_p.data_ptr(), bits_p.data_ptr(), None), "save")
+        assert torch.equal(lat_b[:V], lat_p) and torch.equal(lat_i[:V], lat_p)
+        assert torch.equal(acts_b[:, :V], acts_p) and torch.equal(bits_b[:, :V], bits_p)
+    # backward + weight gradients: gradient rows behind the bound are NaN too (the learner's are zero: nothing may depend on it)
+    gl = torch.randn((M, 784), device="cuda", generator=g).to(torch.bfloat16)
+    gl[V:] = float("nan")
+    nblk = -(-M // F.ENC_OBS_PER_BLOCK)
+    gz_b, gz7_b = nan16((7, M, 49, 128)), nan16((M * 49, 16))
+    gb_b, gb7_b = torch.full((7, nblk, 128), float("nan"), device="cuda"), torch.full((4 * nblk, 16), float("nan"), device="cuda")
+    sc_b = torch.zeros(2, dtype=torch.int32, device="cuda")
+    lat_q = lat_b.clone()
+    gl_q = gl.clone()
+    gl_q[V:] = 0  # (the loss-scale reduction in front of the chain reads all M rows of the incoming gradient: the caller's padding is zero)
+    check(lib.mapf_encoder_backward_bounded(gl_q.data_ptr(), lat_q.data_ptr(), M, cnt.data_ptr(), bits_b.data_ptr(), wpt.data_ptr(), gz_b.data_ptr(),
+                                            gb_b.data_ptr(), gz7_b.data_ptr(), gb7_b.data_ptr(), sc_b.data_ptr(), None), "mapf_encoder_backward_bounded")
+    assert torch.isfinite(gb_b).all() and torch.isfinite(gb7_b).all()
+    assert torch.equal(gz7_b[V * 49:], torch.zeros_like(gz7_b[V * 49:]))
+    ws_m = torch.full((6, 21, 128, 3, 3, 128), float("nan"), device="cuda")
+    check(lib.mapf_encoder_wgrad_multi(gz_b[1].data_ptr(), M * 6272, acts_b[0].data_ptr(), M * 6272, 6, 21, M, cnt.data_ptr(), sc_b.data_ptr(), ws_m.data_ptr(), None),
+          "mapf_encoder_wgrad_multi")
+    ws0 = torch.full((F.ENC_WGRAD0_PARTS, 128, 64), float("nan"), device="cuda")
+    check(lib.mapf_encoder_wgrad0_bounded(gz_b[0].data_ptr(), obs.data_ptr(), 1, M, cnt.data_ptr(), sc_b.data_ptr(), ws0.data_ptr(), None), "mapf_encoder_wgrad0_bounded")
+    assert torch.isfinite(ws_m).all() and torch.isfinite(ws0).all()
+    if V:
+        gz_p, gz7_p = torch.empty((7, V, 49, 128), dtype=torch.float16, device="cuda"), torch.empty((V * 49, 16), dtype=torch.float16, device="cuda")
+        nb = -(-V // F.ENC_OBS_PER_BLOCK)
+        gb_p, gb7_p = torch.empty((7, nb, 128), device="cuda"), torch.empty((4 * nb, 16), device="cuda")
+        sc_p = torch.zeros(2, dtype=torch.int32, device="cuda")
+        check(lib.mapf_encoder_backward(gl[:V].contiguous().data_ptr(), lat_p.data_ptr(), V, bits_p.data_ptr(), wpt.data_ptr(), gz_p.data_ptr(), gb_p.data_ptr(),
+                                        gz7_p.data_ptr(), gb7_p.data_ptr(), sc_p.data_ptr(), None), "mapf_encoder_backward")
+        assert torch.equal(sc_b, sc_p) and torch.equal(gz_b[:, :V], gz_p) and torch.equal(gz7_b[:V * 49], gz7_p)
+        assert torch.allclose(gb_b.sum(1), gb_p.sum(1), rtol=1e-5, atol=1e-6) and torch.allclose(gb7_b.sum(0), gb7_p.sum(0), rtol=1e-5, atol=1e-6)
+        ws_p = torch.empty((6, 21, 128, 3, 3, 128), device="cuda")
+        check(lib.mapf_encoder_wgrad_multi(gz_p[1].data_ptr(), V * 6272, acts_p[0].data_ptr(), V * 6272, 6, 21, V, None, sc_p.data_ptr(), ws_p.data_ptr(), None), "multi")
+        assert torch.equal(ws_m, ws_p)  # (the valid rows are what is partitioned: the same partitions, the same sums)
+        ws0_p = torch.empty((F.ENC_WGRAD0_PARTS, 128, 64), device="cuda")
+        check(lib.mapf_encoder_wgrad0(gz_p[0].data_ptr(), obs.data_ptr(), 1, V, sc_p.data_ptr(), ws0_p.data_ptr(), None), "wgrad0")
+        assert torch.equal(ws0, ws0_p)
+    else:
+        assert float(ws_m.abs().sum()) == 0.0 and float(ws0.abs().sum()) == 0.0 and float(gb_b.abs().sum()) == 0.0
+    # argument checks
+    assert lib.mapf_encoder_forward_bounded(obs.data_ptr(), 1, M, None, wp.data_ptr(), bp.data_ptr(), lat_i.data_ptr(), None) == ERR_INVALID_ARG
+    assert lib.mapf_encoder_wgrad0_bounded(gz_b[0].data_ptr(), obs.data_ptr(), 1, M, None, sc_b.data_ptr(), ws0.data_ptr(), None) == ERR_INVALID_ARG
+
+
+def test_plan_totals():
+    from mapf_rl_amd._lib import check, lib
+
+    c = torch.randint(0, 1000, (6, 777), dtype=torch.int32, device="cuda")
+    t = torch.full((8,), -1, dtype=torch.int32, device="cuda")
+    check(lib.mapf_plan_totals(c.data_ptr(), 6, 777, t.data_ptr(), None), "mapf_plan_totals")
+    assert torch.equal(t[:6].long(), c.long().sum(1)) and int(t[6]) == -1
 
 
 def test_training_step_is_bitwise_repeatable():
