@@ -265,6 +265,12 @@ class GlobalBuffer:
         for line in self.levels.advance(pooled, self.levels.WINDOW * world):
             print(line)
 
+    def advance_levels(self, pooled=None, world=1):
+        """The promotion rule alone (worker.py:211-224), without the statistics' lines: `train.py --promote-interval` checks it more
+        often than it prints.  Returns the per-level lines `stats` would print."""
+        self.drain_outcomes()
+        return self.levels.advance(pooled, self.levels.WINDOW * world)
+
     def ready(self, learning_starts=50000):
         return len(self) >= learning_starts
 

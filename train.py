@@ -62,6 +62,11 @@ def main(argv=None):
     ap.add_argument("--minutes", type=float, default=0.0, help="stop after this many minutes (0 = until --max-updates / curriculum done); several ranks: "
                     "acted on up to 2 x --decide-every actor iterations late (the flag is reduced one decision period, read the next)")
     ap.add_argument("--interval", type=float, default=30.0, help="statistics interval in seconds (train.py:39); several ranks: same lag as --minutes")
+    ap.add_argument("--promote-interval", type=float, default=5.0, help="seconds between two checks of the curriculum's promotion rule and stop "
+                    "criterion (worker.py:211-224,237-250).  The reference checks them with the statistics, every 30 s of a loop that makes ~20 "
+                    "updates/s; at this loop's ~400 updates/s the same wall-clock interval leaves a level that has long passed in place for "
+                    "thousands of updates (to the stop criterion: 282 s with --interval 20, 232 s with --interval 10).  0 = with the "
+                    "statistics only, as the reference does")
     ap.add_argument("--learning-starts", type=int, default=config.learning_starts, help="transitions in EVERY rank's replay before updates start "
                     "(several ranks: same lag as --minutes)")
     ap.add_argument("--batch-size", type=int, default=config.batch_size)
@@ -182,7 +187,7 @@ def main(argv=None):
         K = max(1, a.decide_every)
     cpu = torch.device("cpu")
     pending = None
-    t_start = t_last = time.time()
+    t_start = t_last = t_promote = time.time()
     debt = 0.0
     started = False
     stop = False
@@ -190,7 +195,7 @@ def main(argv=None):
     while learner.counter < a.max_updates and not stop:
         actor_step()
         it += 1
-        stats_now = 0
+        stats_now = promote_now = 0
         if it % K == 0:
             if dist is None:
                 now = time.time()
@@ -199,11 +204,12 @@ def main(argv=None):
                 not_ready = 0 if started else int(len(buffer) < a.learning_starts)  # (reads the device-side ring state)
                 time_up = int(a.minutes > 0 and (now - t_start) > a.minutes * 60)
                 stats_now = int(now - t_last >= a.interval)
+                promote_now = int(not fixed and a.promote_interval > 0 and now - t_promote >= a.promote_interval)
             else:
-                not_ready, time_up, stats_now = int(not started), 0, 0
+                not_ready, time_up, stats_now, promote_now = int(not started), 0, 0, 0
                 if pending is not None:
                     pending[0].wait()
-                    not_ready, time_up, stats_now = pending[1].tolist()
+                    not_ready, time_up, stats_now, promote_now = pending[1].tolist()
             if not started and not not_ready:
                 started = True
                 if rank == 0:
@@ -223,7 +229,19 @@ def main(argv=None):
                 stop = buffer.check_done(pooled, world)  # worker.py:237-250, train.py:41-43
             if astream is not None:
                 astream.wait_stream(torch.cuda.current_stream(dev))  # (new levels were set up on this stream)
-            t_last = now
+            t_last = t_promote = now
+        elif promote_now and not fixed:
+            # the promotion rule and the stop criterion between two statistics (--promote-interval): same calls, nothing printed
+            now = time.time()
+            if astream is not None:
+                astream.synchronize()
+            pooled = buffer.pooled_counts(cpu, ctrl) if dist is not None else None
+            buffer.advance_levels(pooled, world)
+            actor.sync_levels()
+            stop = buffer.check_done(pooled, world)
+            if astream is not None:
+                astream.wait_stream(torch.cuda.current_stream(dev))
+            t_promote = now
         if it % K == 0:
             stop = stop or bool(time_up)
             if dist is not None and not stop:
@@ -233,7 +251,8 @@ def main(argv=None):
                     astream.synchronize()
                 mine = torch.tensor([0 if started else int(len(buffer) < a.learning_starts),
                                      int(a.minutes > 0 and (now - t_start) > a.minutes * 60),
-                                     int(rank == 0 and now - t_last >= a.interval)], dtype=torch.int32)
+                                     int(rank == 0 and now - t_last >= a.interval),
+                                     int(rank == 0 and not fixed and a.promote_interval > 0 and now - t_promote >= a.promote_interval)], dtype=torch.int32)
                 pending = (dist.all_reduce(mine, op=dist.ReduceOp.MAX, group=ctrl, async_op=True), mine)
         if started:
             debt += a.updates_per_iter
@@ -241,6 +260,8 @@ def main(argv=None):
                 learner.update()
                 debt -= 1.0
     if rank == 0:
+        if stop and not fixed and not (a.minutes > 0 and (time.time() - t_start) > a.minutes * 60):
+            print("stop criterion reached: {} updates, {:.0f} s after the start of the loop".format(learner.counter, time.time() - t_start))
         learner.save()
     if dist is not None:
         if pending is not None:
