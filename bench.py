@@ -85,7 +85,7 @@ def parse_args(argv=None):
     ap.add_argument("--curriculum-envs", type=int, default=1024, help="environments per active curriculum level (train.py's default)")
     ap.add_argument("--curriculum-iters", type=int, default=200, help="timed curriculum actor iterations")
     ap.add_argument("--ref-shape-updates", type=int, default=100, help="timed updates at the reference's training shape (and train-loop pairs)")
-    ap.add_argument("--ref-shape-warmup", type=int, default=60, help="untimed updates in front of them (graph captures of the buckets the replay produces)")
+    ap.add_argument("--ref-shape-warmup", type=int, default=150, help="untimed updates in front of them (graph captures of the buckets the replay produces)")
     return ap.parse_args(argv)
 
 
