@@ -36,6 +36,18 @@ def test_level_promotion_and_mixed_levels():
     buf.stat_dict[(2, 10)] = [True] * 179 + [False] * 21
     buf.stats(1.0)
     assert (2, 10) in buf.get_level() and (3, 10) not in buf.get_level()
+    # the promotion rule alone, as train.py --promote-interval applies it between two statistics: same decisions, nothing printed
+    buf.stat_dict[(1, 15)] = [True] * 190 + [False] * 10
+    import contextlib
+    import io
+
+    with contextlib.redirect_stdout(io.StringIO()) as said:
+        lines = buf.advance_levels()
+    assert said.getvalue() == "" and any(l.startswith("(1, 15): 190/200") for l in lines)
+    assert (1, 15) not in buf.get_level() and (1, 20) in buf.get_level() and (2, 15) in buf.get_level()
+    assert sorted(cur.sync_levels()) == sorted(buf.get_level())
+    for _ in range(5):
+        cur.step()
     # the agent count is capped at max_num_agetns and the map at max_map_lenght (worker.py:214,217)
     buf.stat_dict = {(6, 40): [True] * 200}
     buf.stats(1.0)
