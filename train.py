@@ -50,7 +50,9 @@ def _pow2(n):
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--envs", type=int, default=1024, help="lock-step environments per GPU (per active level with the curriculum)")
+    ap.add_argument("--envs", type=int, default=512, help="lock-step environments per GPU (per active level with the curriculum).  The loop makes "
+                    "one update per actor iteration and the curriculum is bound by updates (the stop criterion arrives ~100 k updates in, with the "
+                    "reference's learning-rate milestone): 512 per level reach it in 207-231 s, 1024 in 257 s, 256 in 262 s (DESIGN section 7)")
     ap.add_argument("--agents", type=int, default=None, help="fixed level: number of agents (implies no curriculum)")
     ap.add_argument("--map", type=int, default=None, help="fixed level: map side length (implies no curriculum)")
     ap.add_argument("--curriculum", action="store_true", help="(default) the reference's adaptive schedule; kept for compatibility")
