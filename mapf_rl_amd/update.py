@@ -954,15 +954,18 @@ class FusedUpdate:
         (g_t, c_t), (g_o, c_o) = c_rt.fwd, c_ro.fwd
         # second stream: packs, the target set's row table, the target network's forward; this stream: the online set's row table,
         # then -- behind the packs -- the online network's forward (the critical path: it starts ~60 us into the update)
-        g_ro.replay()  # (first: the host's launches reach the GPU in this order, and this stream's chain is the critical one)
+        # (the host's launches reach the GPU in the order they are issued, a graph launch costs it 10-20 us, and this stream's chain is
+        # the critical one: its row table, the packs it waits for, its forward -- then the target network's two graphs)
+        g_ro.replay()
         with torch.cuda.stream(side):
             g_k.replay()
             packed = torch.cuda.Event()
             packed.record(side)
-            g_rt.replay()
-            g_t.replay()
         cur.wait_event(packed)
         g_o.replay()
+        with torch.cuda.stream(side):
+            g_rt.replay()
+            g_t.replay()
         cur.wait_stream(side)
 
         def cap_head():
