@@ -951,12 +951,21 @@ def ref_shape_legs(M, args, env, dev, rank, world, dist, gen):
     barrier()
     c0, g0 = (fu.graph_captures, fu.graph_replays) if fu is not None else (0, 0)
     U = args.ref_shape_updates
+    from mapf_rl_amd import learner as learner_mod
+
+    timing = world > 1 or learner_mod.FORCE_EXCHANGE
+    if timing:
+        learner.bucket.timing = []
     t_ = time.perf_counter()
     for _ in range(U):
         learner.update()
     t_host_u = time.perf_counter() - t_
     barrier()
     dt_upd = (time.perf_counter() - t_) / U
+    ex_stats = {}
+    if timing:  # (graph mode: the whole exchange follows the captured backward stage -- nothing of it is hidden behind the update here)
+        ex_stats = exchange_stats(learner.bucket, U)
+        learner.bucket.timing = None
     caps = (fu.graph_captures - c0) if fu is not None else None
     reps = (fu.graph_replays - g0) if fu is not None else None
     learner._drop_prefetch()
@@ -1002,6 +1011,11 @@ def ref_shape_legs(M, args, env, dev, rank, world, dist, gen):
         tt = torch.tensor([dt_cur, dt_upd, dt_train, dt_cur_stand], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt_cur, dt_upd, dt_train, dt_cur_stand = [float(v) for v in tt.tolist()]
+        if ex_stats:  # the slowest rank's exchange figures
+            keys = sorted(ex_stats)
+            et = torch.tensor([ex_stats[k] for k in keys], dtype=torch.float64, device=dev)
+            dist.all_reduce(et, op=dist.ReduceOp.MAX)
+            ex_stats = {k: float(v) for k, v in zip(keys, et.tolist())}
     steps_per_iter = world * El * len(REF_LEVELS)
     out = {
         "curriculum_actor_iter_ms": dt_cur * 1e3, "curriculum_actor_iter_host_ms": host_cur * 1e3,
@@ -1024,6 +1038,7 @@ def ref_shape_legs(M, args, env, dev, rank, world, dist, gen):
         "train_loop_ref_shape_config": "one curriculum actor iteration (its own stream, agents moving under the tape policy) + one update per iteration: the loop of "
                                        "`python train.py` once training started",
     }
+    out.update({"learner_ref_shape_" + k: v for k, v in ex_stats.items()})
     del cur, learner, buf
     return out
 

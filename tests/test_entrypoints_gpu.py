@@ -162,6 +162,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert mr["backend"] == "gloo" and mr["world_size"] == 2 and [x["rank"] for x in mr["ranks_seen"]] == [0, 1]
     assert mr["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "rccl_version" in mr
     assert r["learner_exchange_pieces_per_update"] == 2 and r["learner_exchange_begin_ms"] >= 0 and r["learner_exchange_finish_ms"] > 0
+    assert r["learner_ref_shape_exchange_pieces_per_update"] == 2 and r["learner_ref_shape_exchange_finish_ms"] > 0  # (graph mode: behind the backward stage)
     # the interleaved loop costs what its two halves cost (round-4 review: 410 ms beside a 14 ms update and a 4 ms actor iteration --
     # stalls inside PyTorch's gloo path for device tensors, profiles/r05_two_rank_probe.md; the exchange is host-staged through one
     # persistent pinned buffer now, learner.FlatGradBucket._host_staged)
