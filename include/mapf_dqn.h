@@ -377,6 +377,15 @@ int mapf_plan_rows(int T, int B, int N, int Nc, const int16_t *order_dev, const 
                    int32_t *gidx_dev, uint8_t *comm_c_dev, uint16_t *h0_c_dev, int64_t num_rows, int64_t *row_src_dev,
                    uint16_t *obs_rows_dev, const uint8_t *dup_dev, const int32_t *ucnt_dev, int32_t *umap_dev, int32_t *row_tbp_dev,
                    void *stream);
+/* The same for bucket-sized buffers (the graph-replayed update: launch sizes rounded up, true counts on the device only): first
+ * row_src_dev[0 .. fill_urows) = 0 (a padding row gathers observation 0 of the batch), umap_dev[0 .. fill_rows) = 0 and
+ * row_tbp_dev[0 .. fill_rows) = -1 (a padding entry uses distinct row 0 and is skipped by mapf_dedup_sum), inside the same launches. */
+int mapf_plan_rows_padded(int T, int B, int N, int Nc, const int16_t *order_dev, const int32_t *nact_dev, const int32_t *cnt_dev,
+                          const int32_t *nag_dev, const uint8_t *comm_dev, int64_t comm_stride_b, int64_t comm_stride_t,
+                          const uint16_t *hidden_dev, int hidden_is_bf16, const uint16_t *obs_bf16_dev, int64_t obs_stride_b, int64_t obs_stride_t,
+                          int32_t *gidx_dev, uint8_t *comm_c_dev, uint16_t *h0_c_dev, int64_t num_rows, int64_t *row_src_dev,
+                          uint16_t *obs_rows_dev, const uint8_t *dup_dev, const int32_t *ucnt_dev, int32_t *umap_dev, int32_t *row_tbp_dev,
+                          int64_t fill_rows, int64_t fill_urows, void *stream);
 /*
  * Repeated observations (exact reuse: the encoder is a deterministic per-observation function).  mapf_obs_dup: dup u8 [T][B][N] = the
  * FIRST step of the window at which the same agent carried the same 486 values (<= t; t itself for a new observation and for entries
@@ -442,9 +451,12 @@ int mapf_adam_step_dev(int64_t n, float *params_dev, float *grads_dev, float *ex
                        uint16_t *params_bf16_dev, float *scratch_dev, float *norm_out_dev, float lr, float beta1, float beta2, float eps,
                        int64_t *step_dev, float max_norm, void *stream);
 int mapf_to_bf16(const float *src_dev, uint16_t *dst_dev, int64_t n, void *stream);
-/* rows [first_row, last_row) of n <= 16 row-major device buffers := 0; bufs_dev: HOST array of DEVICE pointers (16-byte aligned),
+/* rows [first_row, last_row) of n <= 24 row-major device buffers := 0; bufs_dev: HOST array of DEVICE pointers (16-byte aligned),
  * row_bytes: HOST array of row sizes (multiples of 16). */
 int mapf_zero_rows(void *const *bufs_dev, const int *row_bytes, int n, int64_t first_row, int64_t last_row, void *stream);
+/* The same with the first row read from device memory (int32 [1], clamped to 0..last_row): the graph-replayed update clears the padding
+ * rows of its bucket-sized GEMM operands behind the batch's true entry count (mapf_plan_totals) instead of the whole buffers. n <= 24. */
+int mapf_zero_rows_from(void *const *bufs_dev, const int *row_bytes, int n, const int32_t *first_row_dev, int64_t last_row, void *stream);
 
 #ifdef __cplusplus
 }

@@ -112,6 +112,8 @@ SYMBOLS = [
     ("mapf_dedup_sum", _i, [_i, _i, _i, ctypes.c_int64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("mapf_plan_rows", _i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _i, _vp, ctypes.c_int64, ctypes.c_int64,
                             _vp, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("mapf_plan_rows_padded", _i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _i, _vp, ctypes.c_int64, ctypes.c_int64,
+                            _vp, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp]),
     ("mapf_rows_scatter", _i, [_vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp]),
     ("mapf_dqn_head_loss", _i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _f,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(_vp), _vp]),
@@ -121,6 +123,7 @@ SYMBOLS = [
     ("mapf_adam_step_dev", _i, [ctypes.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _f, _vp]),
     ("mapf_to_bf16", _i, [_vp, _vp, ctypes.c_int64, _vp]),
     ("mapf_zero_rows", _i, [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, ctypes.c_int64, ctypes.c_int64, _vp]),
+    ("mapf_zero_rows_from", _i, [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _vp, ctypes.c_int64, _vp]),
     ("mapf_tall_tn_plan", _i, [ctypes.c_int64, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_int64)]),
     ("mapf_tall_tn", _i, [_vp, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int64, _i, _i, _i, _vp, _vp, _i, _vp, ctypes.c_int64, _vp]),
     ("mapf_sum_parts", _i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i, _i, ctypes.c_int64, _vp, _vp]),

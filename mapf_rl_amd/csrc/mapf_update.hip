@@ -228,6 +228,9 @@ struct PlanRowsArgs {
     const int32_t *ucnt; // [B] distinct observations per window (with dup)
     int32_t *umap;       // [rows] with dup: the row of DISTINCT observations (numbered like the rows, duplicates skipped) an entry uses
     int32_t *row_tbp;    // [rows] optional: (t << 24) | (position << 16) | window of every row
+    // bucket-sized launches (mapf_plan_rows_padded): plan_masks_kernel first initialises row_src[0 .. fill_urows) = 0, umap[0 .. fill_rows) = 0 and
+    // row_tbp[0 .. fill_rows) = -1, so that every padding row behind the real ones is harmless; plan_rows_kernel then writes the real rows
+    long long fill_rows, fill_urows;
 };
 
 constexpr int OBS_DWORDS = 243;  // 486 bf16
@@ -237,6 +240,15 @@ constexpr int OBS_DWORDS = 243;  // 486 bf16
 __global__ void __launch_bounds__(256) plan_masks_kernel(PlanRowsArgs p) {
     __shared__ short s_ord[128];
     const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, T = p.T, B = p.B, N = p.N, Nc = p.Nc;
+    if (p.fill_rows > 0 || p.fill_urows > 0) {  // (grid-stride over all workgroups of this launch; plan_rows_kernel runs behind it)
+        const long long nth = (long long)gridDim.x * gridDim.y * 256, me = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid;
+        if (p.row_src)
+            for (long long i = me; i < p.fill_urows; i += nth) p.row_src[i] = 0;
+        if (p.umap)
+            for (long long i = me; i < p.fill_rows; i += nth) p.umap[i] = 0;
+        if (p.row_tbp)
+            for (long long i = me; i < p.fill_rows; i += nth) p.row_tbp[i] = -1;
+    }
     if (tid < N) s_ord[tid] = p.order[(size_t)b * N + tid];
     __syncthreads();
     if (t < T) {
@@ -775,14 +787,19 @@ __global__ void __launch_bounds__(256) dense_to_rows_kernel(const uint4 *__restr
 // rows [first, last) of up to 16 row-major buffers := 0 (the padding rows behind the compact rows of the recurrence's saved tensors /
 // gradient outputs: they enter the weight-gradient GEMMs, whose K is padded to a multiple of the split size)
 struct ZeroRowsArgs {
-    void *ptr[16];
-    int row_bytes[16];  // multiples of 16
+    void *ptr[24];
+    int row_bytes[24];  // multiples of 16
     int n;
     long long first, last;
+    const int32_t *first_dev;  // optional: the first row to clear, read from device memory (clamped to 0..last)
 };
 __global__ void __launch_bounds__(256) zero_rows_kernel(ZeroRowsArgs a) {
     const int k = blockIdx.y;
     if (k >= a.n) return;
+    if (a.first_dev != nullptr) {
+        const long long f = (long long)*a.first_dev;
+        a.first = f < 0 ? 0 : (f > a.last ? a.last : f);
+    }
     const long long chunks = (a.last - a.first) * (a.row_bytes[k] / 16);
     uint4 *dst = reinterpret_cast<uint4 *>(static_cast<unsigned char *>(a.ptr[k]) + a.first * a.row_bytes[k]);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long long)gridDim.x * 256) dst[i] = make_uint4(0, 0, 0, 0);
@@ -842,11 +859,12 @@ int mapf_plan_totals(const int32_t *counts_dev, int rows, int B, int32_t *totals
     return MAPF_OK;
 }
 
-int mapf_plan_rows(int T, int B, int N, int Nc, const int16_t *order_dev, const int32_t *nact_dev, const int32_t *cnt_dev, const int32_t *nag_dev,
-                   const uint8_t *comm_dev, int64_t comm_stride_b, int64_t comm_stride_t, const uint16_t *hidden_dev, int hidden_is_bf16,
-                   const uint16_t *obs_bf16_dev, int64_t obs_stride_b, int64_t obs_stride_t, int32_t *gidx_dev, uint8_t *comm_c_dev, uint16_t *h0_c_dev,
-                   int64_t num_rows, int64_t *row_src_dev, uint16_t *obs_rows_dev, const uint8_t *dup_dev, const int32_t *ucnt_dev, int32_t *umap_dev,
-                   int32_t *row_tbp_dev, void *stream) {
+static int plan_rows_launch(int T, int B, int N, int Nc, const int16_t *order_dev, const int32_t *nact_dev, const int32_t *cnt_dev, const int32_t *nag_dev,
+                            const uint8_t *comm_dev, int64_t comm_stride_b, int64_t comm_stride_t, const uint16_t *hidden_dev, int hidden_is_bf16,
+                            const uint16_t *obs_bf16_dev, int64_t obs_stride_b, int64_t obs_stride_t, int32_t *gidx_dev, uint8_t *comm_c_dev, uint16_t *h0_c_dev,
+                            int64_t num_rows, int64_t *row_src_dev, uint16_t *obs_rows_dev, const uint8_t *dup_dev, const int32_t *ucnt_dev, int32_t *umap_dev,
+                            int32_t *row_tbp_dev, int64_t fill_rows, int64_t fill_urows, void *stream) {
+    if (fill_rows < 0 || fill_urows < 0) return MAPF_ERR_INVALID_ARG;
     const bool tiled = (Nc == 4 || Nc == 8) && B % (16 / Nc) == 0;  // several windows per 16-row tile (see plan_masks_kernel)
     if (T < 1 || T > MAPF_PLAN_MAX_STEPS || B < 0 || N < 1 || N > 128 || (!tiled && (Nc < 16 || Nc > 128 || (Nc & 15))) || !order_dev || !nact_dev || !cnt_dev ||
         !nag_dev || !comm_dev || !hidden_dev || !gidx_dev || !comm_c_dev || !h0_c_dev)
@@ -860,7 +878,7 @@ int mapf_plan_rows(int T, int B, int N, int Nc, const int16_t *order_dev, const 
     if (B == 0) return MAPF_OK;
     PlanRowsArgs p{T, B, N, Nc, order_dev, nact_dev, cnt_dev, nag_dev, comm_dev, comm_stride_b, comm_stride_t, hidden_dev, hidden_is_bf16 != 0, obs_bf16_dev,
                    obs_stride_b, obs_stride_t, gidx_dev, comm_c_dev, h0_c_dev, reinterpret_cast<long long *>(row_src_dev), dup_dev, ucnt_dev, umap_dev,
-                   row_tbp_dev};
+                   row_tbp_dev, (long long)fill_rows, (long long)fill_urows};
     hipLaunchKernelGGL(plan_masks_kernel, dim3(B, T + 1), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     hipLaunchKernelGGL(plan_rows_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     if (obs_rows_dev && num_rows > 0) {
@@ -871,6 +889,26 @@ int mapf_plan_rows(int T, int B, int N, int Nc, const int16_t *order_dev, const 
     }
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
+}
+
+int mapf_plan_rows(int T, int B, int N, int Nc, const int16_t *order_dev, const int32_t *nact_dev, const int32_t *cnt_dev, const int32_t *nag_dev,
+                   const uint8_t *comm_dev, int64_t comm_stride_b, int64_t comm_stride_t, const uint16_t *hidden_dev, int hidden_is_bf16,
+                   const uint16_t *obs_bf16_dev, int64_t obs_stride_b, int64_t obs_stride_t, int32_t *gidx_dev, uint8_t *comm_c_dev, uint16_t *h0_c_dev,
+                   int64_t num_rows, int64_t *row_src_dev, uint16_t *obs_rows_dev, const uint8_t *dup_dev, const int32_t *ucnt_dev, int32_t *umap_dev,
+                   int32_t *row_tbp_dev, void *stream) {
+    return plan_rows_launch(T, B, N, Nc, order_dev, nact_dev, cnt_dev, nag_dev, comm_dev, comm_stride_b, comm_stride_t, hidden_dev, hidden_is_bf16, obs_bf16_dev,
+                            obs_stride_b, obs_stride_t, gidx_dev, comm_c_dev, h0_c_dev, num_rows, row_src_dev, obs_rows_dev, dup_dev, ucnt_dev, umap_dev,
+                            row_tbp_dev, 0, 0, stream);
+}
+
+int mapf_plan_rows_padded(int T, int B, int N, int Nc, const int16_t *order_dev, const int32_t *nact_dev, const int32_t *cnt_dev, const int32_t *nag_dev,
+                          const uint8_t *comm_dev, int64_t comm_stride_b, int64_t comm_stride_t, const uint16_t *hidden_dev, int hidden_is_bf16,
+                          const uint16_t *obs_bf16_dev, int64_t obs_stride_b, int64_t obs_stride_t, int32_t *gidx_dev, uint8_t *comm_c_dev, uint16_t *h0_c_dev,
+                          int64_t num_rows, int64_t *row_src_dev, uint16_t *obs_rows_dev, const uint8_t *dup_dev, const int32_t *ucnt_dev, int32_t *umap_dev,
+                          int32_t *row_tbp_dev, int64_t fill_rows, int64_t fill_urows, void *stream) {
+    return plan_rows_launch(T, B, N, Nc, order_dev, nact_dev, cnt_dev, nag_dev, comm_dev, comm_stride_b, comm_stride_t, hidden_dev, hidden_is_bf16, obs_bf16_dev,
+                            obs_stride_b, obs_stride_t, gidx_dev, comm_c_dev, h0_c_dev, num_rows, row_src_dev, obs_rows_dev, dup_dev, ucnt_dev, umap_dev,
+                            row_tbp_dev, fill_rows, fill_urows, stream);
 }
 
 int mapf_dqn_head_loss(int B, int To, int Tt, const uint16_t *a0_online_dev, const uint16_t *a0_target_dev, const uint16_t *a0_online_next_dev,
@@ -1063,10 +1101,12 @@ int mapf_rows_scatter(void *rows_dev, const int32_t *idx_dev, void *dense_dev, i
     return MAPF_OK;
 }
 
-int mapf_zero_rows(void *const *bufs_dev, const int *row_bytes, int n, int64_t first_row, int64_t last_row, void *stream) {
-    if (!bufs_dev || !row_bytes || n < 0 || n > 16 || first_row < 0 || last_row < first_row) return MAPF_ERR_INVALID_ARG;
-    if (n == 0 || last_row == first_row) return MAPF_OK;
+static int zero_rows_launch(void *const *bufs_dev, const int *row_bytes, int n, int64_t first_row, const int32_t *first_row_dev, int64_t last_row,
+                            void *stream) {
+    if (!bufs_dev || !row_bytes || n < 0 || n > 24 || first_row < 0 || last_row < first_row) return MAPF_ERR_INVALID_ARG;
+    if (n == 0 || (!first_row_dev && last_row == first_row)) return MAPF_OK;
     ZeroRowsArgs a{};
+    a.first_dev = first_row_dev;
     for (int i = 0; i < n; ++i) {
         if (!bufs_dev[i] || row_bytes[i] < 16 || (row_bytes[i] & 15) || (reinterpret_cast<uintptr_t>(bufs_dev[i]) & 15)) return MAPF_ERR_INVALID_ARG;
         a.ptr[i] = bufs_dev[i];
@@ -1078,6 +1118,15 @@ int mapf_zero_rows(void *const *bufs_dev, const int *row_bytes, int n, int64_t f
     hipLaunchKernelGGL(zero_rows_kernel, dim3(16, n), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     HIP_TRY(hipGetLastError());
     return MAPF_OK;
+}
+
+int mapf_zero_rows(void *const *bufs_dev, const int *row_bytes, int n, int64_t first_row, int64_t last_row, void *stream) {
+    return zero_rows_launch(bufs_dev, row_bytes, n, first_row, nullptr, last_row, stream);
+}
+
+int mapf_zero_rows_from(void *const *bufs_dev, const int *row_bytes, int n, const int32_t *first_row_dev, int64_t last_row, void *stream) {
+    if (!first_row_dev || (reinterpret_cast<uintptr_t>(first_row_dev) & 3) || last_row < 0) return MAPF_ERR_INVALID_ARG;
+    return zero_rows_launch(bufs_dev, row_bytes, n, 0, first_row_dev, last_row, stream);
 }
 
 int mapf_to_bf16(const float *src_dev, uint16_t *dst_dev, int64_t n, void *stream) {

@@ -389,7 +389,7 @@ class FusedUpdate:
             p.nc = self._compact_width(int(h[2 * k + 1].max()), p.B)
             p.urows = int(h[4 + k].sum()) if p.dup is not None else p.rows
             p.true_rows, p.true_urows = p.rows, p.urows
-            p.valid_rows = None  # device-side count of the rows the encoder kernels have to compute (bucket-sized launches only)
+            p.valid_rows = p.valid_entries = None  # device-side counts: rows the encoder kernels compute / entries (bucket-sized launches only)
             if padded:
                 p.nc = self._compact_width(p.N, p.B)
                 p.rows = _round_up(p.rows, self.GRAPH_ROW_STEP)
@@ -397,6 +397,7 @@ class FusedUpdate:
                 if self.BOUNDED_ROWS and pl.get("totals") is not None:
                     i = (4 + k) if p.dup is not None else 2 * k
                     p.valid_rows = pl["totals"][i:i + 1]
+                    p.valid_entries = pl["totals"][2 * k:2 * k + 1]  # (entries of the window set: the rows of the recurrence's tensors)
         return pl
 
     def _compact_width(self, agents, B):
@@ -432,15 +433,23 @@ class FusedUpdate:
         row_src = rows_buffer((), max(p.urows, 1), (), torch.int64, dev)
         p.umap = rows_buffer((), max(p.rows, 1), (), torch.int32, dev) if p.dup is not None else None
         p.row_tbp = rows_buffer((), max(p.rows, 1), (), torch.int32, dev) if p.dup is not None else None
-        if padded:
-            # (fill kernels, not zero_() / torch.zeros: those are hipMemsetAsync calls, i.e. memset NODES of the captured graph -- and on
-            # this runtime a graph holding a (small) memset node faulted at a later replay once other memsets had been issued in
-            # between; see mapf_obs_changed in csrc/mapf_actor.hip.  Nothing that is captured calls hipMemsetAsync.)
+        cm, obs, hid = v["comm"], v["obs"], v["hidden"]
+        if padded and not self.FOLD_FILLS:  # (rounds 4-5, kept for A/B runs: three element-wise fill launches in front of the call)
             row_src.fill_(0)
             if p.umap is not None:
                 p.umap.fill_(0)
                 p.row_tbp.fill_(-1)
-        cm, obs, hid = v["comm"], v["obs"], v["hidden"]
+        elif padded:
+            # the index tables' padding is initialised INSIDE the call (three element-wise fill launches per window set until round 6; never
+            # zero_() / torch.zeros: those are hipMemsetAsync calls, i.e. memset NODES of the captured graph -- and on this runtime a graph
+            # holding a (small) memset node faulted at a later replay once other memsets had been issued in between; see
+            # mapf_obs_changed in csrc/mapf_actor.hip.  Nothing that is captured calls hipMemsetAsync.)
+            check(lib.mapf_plan_rows_padded(T, B, N, Nc, _ptr(p.order), _ptr(p.nact), _ptr(p.cnt), _ptr(p.nag), _ptr(cm), cm.stride(0), cm.stride(1),
+                                            _ptr(hid), int(hid.dtype == torch.bfloat16), _ptr(obs), obs.stride(0), obs.stride(1), _ptr(p.gidx),
+                                            _ptr(p.comm_c), _ptr(p.h0_c), p.urows, _ptr(row_src), _ptr(p.obs_rows), _ptr(p.dup), _ptr(p.ucnt),
+                                            _ptr(p.umap), _ptr(p.row_tbp), max(p.rows, 1) if p.umap is not None else 0, max(p.urows, 1), st),
+                  "mapf_plan_rows_padded")
+            return
         check(lib.mapf_plan_rows(T, B, N, Nc, _ptr(p.order), _ptr(p.nact), _ptr(p.cnt), _ptr(p.nag), _ptr(cm), cm.stride(0), cm.stride(1),
                                  _ptr(hid), int(hid.dtype == torch.bfloat16), _ptr(obs), obs.stride(0), obs.stride(1), _ptr(p.gidx),
                                  _ptr(p.comm_c), _ptr(p.h0_c), p.urows, _ptr(row_src), _ptr(p.obs_rows), _ptr(p.dup), _ptr(p.ucnt), _ptr(p.umap),
@@ -504,6 +513,9 @@ class FusedUpdate:
     # graph mode: the encoder kernels of a bucket-sized launch compute the TRUE number of distinct observations only (read from device
     # memory), not the bucket (the variable: A/B runs)
     BOUNDED_ROWS = os.environ.get("MAPF_BOUNDED_ROWS", "1") != "0"
+    # graph mode: the padding of the index tables is initialised inside mapf_plan_rows_padded and only the padding rows of the GEMM operands
+    # are cleared (mapf_zero_rows_from), instead of fill launches over whole buffers (the variable: A/B runs)
+    FOLD_FILLS = os.environ.get("MAPF_FOLD_FILLS", "1") != "0"
     DEDUP = True  # encode the distinct observations of a batch only (mapf_obs_dup: same agent, consecutive steps, same 486 values)
 
     # ------------------------------------------------------------------ the update
@@ -591,7 +603,10 @@ class FusedUpdate:
         if c.padded:
             # one allocation for everything the tall GEMMs read, one memset: [saves 0, 2, 4, 5 | outputs of the backward 0..5]
             widths = [256, 2 * 256, 2 * 128, 2 * 64, 768, 768, 2 * 768, 2 * 768, 2 * 64, 2 * 384]
-            zero = torch.empty(R * sum(widths), dtype=bf, device=dev).fill_(0)  # (a fill kernel, not a memset node: see _plan_rows)
+            ve = getattr(po, "valid_entries", None) if self.FOLD_FILLS else None
+            zero = torch.empty(R * sum(widths), dtype=bf, device=dev)
+            if ve is None:
+                zero.fill_(0)  # (a fill kernel, not a memset node: see _plan_rows)
             parts, off = [], 0
             for w in widths:
                 parts.append(zero[off:off + R * w])
@@ -599,6 +614,14 @@ class FusedUpdate:
             s0, s2, s4, s5 = parts[0].view(R, 256), parts[1].view(2, R, 256), parts[2].view(2, R, 128), parts[3].view(2, R, 64)
             c.outs_b = [parts[4].view(R, 768), parts[5].view(R, 768), parts[6].view(2, R, 768), parts[7].view(2, R, 768), parts[8].view(2, R, 64),
                         parts[9].view(2, R, 384), torch.empty((B, 2432), dtype=torch.float32, device=dev)]
+            if ve is not None:
+                # only the PADDING rows -- behind this update's true entry count, read from device memory -- are cleared: the kernels write
+                # every row that exists (round 5 filled all 82 MB of these operands per update, 16 us on the main chain)
+                ob = c.outs_b
+                ops = [s0, s2[0], s2[1], s4[0], s4[1], s5[0], s5[1], ob[0], ob[1], ob[2][0], ob[2][1], ob[3][0], ob[3][1], ob[4][0], ob[4][1],
+                       ob[5][0], ob[5][1]]
+                rb = (ctypes.c_int * len(ops))(*[t.shape[-1] * 2 for t in ops])
+                check(lib.mapf_zero_rows_from(_ptr_array(ops), rb, len(ops), _ptr(ve), R, st), "mapf_zero_rows_from")
         else:
             s0, s2, s4, s5 = (rows_buffer((), R, (256,), bf, dev), rows_buffer((2,), R, (256,), bf, dev), rows_buffer((2,), R, (128,), bf, dev),
                               rows_buffer((2,), R, (64,), bf, dev))
@@ -907,7 +930,10 @@ class FusedUpdate:
                 c.rows = tuple(getattr(p, k) for k in ROWS)
                 # THIS update's true row count, copied out of the plan's totals: the prefetch stage overwrites those with the next
                 # batch's while this update's backward stage is still to read them
-                c.valid = p.valid_rows.clone() if p.valid_rows is not None else None
+                c.valid = c.valid_e = None
+                if p.valid_rows is not None:
+                    both = torch.cat([p.valid_rows, p.valid_entries])  # (one small launch for the two words)
+                    c.valid, c.valid_e = both[0:1], both[1:2]
                 c.fwd = None
                 return c
             return fn
@@ -915,7 +941,7 @@ class FusedUpdate:
         def use_rows(p, c):
             for k, t in zip(ROWS, c.rows):
                 setattr(p, k, t)
-            p.valid_rows = c.valid
+            p.valid_rows, p.valid_entries = c.valid, c.valid_e
 
         def cap_target():
             c = _Ctx()

@@ -120,6 +120,60 @@ def test_plan_rows_compact_layout(B, T, N, p, tm):
             assert np.array_equal(cc[t, b], want)
 
 
+def test_plan_rows_padded_initialises_the_padding_and_zero_rows_from_reads_its_bound_on_the_device():
+    """mapf_plan_rows_padded (bucket-sized launches of the graph-replayed update): the real rows equal mapf_plan_rows', every padding row
+    gathers observation 0 of the batch (row_src = 0) and -- with duplicate flags -- uses distinct row 0 and is skipped by the gradient
+    sum (umap = 0, row_tbp = -1).  mapf_zero_rows_from clears rows [*first_dev, last) of its buffers and nothing in front."""
+    from mapf_rl_amd._lib import ERR_INVALID_ARG, check, lib
+
+    B, T, N = 12, 9, 6
+    comm, steps, g = _random_windows(B, T, N, 0.3, 5, False)
+    rel, slot, order, nact, cnt, nag = _plan_mark(comm, steps)
+    obs = torch.rand((B, T, N, 486), device="cuda", generator=g).to(torch.bfloat16)
+    hidden = (torch.randn((B * N, 256), device="cuda", generator=g) * 0.3).to(torch.float16)
+    Nc, rows = 16, int(cnt.sum())
+    pad = rows + 37
+    cm = comm.view(torch.uint8)
+    dup = torch.zeros((T, B, N), dtype=torch.uint8, device="cuda")
+    for t in range(T):
+        dup[t] = t  # every entry is the first appearance of its observation: distinct rows == rows
+    ucnt = cnt.clone()
+
+    def run(padded):
+        n = pad if padded else rows
+        out = dict(gidx=torch.empty((T, B, Nc), dtype=torch.int32, device="cuda"), comm_c=torch.empty((T, B, Nc, Nc), dtype=torch.uint8, device="cuda"),
+                   h0_c=torch.empty((B, Nc, 256), dtype=torch.bfloat16, device="cuda"), obs_rows=torch.full((n, 486), -7.0, dtype=torch.bfloat16, device="cuda"),
+                   row_src=torch.full((n,), -5, dtype=torch.int64, device="cuda"), umap=torch.full((n,), -5, dtype=torch.int32, device="cuda"),
+                   row_tbp=torch.full((n,), -5, dtype=torch.int32, device="cuda"))
+        args = [T, B, N, Nc, _p(order), _p(nact), _p(cnt), _p(nag), _p(cm), cm.stride(0), cm.stride(1), _p(hidden), 0, _p(obs), obs.stride(0), obs.stride(1),
+                _p(out["gidx"]), _p(out["comm_c"]), _p(out["h0_c"]), n, _p(out["row_src"]), _p(out["obs_rows"]), _p(dup), _p(ucnt), _p(out["umap"]), _p(out["row_tbp"])]
+        if padded:
+            check(lib.mapf_plan_rows_padded(*args, n, n, None), "mapf_plan_rows_padded")
+        else:
+            check(lib.mapf_plan_rows(*args, None), "mapf_plan_rows")
+        return out
+
+    a, b = run(False), run(True)
+    for k in ("gidx", "comm_c", "h0_c"):
+        assert torch.equal(a[k], b[k]), k
+    for k in ("obs_rows", "row_src", "umap", "row_tbp"):
+        assert torch.equal(a[k], b[k][:rows]), k
+    assert bool((b["row_src"][rows:] == 0).all()) and bool((b["umap"][rows:] == 0).all()) and bool((b["row_tbp"][rows:] == -1).all())
+    assert torch.equal(b["obs_rows"][rows:], obs.reshape(-1, 486)[0].expand(pad - rows, 486))
+    # mapf_zero_rows_from
+    import ctypes
+
+    x, y = torch.ones((50, 64), dtype=torch.bfloat16, device="cuda"), torch.ones((50, 8), dtype=torch.float32, device="cuda")
+    ptrs, rb = (ctypes.c_void_p * 2)(x.data_ptr(), y.data_ptr()), (ctypes.c_int * 2)(128, 32)
+    for first in (0, 17, 50, 77, -3):
+        x.fill_(1), y.fill_(1)
+        f = torch.tensor([first], dtype=torch.int32, device="cuda")
+        check(lib.mapf_zero_rows_from(ptrs, rb, 2, _p(f), 50, None), "mapf_zero_rows_from")
+        lo = min(max(first, 0), 50)
+        assert bool((x[:lo] == 1).all()) and bool((x[lo:] == 0).all()) and bool((y[:lo] == 1).all()) and bool((y[lo:] == 0).all()), first
+    assert lib.mapf_zero_rows_from(ptrs, rb, 2, None, 50, None) == ERR_INVALID_ARG
+
+
 def test_rows_scatter_round_trip():
     from mapf_rl_amd._lib import check, lib
 
